@@ -1,0 +1,119 @@
+/* libcvcl_hip.so -- C ABI of the MI355X-native CVCL contrastive hot path.
+ *
+ * Drop-in boundary for the path SURVEY.md section 8 names.  The reference has no FFI: every
+ * entry below replaces an *implicit ATen/cuDNN call* that the reference reaches through
+ * torch.nn at the cited line (paths relative to the reference repo root), so a maintainer binds
+ * it with ctypes from the same Python call site (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; every pointer is CALLER-OWNED DEVICE memory,
+ *    contiguous in the documented layout; the library never allocates, never synchronises and
+ *    only enqueues work on the passed hipStream_t (passed as void*; NULL = default stream).
+ *  - return 0 on success, negative CVCL_E* otherwise; cvcl_last_error() gives the thread-local text.
+ *  - scratch comes from the caller: cvcl_*_workspace_bytes() sizes it.
+ *  - dtype: CVCL_F32 = fp32 storage + exact-fp32 MFMA (parity mode, the reference numerics);
+ *           CVCL_BF16 = bf16 storage + bf16 MFMA with fp32 accumulation/statistics (perf mode).
+ *  - image activations inside the library are NHWC ("channels last"); the API takes the
+ *    reference's NCHW fp32 images (multimodal_data_module.py:98-109) and hands back the layer4
+ *    map in NHWC memory, which the host exposes as a logical NCHW tensor view.
+ */
+#ifndef CVCL_HIP_H
+#define CVCL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVCL_ABI_VERSION 1
+
+enum { CVCL_OK = 0, CVCL_EINVAL = -1, CVCL_ELAUNCH = -2, CVCL_EWORKSPACE = -3, CVCL_EUNSUPPORTED = -4 };
+enum { CVCL_F32 = 0, CVCL_BF16 = 1 };
+enum { CVCL_ACT_NONE = 0, CVCL_ACT_RELU = 1, CVCL_ACT_GELU = 2 };
+
+int cvcl_abi_version(void);
+const char* cvcl_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Text encoder, "embedding" branch.  Replaces nn.Embedding + sum/len
+ * (multimodal/multimodal.py:496-503; table built at :311-312, padding_idx = 0).
+ *   table [V,E] f32, tok [B,L] i64, len [B] i64
+ *   -> ret [B,E] f32 = sum_l table[tok[b,l]] / len[b];  out_ble [B,L,E] f32 = table[tok] (may be NULL)
+ * bwd: d_table [V,E] f32 (fully overwritten; row 0 = 0) from d_ret [B,E]; deterministic
+ * (b,l)-ordered accumulation, no atomics.  Token ids outside [0,V) are an error the kernel
+ * reports by writing NaN into the affected rows (the reference raises an index error).        */
+int cvcl_embed_meanpool_fwd(const float* table, const int64_t* tok, const int64_t* len, float* ret,
+                            float* out_ble, int B, int L, int E, int V, void* stream);
+int cvcl_embed_meanpool_bwd(const float* d_ret, const int64_t* tok, const int64_t* len, float* d_table,
+                            int B, int L, int E, int V, void* stream);
+
+/* F.normalize(x, p=2, dim=-1, eps) rows (multimodal/multimodal.py:736,743).
+ *   x [N,E] f32 -> y [N,E], norm [N] (the un-clamped L2 norm, kept for bwd)
+ * bwd: dx = (dy - y (y.dy)) / max(norm,eps)   (dy / eps where norm < eps).                     */
+int cvcl_l2norm_fwd(const float* x, float* y, float* norm, int N, int E, float eps, void* stream);
+int cvcl_l2norm_bwd(const float* y, const float* norm, const float* dy, float* dx, int N, int E, float eps,
+                    void* stream);
+
+/* Similarity logits (multimodal/multimodal.py:755,783-787):
+ *   logits_per_image [Ni,Nt] = (img [Ni,E] . txt [Nt,E]^T) * exp(*neg_log_temp)
+ * logits_per_text is the transposed view of the same buffer (bitwise: match.t()*s).  fp32 MFMA.
+ * bwd: d_img = s * dS . txt, d_txt = s * dS^T . img, d_neg_log_temp = sum(dS * logits) (NULL to skip).
+ * workspace: cvcl_sim_logits_bwd_workspace_bytes.                                               */
+int cvcl_sim_logits_fwd(const float* img, const float* txt, const float* neg_log_temp, float* logits,
+                        int Ni, int Nt, int E, void* stream);
+size_t cvcl_sim_logits_bwd_workspace_bytes(int Ni, int Nt, int E);
+int cvcl_sim_logits_bwd(const float* img, const float* txt, const float* neg_log_temp, const float* logits,
+                        const float* d_logits, float* d_img, float* d_txt, float* d_neg_log_temp,
+                        int Ni, int Nt, int E, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Symmetric InfoNCE with arange labels + accuracies + entropies in one pass over the logits
+ * (multimodal/multimodal.py:801-818, multimodal/utils.py:106-108).
+ *   logits [N,N] f32 (= logits_per_image; logits_per_text is its transpose)
+ *   -> scalars[5] = {infonce, image_accuracy, text_accuracy, image_entropy, text_entropy}
+ *      row_lse [N], col_lse [N] (log-sum-exp per row / column, kept for bwd)
+ * bwd: d_logits [N,N] = *d_loss/(2N) * (softmax_rows + softmax_cols - 2 I).
+ * workspace (fwd): cvcl_infonce_workspace_bytes(N).                                             */
+size_t cvcl_infonce_workspace_bytes(int N);
+int cvcl_infonce_fwd(const float* logits, int N, float* scalars5, float* row_lse, float* col_lse,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int cvcl_infonce_bwd(const float* logits, const float* row_lse, const float* col_lse, const float* d_loss,
+                     float* d_logits, int N, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MFMA GEMM with fused prologue/epilogue -- the 1x1 convolutions of torchvision's Bottleneck
+ * (call site multimodal/multimodal.py:101), nn.Linear fc/head (:190-192), ViT qkv/proj/fc1/fc2
+ * (multimodal/vision_transformer_dino_mugs.py:92-94,113-115) and the text transformer linears.
+ *
+ *   C[M,N] = act( A'[M,K] . W[N,K]^T * (exp(*exp_scale)) + bias[N] ) (+ R[M,N])
+ *   A'     = A, or relu?(A * a_scale[K] + a_shift[K])  (BatchNorm+ReLU of the producer fused into
+ *            the operand load), rows optionally gathered with a spatial stride (1x1 stride-2 conv)
+ *   stats  = per-column sum / sum-of-squares of the stored C (BatchNorm batch statistics of this
+ *            conv's output), one partial row per persistent block: stats[grid_m][2][N] f32
+ * All matrices row-major with the given leading dimensions (elements).  dtype selects the storage
+ * type of A, W, C, R.                                                                            */
+typedef struct {
+    const void* A; const void* W; void* C;
+    int M, N, K, lda, ldw, ldc;
+    /* optional operand prologue (NULL = none) */
+    const float* a_scale; const float* a_shift; int a_relu;
+    /* optional row gather: output row m = (b, oy, ox) reads input row (b, oy*stride, ox*stride) */
+    int gather_ho, gather_wo, gather_hi, gather_wi, gather_stride;   /* gather_stride 0/1 = off */
+    /* optional epilogue */
+    const float* exp_scale; const float* bias; int act;
+    const void* R; int ldr;
+    float* stats; int stats_rows;    /* stats_rows = capacity (>= grid_m returned by cvcl_gemm_grid_m) */
+} cvcl_gemm_args;
+int cvcl_gemm_grid_m(int dtype, int M, int N);
+int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);
+
+/* out[c][r] = in[r][c], f32 (operand re-layout for the weight-gradient GEMMs). */
+int cvcl_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+/* d_bias[n] = sum_m dY[m][n], f32. */
+int cvcl_colsum_f32(const float* dY, float* d_bias, int M, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVCL_HIP_H */

@@ -1,0 +1,109 @@
+// Shared device helpers for libcvcl_hip (gfx950 / CDNA4 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cvcl_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define CVCL_WAVE 64
+
+// thread-local last error text (cvcl_last_error)
+void cvcl_set_error(const char* fmt, ...);
+
+#define CVCL_CHECK_ARG(cond, ...)                \
+    do {                                         \
+        if (!(cond)) {                           \
+            cvcl_set_error(__VA_ARGS__);         \
+            return CVCL_EINVAL;                  \
+        }                                        \
+    } while (0)
+
+#define CVCL_LAUNCH_CHECK()                                                    \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess) {                                                \
+            cvcl_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,      \
+                           hipGetErrorString(e_));                             \
+            return CVCL_ELAUNCH;                                               \
+        }                                                                      \
+    } while (0)
+
+static inline int cvcl_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+
+#ifdef __HIPCC__
+// ---- element type traits -------------------------------------------------------------------
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int kPerChunk = 4;   // elements per 16-byte chunk
+    __device__ static inline float to_f(float v) { return v; }
+    __device__ static inline float from_f(float v) { return v; }
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int kPerChunk = 8;
+    __device__ static inline float to_f(bf16_t v) { return (float)v; }
+    __device__ static inline bf16_t from_f(float v) { return (bf16_t)v; }   // v_cvt_pk_bf16_f32, RNE
+};
+
+// 16-byte chunk <-> floats
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+    f32x4 v;
+    __device__ inline void load(const float* p) { v = *reinterpret_cast<const f32x4*>(p); }
+    __device__ inline void store(float* p) const { *reinterpret_cast<f32x4*>(p) = v; }
+    __device__ inline void zero() { v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    __device__ inline float get(int i) const { return v[i]; }
+    __device__ inline void set(int i, float f) { v[i] = f; }
+};
+template <> struct Chunk<bf16_t> {
+    bf16x8 v;
+    __device__ inline void load(const bf16_t* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ inline void store(bf16_t* p) const { *reinterpret_cast<bf16x8*>(p) = v; }
+    __device__ inline void zero() {
+        u32x4 z = {0u, 0u, 0u, 0u};
+        v = __builtin_bit_cast(bf16x8, z);
+    }
+    __device__ inline float get(int i) const { return (float)v[i]; }
+    __device__ inline void set(int i, float f) { v[i] = (bf16_t)f; }
+};
+
+// ---- wave / block reductions ---------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum through LDS scratch of >= (blockDim/64) floats; result broadcast to all threads
+__device__ inline float block_sum(float v, float* scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ inline float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+#endif  // __HIPCC__

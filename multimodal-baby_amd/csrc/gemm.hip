@@ -1,0 +1,401 @@
+// MFMA GEMM with fused operand prologue / epilogue for gfx950.
+//
+//   C[M,N] = act( A'[M,K] . W[N,K]^T * exp(*exp_scale) + bias ) (+ R)      (see include/cvcl_hip.h)
+//
+// Replaces the implicit ATen/cuDNN calls behind: torchvision Bottleneck 1x1 convolutions (reference
+// call site multimodal/multimodal.py:101), nn.Linear fc/head (:190-192), the ViT linears
+// (multimodal/vision_transformer_dino_mugs.py:92-94,113-115) and image_features @ text_features.T
+// (multimodal/multimodal.py:755).
+//
+// Design (CDNA4):
+//  * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32
+//    tiles); K tile = 128 bytes per row (64 bf16 / 32 fp32) staged through LDS with a 144-byte row
+//    pitch (9 x 16-B slots: ds_read_b128 fragment reads of 16 different rows hit 16 different slots).
+//  * bf16 storage: v_mfma_f32_32x32x16_bf16; fp32 storage: v_mfma_f32_32x32x2_f32 (exact fp32, the
+//    parity mode).  Operands are "swapped" (MFMA-A = weight rows, MFMA-B = activation rows) so each
+//    lane ends up with 4 consecutive output channels of one output row.
+//  * workgroups are persistent over M tiles (grid.x = grid_m, grid.y = N tiles): the per-channel
+//    BatchNorm statistics of the output are accumulated in registers across tiles and written once
+//    per workgroup as a partial row (deterministic, no atomics).  Workgroups (i, j) and (i, j+1)
+//    have linear ids i and i+grid_m (grid_m % 8 == 0) -> same XCD -> the A tile they share is an L2 hit.
+//  * the epilogue goes through LDS so that C is written as full 128-byte row segments (16 B per lane).
+//  * the BatchNorm(+ReLU) of the *producer* layer is applied to A while it is staged (per-K scale /
+//    shift), so a normalised activation tensor is never written to HBM.
+#include "cvcl_common.h"
+
+namespace {
+
+struct GemmDev {
+    const void* A; const void* W; void* C;
+    int M, N, K, lda, ldw, ldc;
+    const float* a_scale; const float* a_shift; int a_relu;
+    int g_ho, g_wo, g_hi, g_wi, g_s;
+    const float* exp_scale; const float* bias; int act;
+    const void* R; int ldr;
+    float* stats;
+    int vec_in;    // A/W rows are 16-byte aligned and K is a whole number of chunks
+    int vec_out;   // C/R rows are 16-byte aligned
+    int num_m_tiles;
+};
+
+template <typename T> struct FragOps;
+template <> struct FragOps<bf16_t> {
+    using Frag = bf16x8;
+    __device__ static inline void mma(f32x16& acc, const Frag& w, const Frag& a) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, acc, 0, 0, 0);
+    }
+};
+template <> struct FragOps<float> {
+    using Frag = f32x4;
+    // The contraction index may be permuted freely as long as both operands agree: lane-half h owns
+    // k = 4*(2g+h)..+3 of the 8-wide group and feeds element s to the s-th 32x32x2 step.
+    __device__ static inline void mma(f32x16& acc, const Frag& w, const Frag& a) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[s], a[s], acc, 0, 0, 0);
+    }
+};
+
+__device__ inline float apply_act(float v, int act) {
+    if (act == CVCL_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == CVCL_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    return v;
+}
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 144;   // LDS row pitch in bytes (128 B of K + 16 B pad)
+
+template <typename T> constexpr int stage_rowb() { return (64 + (sizeof(T) == 2 ? 8 : 4)) * (int)sizeof(T); }
+template <typename T> constexpr int gemm_lds_bytes() {
+    return (BM + BN) * ROWB > 4 * 64 * stage_rowb<T>() ? (BM + BN) * ROWB : 4 * 64 * stage_rowb<T>();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-B chunk
+    constexpr int BK = 8 * EPC;
+    constexpr int SROW = stage_rowb<T>();
+    using Frag = typename FragOps<T>::Frag;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;
+    char* sW = smem + BM * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ W = (const T*)p.W;
+    T* __restrict__ C = (T*)p.C;
+    const T* __restrict__ R = (const T*)p.R;
+
+    const int kc = tid & 7, r0 = tid >> 3;          // staging role: chunk kc of rows r0 + 32 j
+    const float out_scale = p.exp_scale ? expf(*p.exp_scale) : 1.f;
+
+    float st_sum[8], st_sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+
+    for (int mti = blockIdx.x; mti < p.num_m_tiles; mti += gridDim.x) {
+        const int m0 = mti * BM;
+        long a_off[4];
+        bool a_ok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + r0 + 32 * j;
+            a_ok[j] = m < p.M;
+            long row = m;
+            if (p.g_s > 1 && a_ok[j]) {
+                const int hw = p.g_ho * p.g_wo;
+                const int b = m / hw, r = m - b * hw;
+                const int oy = r / p.g_wo, ox = r - oy * p.g_wo;
+                row = ((long)b * p.g_hi + (long)oy * p.g_s) * p.g_wi + (long)ox * p.g_s;
+            }
+            a_off[j] = row * p.lda;
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int k0 = 0; k0 < p.K; k0 += BK) {
+            const int k = k0 + kc * EPC;
+            Chunk<T> ca[4], cw[4];
+            if (p.vec_in) {
+                const bool k_ok = k < p.K;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (a_ok[j] && k_ok) ca[j].load(A + a_off[j] + k); else ca[j].zero();
+                    const int n = n0 + r0 + 32 * j;
+                    if (n < p.N && k_ok) cw[j].load(W + (long)n * p.ldw + k); else cw[j].zero();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + r0 + 32 * j;
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        const bool ok = (k + e) < p.K;
+                        ca[j].set(e, (a_ok[j] && ok) ? ElemTraits<T>::to_f(A[a_off[j] + k + e]) : 0.f);
+                        cw[j].set(e, (n < p.N && ok) ? ElemTraits<T>::to_f(W[(long)n * p.ldw + k + e]) : 0.f);
+                    }
+                }
+            }
+            if (p.a_scale) {       // BatchNorm(+ReLU) of the producer, applied on the fly
+                float sc[EPC], sh[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const bool ok = (k + e) < p.K;
+                    sc[e] = ok ? p.a_scale[k + e] : 0.f;
+                    sh[e] = ok ? p.a_shift[k + e] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        float v = fmaf(ca[j].get(e), sc[e], sh[e]);
+                        if (p.a_relu) v = fmaxf(v, 0.f);
+                        ca[j].set(e, v);
+                    }
+            }
+            __syncthreads();                      // previous K tile fully consumed
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ca[j].store((T*)(sA + (r0 + 32 * j) * ROWB + kc * 16));
+                cw[j].store((T*)(sW + (r0 + 32 * j) * ROWB + kc * 16));
+            }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                Frag fw[2], fa[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    fw[t] = *reinterpret_cast<const Frag*>(sW + (wn * 64 + t * 32 + l31) * ROWB + (g * 2 + h) * 16);
+                    fa[t] = *reinterpret_cast<const Frag*>(sA + (wm * 64 + t * 32 + l31) * ROWB + (g * 2 + h) * 16);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) FragOps<T>::mma(acc[nt][mt], fw[nt], fa[mt]);
+            }
+        }
+
+        // ---- epilogue: registers -> (scale, bias, act, round) -> LDS -> full-row stores ----------
+        __syncthreads();
+        char* stg = smem + wave * 64 * SROW;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n_local = nt * 32 + 8 * g + 4 * h;
+                    const int n_glob = n0 + wn * 64 + n_local;
+                    T q[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[nt][mt][4 * g + e] * out_scale;
+                        if (p.bias && n_glob + e < p.N) v += p.bias[n_glob + e];
+                        q[e] = ElemTraits<T>::from_f(apply_act(v, p.act));
+                    }
+                    T* dst = (T*)(stg + (mt * 32 + l31) * SROW) + n_local;
+                    if constexpr (sizeof(T) == 2) {
+                        *reinterpret_cast<bf16x4*>(dst) = bf16x4{q[0], q[1], q[2], q[3]};
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{q[0], q[1], q[2], q[3]};
+                    }
+                }
+        // (wave-private staging region: LDS ops of one wave complete in order, no barrier needed)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = j * 8 + (lane >> 3), colc = (lane & 7) * 8;
+            const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + colc;
+            const T* src = (const T*)(stg + row * SROW) + colc;
+            float v[8];
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 t = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+            } else {
+                f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
+            }
+            if (m < p.M && n < p.N) {
+                const bool full = (n + 8 <= p.N) && p.vec_out;
+                if (R) {
+                    if (full) {
+                        if constexpr (sizeof(T) == 2) {
+                            bf16x8 t = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                        } else {
+                            f32x4 t0 = *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
+                            f32x4 t1 = *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (n + e < p.N) v[e] += ElemTraits<T>::to_f(R[(long)m * p.ldr + n + e]);
+                    }
+                }
+                T o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    o[e] = ElemTraits<T>::from_f(v[e]);
+                    if (n + e < p.N) {                       // statistics of the tensor as stored
+                        const float s = ElemTraits<T>::to_f(o[e]);
+                        st_sum[e] += s;
+                        st_sq[e] = fmaf(s, s, st_sq[e]);
+                    }
+                }
+                T* dst = C + (long)m * p.ldc + n;
+                if (full) {
+                    if constexpr (sizeof(T) == 2) {
+                        *reinterpret_cast<bf16x8*>(dst) = bf16x8{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{o[0], o[1], o[2], o[3]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{o[4], o[5], o[6], o[7]};
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < p.N) dst[e] = o[e];
+                }
+            }
+        }
+        __syncthreads();       // staging region is about to be overwritten by the next tile's operands
+    }
+
+    if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = 8; o <= 32; o <<= 1) {
+                st_sum[e] += __shfl_xor(st_sum[e], o, 64);
+                st_sq[e] += __shfl_xor(st_sq[e], o, 64);
+            }
+        }
+        __syncthreads();
+        float* red = (float*)smem;                  // [4 waves][2][64]
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * 64 + lane * 8 + e] = st_sum[e];
+                red[(wave * 2 + 1) * 64 + lane * 8 + e] = st_sq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wn_ = tid >> 6, c = tid & 63, n = n0 + tid;
+            if (n < p.N) {
+                const float s = red[((0 + 2 * wn_) * 2 + 0) * 64 + c] + red[((1 + 2 * wn_) * 2 + 0) * 64 + c];
+                const float q = red[((0 + 2 * wn_) * 2 + 1) * 64 + c] + red[((1 + 2 * wn_) * 2 + 1) * 64 + c];
+                p.stats[((long)blockIdx.x * 2 + 0) * p.N + n] = s;
+                p.stats[((long)blockIdx.x * 2 + 1) * p.N + n] = q;
+            }
+        }
+    }
+}
+
+__global__ void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = by + i, c = bx + threadIdx.x;
+        tile[i][threadIdx.x] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int c = bx + i, r = by + threadIdx.x;
+        if (c < cols && r < rows) out[(long)c * rows + r] = tile[threadIdx.x][i];
+    }
+}
+
+// d_bias[n] = sum_m dY[m][n]; one workgroup per 64 columns, 4 row-slices reduced through LDS in a fixed order
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ dY, float* __restrict__ out, int M, int N) {
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, s = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
+    float acc = 0.f;
+    if (n < N)
+        for (int m = s; m < M; m += 4) acc += dY[(long)m * N + n];
+    part[s][c] = acc;
+    __syncthreads();
+    if (s == 0 && n < N) out[n] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+}
+
+int grid_m_for(int M, int N) {
+    const int tiles = cvcl_div_up(M, BM), ntn = cvcl_div_up(N, BN);
+    int target = 768 / ntn;                 // ~3 resident workgroups per CU over 256 CUs
+    if (target < 8) target = 8;
+    target &= ~7;                           // multiple of 8: (i, j) and (i, j+1) share an XCD
+    return tiles < target ? tiles : target;
+}
+
+template <typename T>
+int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    GemmDev d;
+    d.A = a->A; d.W = a->W; d.C = a->C;
+    d.M = a->M; d.N = a->N; d.K = a->K; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc;
+    d.a_scale = a->a_scale; d.a_shift = a->a_shift; d.a_relu = a->a_relu;
+    d.g_ho = a->gather_ho; d.g_wo = a->gather_wo; d.g_hi = a->gather_hi; d.g_wi = a->gather_wi;
+    d.g_s = a->gather_stride;
+    d.exp_scale = a->exp_scale; d.bias = a->bias; d.act = a->act;
+    d.R = a->R; d.ldr = a->ldr; d.stats = a->stats;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    d.vec_in = (a->K % EPC == 0) && (a->lda % EPC == 0) && (a->ldw % EPC == 0) && al16(a->A) && al16(a->W);
+    d.vec_out = (a->ldc % EPC == 0) && al16(a->C) && (!a->R || ((a->ldr % EPC == 0) && al16(a->R)));
+    d.num_m_tiles = cvcl_div_up(a->M, BM);
+    const int gm = grid_m_for(a->M, a->N);
+    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
+    static bool attr_set = false;
+    constexpr int lds = gemm_lds_bytes<T>();
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", lds);
+            return CVCL_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid(gm, cvcl_div_up(a->N, BN));
+    hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(256), lds, stream, d);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+}  // namespace
+
+extern "C" int cvcl_gemm_grid_m(int dtype, int M, int N) {
+    (void)dtype;
+    return grid_m_for(M, N);
+}
+
+extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {
+    CVCL_CHECK_ARG(a && a->A && a->W && a->C, "cvcl_gemm: null operand");
+    CVCL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "cvcl_gemm: bad shape %d %d %d", a->M, a->N, a->K);
+    CVCL_CHECK_ARG((a->a_scale == nullptr) == (a->a_shift == nullptr), "cvcl_gemm: a_scale/a_shift must come together");
+    if (dtype == CVCL_F32) return launch_gemm<float>(a, (hipStream_t)stream);
+    if (dtype == CVCL_BF16) return launch_gemm<bf16_t>(a, (hipStream_t)stream);
+    cvcl_set_error("cvcl_gemm: unknown dtype %d", dtype);
+    return CVCL_EINVAL;
+}
+
+extern "C" int cvcl_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
+    CVCL_CHECK_ARG(in && out && rows > 0 && cols > 0, "cvcl_transpose_f32: bad args");
+    dim3 grid(cvcl_div_up(cols, 32), cvcl_div_up(rows, 32));
+    hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, in, out, rows, cols);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_colsum_f32(const float* dY, float* d_bias, int M, int N, void* stream) {
+    CVCL_CHECK_ARG(dY && d_bias && M > 0 && N > 0, "cvcl_colsum_f32: bad args");
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(cvcl_div_up(N, 64)), dim3(256), 0, (hipStream_t)stream, dY, d_bias, M, N);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}

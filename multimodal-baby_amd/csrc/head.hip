@@ -1,0 +1,370 @@
+// Contrastive head kernels: embedding mean-pool, L2 normalise, similarity logits, symmetric InfoNCE.
+// All fp32 (the reference computes these in fp32; they are latency/HBM-bound scans, not GEMM work,
+// except the similarity contraction which runs on the exact-fp32 MFMA GEMM of gemm.hip).
+#include "cvcl_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// embedding gather + mean-pool                                   multimodal/multimodal.py:496-503
+// one workgroup per utterance; lanes stride over E so every table row is read as one coalesced burst
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void embed_meanpool_fwd_kernel(const float* __restrict__ table,
+                                                                 const int64_t* __restrict__ tok,
+                                                                 const int64_t* __restrict__ len,
+                                                                 float* __restrict__ ret, float* __restrict__ out,
+                                                                 int L, int E, int V) {
+    const int b = blockIdx.x;
+    const float inv_den = (float)len[b];
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const int64_t t = tok[(long)b * L + l];
+            const float v = (t >= 0 && t < V) ? table[t * E + e] : NAN;
+            if (out) out[((long)b * L + l) * E + e] = v;
+            acc += v;
+        }
+        ret[(long)b * E + e] = acc / inv_den;
+    }
+}
+
+// one workgroup per vocabulary row: scan the B*L tokens in (b,l) order, 128 at a time (ballot), and
+// accumulate the matching utterances' d_ret[b]/len[b] in registers.  Deterministic, no atomics,
+// writes every row (zeros where the word does not occur; row 0 = padding_idx gets no gradient).
+__global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __restrict__ d_ret,
+                                                                 const int64_t* __restrict__ tok,
+                                                                 const int64_t* __restrict__ len,
+                                                                 float* __restrict__ d_table, int B, int L, int E) {
+    __shared__ unsigned long long masks[2][2];
+    const int v = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const int total = B * L;
+    constexpr int MAXR = 8;                        // E <= 128 * MAXR handled in registers per pass
+    for (int ebase = 0; ebase < E; ebase += 128 * MAXR) {
+        float acc[MAXR];
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) acc[i] = 0.f;
+        if (v != 0) {
+            int par = 0;
+            for (int c = 0; c < total; c += 128, par ^= 1) {
+                const int idx = c + tid;
+                const bool hit = idx < total && tok[idx] == (int64_t)v;
+                const unsigned long long m = __ballot(hit);
+                if ((tid & 63) == 0) masks[par][wave] = m;
+                __syncthreads();
+                for (int w = 0; w < 2; ++w) {
+                    unsigned long long mm = masks[par][w];
+                    while (mm) {
+                        const int bit = __ffsll((long long)mm) - 1;
+                        mm &= mm - 1;
+                        const int bb = (c + w * 64 + bit) / L;
+                        const float den = (float)len[bb];
+#pragma unroll
+                        for (int i = 0; i < MAXR; ++i) {
+                            const int e = ebase + tid + 128 * i;
+                            if (e < E) acc[i] += d_ret[(long)bb * E + e] / den;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int e = ebase + tid + 128 * i;
+            if (e < E) d_table[(long)v * E + e] = acc[i];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// F.normalize rows                                               multimodal/multimodal.py:736,743
+// one wave per row, 4 rows per workgroup
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         float* __restrict__ norm, int N, int E, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* xr = x + (long)row * E;
+    float ss = 0.f;
+    for (int e = lane; e < E; e += 64) ss = fmaf(xr[e], xr[e], ss);
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    const float den = fmaxf(nrm, eps);
+    for (int e = lane; e < E; e += 64) y[(long)row * E + e] = xr[e] / den;
+    if (lane == 0) norm[row] = nrm;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ norm,
+                                                         const float* __restrict__ dy, float* __restrict__ dx,
+                                                         int N, int E, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* yr = y + (long)row * E;
+    const float* gr = dy + (long)row * E;
+    float dot = 0.f;
+    for (int e = lane; e < E; e += 64) dot = fmaf(yr[e], gr[e], dot);
+    dot = wave_sum(dot);
+    const float nrm = norm[row];
+    if (nrm < eps) {                 // clamp_min active: y = x / eps, no projection term
+        for (int e = lane; e < E; e += 64) dx[(long)row * E + e] = gr[e] / eps;
+    } else {
+        for (int e = lane; e < E; e += 64) dx[(long)row * E + e] = (gr[e] - yr[e] * dot) / nrm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// symmetric InfoNCE                        multimodal/multimodal.py:801-818, multimodal/utils.py:106-108
+// rows: one wave per row.  columns: 64 columns x 16 row-slices per workgroup, online softmax per slice.
+// per-row/column results: ce = lse - diag, hit = (argmax == index), entropy = lse - sum p x.
+// ---------------------------------------------------------------------------------------------
+struct OnlineSm {                    // running max m, sum exp(x-m), sum x exp(x-m), argmax
+    float m, s, t;
+    int arg;
+    __device__ inline void init() { m = -INFINITY; s = 0.f; t = 0.f; arg = 0x7fffffff; }
+    __device__ inline void push(float x, int idx) {
+        if (x > m) {
+            const float r = expf(m - x);          // exp(-inf) = 0 on the first element
+            s = s * r + 1.f;
+            t = t * r + x;
+            m = x;
+            arg = idx;
+        } else {
+            const float e = expf(x - m);
+            s += e;
+            t = fmaf(x, e, t);
+        }
+    }
+    __device__ inline void merge(float m2, float s2, float t2, int arg2) {
+        if (m2 > m || (m2 == m && arg2 < arg)) arg = arg2;
+        const float mm = fmaxf(m, m2);
+        if (mm == -INFINITY) return;
+        const float r1 = expf(m - mm), r2 = expf(m2 - mm);
+        s = s * r1 + s2 * r2;
+        t = t * r1 + t2 * r2;
+        m = mm;
+    }
+};
+
+__global__ __launch_bounds__(256) void infonce_rows_kernel(const float* __restrict__ logits, int N,
+                                                           float* __restrict__ row_lse, float* __restrict__ ws) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* xr = logits + (long)row * N;
+    OnlineSm st;
+    st.init();
+    for (int j = lane; j < N; j += 64) st.push(xr[j], j);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(st.m, o, 64), s2 = __shfl_xor(st.s, o, 64), t2 = __shfl_xor(st.t, o, 64);
+        const int a2 = __shfl_xor(st.arg, o, 64);
+        st.merge(m2, s2, t2, a2);
+    }
+    if (lane == 0) {
+        const float lse = st.m + logf(st.s);
+        row_lse[row] = lse;
+        ws[0 * N + row] = lse - xr[row];                 // cross entropy of this row
+        ws[1 * N + row] = (st.arg == row) ? 1.f : 0.f;   // argmax hit
+        ws[2 * N + row] = lse - st.t / st.s;             // entropy
+    }
+}
+
+__global__ __launch_bounds__(1024) void infonce_cols_kernel(const float* __restrict__ logits, int N,
+                                                            float* __restrict__ col_lse, float* __restrict__ ws) {
+    __shared__ float sm_m[16][64], sm_s[16][64], sm_t[16][64];
+    __shared__ int sm_a[16][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    OnlineSm st;
+    st.init();
+    if (col < N)
+        for (int r = sl; r < N; r += 16) st.push(logits[(long)r * N + col], r);
+    sm_m[sl][c] = st.m; sm_s[sl][c] = st.s; sm_t[sl][c] = st.t; sm_a[sl][c] = st.arg;
+    __syncthreads();
+    if (sl == 0 && col < N) {
+        for (int i = 1; i < 16; ++i) st.merge(sm_m[i][c], sm_s[i][c], sm_t[i][c], sm_a[i][c]);
+        const float lse = st.m + logf(st.s);
+        col_lse[col] = lse;
+        ws[3 * N + col] = lse - logits[(long)col * N + col];
+        ws[4 * N + col] = (st.arg == col) ? 1.f : 0.f;
+        ws[5 * N + col] = lse - st.t / st.s;
+    }
+}
+
+// scalars = {infonce, image_accuracy, text_accuracy, image_entropy, text_entropy}; fixed summation order
+__global__ __launch_bounds__(256) void infonce_finalize_kernel(const float* __restrict__ ws, int N,
+                                                               float* __restrict__ scalars) {
+    __shared__ float scratch[8];
+    float a[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float v = 0.f;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) v += ws[k * N + i];
+        a[k] = block_sum(v, scratch);
+    }
+    if (threadIdx.x == 0) {
+        const float n = (float)N;
+        scalars[0] = (a[0] / n + a[3] / n) / 2.f;
+        scalars[1] = a[1] / n;
+        scalars[2] = a[4] / n;
+        scalars[3] = a[2] / n;
+        scalars[4] = a[5] / n;
+    }
+}
+
+__global__ __launch_bounds__(256) void infonce_bwd_kernel(const float* __restrict__ logits,
+                                                          const float* __restrict__ row_lse,
+                                                          const float* __restrict__ col_lse,
+                                                          const float* __restrict__ d_loss,
+                                                          float* __restrict__ d_logits, int N) {
+    const float g = *d_loss / (2.f * (float)N);
+    const long total = (long)N * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / N), c = (int)(i - (long)r * N);
+        const float x = logits[i];
+        float v = expf(x - row_lse[r]) + expf(x - col_lse[c]);
+        if (r == c) v -= 2.f;
+        d_logits[i] = g * v;
+    }
+}
+
+// partial[b] = sum over a grid-strided slice of a[i]*b[i]; final = fixed-order sum of partials
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          long n, float* __restrict__ partial) {
+    __shared__ float scratch[8];
+    float v = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        v = fmaf(a[i], b[i], v);
+    v = block_sum(v, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ float scratch[8];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
+    v = block_sum(v, scratch);
+    if (threadIdx.x == 0) *out = v;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int cvcl_embed_meanpool_fwd(const float* table, const int64_t* tok, const int64_t* len, float* ret,
+                                       float* out_ble, int B, int L, int E, int V, void* stream) {
+    CVCL_CHECK_ARG(table && tok && len && ret, "cvcl_embed_meanpool_fwd: null pointer");
+    CVCL_CHECK_ARG(B > 0 && L > 0 && E > 0 && V > 0, "cvcl_embed_meanpool_fwd: bad shape");
+    hipLaunchKernelGGL(embed_meanpool_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, table, tok, len, ret,
+                       out_ble, L, E, V);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_embed_meanpool_bwd(const float* d_ret, const int64_t* tok, const int64_t* len, float* d_table,
+                                       int B, int L, int E, int V, void* stream) {
+    CVCL_CHECK_ARG(d_ret && tok && len && d_table, "cvcl_embed_meanpool_bwd: null pointer");
+    CVCL_CHECK_ARG(B > 0 && L > 0 && E > 0 && V > 0, "cvcl_embed_meanpool_bwd: bad shape");
+    hipLaunchKernelGGL(embed_meanpool_bwd_kernel, dim3(V), dim3(128), 0, (hipStream_t)stream, d_ret, tok, len, d_table,
+                       B, L, E);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_l2norm_fwd(const float* x, float* y, float* norm, int N, int E, float eps, void* stream) {
+    CVCL_CHECK_ARG(x && y && norm && N > 0 && E > 0, "cvcl_l2norm_fwd: bad args");
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cvcl_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, x, y, norm, N, E, eps);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_l2norm_bwd(const float* y, const float* norm, const float* dy, float* dx, int N, int E, float eps,
+                               void* stream) {
+    CVCL_CHECK_ARG(y && norm && dy && dx && N > 0 && E > 0, "cvcl_l2norm_bwd: bad args");
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cvcl_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, y, norm, dy, dx, N, E, eps);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_sim_logits_fwd(const float* img, const float* txt, const float* neg_log_temp, float* logits,
+                                   int Ni, int Nt, int E, void* stream) {
+    CVCL_CHECK_ARG(img && txt && neg_log_temp && logits, "cvcl_sim_logits_fwd: null pointer");
+    cvcl_gemm_args a = {};
+    a.A = img; a.W = txt; a.C = logits;
+    a.M = Ni; a.N = Nt; a.K = E; a.lda = E; a.ldw = E; a.ldc = Nt;
+    a.exp_scale = neg_log_temp;
+    return cvcl_gemm(CVCL_F32, &a, stream);
+}
+
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t cvcl_sim_logits_bwd_workspace_bytes(int Ni, int Nt, int E) {
+    return al256((size_t)E * Nt * 4) + al256((size_t)E * Ni * 4) + al256((size_t)Ni * Nt * 4) + al256(256 * 4);
+}
+
+extern "C" int cvcl_sim_logits_bwd(const float* img, const float* txt, const float* neg_log_temp, const float* logits,
+                                   const float* d_logits, float* d_img, float* d_txt, float* d_neg_log_temp,
+                                   int Ni, int Nt, int E, void* workspace, size_t workspace_bytes, void* stream) {
+    CVCL_CHECK_ARG(img && txt && neg_log_temp && d_logits && workspace, "cvcl_sim_logits_bwd: null pointer");
+    if (workspace_bytes < cvcl_sim_logits_bwd_workspace_bytes(Ni, Nt, E)) {
+        cvcl_set_error("cvcl_sim_logits_bwd: workspace too small");
+        return CVCL_EWORKSPACE;
+    }
+    char* w = (char*)workspace;
+    float* txtT = (float*)w; w += al256((size_t)E * Nt * 4);
+    float* imgT = (float*)w; w += al256((size_t)E * Ni * 4);
+    float* dST = (float*)w;  w += al256((size_t)Ni * Nt * 4);
+    float* part = (float*)w;
+    int rc;
+    if (d_img) {                                   // d_img = s * dS . txt
+        if ((rc = cvcl_transpose_f32(txt, txtT, Nt, E, stream))) return rc;
+        cvcl_gemm_args a = {};
+        a.A = d_logits; a.W = txtT; a.C = d_img;
+        a.M = Ni; a.N = E; a.K = Nt; a.lda = Nt; a.ldw = Nt; a.ldc = E;
+        a.exp_scale = neg_log_temp;
+        if ((rc = cvcl_gemm(CVCL_F32, &a, stream))) return rc;
+    }
+    if (d_txt) {                                   // d_txt = s * dS^T . img
+        if ((rc = cvcl_transpose_f32(img, imgT, Ni, E, stream))) return rc;
+        if ((rc = cvcl_transpose_f32(d_logits, dST, Ni, Nt, stream))) return rc;
+        cvcl_gemm_args a = {};
+        a.A = dST; a.W = imgT; a.C = d_txt;
+        a.M = Nt; a.N = E; a.K = Ni; a.lda = Ni; a.ldw = Ni; a.ldc = E;
+        a.exp_scale = neg_log_temp;
+        if ((rc = cvcl_gemm(CVCL_F32, &a, stream))) return rc;
+    }
+    if (d_neg_log_temp) {                          // d/d(log s) of s*M  =  sum(dS * logits)
+        CVCL_CHECK_ARG(logits, "cvcl_sim_logits_bwd: logits needed for the temperature gradient");
+        hipLaunchKernelGGL(dot_partial_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, d_logits, logits,
+                           (long)Ni * Nt, part);
+        hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, 256, d_neg_log_temp);
+        CVCL_LAUNCH_CHECK();
+    }
+    return CVCL_OK;
+}
+
+extern "C" size_t cvcl_infonce_workspace_bytes(int N) { return (size_t)6 * N * sizeof(float); }
+
+extern "C" int cvcl_infonce_fwd(const float* logits, int N, float* scalars5, float* row_lse, float* col_lse,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    CVCL_CHECK_ARG(logits && scalars5 && row_lse && col_lse && workspace && N > 0, "cvcl_infonce_fwd: bad args");
+    if (workspace_bytes < cvcl_infonce_workspace_bytes(N)) {
+        cvcl_set_error("cvcl_infonce_fwd: workspace too small");
+        return CVCL_EWORKSPACE;
+    }
+    float* ws = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(infonce_rows_kernel, dim3(cvcl_div_up(N, 4)), dim3(256), 0, s, logits, N, row_lse, ws);
+    hipLaunchKernelGGL(infonce_cols_kernel, dim3(cvcl_div_up(N, 64)), dim3(1024), 0, s, logits, N, col_lse, ws);
+    hipLaunchKernelGGL(infonce_finalize_kernel, dim3(1), dim3(256), 0, s, ws, N, scalars5);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_infonce_bwd(const float* logits, const float* row_lse, const float* col_lse, const float* d_loss,
+                                float* d_logits, int N, void* stream) {
+    CVCL_CHECK_ARG(logits && row_lse && col_lse && d_loss && d_logits && N > 0, "cvcl_infonce_bwd: bad args");
+    const long total = (long)N * N;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(infonce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, row_lse, col_lse,
+                       d_loss, d_logits, N);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}

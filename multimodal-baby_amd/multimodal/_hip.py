@@ -1,0 +1,165 @@
+"""ctypes binding of libcvcl_hip.so (the C ABI declared in include/cvcl_hip.h).
+
+The library is loaded AFTER torch so that its DT_NEEDED ``libamdhip64.so.7`` resolves to the HIP
+runtime torch already mapped (same soname) -- one runtime per process, so torch's stream handles
+and device pointers are valid inside the library.  There is no CPU fallback: if the library is
+missing or a tensor is not a contiguous device tensor the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvcl_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+ABI_VERSION = 1
+
+
+class CvclError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldw", C.c_int), ("ldc", C.c_int),
+        ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_relu", C.c_int),
+        ("gather_ho", C.c_int), ("gather_wo", C.c_int), ("gather_hi", C.c_int), ("gather_wi", C.c_int),
+        ("gather_stride", C.c_int),
+        ("exp_scale", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int),
+        ("R", C.c_void_p), ("ldr", C.c_int),
+        ("stats", C.c_void_p), ("stats_rows", C.c_int),
+    ]
+
+
+class ConvBnParams(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p)]
+
+
+_P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/cvcl_hip.h declares
+SIGNATURES = {
+    "cvcl_abi_version": (_I, []),
+    "cvcl_last_error": (C.c_char_p, []),
+    "cvcl_embed_meanpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_embed_meanpool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _F, _P]),
+    "cvcl_l2norm_bwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "cvcl_sim_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_sim_logits_bwd_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "cvcl_sim_logits_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
+    "cvcl_infonce_workspace_bytes": (_SZ, [_I]),
+    "cvcl_infonce_fwd": (_I, [_P, _I, _P, _P, _P, _P, _SZ, _P]),
+    "cvcl_infonce_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P]),
+    "cvcl_gemm_grid_m": (_I, [_I, _I, _I]),
+    "cvcl_gemm": (_I, [_I, C.POINTER(GemmArgs), _P]),
+    "cvcl_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
+    "cvcl_colsum_f32": (_I, [_P, _P, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """Load the library (idempotent) and bind every declared symbol; raises CvclError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("CVCL_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise CvclError(f"libcvcl_hip.so not found at {path}: build it with `python multimodal-baby_amd/build.py` "
+                        "(the CVCL hot path has no CPU fallback)")
+    try:
+        lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError as e:                                   # pragma: no cover
+        raise CvclError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CvclError(f"{path} does not export {name} (ABI mismatch)") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.cvcl_abi_version() != ABI_VERSION:
+        raise CvclError(f"ABI version {lib.cvcl_abi_version()} != {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def lib():
+    return load()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().cvcl_last_error().decode(errors="replace")
+        raise CvclError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None, dtype=None) -> int | None:
+    """Device pointer of a contiguous CUDA(=HIP) tensor; loud failure otherwise."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CvclError("the CVCL HIP path needs device tensors (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise CvclError("non-contiguous tensor passed to libcvcl_hip")
+    if dtype is not None and t.dtype != dtype:
+        raise CvclError(f"expected dtype {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def torch_dtype(dt: int):
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def cvcl_dtype(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise CvclError(f"unsupported storage dtype {t}")
+
+
+def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None, a_shift=None, a_relu=False,
+         exp_scale=None, gather=None, stats=None, M=None, lda=None):
+    """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype."""
+    dt = cvcl_dtype(A.dtype)
+    if W.dtype != A.dtype:
+        raise CvclError("gemm operands must share a dtype")
+    K = W.shape[1]
+    N = W.shape[0]
+    if M is None:
+        M = A.numel() // A.shape[-1]
+    lda = lda if lda is not None else A.shape[-1]
+    if out is None:
+        out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    a = GemmArgs()
+    a.A, a.W, a.C = ptr(A), ptr(W), ptr(out)
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, lda, K, N
+    a.a_scale, a.a_shift, a.a_relu = ptr(a_scale, torch.float32), ptr(a_shift, torch.float32), int(a_relu)
+    if gather is not None:
+        a.gather_ho, a.gather_wo, a.gather_hi, a.gather_wi, a.gather_stride = gather
+    a.exp_scale, a.bias, a.act = ptr(exp_scale, torch.float32), ptr(bias, torch.float32), act
+    if residual is not None:
+        if residual.dtype != A.dtype:
+            raise CvclError("residual dtype mismatch")
+        a.R, a.ldr = ptr(residual), N
+    if stats is not None:
+        a.stats, a.stats_rows = ptr(stats, torch.float32), stats.shape[0]
+    check(lib().cvcl_gemm(dt, C.byref(a), stream_ptr()), "cvcl_gemm")
+    return out
+
+
+def gemm_grid_m(dtype: int, M: int, N: int) -> int:
+    return lib().cvcl_gemm_grid_m(dtype, M, N)

@@ -1,0 +1,192 @@
+"""torch.autograd bridges onto the HIP C ABI for the contrastive head and the trainable projections.
+
+PyTorch owns device memory, autograd bookkeeping and the optimizer; every arithmetic step on the
+path is a libcvcl_hip kernel.  Functions raise if handed CPU tensors (no fallback by design).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip as H
+
+_F = torch.float32
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+class EmbedMeanPool(torch.autograd.Function):
+    """multimodal/multimodal.py:496-503 (reference): embedding gather, sum over L, divide by length."""
+
+    @staticmethod
+    def forward(ctx, table, tok, length, want_output: bool):
+        B, L = tok.shape
+        V, E = table.shape
+        ret = torch.empty(B, E, dtype=_F, device=table.device)
+        out = torch.empty(B, L, E, dtype=_F, device=table.device) if want_output else None
+        H.check(H.lib().cvcl_embed_meanpool_fwd(H.ptr(table, _F), H.ptr(tok, torch.int64), H.ptr(length, torch.int64),
+                                               H.ptr(ret), H.ptr(out), B, L, E, V, H.stream_ptr()),
+                "cvcl_embed_meanpool_fwd")
+        ctx.save_for_backward(tok, length)
+        ctx.shape = (V, E)
+        ctx.mark_non_differentiable(*([out] if out is not None else []))
+        return ret, out
+
+    @staticmethod
+    def backward(ctx, d_ret, _d_out):
+        tok, length = ctx.saved_tensors
+        V, E = ctx.shape
+        B, L = tok.shape
+        d_table = torch.empty(V, E, dtype=_F, device=d_ret.device)
+        H.check(H.lib().cvcl_embed_meanpool_bwd(H.ptr(d_ret.contiguous(), _F), H.ptr(tok), H.ptr(length),
+                                               H.ptr(d_table), B, L, E, V, H.stream_ptr()),
+                "cvcl_embed_meanpool_bwd")
+        return d_table, None, None, None
+
+
+class L2Normalize(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=-1) (reference multimodal/multimodal.py:736,743)."""
+
+    @staticmethod
+    def forward(ctx, x, eps: float):
+        x = x.contiguous()
+        N, E = x.shape
+        y = torch.empty_like(x)
+        norm = torch.empty(N, dtype=_F, device=x.device)
+        H.check(H.lib().cvcl_l2norm_fwd(H.ptr(x, _F), H.ptr(y), H.ptr(norm), N, E, eps, H.stream_ptr()), "cvcl_l2norm_fwd")
+        ctx.save_for_backward(y, norm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, norm = ctx.saved_tensors
+        N, E = y.shape
+        dx = torch.empty_like(y)
+        H.check(H.lib().cvcl_l2norm_bwd(H.ptr(y), H.ptr(norm), H.ptr(dy.contiguous(), _F), H.ptr(dx), N, E, ctx.eps,
+                                       H.stream_ptr()), "cvcl_l2norm_bwd")
+        return dx, None
+
+
+class SimLogits(torch.autograd.Function):
+    """logits_per_image = (img @ txt.T) * exp(neg_log_temp) (reference multimodal/multimodal.py:755,783-787)."""
+
+    @staticmethod
+    def forward(ctx, img, txt, neg_log_temp):
+        img, txt = img.contiguous(), txt.contiguous()
+        Ni, E = img.shape
+        Nt = txt.shape[0]
+        nlt = neg_log_temp.reshape(1).contiguous()
+        logits = torch.empty(Ni, Nt, dtype=_F, device=img.device)
+        H.check(H.lib().cvcl_sim_logits_fwd(H.ptr(img, _F), H.ptr(txt, _F), H.ptr(nlt, _F), H.ptr(logits), Ni, Nt, E,
+                                           H.stream_ptr()), "cvcl_sim_logits_fwd")
+        ctx.save_for_backward(img, txt, nlt, logits)
+        ctx.temp_shape = neg_log_temp.shape
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        img, txt, nlt, logits = ctx.saved_tensors
+        Ni, E = img.shape
+        Nt = txt.shape[0]
+        need_i, need_t, need_s = ctx.needs_input_grad
+        d_img = torch.empty_like(img) if need_i else None
+        d_txt = torch.empty_like(txt) if need_t else None
+        d_s = torch.empty(1, dtype=_F, device=img.device) if need_s else None
+        nb = H.lib().cvcl_sim_logits_bwd_workspace_bytes(Ni, Nt, E)
+        ws = _ws(nb, img.device)
+        H.check(H.lib().cvcl_sim_logits_bwd(H.ptr(img), H.ptr(txt), H.ptr(nlt), H.ptr(logits),
+                                           H.ptr(d_logits.contiguous(), _F), H.ptr(d_img), H.ptr(d_txt), H.ptr(d_s),
+                                           Ni, Nt, E, H.ptr(ws), nb, H.stream_ptr()), "cvcl_sim_logits_bwd")
+        return d_img, d_txt, (d_s.reshape(ctx.temp_shape) if need_s else None)
+
+
+class InfoNCE(torch.autograd.Function):
+    """Symmetric InfoNCE + accuracies + entropies (reference multimodal/multimodal.py:801-818)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        logits = logits.contiguous()
+        N = logits.shape[0]
+        assert logits.shape[1] == N, "the contrastive loss needs square logits"
+        dev = logits.device
+        scalars = torch.empty(5, dtype=_F, device=dev)
+        row_lse = torch.empty(N, dtype=_F, device=dev)
+        col_lse = torch.empty(N, dtype=_F, device=dev)
+        nb = H.lib().cvcl_infonce_workspace_bytes(N)
+        ws = _ws(nb, dev)
+        H.check(H.lib().cvcl_infonce_fwd(H.ptr(logits, _F), N, H.ptr(scalars), H.ptr(row_lse), H.ptr(col_lse),
+                                        H.ptr(ws), nb, H.stream_ptr()), "cvcl_infonce_fwd")
+        ctx.save_for_backward(logits, row_lse, col_lse)
+        loss = scalars[0].clone()
+        metrics = scalars[1:].clone()
+        ctx.mark_non_differentiable(metrics)
+        return loss, metrics
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_metrics):
+        logits, row_lse, col_lse = ctx.saved_tensors
+        N = logits.shape[0]
+        d_logits = torch.empty_like(logits)
+        g = d_loss.reshape(1).to(_F).contiguous()
+        H.check(H.lib().cvcl_infonce_bwd(H.ptr(logits), H.ptr(row_lse), H.ptr(col_lse), H.ptr(g), H.ptr(d_logits), N,
+                                        H.stream_ptr()), "cvcl_infonce_bwd")
+        return d_logits
+
+
+class LinearF32(torch.autograd.Function):
+    """nn.Linear in fp32 on the exact-fp32 MFMA GEMM (fc 2048->E, multimodal/multimodal.py:192; ViT head :190)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        y = H.gemm(x, weight.contiguous(), bias=bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = weight.shape[0]
+        need_x, need_w, need_b = ctx.needs_input_grad
+        dx = dw = db = None
+        s = H.stream_ptr()
+        if need_w:                                   # dW[N,K] = dY^T[N,M] . X[M,K]  ->  A=dY^T, W'=X^T
+            dyT = torch.empty(N, M, dtype=_F, device=x.device)
+            xT = torch.empty(K, M, dtype=_F, device=x.device)
+            H.check(H.lib().cvcl_transpose_f32(H.ptr(dy), H.ptr(dyT), M, N, s), "cvcl_transpose_f32")
+            H.check(H.lib().cvcl_transpose_f32(H.ptr(x), H.ptr(xT), M, K, s), "cvcl_transpose_f32")
+            dw = H.gemm(dyT, xT)
+        if need_x:                                   # dX[M,K] = dY[M,N] . W[N,K]  ->  W' = W^T [K,N]
+            wT = torch.empty(K, N, dtype=_F, device=x.device)
+            H.check(H.lib().cvcl_transpose_f32(H.ptr(weight.contiguous()), H.ptr(wT), N, K, s), "cvcl_transpose_f32")
+            dx = H.gemm(dy, wT)
+        if need_b and ctx.has_bias:
+            db = torch.empty(N, dtype=_F, device=x.device)
+            H.check(H.lib().cvcl_colsum_f32(H.ptr(dy), H.ptr(db), M, N, s), "cvcl_colsum_f32")
+        return dx, dw, db
+
+
+def embed_meanpool(table, tok, length, want_output=True):
+    return EmbedMeanPool.apply(table, tok, length, want_output)
+
+
+def l2_normalize(x, eps: float = 1e-12):
+    return L2Normalize.apply(x, eps)
+
+
+def sim_logits(img, txt, neg_log_temp):
+    return SimLogits.apply(img, txt, neg_log_temp)
+
+
+def infonce(logits):
+    """-> (loss, metrics[4] = image_accuracy, text_accuracy, image_entropy, text_entropy)"""
+    return InfoNCE.apply(logits)
+
+
+def linear_f32(x, weight, bias=None):
+    return LinearF32.apply(x, weight, bias)

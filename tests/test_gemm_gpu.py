@@ -1,0 +1,110 @@
+"""GPU parity: the fused MFMA GEMM (cvcl_gemm) vs fp64 matmul of the oracle's storage-point model.
+fp32 mode: exact-fp32 MFMA, tolerance 2e-5 rel.  bf16 mode: operands/outputs rounded to bf16 with
+fp32 accumulation -> compare against the same rounding applied in fp64 math, tolerance 1 bf16 ulp."""
+import pytest
+import torch
+
+import cvcl_oracle as O
+from conftest import maxrel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from multimodal import _hip
+    return _hip
+
+
+def _ref(A, W, *, bias=None, act=0, residual=None, a_scale=None, a_shift=None, a_relu=False, scale=1.0, bf16=False):
+    q = O.bf16_round if bf16 else (lambda t: t)
+    a = A.double()
+    if a_scale is not None:
+        a = torch.addcmul(a_shift.double(), a, a_scale.double()) if False else a * a_scale.double() + a_shift.double()
+        if a_relu:
+            a = torch.relu(a)
+        a = q(a.float()).double()
+    y = a @ W.double().t() * scale
+    if bias is not None:
+        y = y + bias.double()
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = O.gelu_erf(y)
+    y = q(y.float()).double()
+    if residual is not None:
+        y = q((y + residual.double()).float()).double()
+    return y
+
+
+SHAPES = [(128, 128, 64), (256, 256, 256), (300, 130, 72), (1, 5, 8), (1000, 512, 2048), (6272, 128, 64), (77, 2304, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gemm_plain(H, dev, M, N, K, dt):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5          # asymmetric operands: catches transposes
+    bf = dt == "bf16"
+    tdt = torch.bfloat16 if bf else torch.float32
+    Aq, Wq = A.to(tdt), W.to(tdt)
+    y = H.gemm(Aq.to(dev), Wq.to(dev))
+    ref = _ref(Aq.float(), Wq.float(), bf16=bf)
+    tol = 8e-3 if bf else 2e-5                              # bf16: 1 ulp = 2^-8 relative to the element
+    assert y.shape == (M, N) and y.dtype == tdt
+    err = (y.double().cpu() - ref).abs()
+    assert float((err / (ref.abs() + ref.abs().max() * 1e-2)).max()) < tol
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gemm_fused_everything(H, dev, dt):
+    """BN+ReLU operand prologue, bias, GELU/ReLU, residual and the BatchNorm statistics epilogue."""
+    M, N, K = 3136, 256, 128
+    g = torch.Generator().manual_seed(11)
+    bf = dt == "bf16"
+    tdt = torch.bfloat16 if bf else torch.float32
+    A = torch.randn(M, K, generator=g).to(tdt)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(tdt)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g).to(tdt)
+    for act in (0, 1, 2):
+        rows = H.gemm_grid_m(H.BF16 if bf else H.F32, M, N)
+        stats = torch.full((rows, 2, N), float("nan"), device=dev)
+        y = H.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act=act, residual=R.to(dev), a_scale=sc.to(dev),
+                   a_shift=sh.to(dev), a_relu=True, stats=stats)
+        ref = _ref(A.float(), W.float(), bias=bias, act=act, residual=R.float(), a_scale=sc, a_shift=sh, a_relu=True, bf16=bf)
+        err = (y.double().cpu() - ref).abs()
+        assert float((err / (ref.abs() + ref.abs().max() * 1e-2)).max()) < (1.6e-2 if bf else 3e-5), act
+        # statistics are those of the tensor as stored
+        s = stats.double().sum(dim=0).cpu()
+        ys = y.double().cpu()
+        assert maxrel(s[0], ys.sum(dim=0)) < 1e-5 and maxrel(s[1], (ys * ys).sum(dim=0)) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_gemm_strided_gather(H, dev, dt):
+    """1x1 stride-2 convolution (Bottleneck downsample) = GEMM over gathered rows of an NHWC tensor."""
+    B, Hi, Wi, Cin, Cout = 3, 14, 14, 64, 128
+    g = torch.Generator().manual_seed(5)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    x = torch.randn(B, Hi, Wi, Cin, generator=g).to(tdt)
+    W = (torch.randn(Cout, Cin, generator=g) / 8).to(tdt)
+    Ho, Wo = Hi // 2, Wi // 2
+    y = H.gemm(x.to(dev), W.to(dev), M=B * Ho * Wo, gather=(Ho, Wo, Hi, Wi, 2))
+    ref = _ref(x[:, ::2, ::2].reshape(-1, Cin).float(), W.float(), bf16=dt == "bf16")
+    err = (y.double().cpu() - ref).abs()
+    assert float((err / (ref.abs() + ref.abs().max() * 1e-2)).max()) < (8e-3 if dt == "bf16" else 2e-5)
+
+
+def test_gemm_linearity_full_size(H, dev):
+    """Size-independent property at a BASELINE-size shape (layer1 conv3: M = 256*56*56): G(a+b) = G(a)+G(b) in fp32."""
+    M, N, K = 256 * 56 * 56 // 8, 256, 128
+    g = torch.Generator(device="cpu").manual_seed(1)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    a = torch.randn(M, K, device=dev)
+    b = torch.randn(M, K, device=dev)
+    lhs = H.gemm(a + b, W)
+    rhs = H.gemm(a, W) + H.gemm(b, W)
+    assert maxrel(lhs, rhs) < 1e-5
