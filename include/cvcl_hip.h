@@ -113,6 +113,60 @@ int cvcl_transpose_f32(const float* in, float* out, int rows, int cols, void* st
 /* d_bias[n] = sum_m dY[m][n], f32. */
 int cvcl_colsum_f32(const float* dY, float* d_bias, int M, int N, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * ResNeXt-50 32x4d trunk = torchvision.models.resnext50_32x4d (third-party; reference call sites
+ * multimodal/multimodal.py:96-102,155-158, multimodal/utils.py:207-209).  NHWC activations.
+ * "raw" = convolution output before BatchNorm; every conv kernel emits per-channel sum / sumsq
+ * partial rows stats[rows][2][C] of what it stored; cvcl_bn_finalize turns them into (scale, shift)
+ * + running-stat EMA (nn.BatchNorm2d train mode: eps 1e-5, momentum 0.1, unbiased running var,
+ * num_batches_tracked += 1); consumers apply scale/shift(+ReLU) on load.                          */
+enum { CVCL_PACK_DENSE = 0, CVCL_PACK_STEM7 = 1, CVCL_PACK_GCONV3 = 2 };
+
+typedef struct {
+    const void* w;                 /* conv weight packed by cvcl_pack_conv_weight (dtype of the run) */
+    const float* gamma; const float* beta;          /* BatchNorm weight / bias                       */
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* updated when training */
+} cvcl_convbn_params;
+
+int cvcl_bn_finalize(const float* stats, int rows, long count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                     float eps, float* scale, float* shift, int C, void* stream);
+int cvcl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, float* scale, float* shift, int C, void* stream);
+int cvcl_col_stats_rows(long rows);
+int cvcl_col_stats(int dtype, const void* x, long rows, int C, float* stats, int stats_rows, void* stream);
+
+/* weights arrive in the reference layout (OIHW fp32, device) and are re-laid-out once per weight version */
+size_t cvcl_packed_weight_bytes(int dtype, int kind, int cout, int cin_per_group, int k);
+int cvcl_pack_conv_weight(int dtype, int kind, const float* w_oihw, void* out, int cout, int cin_per_group, int k,
+                          void* stream);
+
+/* conv1 7x7/2 pad 3, 3->64: x NCHW f32 [B,3,H,W] -> y NHWC raw [B,H/2,W/2,64] (+stats) */
+int cvcl_stem_conv_stats_rows(int dtype, int B, int H, int W);
+int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void* y_nhwc, float* stats, int stats_rows,
+                      int B, int H, int W, void* stream);
+/* relu(bn(x)) then maxpool 3x3/2 pad 1: [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
+int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int B, int H, int W,
+                         int C, void* stream);
+/* grouped 3x3 conv pad 1 stride 1|2 on relu(x*a_scale+a_shift): [B,H,W,C] -> raw [B,Ho,Wo,C] (+stats) */
+int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int stride);
+int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed, void* y,
+                  float* stats, int stats_rows, int B, int H, int W, int C, int groups, int stride, void* stream);
+/* out = relu(raw*scale+shift + (idn | idn*idn_scale+idn_shift)), [rows, C] */
+int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, const float* shift, const void* idn,
+                     const float* idn_scale, const float* idn_shift, void* out, long rows, int C, void* stream);
+/* adaptive avgpool to 1x1 + flatten: [B,HW,C] -> [B,C] f32 */
+int cvcl_avgpool(int dtype, const void* x, float* out, int B, int HW, int C, void* stream);
+
+/* Whole trunk in one call: conv1..layer4 + avgpool.  layers[53] in torchvision state_dict order
+ * (conv1; per block conv1, conv2, conv3, [downsample.0]).  training != 0: batch statistics + running
+ * stat updates (what the reference does even with a frozen CNN: Lightning keeps .train()).
+ * -> layer4_out_nhwc [B,H/32,W/32,2048] (dtype), pooled [B,2048] f32.                             */
+size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W);
+int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
+                       const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
+                       void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,7 @@ void cvcl_set_error(const char* fmt, ...);
         }                                                                      \
     } while (0)
 
-static inline int cvcl_div_up(long a, long b) { return (int)((a + b - 1) / b); }
+__host__ __device__ static inline int cvcl_div_up(long a, long b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__
 // ---- element type traits -------------------------------------------------------------------

@@ -1,0 +1,814 @@
+// ResNeXt-50 32x4d image-encoder blocks for gfx950 (reference: torchvision.models.resnext50_32x4d
+// reached at multimodal/multimodal.py:101 through VisionEncoder.forward; factory :155-158, utils.py:207-209).
+//
+// Activations are NHWC.  "raw" tensors are convolution outputs *before* BatchNorm: every convolution
+// kernel also emits per-channel sum / sum-of-squares partial rows of what it stored, bn_finalize turns
+// them into a per-channel (scale, shift) and updates the running statistics, and the *consumer* of
+// the raw tensor applies scale/shift(+ReLU) while loading.  A normalised tensor is materialised only
+// where the network needs it twice (block outputs, max-pool output).
+//
+//   stem 7x7/2 (3->64)   : bf16: MFMA 16x16x32, B-operand gathered straight from an LDS image patch
+//                          (k ordered (c, ky, kx padded to 8): 8 consecutive k = 8 consecutive pixels)
+//   grouped 3x3 (32 grps): bf16: MFMA 16x16x32 on 16-channel units (block-diagonal weights for 4/8
+//                          channels per group, one tap x 32 channels per step for 32 per group),
+//                          input band staged in LDS with BN+ReLU applied on the way in
+//   fp32 (parity mode)   : direct VALU kernels with identical semantics + a column-statistics pass
+#include "cvcl_common.h"
+
+namespace {
+
+constexpr int kMaxStatsRows = 1024;
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping
+// ------------------------------------------------------------------------------------------------
+// stats [rows][2][C] partial sums -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale;
+// running_mean/var EMA with the unbiased variance (nn.BatchNorm2d train mode), num_batches_tracked += 1.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          int64_t* __restrict__ nbt, float momentum, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift, int C) {
+    __shared__ double ps[4][64], pq[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, ch = blockIdx.x * 64 + c;
+    double s = 0.0, q = 0.0;
+    if (ch < C) {
+        for (int r = sl; r < rows; r += 4) {
+            s += (double)stats[((long)r * 2 + 0) * C + ch];
+            q += (double)stats[((long)r * 2 + 1) * C + ch];
+        }
+    }
+    ps[sl][c] = s;
+    pq[sl][c] = q;
+    __syncthreads();
+    if (sl == 0 && ch < C) {
+        s = (ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c]);
+        q = (pq[0][c] + pq[1][c]) + (pq[2][c] + pq[3][c]);
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float sc = gamma[ch] / sqrtf((float)var + eps);
+        scale[ch] = sc;
+        shift[ch] = beta[ch] - (float)mean * sc;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
+            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+        }
+    }
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < C) {
+        const float sc = gamma[ch] / sqrtf(rv[ch] + eps);
+        scale[ch] = sc;
+        shift[ch] = beta[ch] - rm[ch] * sc;
+    }
+}
+
+// per-column sum / sumsq partial rows of a stored [rows, C] tensor (fp32 parity path + tests)
+template <typename T>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, long rows, int C, float* __restrict__ stats) {
+    __shared__ float ps[4][64], pq[4][64];
+    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, ch = blockIdx.y * 64 + c;
+    float s = 0.f, q = 0.f;
+    if (ch < C) {
+        for (long r = (long)blockIdx.x * 4 + sl; r < rows; r += (long)gridDim.x * 4) {
+            const float v = ElemTraits<T>::to_f(x[r * C + ch]);
+            s += v;
+            q = fmaf(v, v, q);
+        }
+    }
+    ps[sl][c] = s;
+    pq[sl][c] = q;
+    __syncthreads();
+    if (sl == 0 && ch < C) {
+        stats[((long)blockIdx.x * 2 + 0) * C + ch] = (ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c]);
+        stats[((long)blockIdx.x * 2 + 1) * C + ch] = (pq[0][c] + pq[1][c]) + (pq[2][c] + pq[3][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (reference layout OIHW fp32 -> kernel layout)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = ElemTraits<T>::from_f(in[i]);
+}
+
+// stem: [64][3][7][7] -> bf16 [4 ntile][6 kstep][16 n][32 k], k = kblock*8 + kx, r = 4*kstep + kblock = c*7 + ky
+__global__ void pack_stem_kernel(const float* __restrict__ w, bf16_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 6 * 16 * 32) return;
+    const int k = i & 31, n = (i >> 5) & 15, ks = (i >> 9) % 6, nt = i / (6 * 512);
+    const int r = 4 * ks + (k >> 3), kx = k & 7;
+    float v = 0.f;
+    if (r < 21 && kx < 7) {
+        const int c = r / 7, ky = r % 7;
+        v = w[((nt * 16 + n) * 3 + c) * 49 + ky * 7 + kx];
+    }
+    out[i] = (bf16_t)v;
+}
+
+// grouped 3x3: [C][cg][3][3] -> bf16 units of [KS][16 n][32 k]
+//   cg <= 16: unit = 16-channel chunk, KS = 5, k = tapsel*16 + ci, tap = 2*ks + tapsel (tap 9 = zero),
+//             block-diagonal: zero where input channel and output channel are in different groups
+//   cg == 32: unit = (group, ntile), KS = 9 (= tap), k = ci
+__global__ void pack_gconv_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int C, int cg) {
+    const int KS = cg == 32 ? 9 : 5;
+    const long total = (long)(C / 16) * KS * 512;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i & 31), n = (int)((i >> 5) & 15), ks = (int)((i >> 9) % KS), unit = (int)(i / ((long)KS * 512));
+    const int co = unit * 16 + n;
+    float v = 0.f;
+    if (cg == 32) {
+        v = w[((long)co * 32 + k) * 9 + ks];
+    } else {
+        const int tap = 2 * ks + (k >> 4), ci_abs = unit * 16 + (k & 15);
+        if (tap < 9 && ci_abs / cg == co / cg) v = w[((long)co * cg + (ci_abs % cg)) * 9 + tap];
+    }
+    out[i] = (bf16_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem 7x7 stride 2 pad 3, NCHW fp32 image -> NHWC raw                       (bf16, MFMA)
+// ------------------------------------------------------------------------------------------------
+constexpr int STEM_TH = 4;                 // output rows per work item
+constexpr int STEM_ROWS = 2 * STEM_TH + 5; // input rows per channel
+constexpr int STEM_PITCH = 144;            // dwords per patch row (288 bf16 >= 224 + 6 + 8 slack); 144 % 32 == 16
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                        bf16_t* __restrict__ y, float* __restrict__ stats,
+                                                        int B, int Hin, int Win) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* patch = (unsigned int*)smem;                 // [3*STEM_ROWS][STEM_PITCH] dwords (2 bf16 each)
+    const int Ho = Hin / 2, Wo = Win / 2;
+    const int bands = cvcl_div_up(Ho, STEM_TH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pix = lane & 15, kb = lane >> 4;
+
+    bf16x8 wf[4][6];                                           // all 64 output channels' weights, register resident
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+            wf[nt][ks] = *reinterpret_cast<const bf16x8*>(wp + ((nt * 6 + ks) * 16 + pix) * 32 + kb * 8);
+
+    float ssum[4][4], ssq[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { ssum[a][b] = 0.f; ssq[a][b] = 0.f; }
+
+    const int mtiles_per_row = cvcl_div_up(Wo, 16);
+    for (int item = blockIdx.x; item < B * bands; item += gridDim.x) {
+        const int b = item / bands, band = item - b * bands;
+        const int oy0 = band * STEM_TH;
+        __syncthreads();
+        // stage: rows (c, iy) <- x[b][c][2*oy0 - 3 + iy][*], bf16, with 3 zero columns of padding on the left
+        for (int r = 0; r < 3 * STEM_ROWS; ++r) {
+            const int c = r / STEM_ROWS, iy = r - c * STEM_ROWS;
+            const int yin = 2 * oy0 - 3 + iy;
+            const bool row_ok = yin >= 0 && yin < Hin;
+            const float* src = x + (((long)b * 3 + c) * Hin + (row_ok ? yin : 0)) * Win;
+            bf16_t* dst = (bf16_t*)(patch + r * STEM_PITCH);
+            for (int col = tid; col < 2 * STEM_PITCH; col += 256) {
+                const int xin = col - 3;
+                const float v = (row_ok && xin >= 0 && xin < Win) ? src[xin] : 0.f;
+                dst[col] = (bf16_t)v;
+            }
+        }
+        __syncthreads();
+        const int n_mt = STEM_TH * mtiles_per_row;
+        for (int mt = wave; mt < n_mt; mt += 4) {
+            const int ty = mt / mtiles_per_row, ox0 = (mt - ty * mtiles_per_row) * 16;
+            const int oy = oy0 + ty, ox = ox0 + pix;
+            f32x4 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                int r = 4 * ks + kb;
+                if (r > 20) r = 20;                                // padded k: weights are zero there
+                const int c = r / 7, ky = r - c * 7;
+                const unsigned int* src = patch + (c * STEM_ROWS + 2 * ty + ky) * STEM_PITCH + (ox < Wo ? ox : 0);
+                u32x4 raw = {src[0], src[1], src[2], src[3]};      // 8 consecutive input pixels (kx = 0..7)
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], bfrag, acc[nt], 0, 0, 0);
+            }
+            if (oy < Ho && ox < Wo) {
+                bf16_t* dst = y + (((long)b * Ho + oy) * Wo + ox) * 64 + kb * 4;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    bf16x4 o = {(bf16_t)acc[nt][0], (bf16_t)acc[nt][1], (bf16_t)acc[nt][2], (bf16_t)acc[nt][3]};
+                    *reinterpret_cast<bf16x4*>(dst + nt * 16) = o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float s = (float)o[e];
+                        ssum[nt][e] += s;
+                        ssq[nt][e] = fmaf(s, s, ssq[nt][e]);
+                    }
+                }
+            }
+        }
+    }
+    // statistics: reduce over the 16 pixel lanes, then over the 4 waves; channel = nt*16 + kb*4 + e
+    __syncthreads();
+    float* red = (float*)smem;                                    // [4 waves][2][64]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = ssum[nt][e], q = ssq[nt][e];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+            if (pix == 0) {
+                red[(wave * 2 + 0) * 64 + nt * 16 + kb * 4 + e] = s;
+                red[(wave * 2 + 1) * 64 + nt * 16 + kb * 4 + e] = q;
+            }
+        }
+    __syncthreads();
+    if (tid < 128) {
+        const int which = tid >> 6, c = tid & 63;
+        const float v = (red[(0 * 2 + which) * 64 + c] + red[(1 * 2 + which) * 64 + c]) +
+                        (red[(2 * 2 + which) * 64 + c] + red[(3 * 2 + which) * 64 + c]);
+        stats[((long)blockIdx.x * 2 + which) * 64 + c] = v;
+    }
+}
+
+// fp32 parity path: direct convolution, one thread per (pixel, output channel); weights in OIHW
+__global__ __launch_bounds__(256) void stem_direct_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ y, int B, int Hin, int Win) {
+    const int Ho = Hin / 2, Wo = Win / 2;
+    const long total = (long)B * Ho * Wo * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i & 63);
+        const long p = i >> 6;
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
+        float acc = 0.f;
+        for (int c = 0; c < 3; ++c)
+            for (int ky = 0; ky < 7; ++ky) {
+                const int yin = 2 * oy - 3 + ky;
+                if (yin < 0 || yin >= Hin) continue;
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int xin = 2 * ox - 3 + kx;
+                    if (xin < 0 || xin >= Win) continue;
+                    acc = fmaf(x[(((long)b * 3 + c) * Hin + yin) * Win + xin], w[((co * 3 + c) * 7 + ky) * 7 + kx], acc);
+                }
+            }
+        y[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN + ReLU + maxpool 3x3 stride 2 pad 1 (NHWC), 8 channels per thread
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, T* __restrict__ y,
+                                                              int B, int H, int W, int C) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, CC = C / 8;
+    const long total = (long)B * Ho * Wo * CC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % CC);
+        const long p = i / CC;
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
+        float sc[8], sh[8], m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; m[e] = 0.f; }  // relu output >= 0
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yin = 2 * oy - 1 + ky;
+            if (yin < 0 || yin >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xin = 2 * ox - 1 + kx;
+                if (xin < 0 || xin >= W) continue;
+                const T* src = x + (((long)b * H + yin) * W + xin) * C + cc * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], fmaf(ElemTraits<T>::to_f(src[e]), sc[e], sh[e]));
+            }
+        }
+        T* dst = y + (((long)b * Ho + oy) * Wo + ox) * C + cc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dst[e] = ElemTraits<T>::from_f(m[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped 3x3 convolution, pad 1, stride 1|2, NHWC raw in (BN+ReLU applied on load) -> NHWC raw out
+// ------------------------------------------------------------------------------------------------
+constexpr int GC_CS = 64;                  // channels per workgroup slab
+constexpr int GC_PIXB = 144;               // LDS bytes per staged pixel (128 B of channels + 16 B pad)
+
+struct GconvDev {
+    const void* x; const float* a_scale; const float* a_shift; const void* w; void* y; float* stats;
+    int B, H, W, C, cg, stride, Ho, Wo, TH, bands, rows_in;
+};
+
+__global__ __launch_bounds__(256) void gconv_mfma_kernel(GconvDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const bf16_t* __restrict__ x = (const bf16_t*)p.x;
+    bf16_t* __restrict__ y = (bf16_t*)p.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pix = lane & 15, kb = lane >> 4;
+    const int slab = blockIdx.y, c0 = slab * GC_CS;
+    const int Wp = p.W + 2;                                       // staged row width incl. halo columns
+    const bool wide = p.cg == 32;
+    const int KS = wide ? 9 : 5;
+    // this wave's unit: 16 output channels [c0 + 16*wave, +16); for cg == 32 the unit's inputs are the
+    // 32 channels of its group, else the same 16 channels (block-diagonal weights)
+    const int unit = c0 / 16 + wave;
+    const bf16_t* wu = (const bf16_t*)p.w + (long)unit * KS * 512;
+    bf16x8 wf[9];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks)
+        if (ks < KS) wf[ks] = *reinterpret_cast<const bf16x8*>(wu + (ks * 16 + pix) * 32 + kb * 8);
+    const int in_ch_off = wide ? ((wave >> 1) * 32 + kb * 8) : (wave * 16 + (kb & 1) * 8);   // within the slab
+
+    // staging role: 8 chunks (of 8 channels) per pixel, 32 pixels per pass
+    const int s_chunk = tid & 7, s_pix0 = tid >> 3;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = p.a_scale[c0 + s_chunk * 8 + e];
+        sh[e] = p.a_shift[c0 + s_chunk * 8 + e];
+    }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+
+    const int npix_in = p.rows_in * Wp;
+    const int n_out = p.TH * p.Wo, n_mt = cvcl_div_up(n_out, 16);
+    for (int item = blockIdx.x; item < p.B * p.bands; item += gridDim.x) {
+        const int b = item / p.bands, band = item - b * p.bands;
+        const int oy0 = band * p.TH;
+        const int iy0 = oy0 * p.stride - 1;                       // first staged input row
+        __syncthreads();
+        for (int pi = s_pix0; pi < npix_in; pi += 32) {
+            const int ry = pi / Wp, rx = pi - ry * Wp;
+            const int yin = iy0 + ry, xin = rx - 1;
+            bf16x8 v;
+            if (yin >= 0 && yin < p.H && xin >= 0 && xin < p.W) {
+                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(x + (((long)b * p.H + yin) * p.W + xin) * p.C + c0 + s_chunk * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)raw[e], sc[e], sh[e]), 0.f);
+            } else {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                v = __builtin_bit_cast(bf16x8, z);               // zero padding lives in the post-activation domain
+            }
+            *reinterpret_cast<bf16x8*>(smem + pi * GC_PIXB + s_chunk * 16) = v;
+        }
+        __syncthreads();
+        for (int mt = 0; mt < n_mt; ++mt) {
+            const int q = mt * 16 + pix;
+            const bool ok_q = q < n_out;
+            const int ty = ok_q ? q / p.Wo : 0, ox = ok_q ? q - ty * p.Wo : 0;
+            const int base = ((ty * p.stride) * Wp + ox * p.stride);           // staged pixel of tap (0,0)
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 9; ++ks) {
+                if (ks < KS) {
+                    int tap = wide ? ks : 2 * ks + (kb >> 1);
+                    if (tap > 8) tap = 8;                                      // padded tap: zero weights
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + (base + ky * Wp + kx) * GC_PIXB + in_ch_off * 2);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a, acc, 0, 0, 0);
+                }
+            }
+            const int oy = oy0 + ty;
+            if (ok_q && oy < p.Ho) {
+                bf16x4 o = {(bf16_t)acc[0], (bf16_t)acc[1], (bf16_t)acc[2], (bf16_t)acc[3]};
+                *reinterpret_cast<bf16x4*>(y + (((long)b * p.Ho + oy) * p.Wo + ox) * p.C + c0 + wave * 16 + kb * 4) = o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = (float)o[e];
+                    ssum[e] += s;
+                    ssq[e] = fmaf(s, s, ssq[e]);
+                }
+            }
+        }
+    }
+    // per-channel partial sums: reduce over the 16 pixel lanes; channel = c0 + wave*16 + kb*4 + e
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float s = ssum[e], q = ssq[e];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+        if (pix == 0 && p.stats) {
+            const int ch = c0 + wave * 16 + kb * 4 + e;
+            p.stats[((long)blockIdx.x * 2 + 0) * p.C + ch] = s;
+            p.stats[((long)blockIdx.x * 2 + 1) * p.C + ch] = q;
+        }
+    }
+}
+
+// fp32 parity path: direct grouped convolution, weights in the reference OIHW layout [C][cg][3][3]
+__global__ __launch_bounds__(256) void gconv_direct_f32_kernel(const float* __restrict__ x, const float* __restrict__ a_scale,
+                                                               const float* __restrict__ a_shift, const float* __restrict__ w,
+                                                               float* __restrict__ y, int B, int H, int W, int C, int cg,
+                                                               int stride, int Ho, int Wo) {
+    const long total = (long)B * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % C);
+        const long pp = i / C;
+        const int ox = (int)(pp % Wo), oy = (int)((pp / Wo) % Ho), b = (int)(pp / ((long)Wo * Ho));
+        const int g0 = (co / cg) * cg;
+        float acc = 0.f;
+        for (int ci = 0; ci < cg; ++ci) {
+            const float sc = a_scale[g0 + ci], sh = a_shift[g0 + ci];
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yin = oy * stride - 1 + ky;
+                if (yin < 0 || yin >= H) continue;
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xin = ox * stride - 1 + kx;
+                    if (xin < 0 || xin >= W) continue;
+                    const float v = fmaxf(fmaf(x[(((long)b * H + yin) * W + xin) * C + g0 + ci], sc, sh), 0.f);
+                    acc = fmaf(v, w[((long)co * cg + ci) * 9 + ky * 3 + kx], acc);
+                }
+            }
+        }
+        y[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = relu(raw * scale + shift + identity),  identity = idn  or  idn * idn_scale + idn_shift
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bn_add_relu_kernel(const T* __restrict__ raw, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const T* __restrict__ idn,
+                                                          const float* __restrict__ idn_scale,
+                                                          const float* __restrict__ idn_shift, T* __restrict__ out,
+                                                          long rows, int C) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int CC = C / EPC;
+    const long total = rows * CC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CC) * EPC;
+        Chunk<T> a, d, o;
+        a.load(raw + i * EPC);
+        d.load(idn + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float v = fmaf(a.get(e), scale[c + e], shift[c + e]);
+            float r = d.get(e);
+            if (idn_scale) r = fmaf(r, idn_scale[c + e], idn_shift[c + e]);
+            o.set(e, fmaxf(v + r, 0.f));
+        }
+        o.store(out + i * EPC);
+    }
+}
+
+// global average pool: [B, HW, C] -> [B, C] fp32
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, int B, int HW, int C) {
+    const long total = (long)B * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long b = i / C;
+        float acc = 0.f;
+        for (int p = 0; p < HW; ++p) acc += ElemTraits<T>::to_f(x[(b * HW + p) * C + c]);
+        out[i] = acc / (float)HW;
+    }
+}
+
+int grid_for(long total, int per_block = 256, int cap = 4096) {
+    long g = (total + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                float eps, float* scale, float* shift, int C, void* stream) {
+    CVCL_CHECK_ARG(stats && gamma && beta && scale && shift && rows > 0 && count > 0 && C > 0, "cvcl_bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 64)), dim3(256), 0, (hipStream_t)stream, stats, rows,
+                       (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                       shift, C);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+    CVCL_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "cvcl_bn_eval_affine: bad args");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cvcl_div_up(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, scale, shift, C);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_col_stats_rows(long rows) {
+    long g = (rows + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g > 256 ? 256 : g);
+}
+
+extern "C" int cvcl_col_stats(int dtype, const void* x, long rows, int C, float* stats, int stats_rows, void* stream) {
+    CVCL_CHECK_ARG(x && stats && rows > 0 && C > 0, "cvcl_col_stats: bad args");
+    const int g = cvcl_col_stats_rows(rows);
+    CVCL_CHECK_ARG(stats_rows >= g, "cvcl_col_stats: stats_rows %d < %d", stats_rows, g);
+    dim3 grid(g, cvcl_div_up(C, 64));
+    if (dtype == CVCL_F32)
+        hipLaunchKernelGGL(col_stats_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, rows, C, stats);
+    else
+        hipLaunchKernelGGL(col_stats_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, rows, C, stats);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" size_t cvcl_packed_weight_bytes(int dtype, int kind, int cout, int cin_per_group, int k) {
+    const size_t es = dtype == CVCL_BF16 ? 2 : 4;
+    if (dtype == CVCL_F32 || kind == CVCL_PACK_DENSE) return (size_t)cout * cin_per_group * k * k * es;
+    if (kind == CVCL_PACK_STEM7) return (size_t)4 * 6 * 512 * 2;
+    if (kind == CVCL_PACK_GCONV3) return (size_t)(cout / 16) * (cin_per_group == 32 ? 9 : 5) * 512 * 2;
+    return 0;
+}
+
+extern "C" int cvcl_pack_conv_weight(int dtype, int kind, const float* w_oihw, void* out, int cout, int cin_per_group,
+                                     int k, void* stream) {
+    CVCL_CHECK_ARG(w_oihw && out && cout > 0 && cin_per_group > 0, "cvcl_pack_conv_weight: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)cout * cin_per_group * k * k;
+    if (dtype == CVCL_F32) {                       // parity mode keeps the reference layout
+        hipLaunchKernelGGL(cast_kernel<float>, dim3(grid_for(n)), dim3(256), 0, s, w_oihw, (float*)out, n);
+    } else if (kind == CVCL_PACK_DENSE) {
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, s, w_oihw, (bf16_t*)out, n);
+    } else if (kind == CVCL_PACK_STEM7) {
+        CVCL_CHECK_ARG(cout == 64 && cin_per_group == 3 && k == 7, "cvcl_pack_conv_weight: stem must be 64x3x7x7");
+        hipLaunchKernelGGL(pack_stem_kernel, dim3(cvcl_div_up(4 * 6 * 512, 256)), dim3(256), 0, s, w_oihw, (bf16_t*)out);
+    } else if (kind == CVCL_PACK_GCONV3) {
+        CVCL_CHECK_ARG(k == 3 && (cin_per_group == 4 || cin_per_group == 8 || cin_per_group == 16 || cin_per_group == 32) &&
+                           cout % 64 == 0, "cvcl_pack_conv_weight: unsupported grouped conv %d/%d", cout, cin_per_group);
+        const long total = (long)(cout / 16) * (cin_per_group == 32 ? 9 : 5) * 512;
+        hipLaunchKernelGGL(pack_gconv_kernel, dim3(cvcl_div_up(total, 256)), dim3(256), 0, s, w_oihw, (bf16_t*)out, cout,
+                           cin_per_group);
+    } else {
+        cvcl_set_error("cvcl_pack_conv_weight: unknown kind %d", kind);
+        return CVCL_EINVAL;
+    }
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+static int stem_grid(int B, int Hin) {
+    const int items = B * cvcl_div_up(Hin / 2, STEM_TH);
+    return items < 512 ? items : 512;
+}
+
+extern "C" int cvcl_stem_conv_stats_rows(int dtype, int B, int H, int W) {
+    if (dtype == CVCL_BF16) return stem_grid(B, H);
+    return cvcl_col_stats_rows((long)B * (H / 2) * (W / 2));
+}
+
+extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void* y_nhwc, float* stats,
+                                 int stats_rows, int B, int H, int W, void* stream) {
+    CVCL_CHECK_ARG(x_nchw && w_packed && y_nhwc && B > 0 && H % 2 == 0 && W % 2 == 0, "cvcl_stem_conv7x7: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CVCL_BF16) {
+        CVCL_CHECK_ARG(W + 6 + 8 <= 2 * STEM_PITCH, "cvcl_stem_conv7x7: width %d too large for the staged patch", W);
+        const int g = stem_grid(B, H);
+        CVCL_CHECK_ARG(!stats || stats_rows >= g, "cvcl_stem_conv7x7: stats_rows %d < %d", stats_rows, g);
+        const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4;
+        float* st = stats;
+        CVCL_CHECK_ARG(st, "cvcl_stem_conv7x7: the bf16 kernel always emits statistics; pass a buffer");
+        hipLaunchKernelGGL(stem_mfma_kernel, dim3(g), dim3(256), lds, s, x_nchw, (const bf16_t*)w_packed, (bf16_t*)y_nhwc,
+                           st, B, H, W);
+        CVCL_LAUNCH_CHECK();
+        return CVCL_OK;
+    }
+    const long total = (long)B * (H / 2) * (W / 2) * 64;
+    hipLaunchKernelGGL(stem_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, x_nchw,
+                       (const float*)w_packed, (float*)y_nhwc, B, H, W);
+    CVCL_LAUNCH_CHECK();
+    if (stats) return cvcl_col_stats(CVCL_F32, y_nhwc, (long)B * (H / 2) * (W / 2), 64, stats, stats_rows, stream);
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int B,
+                                    int H, int W, int C, void* stream) {
+    CVCL_CHECK_ARG(x && scale && shift && y && C % 8 == 0, "cvcl_bn_relu_maxpool: bad args");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long total = (long)B * Ho * Wo * (C / 8);
+    if (dtype == CVCL_F32)
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, scale, shift, (float*)y, B, H, W, C);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, scale, shift, (bf16_t*)y, B, H, W, C);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+namespace {
+struct GconvPlan { int TH, bands, rows_in, grid_x; size_t lds; };
+GconvPlan gconv_plan(int B, int H, int W, int stride) {
+    GconvPlan g;
+    const int Ho = (H - 1) / stride + 1, Wp = W + 2;
+    // output rows per work item: keep the staged band under ~60 KiB so two workgroups fit a CU
+    int TH = Ho;
+    while (TH > 1 && (size_t)((TH - 1) * stride + 3) * Wp * GC_PIXB > 60 * 1024) TH = (TH + 1) / 2;
+    g.TH = TH;
+    g.bands = cvcl_div_up(Ho, TH);
+    g.rows_in = (TH - 1) * stride + 3;
+    g.lds = (size_t)g.rows_in * Wp * GC_PIXB;
+    const int items = B * g.bands;
+    g.grid_x = items < 256 ? items : 256;
+    return g;
+}
+}  // namespace
+
+extern "C" int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int stride) {
+    if (dtype == CVCL_BF16) return gconv_plan(B, H, W, stride).grid_x;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    return cvcl_col_stats_rows((long)B * Ho * Wo);
+}
+
+extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed,
+                             void* y, float* stats, int stats_rows, int B, int H, int W, int C, int groups, int stride,
+                             void* stream) {
+    CVCL_CHECK_ARG(x && a_scale && a_shift && w_packed && y, "cvcl_gconv3x3: null pointer");
+    CVCL_CHECK_ARG(B > 0 && (stride == 1 || stride == 2) && groups > 0 && C % groups == 0, "cvcl_gconv3x3: bad shape");
+    const int cg = C / groups;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CVCL_BF16) {
+        CVCL_CHECK_ARG((cg == 4 || cg == 8 || cg == 16 || cg == 32) && C % GC_CS == 0,
+                       "cvcl_gconv3x3: unsupported channels-per-group %d (C=%d)", cg, C);
+        const GconvPlan g = gconv_plan(B, H, W, stride);
+        CVCL_CHECK_ARG(g.lds <= 160 * 1024, "cvcl_gconv3x3: feature map too wide for one LDS band (%zu B)", g.lds);
+        CVCL_CHECK_ARG(!stats || stats_rows >= g.grid_x, "cvcl_gconv3x3: stats_rows %d < %d", stats_rows, g.grid_x);
+        GconvDev d;
+        d.x = x; d.a_scale = a_scale; d.a_shift = a_shift; d.w = w_packed; d.y = y; d.stats = stats;
+        d.B = B; d.H = H; d.W = W; d.C = C; d.cg = cg; d.stride = stride; d.Ho = Ho; d.Wo = Wo;
+        d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)gconv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
+                return CVCL_ELAUNCH;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gconv_mfma_kernel, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
+        CVCL_LAUNCH_CHECK();
+        return CVCL_OK;
+    }
+    const long total = (long)B * Ho * Wo * C;
+    hipLaunchKernelGGL(gconv_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, (const float*)x, a_scale,
+                       a_shift, (const float*)w_packed, (float*)y, B, H, W, C, cg, stride, Ho, Wo);
+    CVCL_LAUNCH_CHECK();
+    if (stats) return cvcl_col_stats(CVCL_F32, y, (long)B * Ho * Wo, C, stats, stats_rows, stream);
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, const float* shift, const void* idn,
+                                const float* idn_scale, const float* idn_shift, void* out, long rows, int C, void* stream) {
+    CVCL_CHECK_ARG(raw && scale && shift && idn && out && rows > 0 && C % 8 == 0, "cvcl_bn_add_relu: bad args");
+    CVCL_CHECK_ARG((idn_scale == nullptr) == (idn_shift == nullptr), "cvcl_bn_add_relu: idn_scale/idn_shift pair");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == CVCL_F32)
+        hipLaunchKernelGGL(bn_add_relu_kernel<float>, dim3(grid_for(rows * (C / 4), 256, 8192)), dim3(256), 0, s, (const float*)raw,
+                           scale, shift, (const float*)idn, idn_scale, idn_shift, (float*)out, rows, C);
+    else
+        hipLaunchKernelGGL(bn_add_relu_kernel<bf16_t>, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, s, (const bf16_t*)raw,
+                           scale, shift, (const bf16_t*)idn, idn_scale, idn_shift, (bf16_t*)out, rows, C);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_avgpool(int dtype, const void* x, float* out, int B, int HW, int C, void* stream) {
+    CVCL_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "cvcl_avgpool: bad args");
+    if (dtype == CVCL_F32)
+        hipLaunchKernelGGL(avgpool_kernel<float>, dim3(grid_for((long)B * C)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, B, HW, C);
+    else
+        hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(grid_for((long)B * C)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, out, B, HW, C);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole-network forward (one C call enqueues every kernel of the trunk on the caller's stream)
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Spec { int cin, cout, k, stride, groups; };
+constexpr int kLayers[4] = {3, 4, 6, 3};
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline size_t act_elems(int B, int H, int W) {
+    // largest activation: stem output [B, H/2, W/2, 64] == layer1 tensors [B, H/4, W/4, 256]
+    return (size_t)B * (H / 2) * (W / 2) * 64;
+}
+}  // namespace
+
+extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W) {
+    const size_t es = dtype == CVCL_BF16 ? 2 : 4;
+    return 5 * al256(act_elems(B, H, W) * es) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)53 * 2 * 2048 * 4);
+}
+
+extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
+                                  const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
+                                  void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream) {
+    CVCL_CHECK_ARG(x_nchw && layers && workspace && layer4_out_nhwc && pooled, "cvcl_resnext50_fwd: null pointer");
+    CVCL_CHECK_ARG(n_layers == 53, "cvcl_resnext50_fwd: expected 53 conv+bn layers, got %d", n_layers);
+    CVCL_CHECK_ARG(B > 0 && H % 32 == 0 && W % 32 == 0, "cvcl_resnext50_fwd: H, W must be multiples of 32");
+    if (workspace_bytes < cvcl_resnext50_workspace_bytes(dtype, B, H, W)) {
+        cvcl_set_error("cvcl_resnext50_fwd: workspace too small");
+        return CVCL_EWORKSPACE;
+    }
+    const size_t es = dtype == CVCL_BF16 ? 2 : 4;
+    char* w = (char*)workspace;
+    char* buf[5];
+    for (int i = 0; i < 5; ++i) { buf[i] = w; w += al256(act_elems(B, H, W) * es); }
+    float* stats = (float*)w; w += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
+    float* affine = (float*)w;
+    int rc, li = 0;
+
+    // (scale, shift) of layer l live at affine + l * 4096
+    auto scale_of = [&](int l) { return affine + (size_t)l * 4096; };
+    auto shift_of = [&](int l) { return affine + (size_t)l * 4096 + 2048; };
+    auto finalize = [&](int l, int rows, long count, int C) -> int {
+        const cvcl_convbn_params& L = layers[l];
+        if (training)
+            return cvcl_bn_finalize(stats, rows, count, L.gamma, L.beta, L.running_mean, L.running_var,
+                                    L.num_batches_tracked, momentum, eps, scale_of(l), shift_of(l), C, stream);
+        return cvcl_bn_eval_affine(L.gamma, L.beta, L.running_mean, L.running_var, eps, scale_of(l), shift_of(l), C, stream);
+    };
+
+    // ---- stem ----
+    int h = H / 2, wd = W / 2;
+    char* RAW = buf[2];
+    const int srows = cvcl_stem_conv_stats_rows(dtype, B, H, W);
+    if ((rc = cvcl_stem_conv7x7(dtype, x_nchw, layers[0].w, RAW, stats, kMaxStatsRows, B, H, W, stream))) return rc;
+    if ((rc = finalize(0, srows, (long)B * h * wd, 64))) return rc;
+    char* X = buf[0];
+    char* OUT = buf[1];
+    if ((rc = cvcl_bn_relu_maxpool(dtype, RAW, scale_of(0), shift_of(0), X, B, h, wd, 64, stream))) return rc;
+    h /= 2; wd /= 2;
+    li = 1;
+    int inplanes = 64;
+    for (int stage = 0; stage < 4; ++stage) {
+        const int planes = 64 << stage, width = planes * 2, outc = planes * 4;
+        for (int bi = 0; bi < kLayers[stage]; ++bi) {
+            const int stride = (stage > 0 && bi == 0) ? 2 : 1;
+            const int ho = h / stride, wo = wd / stride;
+            const long m_in = (long)B * h * wd, m_out = (long)B * ho * wo;
+            const int l1 = li, l2 = li + 1, l3 = li + 2, ld = li + 3;
+            char *R1 = buf[2], *R2 = buf[3], *R3 = buf[2], *RD = buf[4];
+            const bool last = (stage == 3 && bi == kLayers[3] - 1);
+            // conv1 1x1: X [m_in, inplanes] -> R1 [m_in, width]
+            {
+                cvcl_gemm_args a = {};
+                a.A = X; a.W = layers[l1].w; a.C = R1;
+                a.M = (int)m_in; a.N = width; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = width;
+                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
+                if ((rc = finalize(l1, cvcl_gemm_grid_m(dtype, a.M, a.N), m_in, width))) return rc;
+            }
+            // conv2 grouped 3x3 (stride here): R1 -> R2 [m_out, width], BN1+ReLU fused into the load
+            if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), layers[l2].w, R2, training ? stats : nullptr,
+                                    kMaxStatsRows, B, h, wd, width, 32, stride, stream))) return rc;
+            if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, stride), m_out, width))) return rc;
+            // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc]
+            {
+                cvcl_gemm_args a = {};
+                a.A = R2; a.W = layers[l3].w; a.C = R3;
+                a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
+                a.a_scale = scale_of(l2); a.a_shift = shift_of(l2); a.a_relu = 1;
+                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
+                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N), m_out, outc))) return rc;
+            }
+            char* dst = last ? (char*)layer4_out_nhwc : OUT;
+            if (bi == 0) {
+                // downsample 1x1 stride s: X -> RD [m_out, outc]
+                cvcl_gemm_args a = {};
+                a.A = X; a.W = layers[ld].w; a.C = RD;
+                a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
+                if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
+                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
+                if ((rc = finalize(ld, cvcl_gemm_grid_m(dtype, a.M, a.N), m_out, outc))) return rc;
+                if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), RD, scale_of(ld), shift_of(ld), dst, m_out,
+                                           outc, stream))) return rc;
+                li += 4;
+            } else {
+                if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), X, nullptr, nullptr, dst, m_out, outc,
+                                           stream))) return rc;
+                li += 3;
+            }
+            char* t = X; X = dst; OUT = (t == (char*)layer4_out_nhwc) ? OUT : t;
+            h = ho; wd = wo; inplanes = outc;
+        }
+    }
+    return cvcl_avgpool(dtype, layer4_out_nhwc, pooled, B, h * wd, 2048, stream);
+}

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvcl_hip.so")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ABI_VERSION = 1
+PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 
 
 class CvclError(RuntimeError):
@@ -62,6 +63,21 @@ SIGNATURES = {
     "cvcl_gemm": (_I, [_I, C.POINTER(GemmArgs), _P]),
     "cvcl_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "cvcl_colsum_f32": (_I, [_P, _P, _I, _I, _P]),
+    "cvcl_bn_finalize": (_I, [_P, _I, C.c_long, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P]),
+    "cvcl_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "cvcl_col_stats_rows": (_I, [C.c_long]),
+    "cvcl_col_stats": (_I, [_I, _P, C.c_long, _I, _P, _I, _P]),
+    "cvcl_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "cvcl_pack_conv_weight": (_I, [_I, _I, _P, _P, _I, _I, _I, _P]),
+    "cvcl_stem_conv_stats_rows": (_I, [_I, _I, _I, _I]),
+    "cvcl_stem_conv7x7": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_bn_relu_maxpool": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_gconv3x3_stats_rows": (_I, [_I, _I, _I, _I, _I]),
+    "cvcl_gconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cvcl_bn_add_relu": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _P]),
+    "cvcl_avgpool": (_I, [_I, _P, _P, _I, _I, _I, _P]),
+    "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }
 
 _lib = None

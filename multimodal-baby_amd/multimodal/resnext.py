@@ -1,0 +1,161 @@
+"""ResNeXt-50 32x4d with torchvision's module tree / state_dict keys, computed by libcvcl_hip.
+
+The reference gets this network from ``torchvision.models.resnext50_32x4d``
+(multimodal/multimodal.py:155-158, multimodal/utils.py:207-209 in the reference).  Here the
+``nn.Conv2d`` / ``nn.BatchNorm2d`` children are *parameter containers only* (same names, shapes and
+init as torchvision, so checkpoints interchange); ``forward`` hands their tensors to
+``cvcl_resnext50_fwd`` which enqueues the whole trunk as hand-written HIP kernels.  There is no
+PyTorch-op fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _hip as H
+from . import ops
+
+LAYERS = (3, 4, 6, 3)
+GROUPS, WIDTH_PER_GROUP = 32, 4
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        width = int(planes * (WIDTH_PER_GROUP / 64.0)) * GROUPS
+        self.conv1 = nn.Conv2d(inplanes, width, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, groups=GROUPS, bias=False)
+        self.bn2 = nn.BatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):  # pragma: no cover - blocks are never run one by one
+        raise H.CvclError("ResNeXt blocks are parameter containers; run the whole trunk through ResNet.forward")
+
+
+class _Stage(nn.Sequential):
+    """layer{1..4}: holds the Bottlenecks; called with the already-computed stage output so that
+    forward hooks registered on it (the reference's ``Hook(model.layer4)``, attention_maps.py:83-101)
+    observe the feature map exactly as with torchvision."""
+
+    def forward(self, feature_map):
+        return feature_map
+
+
+class ResNet(nn.Module):
+    def __init__(self, num_classes: int = 1000):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        inplanes = 64
+        for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), LAYERS), start=1):
+            mods = []
+            for bi in range(blocks):
+                stride = 2 if (li > 1 and bi == 0) else 1
+                ds = None
+                if bi == 0:
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False), nn.BatchNorm2d(planes * 4))
+                mods.append(Bottleneck(inplanes, planes, stride, ds))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", _Stage(*mods))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, num_classes)
+        for m in self.modules():                       # torchvision's init (zero_init_residual=False)
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self.compute_dtype = torch.float32             # torch.bfloat16 = perf mode
+        self._pack_cache = {}
+        self._ws_cache = {}
+
+    # ---- (conv, bn) pairs in torchvision state_dict order -----------------------------------
+    def conv_bn_pairs(self):
+        pairs = [(self.conv1, self.bn1, H.PACK_STEM7)]
+        for li in (1, 2, 3, 4):
+            for blk in getattr(self, f"layer{li}"):
+                pairs.append((blk.conv1, blk.bn1, H.PACK_DENSE))
+                pairs.append((blk.conv2, blk.bn2, H.PACK_GCONV3))
+                pairs.append((blk.conv3, blk.bn3, H.PACK_DENSE))
+                if blk.downsample is not None:
+                    pairs.append((blk.downsample[0], blk.downsample[1], H.PACK_DENSE))
+        return pairs
+
+    def _packed_layers(self, dt: int, device):
+        """Re-lay-out conv weights for the kernels (once per weight version) and build the C array."""
+        pairs = self.conv_bn_pairs()
+        key = (dt, str(device)) + tuple((c.weight.data_ptr(), c.weight._version, b.running_mean.data_ptr()) for c, b, _ in pairs)
+        hit = self._pack_cache.get("k")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        lib = H.lib()
+        arr = (H.ConvBnParams * len(pairs))()
+        keep = []
+        for i, (conv, bn, kind) in enumerate(pairs):
+            w = conv.weight.detach()
+            cout, cing, k, _ = w.shape
+            nb = lib.cvcl_packed_weight_bytes(dt, kind, cout, cing, k)
+            buf = torch.empty(nb, dtype=torch.uint8, device=device)
+            H.check(lib.cvcl_pack_conv_weight(dt, kind, H.ptr(w.contiguous(), torch.float32), H.ptr(buf), cout, cing, k,
+                                              H.stream_ptr()), "cvcl_pack_conv_weight")
+            keep.append(buf)
+            arr[i].w = buf.data_ptr()
+            arr[i].gamma = H.ptr(bn.weight.detach(), torch.float32)
+            arr[i].beta = H.ptr(bn.bias.detach(), torch.float32)
+            arr[i].running_mean = H.ptr(bn.running_mean, torch.float32)
+            arr[i].running_var = H.ptr(bn.running_var, torch.float32)
+            arr[i].num_batches_tracked = H.ptr(bn.num_batches_tracked, torch.int64)
+        self._pack_cache["k"] = (key, (arr, keep))
+        return arr, keep
+
+    def trunk(self, x: torch.Tensor):
+        """conv1 .. layer4 + avgpool.  -> (pooled [B,2048] f32, layer4 map as a logical NCHW view)."""
+        if any(p.requires_grad for c, b, _ in self.conv_bn_pairs() for p in (c.weight, b.weight, b.bias)) and torch.is_grad_enabled():
+            raise NotImplementedError("fine-tuning the ResNeXt trunk needs its backward kernels, which this build does "
+                                      "not ship yet (frozen-CNN configurations only); see DESIGN.md")
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
+        x = x.contiguous()
+        B, _, Hh, Ww = x.shape
+        dt = H.cvcl_dtype(self.compute_dtype)
+        lib = H.lib()
+        with torch.no_grad():
+            arr, _keep = self._packed_layers(dt, x.device)
+            nb = lib.cvcl_resnext50_workspace_bytes(dt, B, Hh, Ww)
+            ws = self._ws_cache.get((nb, str(x.device)))
+            if ws is None:
+                self._ws_cache.clear()
+                ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                self._ws_cache[(nb, str(x.device))] = ws
+            fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
+            pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
+            H.check(lib.cvcl_resnext50_fwd(dt, B, Hh, Ww, int(self.training), H.ptr(x), arr, len(arr), H.ptr(ws), nb,
+                                           H.ptr(fmap), H.ptr(pooled), BN_MOMENTUM, BN_EPS, H.stream_ptr()),
+                    "cvcl_resnext50_fwd")
+        return pooled, fmap.permute(0, 3, 1, 2)
+
+    def forward(self, x):
+        pooled, fmap = self.trunk(x)
+        self.layer4(fmap)                                # fires forward hooks registered on layer4
+        if isinstance(self.fc, nn.Linear):
+            return ops.linear_f32(pooled, self.fc.weight, self.fc.bias)
+        return self.fc(pooled)                           # e.g. nn.Identity (utils.build_dino_mugs)
+
+
+def resnext50_32x4d(pretrained: bool = False, **kwargs) -> ResNet:
+    if pretrained:
+        raise H.CvclError("no network in this environment: ImageNet-pretrained torchvision weights are unavailable")
+    return ResNet(**kwargs)

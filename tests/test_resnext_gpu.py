@@ -1,0 +1,231 @@
+"""GPU parity: ResNeXt-50 trunk kernels through the C ABI vs the oracle.
+
+fp32 mode (parity mode) is compared with the oracle's fp32 arithmetic; bf16 mode with the oracle's
+storage-point emulation (``quant=bf16_round``: operands/stored activations rounded to bf16, fp32
+accumulation and statistics), which isolates kernel bugs from expected bf16 rounding.
+The oracle's ResNeXt is parity-unpinned by the reference (torchvision absent): see oracle header."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cvcl_oracle as O
+from conftest import maxrel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from multimodal import _hip
+    return _hip
+
+
+def _t(dt):
+    return torch.bfloat16 if dt == "bf16" else torch.float32
+
+
+def _q(dt):
+    return O.bf16_round if dt == "bf16" else (lambda t: t)
+
+
+def nhwc(t):          # NCHW (oracle) -> NHWC contiguous
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def pack(H, dt, kind, w, dev):
+    cd = H.BF16 if dt == "bf16" else H.F32
+    cout, cing, k, _ = w.shape
+    nb = H.lib().cvcl_packed_weight_bytes(cd, kind, cout, cing, k)
+    buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+    H.check(H.lib().cvcl_pack_conv_weight(cd, kind, H.ptr(w.to(dev).contiguous()), H.ptr(buf), cout, cing, k, H.stream_ptr()), "pack")
+    return buf
+
+
+def stats_tensor(rows, C, dev):
+    return torch.full((rows, 2, C), float("nan"), device=dev)
+
+
+def check_stats(stats, rows, y):
+    s = stats[:rows].double().sum(dim=0).cpu()
+    yd = y.double().cpu().reshape(-1, y.shape[-1])
+    assert maxrel(s[0], yd.sum(dim=0)) < 2e-5
+    assert maxrel(s[1], (yd * yd).sum(dim=0)) < 2e-5
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,S", [(2, 64), (1, 224)])
+def test_stem(H, dev, dt, B, S):
+    g = torch.Generator().manual_seed(S)
+    x = torch.randn(B, 3, S, S, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    q = _q(dt)
+    ref = F.conv2d(q(x), q(w), None, 2, 3)
+    cd = H.BF16 if dt == "bf16" else H.F32
+    wp = pack(H, dt, H.PACK_STEM7, w, dev)
+    y = torch.empty(B, S // 2, S // 2, 64, dtype=_t(dt), device=dev)
+    rows = H.lib().cvcl_stem_conv_stats_rows(cd, B, S, S)
+    st = stats_tensor(rows, 64, dev)
+    H.check(H.lib().cvcl_stem_conv7x7(cd, H.ptr(x.to(dev)), H.ptr(wp), H.ptr(y), H.ptr(st), rows, B, S, S, H.stream_ptr()), "stem")
+    assert maxrel(y.float(), nhwc(ref)) < (6e-3 if dt == "bf16" else 2e-5)
+    check_stats(st, rows, y)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_bn_finalize_and_maxpool(H, dev, dt):
+    g = torch.Generator().manual_seed(2)
+    B, S, Cn = 2, 16, 64
+    raw = (torch.randn(B, Cn, S, S, generator=g) * 2 + 0.5)
+    raw = _q(dt)(raw)
+    p = {"bn.weight": torch.rand(Cn, generator=g) + 0.5, "bn.bias": torch.randn(Cn, generator=g),
+         "bn.running_mean": torch.randn(Cn, generator=g), "bn.running_var": torch.rand(Cn, generator=g) + 0.5,
+         "bn.num_batches_tracked": torch.tensor(3)}
+    so = {}
+    yo = torch.relu(O.batch_norm(raw, p, "bn", True, so))
+    pool_o = F.max_pool2d(yo, 3, 2, 1)
+    cd = H.BF16 if dt == "bf16" else H.F32
+    xr = nhwc(raw).to(_t(dt)).to(dev)
+    rows = H.lib().cvcl_col_stats_rows(B * S * S)
+    st = stats_tensor(rows, Cn, dev)
+    H.check(H.lib().cvcl_col_stats(cd, H.ptr(xr), B * S * S, Cn, H.ptr(st), rows, H.stream_ptr()), "col_stats")
+    check_stats(st, rows, xr)
+    d = {k: v.clone().to(dev) for k, v in p.items()}
+    scale, shift = torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)
+    H.check(H.lib().cvcl_bn_finalize(H.ptr(st), rows, B * S * S, H.ptr(d["bn.weight"]), H.ptr(d["bn.bias"]),
+                                     H.ptr(d["bn.running_mean"]), H.ptr(d["bn.running_var"]),
+                                     H.ptr(d["bn.num_batches_tracked"]), 0.1, 1e-5, H.ptr(scale), H.ptr(shift), Cn,
+                                     H.stream_ptr()), "bn_finalize")
+    assert maxrel(d["bn.running_mean"], so["bn.running_mean"]) < 1e-5
+    assert maxrel(d["bn.running_var"], so["bn.running_var"]) < 1e-5
+    assert int(d["bn.num_batches_tracked"]) == 4
+    y = torch.empty(B, S // 2, S // 2, Cn, dtype=_t(dt), device=dev)
+    H.check(H.lib().cvcl_bn_relu_maxpool(cd, H.ptr(xr), H.ptr(scale), H.ptr(shift), H.ptr(y), B, S, S, Cn, H.stream_ptr()), "maxpool")
+    assert maxrel(y.float(), nhwc(_q(dt)(pool_o))) < (5e-3 if dt == "bf16" else 1e-5)
+    # eval-mode affine
+    H.check(H.lib().cvcl_bn_eval_affine(H.ptr(d["bn.weight"]), H.ptr(d["bn.bias"]), H.ptr(d["bn.running_mean"]),
+                                        H.ptr(d["bn.running_var"]), 1e-5, H.ptr(scale), H.ptr(shift), Cn, H.stream_ptr()), "affine")
+    ref_scale = d["bn.weight"].cpu() / torch.sqrt(d["bn.running_var"].cpu() + 1e-5)
+    assert maxrel(scale, ref_scale) < 1e-6
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("C_,S,stride,B", [(128, 16, 1, 2), (256, 16, 2, 2), (256, 28, 1, 1), (512, 14, 2, 3),
+                                           (512, 14, 1, 2), (1024, 14, 2, 2), (1024, 7, 1, 5), (128, 56, 1, 1)])
+def test_gconv(H, dev, dt, C_, S, stride, B):
+    """grouped 3x3, 32 groups, all channels-per-group the network uses (4, 8, 16, 32), both strides,
+    with the producer's BN+ReLU fused into the operand load and zero padding applied after it."""
+    g = torch.Generator().manual_seed(C_ + S + stride)
+    cg = C_ // 32
+    x = torch.randn(B, C_, S, S, generator=g)
+    w = torch.randn(C_, cg, 3, 3, generator=g) / (3 * cg ** 0.5)
+    sc, sh = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.5
+    q = _q(dt)
+    xq = q(x)
+    act = q(torch.relu(xq * sc[None, :, None, None] + sh[None, :, None, None]))
+    ref = q(F.conv2d(act, q(w), None, stride, 1, 1, 32))
+    cd = H.BF16 if dt == "bf16" else H.F32
+    wp = pack(H, dt, H.PACK_GCONV3, w, dev)
+    So = (S - 1) // stride + 1
+    y = torch.empty(B, So, So, C_, dtype=_t(dt), device=dev)
+    rows = H.lib().cvcl_gconv3x3_stats_rows(cd, B, S, S, stride)
+    st = stats_tensor(rows, C_, dev)
+    H.check(H.lib().cvcl_gconv3x3(cd, H.ptr(nhwc(xq).to(_t(dt)).to(dev)), H.ptr(sc.to(dev)), H.ptr(sh.to(dev)), H.ptr(wp),
+                                  H.ptr(y), H.ptr(st), rows, B, S, S, C_, 32, stride, H.stream_ptr()), "gconv")
+    assert maxrel(y.float(), nhwc(ref)) < (8e-3 if dt == "bf16" else 2e-5)
+    check_stats(st, rows, y)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_bn_add_relu_and_avgpool(H, dev, dt):
+    g = torch.Generator().manual_seed(9)
+    rows, Cn = 2 * 49, 2048
+    q = _q(dt)
+    raw, idn = q(torch.randn(rows, Cn, generator=g)), q(torch.randn(rows, Cn, generator=g))
+    s1, b1 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g)
+    s2, b2 = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g)
+    cd = H.BF16 if dt == "bf16" else H.F32
+    d = lambda t: t.to(dev)
+    out = torch.empty(rows, Cn, dtype=_t(dt), device=dev)
+    for with_ds in (False, True):
+        ref = torch.relu(raw * s1 + b1 + (idn * s2 + b2 if with_ds else idn))
+        H.check(H.lib().cvcl_bn_add_relu(cd, H.ptr(d(raw.to(_t(dt)))), H.ptr(d(s1)), H.ptr(d(b1)), H.ptr(d(idn.to(_t(dt)))),
+                                         H.ptr(d(s2)) if with_ds else None, H.ptr(d(b2)) if with_ds else None, H.ptr(out),
+                                         rows, Cn, H.stream_ptr()), "bn_add_relu")
+        assert maxrel(out.float(), q(ref)) < (5e-3 if dt == "bf16" else 1e-6)
+    pooled = torch.empty(2, Cn, device=dev)
+    H.check(H.lib().cvcl_avgpool(cd, H.ptr(out), H.ptr(pooled), 2, 49, Cn, H.stream_ptr()), "avgpool")
+    assert maxrel(pooled, out.float().reshape(2, 49, Cn).mean(dim=1)) < 1e-5
+
+
+def _load_oracle_params_into(model, p):
+    sd = model.state_dict()
+    for k, v in p.items():
+        assert k in sd, k
+        sd[k].copy_(v)
+
+
+@pytest.mark.parametrize("dt,training", [("f32", True), ("f32", False), ("bf16", True), ("bf16", False)])
+@pytest.mark.parametrize("B,S", [(2, 224), (3, 64)])
+def test_trunk_vs_oracle(H, dev, dt, training, B, S):
+    """Whole trunk (53 conv+BN, pools) through cvcl_resnext50_fwd vs the oracle; running statistics too."""
+    from multimodal.resnext import ResNet
+    p = O.resnext50_random_params(seed=1)
+    g = torch.Generator().manual_seed(B * S)
+    # non-trivial BN parameters / running stats so eval mode and the affine are exercised
+    for k in list(p.keys()):
+        if k.endswith("running_mean"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            p[k] = torch.rand(p[k].shape, generator=g) * 0.5 + 0.75
+        elif ("bn" in k or "downsample.1" in k) and k.endswith(".weight"):
+            p[k] = torch.rand(p[k].shape, generator=g) * 0.5 + 0.75
+        elif ("bn" in k or "downsample.1" in k) and k.endswith(".bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.1
+    x = torch.randn(B, 3, S, S, generator=g)
+    stats_o = {}
+    pooled_o, fmap_o = O.resnext50_forward(p, x, training, _q(dt) if dt == "bf16" else None, stats_out=stats_o)
+    model = ResNet()
+    _load_oracle_params_into(model, p)
+    model = model.to(dev)
+    model.compute_dtype = _t(dt)
+    model.train(training)
+    for prm in model.parameters():
+        prm.requires_grad_(False)
+    pooled, fmap = model.trunk(x.to(dev))
+    tol = 3e-2 if dt == "bf16" else 2e-4
+    e_p, e_f = maxrel(pooled, pooled_o), maxrel(fmap.float(), fmap_o)
+    print(f"trunk {dt} train={training} B={B} S={S}: pooled rel err {e_p:.2e}, layer4 map rel err {e_f:.2e}")
+    assert fmap.shape == fmap_o.shape
+    assert e_p < tol and e_f < tol
+    sd = model.state_dict()
+    if training:
+        for k in ("bn1.running_mean", "layer1.0.bn2.running_var", "layer2.0.downsample.1.running_mean",
+                  "layer4.2.bn3.running_var", "layer3.5.bn1.running_mean"):
+            assert maxrel(sd[k], stats_o[k]) < (2e-2 if dt == "bf16" else 1e-4), k
+        assert int(sd["layer4.2.bn3.num_batches_tracked"]) == 1
+    else:
+        assert torch.equal(sd["bn1.running_mean"].cpu(), p["bn1.running_mean"])
+        assert int(sd["bn1.num_batches_tracked"]) == 0
+
+
+def test_trunk_properties_full_batch(H, dev):
+    """BASELINE batch (256 x 224 x 224, bf16): eval-mode per-sample independence (a sample's features do not
+    depend on its batch-mates) and determinism (bit-identical reruns)."""
+    from multimodal.resnext import ResNet
+    torch.manual_seed(0)
+    model = ResNet().to(dev).eval()
+    model.compute_dtype = torch.bfloat16
+    for prm in model.parameters():
+        prm.requires_grad_(False)
+    x = torch.randn(256, 3, 224, 224, device=dev)
+    p1, f1 = model.trunk(x)
+    p2, _ = model.trunk(x)
+    assert torch.equal(p1, p2)
+    p3, _ = model.trunk(x[100:104].contiguous())
+    assert torch.equal(p1[100:104], p3)
+    assert torch.isfinite(p1).all()
+    model.train()
+    p4, _ = model.trunk(x)
+    p5, _ = model.trunk(x)
+    assert torch.equal(p4, p5)                      # train-mode statistics are deterministic (no atomics)
