@@ -169,7 +169,7 @@ def transformer_text(p: Dict[str, Tensor], x: Tensor, x_len: Tensor, pos_embed_t
 # --------------------------------------------------------------------------------------
 def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
     """``F.normalize(x, p=2, dim=-1)``: ``x / max(||x||_2, eps)``."""
-    n = torch.sqrt((x * x).sum(dim=-1, keepdim=True))
+    n = torch.linalg.vector_norm(x, 2, dim=-1, keepdim=True)   # zero-safe subgradient, as F.normalize
     return x / torch.clamp(n, min=eps)
 
 
