@@ -1,0 +1,227 @@
+"""CVCL contrastive train-step benchmark on MI355X (driver contract: see the task prompt / DESIGN.md).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM: ResNeXt-50
+forward (bf16 MFMA trunk, BN in train mode), embedding mean-pool, L2 normalise, [RCCL feature all-gather],
+similarity logits, symmetric InfoNCE, backward of the trainable set (fc + embedding), [RCCL gradient
+all-reduce], AdamW.  Workload = BASELINE.json configs[1] (C2), weak scaling (256 pairs per GPU).
+
+Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (timed live with
+HIP events on the launch stream in a second pass of the same steps, so the events do not perturb the
+headline number) and a CPU baseline (the oracle restatement on the host cores, bounded sample).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "multimodal-baby_amd"))
+
+import torch                                   # noqa: E402
+import torch.distributed as dist               # noqa: E402
+
+METRIC = "image-text pairs/sec, CVCL ResNeXt+embed 224², bs256, 1/2/4/8 MI355X"
+PER_GPU_BATCH = 256
+EMBEDDING_DIM = 512
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def c2_args():
+    import types
+    return argparse.Namespace(
+        embedding_type="flat", embedding_dim=EMBEDDING_DIM, pretrained_cnn=False, cnn_model="resnext50_32x4d",
+        cnn_dino=False, vit_dino=False, finetune_cnn=False, text_encoder="embedding", captioning=False,
+        attention=False, attention_gate=False, crange=1, dropout_i=0.5, dropout_o=0.0, pos_embed_type="no_pos_embed",
+        normalize_features=True, sim="max", temperature=0.07, fix_temperature=True, tie=True, bias=True,
+        optimizer=torch.optim.AdamW, lr=1e-4, weight_decay=0.1, lr_scheduler=False, lambda_mm=1.0, lambda_lm=0.0,
+        lambda_ar=0.0, optimize_unused=True, local_negatives=False)
+
+
+def synthetic_batch_on_device(batch, seed, device, vocab=2350):
+    """rand -> ImageNet normalise; <sos> w1 w2 w3 <eos>, generated once on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    img = torch.rand(batch, 3, 224, 224, generator=g, device=device)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
+    img = ((img - mean) / std).contiguous()
+    words = torch.randint(4, vocab, (batch, 3), generator=g, device=device)
+    tok = torch.cat([torch.full((batch, 1), 2, device=device), words, torch.full((batch, 1), 3, device=device)], 1).long()
+    ln = torch.full((batch,), 5, dtype=torch.long, device=device)
+    return img, tok.contiguous(), ln
+
+
+def gemm_algorithmic_work(B):
+    """Algorithmic bytes / flops of the 52 bf16 1x1-conv GEMM launches of one ResNeXt-50 forward at batch B:
+    every operand element moved once (A rows actually used, W, C), 2 bytes each; 2*M*N*K flops."""
+    nbytes = flops = launches = 0
+    inplanes, h = 64, 56
+    for stage, blocks in enumerate((3, 4, 6, 3)):
+        planes = 64 << stage
+        width, outc = planes * 2, planes * 4
+        for bi in range(blocks):
+            stride = 2 if (stage > 0 and bi == 0) else 1
+            ho = h // stride
+            m_in, m_out = B * h * h, B * ho * ho
+            convs = [(m_in, width, inplanes), (m_out, outc, width)]
+            if bi == 0:
+                convs.append((m_out, outc, inplanes))
+            for (m, n, k) in convs:
+                nbytes += 2 * (m * k + n * k + m * n)
+                flops += 2 * m * n * k
+                launches += 1
+            h, inplanes = ho, outc
+    return nbytes, flops, launches
+
+
+def cpu_baseline(sample_batch=64, steps=2):
+    """The oracle (CPU restatement of the reference step: fwd + InfoNCE + bwd(trainable) + AdamW) timed on the
+    host cores on a bounded sample of the same workload: `steps` steps at batch `sample_batch`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cvcl_oracle as O
+    threads = torch.get_num_threads()
+    p = O.cvcl_random_params(EMBEDDING_DIM, seed=0)
+    step = O.CpuTrainStep(p, lr=1e-4, weight_decay=0.1, normalize_features=True)
+    img, tok, ln = O.synthetic_batch(sample_batch, seed=0)
+    step.step(img, tok, ln)                                   # untimed warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.step(img, tok, ln)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_batch * steps / dt, 2), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} train steps at batch {sample_batch} (same per-pair work as the batch-256 step: "
+                      f"ResNeXt-50 fwd with train-mode BN + embedding + InfoNCE + bwd + AdamW), fp32, torch "
+                      f"{torch.__version__} CPU, {threads} threads of {os.cpu_count()} cpus, {dt:.1f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "32"])
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the CVCL hot path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")           # RCCL on ROCm
+
+    from multimodal import _hip as H
+    from multimodal import parallel
+    from multimodal.multimodal import TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import read_vocab
+    from multimodal.multimodal_lit import MultiModalLitModel
+
+    torch.manual_seed(0)
+    args = c2_args()
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        ve = VisionEncoder(args)
+        te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args)
+        lit = MultiModalLitModel(ve, te, args)
+    lit.to(device)
+    lit.set_precision(a.precision)
+    lit.train()                                           # Lightning keeps .train(): BN uses batch statistics
+    opt = lit.configure_optimizers()
+    engine = parallel.DataParallelEngine(device, global_negatives=True).attach(lit)
+    batch = synthetic_batch_on_device(PER_GPU_BATCH, seed=rank, device=device) + (None,)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = lit.training_step(batch, 0)
+        out["loss"].backward()
+        engine.reduce_gradients()
+        opt.step()
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out["loss"])
+    pairs = world * PER_GPU_BATCH * a.steps
+    value = pairs / elapsed
+
+    roofline = None
+    breakdown = None
+    if not a.no_roofline:
+        # second pass of the same steps with HIP events around every launch (on the launch stream)
+        nprof = min(a.steps, 10)
+        H.prof_enable(True)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        prof = H.prof_collect()
+        H.prof_enable(False)
+        breakdown = {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1] > 0}
+        dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+        nbytes, flops, launches = gemm_algorithmic_work(PER_GPU_BATCH)
+        g_ms, g_n = prof["gemm"]
+        avg_s = g_ms / max(g_n, 1) * 1e-3
+        per_launch_bytes = nbytes / launches
+        achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        roofline = {"kernel": "gemm_kernel<bf16> (1x1-conv MFMA GEMM, fused BN-apply prologue + BN-stats epilogue)",
+                    "dominant_class_by_time": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": g_n // nprof, "avg_launch_us": round(avg_s * 1e6, 2),
+                    "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                    "mfma_tflops": round(flops / launches / avg_s / 1e12, 1) if avg_s > 0 else 0.0,
+                    "mfma_frac_of_bf16_dense_peak": round(flops / launches / avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if avg_s > 0 else 0.0}
+        if world > 1:
+            dist.barrier()
+
+    if rank == 0:
+        line = {"metric": METRIC, "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
+                "data": "synthetic",
+                "config": {"workload": "C2 = BASELINE configs[1]: CVCL saycam_contrastive, frozen random-init ResNeXt-50 "
+                                       "32x4d (BN train mode) + embedding mean-pool text encoder, E=512, L2-normalised, "
+                                       "fixed tau 0.07, 224x224 frames + 3-word utterances; full step = fwd + InfoNCE + "
+                                       "bwd(fc, embedding) + AdamW",
+                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,
+                           "negatives": "global (RCCL all-gather)" if world > 1 else "local (single GPU)",
+                           "parallelism": f"dp{world}"},
+                "final_loss": round(loss, 5)}
+        if roofline is not None:
+            line["roofline"] = roofline
+            line["kernel_ms_per_step"] = breakdown
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

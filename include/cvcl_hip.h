@@ -36,6 +36,15 @@ enum { CVCL_ACT_NONE = 0, CVCL_ACT_RELU = 1, CVCL_ACT_GELU = 2 };
 int cvcl_abi_version(void);
 const char* cvcl_last_error(void);
 
+/* Optional measurement aid (bench.py roofline): while enabled, every kernel launch is bracketed by
+ * hipEvents recorded on the stream the kernel is launched on; cvcl_prof_collect synchronises them and
+ * returns the summed device time and launch count per kernel class.  Off by default (zero overhead).  */
+enum { CVCL_K_GEMM = 0, CVCL_K_GCONV = 1, CVCL_K_STEM = 2, CVCL_K_BN_FINALIZE = 3, CVCL_K_BN_ADD_RELU = 4,
+       CVCL_K_MAXPOOL = 5, CVCL_K_AVGPOOL = 6, CVCL_K_HEAD = 7, CVCL_K_OTHER = 8, CVCL_K_ATTENTION = 9,
+       CVCL_K_LAYERNORM = 10, CVCL_K_LSTM = 11, CVCL_K_GEMM_F32 = 12, CVCL_K_NCLASSES = 13 };
+int cvcl_prof_enable(int on);
+int cvcl_prof_collect(double* ms_per_class, long* launches_per_class, int n_classes);
+
 /* ------------------------------------------------------------------------------------------
  * Text encoder, "embedding" branch.  Replaces nn.Embedding + sum/len
  * (multimodal/multimodal.py:496-503; table built at :311-312, padding_idx = 0).
@@ -80,6 +89,9 @@ int cvcl_infonce_fwd(const float* logits, int N, float* scalars5, float* row_lse
                      void* workspace, size_t workspace_bytes, void* stream);
 int cvcl_infonce_bwd(const float* logits, const float* row_lse, const float* col_lse, const float* d_loss,
                      float* d_logits, int N, void* stream);
+
+/* get_entropy(logits, dim=-1) (multimodal/utils.py:106-108): out[r] = -sum_j p log p of softmax(x[r,:]). */
+int cvcl_row_entropy(const float* x, float* out, int R, int N, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * MFMA GEMM with fused prologue/epilogue -- the 1x1 convolutions of torchvision's Bottleneck

@@ -1,6 +1,10 @@
-// Error plumbing + version query of libcvcl_hip.so (no exceptions cross the C ABI).
+// Error plumbing, version query and the optional per-kernel-class HIP-event timer of libcvcl_hip.so
+// (no exceptions cross the C ABI).
+#include <hip/hip_runtime.h>
+
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 
 #include "../../include/cvcl_hip.h"
 
@@ -15,3 +19,50 @@ void cvcl_set_error(const char* fmt, ...) {
 
 extern "C" int cvcl_abi_version(void) { return CVCL_ABI_VERSION; }
 extern "C" const char* cvcl_last_error(void) { return g_err; }
+
+// ---- per-kernel-class timing with HIP events recorded on the stream each kernel is launched on ----
+namespace {
+struct Rec { hipEvent_t a, b; int cls; };
+bool g_prof = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+}  // namespace
+
+bool cvcl_prof_on() { return g_prof; }
+void* cvcl_prof_begin(void* stream, int cls) {
+    if (!g_prof) return nullptr;
+    Rec r{get_event(), get_event(), cls};
+    if (!r.a || !r.b) return nullptr;
+    (void)hipEventRecord(r.a, (hipStream_t)stream);
+    g_recs.push_back(r);
+    return (void*)(uintptr_t)g_recs.size();          // 1-based handle
+}
+void cvcl_prof_end(void* handle, void* stream) {
+    if (!handle) return;
+    (void)hipEventRecord(g_recs[(uintptr_t)handle - 1].b, (hipStream_t)stream);
+}
+
+extern "C" int cvcl_prof_enable(int on) {
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    g_prof = on != 0;
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_prof_collect(double* ms_per_class, long* launches_per_class, int n_classes) {
+    if (!ms_per_class || !launches_per_class || n_classes <= 0) { cvcl_set_error("cvcl_prof_collect: bad args"); return CVCL_EINVAL; }
+    for (int i = 0; i < n_classes; ++i) { ms_per_class[i] = 0.0; launches_per_class[i] = 0; }
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) { cvcl_set_error("cvcl_prof_collect: event sync failed"); return CVCL_ELAUNCH; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        if (r.cls >= 0 && r.cls < n_classes) { ms_per_class[r.cls] += ms; launches_per_class[r.cls] += 1; }
+    }
+    return CVCL_OK;
+}

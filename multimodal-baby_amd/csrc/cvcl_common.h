@@ -18,6 +18,16 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // thread-local last error text (cvcl_last_error)
 void cvcl_set_error(const char* fmt, ...);
 
+// optional HIP-event timing of a launch (see cvcl_prof_enable in include/cvcl_hip.h)
+bool cvcl_prof_on();
+void* cvcl_prof_begin(void* stream, int cls);
+void cvcl_prof_end(void* handle, void* stream);
+struct CvclProfScope {
+    void* h; void* s;
+    CvclProfScope(void* stream, int cls) : h(cvcl_prof_begin(stream, cls)), s(stream) {}
+    ~CvclProfScope() { cvcl_prof_end(h, s); }
+};
+
 #define CVCL_CHECK_ARG(cond, ...)                \
     do {                                         \
         if (!(cond)) {                           \

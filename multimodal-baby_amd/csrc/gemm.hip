@@ -363,6 +363,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(gm, cvcl_div_up(a->N, BN));
+    CvclProfScope prof(stream, sizeof(T) == 2 ? CVCL_K_GEMM : CVCL_K_GEMM_F32);
     hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(256), lds, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -388,6 +389,7 @@ extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {
 extern "C" int cvcl_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
     CVCL_CHECK_ARG(in && out && rows > 0 && cols > 0, "cvcl_transpose_f32: bad args");
     dim3 grid(cvcl_div_up(cols, 32), cvcl_div_up(rows, 32));
+    CvclProfScope prof(stream, CVCL_K_OTHER);
     hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, in, out, rows, cols);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -395,6 +397,7 @@ extern "C" int cvcl_transpose_f32(const float* in, float* out, int rows, int col
 
 extern "C" int cvcl_colsum_f32(const float* dY, float* d_bias, int M, int N, void* stream) {
     CVCL_CHECK_ARG(dY && d_bias && M > 0 && N > 0, "cvcl_colsum_f32: bad args");
+    CvclProfScope prof(stream, CVCL_K_OTHER);
     hipLaunchKernelGGL(colsum_f32_kernel, dim3(cvcl_div_up(N, 64)), dim3(256), 0, (hipStream_t)stream, dY, d_bias, M, N);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;

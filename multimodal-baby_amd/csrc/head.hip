@@ -189,6 +189,22 @@ __global__ __launch_bounds__(1024) void infonce_cols_kernel(const float* __restr
     }
 }
 
+// out[r] = entropy of softmax(x[r, :])  (get_entropy, reference multimodal/utils.py:106-108); one wave per row
+__global__ __launch_bounds__(256) void row_entropy_kernel(const float* __restrict__ x, float* __restrict__ out, int R, int N) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    OnlineSm st;
+    st.init();
+    for (int j = lane; j < N; j += 64) st.push(x[(long)row * N + j], j);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(st.m, o, 64), s2 = __shfl_xor(st.s, o, 64), t2 = __shfl_xor(st.t, o, 64);
+        const int a2 = __shfl_xor(st.arg, o, 64);
+        st.merge(m2, s2, t2, a2);
+    }
+    if (lane == 0) out[row] = st.m + logf(st.s) - st.t / st.s;
+}
+
 // scalars = {infonce, image_accuracy, text_accuracy, image_entropy, text_entropy}; fixed summation order
 __global__ __launch_bounds__(256) void infonce_finalize_kernel(const float* __restrict__ ws, int N,
                                                                float* __restrict__ scalars) {
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict_
 extern "C" int cvcl_embed_meanpool_fwd(const float* table, const int64_t* tok, const int64_t* len, float* ret,
                                        float* out_ble, int B, int L, int E, int V, void* stream) {
     CVCL_CHECK_ARG(table && tok && len && ret, "cvcl_embed_meanpool_fwd: null pointer");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
     CVCL_CHECK_ARG(B > 0 && L > 0 && E > 0 && V > 0, "cvcl_embed_meanpool_fwd: bad shape");
     hipLaunchKernelGGL(embed_meanpool_fwd_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, table, tok, len, ret,
                        out_ble, L, E, V);
@@ -260,6 +277,7 @@ extern "C" int cvcl_embed_meanpool_fwd(const float* table, const int64_t* tok, c
 extern "C" int cvcl_embed_meanpool_bwd(const float* d_ret, const int64_t* tok, const int64_t* len, float* d_table,
                                        int B, int L, int E, int V, void* stream) {
     CVCL_CHECK_ARG(d_ret && tok && len && d_table, "cvcl_embed_meanpool_bwd: null pointer");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
     CVCL_CHECK_ARG(B > 0 && L > 0 && E > 0 && V > 0, "cvcl_embed_meanpool_bwd: bad shape");
     hipLaunchKernelGGL(embed_meanpool_bwd_kernel, dim3(V), dim3(128), 0, (hipStream_t)stream, d_ret, tok, len, d_table,
                        B, L, E);
@@ -269,6 +287,7 @@ extern "C" int cvcl_embed_meanpool_bwd(const float* d_ret, const int64_t* tok, c
 
 extern "C" int cvcl_l2norm_fwd(const float* x, float* y, float* norm, int N, int E, float eps, void* stream) {
     CVCL_CHECK_ARG(x && y && norm && N > 0 && E > 0, "cvcl_l2norm_fwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
     hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cvcl_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, x, y, norm, N, E, eps);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -277,6 +296,7 @@ extern "C" int cvcl_l2norm_fwd(const float* x, float* y, float* norm, int N, int
 extern "C" int cvcl_l2norm_bwd(const float* y, const float* norm, const float* dy, float* dx, int N, int E, float eps,
                                void* stream) {
     CVCL_CHECK_ARG(y && norm && dy && dx && N > 0 && E > 0, "cvcl_l2norm_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cvcl_div_up(N, 4)), dim3(256), 0, (hipStream_t)stream, y, norm, dy, dx, N, E, eps);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -330,6 +350,7 @@ extern "C" int cvcl_sim_logits_bwd(const float* img, const float* txt, const flo
         if ((rc = cvcl_gemm(CVCL_F32, &a, stream))) return rc;
     }
     if (d_neg_log_temp) {                          // d/d(log s) of s*M  =  sum(dS * logits)
+        CvclProfScope prof(stream, CVCL_K_HEAD);
         CVCL_CHECK_ARG(logits, "cvcl_sim_logits_bwd: logits needed for the temperature gradient");
         hipLaunchKernelGGL(dot_partial_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, d_logits, logits,
                            (long)Ni * Nt, part);
@@ -344,6 +365,7 @@ extern "C" size_t cvcl_infonce_workspace_bytes(int N) { return (size_t)6 * N * s
 extern "C" int cvcl_infonce_fwd(const float* logits, int N, float* scalars5, float* row_lse, float* col_lse,
                                 void* workspace, size_t workspace_bytes, void* stream) {
     CVCL_CHECK_ARG(logits && scalars5 && row_lse && col_lse && workspace && N > 0, "cvcl_infonce_fwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
     if (workspace_bytes < cvcl_infonce_workspace_bytes(N)) {
         cvcl_set_error("cvcl_infonce_fwd: workspace too small");
         return CVCL_EWORKSPACE;
@@ -360,11 +382,20 @@ extern "C" int cvcl_infonce_fwd(const float* logits, int N, float* scalars5, flo
 extern "C" int cvcl_infonce_bwd(const float* logits, const float* row_lse, const float* col_lse, const float* d_loss,
                                 float* d_logits, int N, void* stream) {
     CVCL_CHECK_ARG(logits && row_lse && col_lse && d_loss && d_logits && N > 0, "cvcl_infonce_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
     const long total = (long)N * N;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(infonce_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits, row_lse, col_lse,
                        d_loss, d_logits, N);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_row_entropy(const float* x, float* out, int R, int N, void* stream) {
+    CVCL_CHECK_ARG(x && out && R > 0 && N > 0, "cvcl_row_entropy: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(row_entropy_kernel, dim3(cvcl_div_up(R, 4)), dim3(256), 0, (hipStream_t)stream, x, out, R, N);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

@@ -492,6 +492,7 @@ extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const 
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                 float eps, float* scale, float* shift, int C, void* stream) {
     CVCL_CHECK_ARG(stats && gamma && beta && scale && shift && rows > 0 && count > 0 && C > 0, "cvcl_bn_finalize: bad args");
+    CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 64)), dim3(256), 0, (hipStream_t)stream, stats, rows,
                        (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                        shift, C);
@@ -502,6 +503,7 @@ extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const 
 extern "C" int cvcl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                                    const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
     CVCL_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "cvcl_bn_eval_affine: bad args");
+    CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cvcl_div_up(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
                        running_mean, running_var, eps, scale, shift, C);
     CVCL_LAUNCH_CHECK();
@@ -516,6 +518,7 @@ extern "C" int cvcl_col_stats_rows(long rows) {
 
 extern "C" int cvcl_col_stats(int dtype, const void* x, long rows, int C, float* stats, int stats_rows, void* stream) {
     CVCL_CHECK_ARG(x && stats && rows > 0 && C > 0, "cvcl_col_stats: bad args");
+    CvclProfScope prof(stream, CVCL_K_OTHER);
     const int g = cvcl_col_stats_rows(rows);
     CVCL_CHECK_ARG(stats_rows >= g, "cvcl_col_stats: stats_rows %d < %d", stats_rows, g);
     dim3 grid(g, cvcl_div_up(C, 64));
@@ -538,6 +541,7 @@ extern "C" size_t cvcl_packed_weight_bytes(int dtype, int kind, int cout, int ci
 extern "C" int cvcl_pack_conv_weight(int dtype, int kind, const float* w_oihw, void* out, int cout, int cin_per_group,
                                      int k, void* stream) {
     CVCL_CHECK_ARG(w_oihw && out && cout > 0 && cin_per_group > 0, "cvcl_pack_conv_weight: bad args");
+    CvclProfScope prof(stream, CVCL_K_OTHER);
     hipStream_t s = (hipStream_t)stream;
     const long n = (long)cout * cin_per_group * k * k;
     if (dtype == CVCL_F32) {                       // parity mode keeps the reference layout
@@ -582,14 +586,16 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
         const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4;
         float* st = stats;
         CVCL_CHECK_ARG(st, "cvcl_stem_conv7x7: the bf16 kernel always emits statistics; pass a buffer");
+        CvclProfScope prof(stream, CVCL_K_STEM);
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(g), dim3(256), lds, s, x_nchw, (const bf16_t*)w_packed, (bf16_t*)y_nhwc,
                            st, B, H, W);
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }
     const long total = (long)B * (H / 2) * (W / 2) * 64;
+    { CvclProfScope prof(stream, CVCL_K_STEM);
     hipLaunchKernelGGL(stem_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, x_nchw,
-                       (const float*)w_packed, (float*)y_nhwc, B, H, W);
+                       (const float*)w_packed, (float*)y_nhwc, B, H, W); }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y_nhwc, (long)B * (H / 2) * (W / 2), 64, stats, stats_rows, stream);
     return CVCL_OK;
@@ -598,6 +604,7 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
 extern "C" int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int B,
                                     int H, int W, int C, void* stream) {
     CVCL_CHECK_ARG(x && scale && shift && y && C % 8 == 0, "cvcl_bn_relu_maxpool: bad args");
+    CvclProfScope prof(stream, CVCL_K_MAXPOOL);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long total = (long)B * Ho * Wo * (C / 8);
     if (dtype == CVCL_F32)
@@ -660,13 +667,15 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
             }
             attr_set = true;
         }
+        CvclProfScope prof(stream, CVCL_K_GCONV);
         hipLaunchKernelGGL(gconv_mfma_kernel, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }
     const long total = (long)B * Ho * Wo * C;
+    { CvclProfScope prof(stream, CVCL_K_GCONV);
     hipLaunchKernelGGL(gconv_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, (const float*)x, a_scale,
-                       a_shift, (const float*)w_packed, (float*)y, B, H, W, C, cg, stride, Ho, Wo);
+                       a_shift, (const float*)w_packed, (float*)y, B, H, W, C, cg, stride, Ho, Wo); }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y, (long)B * Ho * Wo, C, stats, stats_rows, stream);
     return CVCL_OK;
@@ -675,6 +684,7 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
 extern "C" int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, const float* shift, const void* idn,
                                 const float* idn_scale, const float* idn_shift, void* out, long rows, int C, void* stream) {
     CVCL_CHECK_ARG(raw && scale && shift && idn && out && rows > 0 && C % 8 == 0, "cvcl_bn_add_relu: bad args");
+    CvclProfScope prof(stream, CVCL_K_BN_ADD_RELU);
     CVCL_CHECK_ARG((idn_scale == nullptr) == (idn_shift == nullptr), "cvcl_bn_add_relu: idn_scale/idn_shift pair");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_F32)
@@ -689,6 +699,7 @@ extern "C" int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, 
 
 extern "C" int cvcl_avgpool(int dtype, const void* x, float* out, int B, int HW, int C, void* stream) {
     CVCL_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "cvcl_avgpool: bad args");
+    CvclProfScope prof(stream, CVCL_K_AVGPOOL);
     if (dtype == CVCL_F32)
         hipLaunchKernelGGL(avgpool_kernel<float>, dim3(grid_for((long)B * C)), dim3(256), 0, (hipStream_t)stream, (const float*)x, out, B, HW, C);
     else

@@ -19,6 +19,8 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ABI_VERSION = 1
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
+KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
+                  "other", "attention", "layernorm", "lstm", "gemm_f32")
 
 
 class CvclError(RuntimeError):
@@ -49,6 +51,8 @@ _P, _I, _F, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "cvcl_abi_version": (_I, []),
     "cvcl_last_error": (C.c_char_p, []),
+    "cvcl_prof_enable": (_I, [_I]),
+    "cvcl_prof_collect": (_I, [_P, _P, _I]),
     "cvcl_embed_meanpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_embed_meanpool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _F, _P]),
@@ -59,6 +63,7 @@ SIGNATURES = {
     "cvcl_infonce_workspace_bytes": (_SZ, [_I]),
     "cvcl_infonce_fwd": (_I, [_P, _I, _P, _P, _P, _P, _SZ, _P]),
     "cvcl_infonce_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P]),
+    "cvcl_row_entropy": (_I, [_P, _P, _I, _I, _P]),
     "cvcl_gemm_grid_m": (_I, [_I, _I, _I]),
     "cvcl_gemm": (_I, [_I, C.POINTER(GemmArgs), _P]),
     "cvcl_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
@@ -179,3 +184,16 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
 
 def gemm_grid_m(dtype: int, M: int, N: int) -> int:
     return lib().cvcl_gemm_grid_m(dtype, M, N)
+
+
+def prof_enable(on: bool):
+    check(lib().cvcl_prof_enable(int(on)), "cvcl_prof_enable")
+
+
+def prof_collect():
+    """-> {class_name: (total_ms, launches)} for the launches recorded since prof_enable(True)."""
+    n = len(KERNEL_CLASSES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_long * n)()
+    check(lib().cvcl_prof_collect(ms, cnt, n), "cvcl_prof_collect")
+    return {KERNEL_CLASSES[i]: (ms[i], cnt[i]) for i in range(n)}

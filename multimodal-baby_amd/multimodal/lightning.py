@@ -1,0 +1,164 @@
+"""The slice of pytorch_lightning 1.6 that train.py and MultiModalLitModel rely on.
+
+pytorch_lightning is not installed in this image, and the reference pins 1.6.0 whose Trainer predates
+ROCm 7 wheels; this module provides ``LightningModule`` / ``LightningDataModule`` / ``Trainer`` /
+``seed_everything`` with the behaviours the entry point uses: the Trainer CLI flags, ``--fast_dev_run``,
+the fit loop (train()/eval(), batch to device, training_step -> backward -> optimizer.step), self.log
+collection, ``save_hyperparameters`` and a one-process-per-GPU data-parallel mode over RCCL."""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def seed_everything(seed: int):
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    os.environ["PL_GLOBAL_SEED"] = str(seed)
+    return seed
+
+
+def _str2bool(v):
+    if isinstance(v, bool):
+        return v
+    return str(v).lower() in ("1", "true", "yes", "y")
+
+
+class LightningDataModule:
+    def __init__(self):
+        pass
+
+    def prepare_data(self, *a, **k):
+        pass
+
+    def setup(self, *a, **k):
+        pass
+
+
+class LightningModule(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._logged = {}
+        self.hparams = {}
+        self.trainer = None
+
+    def save_hyperparameters(self, *args, **kwargs):
+        import inspect
+        frame = inspect.currentframe().f_back
+        local = frame.f_locals
+        self.hparams = {k: v for k, v in local.items() if k not in ("self", "__class__")}
+
+    def log(self, name, value, *args, **kwargs):
+        self._logged[name] = value
+
+    @property
+    def device(self):
+        for p in self.parameters():
+            return p.device
+        return torch.device("cpu")
+
+    def configure_optimizers(self):
+        raise NotImplementedError
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
+        ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
+        model = cls(**ckpt["hyper_parameters"])
+        model.load_state_dict(ckpt["state_dict"])
+        return model
+
+
+def _move(batch, device):
+    if torch.is_tensor(batch):
+        return batch.to(device, non_blocking=True)
+    if isinstance(batch, (list, tuple)):
+        return type(batch)(_move(b, device) for b in batch)
+    return batch
+
+
+class Trainer:
+    """Minimal fit loop with the flags the reference's configs use."""
+
+    FLAGS = (("gpus", int, 0), ("max_epochs", int, 1), ("check_val_every_n_epoch", int, 1),
+             ("checkpoint_callback", _str2bool, True), ("logger", _str2bool, True), ("fast_dev_run", None, False),
+             ("strategy", str, None), ("devices", int, None), ("precision", str, "32"), ("limit_train_batches", int, None))
+
+    @classmethod
+    def add_argparse_args(cls, parser):
+        for name, typ, default in cls.FLAGS:
+            if name == "fast_dev_run":
+                parser.add_argument("--fast_dev_run", nargs="?", const=True, default=False, type=_str2bool)
+            else:
+                parser.add_argument("--" + name, type=typ, default=default)
+        return parser
+
+    @classmethod
+    def from_argparse_args(cls, args, **kwargs):
+        kw = {name: getattr(args, name, default) for name, _t, default in cls.FLAGS}
+        kw.update(kwargs)
+        return cls(**kw)
+
+    def __init__(self, gpus=0, max_epochs=1, check_val_every_n_epoch=1, checkpoint_callback=True, logger=True,
+                 fast_dev_run=False, strategy=None, devices=None, precision="32", limit_train_batches=None,
+                 callbacks=None, enable_checkpointing=None, **_ignored):
+        self.gpus, self.max_epochs = gpus or 0, max_epochs
+        self.fast_dev_run = fast_dev_run
+        self.precision = str(precision)
+        self.limit_train_batches = 1 if fast_dev_run else limit_train_batches
+        if fast_dev_run:
+            self.max_epochs = 1
+        self.callbacks = callbacks or []
+        self.logged_metrics = {}
+        self.global_step = 0
+
+    def _device(self):
+        if self.gpus and self.gpus > 0:
+            if not torch.cuda.is_available():
+                raise RuntimeError("--gpus > 0 but no GPU is visible")
+            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+        return torch.device("cpu")
+
+    def fit(self, model, datamodule=None, ckpt_path=None):
+        from . import parallel
+        device = self._device()
+        engine = parallel.DataParallelEngine.from_env(device)
+        model.trainer = self
+        datamodule.prepare_data()
+        datamodule.setup()
+        model.to(device)
+        if hasattr(model, "set_precision"):
+            model.set_precision(self.precision)
+        opt = model.configure_optimizers()
+        sched = None
+        if isinstance(opt, dict):
+            sched, opt = opt.get("lr_scheduler"), opt["optimizer"]
+        if ckpt_path is not None and os.path.exists(str(ckpt_path)):
+            ckpt = torch.load(str(ckpt_path), map_location="cpu", weights_only=False)
+            model.load_state_dict(ckpt["state_dict"])
+        engine.attach(model)
+        for epoch in range(self.max_epochs):
+            model.train()
+            outs = []
+            for bi, batch in enumerate(datamodule.train_dataloader()):
+                if self.limit_train_batches is not None and bi >= self.limit_train_batches:
+                    break
+                batch = _move(batch, device)
+                opt.zero_grad(set_to_none=True)
+                out = model.training_step(batch, bi)
+                out["loss"].backward()
+                engine.reduce_gradients()
+                opt.step()
+                self.global_step += 1
+                outs.append({k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()})
+            if hasattr(model, "training_epoch_end") and outs:
+                model.training_epoch_end(outs)
+            self.logged_metrics.update(model._logged)
+            if sched is not None and "val_loss" in self.logged_metrics:
+                sched["scheduler"].step(float(self.logged_metrics["val_loss"]))
+        return self

@@ -1,0 +1,342 @@
+"""CVCL model classes with the reference's surface, computed by libcvcl_hip (MI355X).
+
+Same class names, constructor signatures, ``add_to_argparse`` flags, return tuples and parameter names as
+the reference ``multimodal/multimodal.py`` (VisionEncoder :56-194, TextEncoder :278-688, MultiModalModel
+:691-822, LanguageModel :825-960) for the flat / contrastive path; every arithmetic step is a HIP kernel
+reached through the C ABI (``ops.py`` / ``resnext.py`` / ``vision_transformer_dino_mugs.py``).  Branches
+the contrastive configurations never take (spatial similarity, cbow, captioning/attention LM, beam
+search) raise NotImplementedError instead of silently falling back to PyTorch ops.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops, parallel, resnext
+from .attention_maps import Hook
+from .multimodal_data_module import MAX_LEN_UTTERANCE, PAD_TOKEN_ID
+from .utils import load_model
+
+TEXT_ENCODER = "embedding"
+ATTENTION_ACTIVATION = "relu"
+EMBEDDING_TYPE = "flat"
+EMBEDDING_DIM = 128
+CRANGE = 1
+DROPOUT_I = 0.0
+DROPOUT_O = 0.0
+PRETRAINED_CNN = True
+FINETUNE_CNN = False
+NORMALIZE_FEATURES = False
+SIM = "max"
+TEMPERATURE = 0.07
+FIX_TEMPERATURE = False
+CNN_MODEL = "models/TC-S-resnext.tar"
+CNN_DINO = False
+VIT_DINO = False
+POS_EMBED_TYPE = "no_pos_embed"
+
+_TORCHVISION_MODELS = {"resnext50_32x4d": resnext.resnext50_32x4d}
+
+
+def set_parameter_requires_grad(model, feature_extracting=True):
+    if feature_extracting:
+        for param in model.parameters():
+            param.requires_grad = False
+
+
+class VisionEncoder(nn.Module):
+    """ResNeXt-50 / DINO ViT image encoder + linear projection to the embedding space."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = vars(args) if args is not None else {}
+        self.embedding_type = self.args.get("embedding_type")
+        self.embedding_dim = self.args.get("embedding_dim")
+        self.pretrained_cnn = self.args.get("pretrained_cnn")
+        self.cnn_model = self.args.get("cnn_model", CNN_MODEL)
+        self.cnn_dino = self.args.get("cnn_dino", CNN_DINO)
+        self.vit_dino = self.args.get("vit_dino", VIT_DINO)
+        self.finetune_cnn = self.args.get("finetune_cnn")
+        self.model = self._load_pretrained_cnn()
+
+    @staticmethod
+    def add_to_argparse(parser):
+        parser.add_argument("--pretrained_cnn", action="store_true", help="use pretrained CNN")
+        parser.add_argument("--cnn_model", type=str, default=CNN_MODEL)
+        parser.add_argument("--cnn_dino", action="store_true", default=CNN_DINO)
+        parser.add_argument("--vit_dino", action="store_true", default=VIT_DINO)
+        parser.add_argument("--finetune_cnn", action="store_true")
+
+    def forward(self, x):
+        if getattr(self, "vit_dino", False):
+            cls = self.model(x)                               # pre-head cls token (reference :91)
+            return ops.linear_f32(cls, self.model.head.weight, self.model.head.bias), None   # reference :92
+        if self.embedding_type == "spatial":
+            raise NotImplementedError("spatial embeddings are outside the contrastive hot path (SURVEY.md 8f4)")
+        with Hook(self.model.layer4, requires_grad=False) as hook:    # reference :100-102
+            features = self.model(x)
+            feature_map = hook.activation
+        return features, feature_map
+
+    @property
+    def last_cnn_out_dim(self):
+        return 768 if self.vit_dino else 2048
+
+    def set_compute_dtype(self, dtype):
+        self.model.compute_dtype = dtype
+
+    def _load_pretrained_cnn(self):
+        if self.cnn_dino:
+            print("Loading DINO resnext model!")
+            model = load_model("dino_sfp_resnext50", self.pretrained_cnn)
+        elif self.vit_dino:
+            print("Loading DINO vision transformer model!")
+            model = load_model("dino_sfp_vitb14", self.pretrained_cnn)
+        else:
+            name, checkpoint_path = self.cnn_model, None
+            if name not in _TORCHVISION_MODELS:
+                checkpoint_path = self.cnn_model
+                if "resnext" not in name:
+                    raise AssertionError(f"Unable to recognize the model name of {name}")
+                name = "resnext50_32x4d"
+            model = _TORCHVISION_MODELS[name](pretrained=bool(self.pretrained_cnn and not checkpoint_path))
+            model.fc = nn.Linear(self.last_cnn_out_dim, 2765, bias=True)
+            if self.pretrained_cnn and checkpoint_path:
+                print("Loading pretrained CNN!")
+                ckpt = torch.load(checkpoint_path, map_location="cpu")
+                model.load_state_dict({k[len("module."):]: v for k, v in ckpt["model_state_dict"].items()})
+        if not self.finetune_cnn:
+            print("Freezing CNN layers!")
+            set_parameter_requires_grad(model)
+        else:
+            print("Fine-tuning CNN layers!")
+        if self.embedding_type == "spatial":
+            raise NotImplementedError("spatial embeddings are outside the contrastive hot path (SURVEY.md 8f4)")
+        if self.embedding_type == "flat":
+            print("Adding linear layer to vision encoder!")
+            if self.vit_dino:
+                model.head = nn.Linear(self.last_cnn_out_dim, self.embedding_dim)
+            else:
+                model.fc = nn.Linear(self.last_cnn_out_dim, self.embedding_dim)
+        return model
+
+
+class LockedDropout(nn.Module):
+    """Dropout mask shared along ``dim`` (reference :46-53).  Identity in eval mode / p = 0."""
+
+    def forward(self, x, dropout, dim=1):
+        if not (self.training and dropout):
+            return x
+        raise NotImplementedError("train-mode locked dropout needs the LSTM backward kernels (not in this build)")
+
+
+class TextEncoder(nn.Module):
+    """Embedding mean-pool / LSTM / one-layer transformer text encoder."""
+
+    def __init__(self, vocab, image_feature_map_dim, args):
+        super().__init__()
+        self.args = vars(args) if args is not None else {}
+        self.text_encoder = self.args.get("text_encoder")
+        self._captioning = self.args.get("captioning", False)
+        self._attention = self.args.get("attention", False)
+        self._attention_gate = self.args.get("attention_gate", False)
+        self.embedding_type = self.args.get("embedding_type")
+        self.embedding_dim = self.args.get("embedding_dim")
+        self.hidden_dim = self.embedding_dim
+        self.input_dim = self.embedding_dim
+        self.crange = self.args.get("crange")
+        self.dropout_i = self.args.get("dropout_i")
+        self.dropout_o = self.args.get("dropout_o")
+        self.pos_embed_type = self.args.get("pos_embed_type", POS_EMBED_TYPE)
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if self._captioning or self._attention:
+            raise NotImplementedError("captioning / attention LM branches are outside the contrastive hot path")
+        self.vocab = vocab
+        self.word2idx = self.vocab
+        self.idx2word = {idx: word for word, idx in self.vocab.items()}
+        self.embedding = nn.Embedding(self.vocab_size, self.embedding_dim, padding_idx=0)
+        if self.text_encoder in ("lstm", "bilstm"):
+            self.lstm = nn.LSTM(self.input_dim, self.hidden_dim, bidirectional=self.text_encoder == "bilstm")
+        elif self.text_encoder == "transformer":
+            print("Building transformer text encoder!")
+            import copy
+            self.encoder_layer = nn.TransformerEncoderLayer(d_model=self.embedding_dim, nhead=8)
+            # reference :322 -- nn.TransformerEncoder deep-copies the layer, leaving `encoder_layer.*` as a
+            # dead duplicate parameter set in the state_dict; kept for checkpoint parity
+            self.transformer_encoder = nn.Module()
+            self.transformer_encoder.layers = nn.ModuleList([copy.deepcopy(self.encoder_layer)])
+            if self.pos_embed_type == "sinusoidal":
+                pe = torch.zeros(MAX_LEN_UTTERANCE, self.embedding_dim)
+                position = torch.arange(0, MAX_LEN_UTTERANCE).unsqueeze(1)
+                div = torch.exp(torch.arange(0, self.embedding_dim, 2) * -(math.log(10000.0) / self.embedding_dim))
+                pe[:, 0::2] = torch.sin(position * div)
+                pe[:, 1::2] = torch.cos(position * div)
+                self.register_buffer("pos_embed", pe.unsqueeze(1))
+            elif self.pos_embed_type == "learned":
+                self.pos_embed = nn.Parameter(torch.zeros(MAX_LEN_UTTERANCE, 1, self.embedding_dim))
+        self.lockdrop = LockedDropout()
+        self.output_dropout = nn.Dropout(self.dropout_o)
+
+    @staticmethod
+    def add_to_argparse(parser):
+        parser.add_argument("--text_encoder", type=str, default=TEXT_ENCODER,
+                            choices=["embedding", "cbow", "lstm", "bilstm", "transformer"])
+        parser.add_argument("--captioning", action="store_true")
+        parser.add_argument("--attention", action="store_true")
+        parser.add_argument("--attention_activation", type=str, default=ATTENTION_ACTIVATION, choices=["relu", "tanh"])
+        parser.add_argument("--attention_gate", action="store_true")
+        parser.add_argument("--crange", type=int, default=CRANGE)
+        parser.add_argument("--dropout_i", type=float, default=DROPOUT_I)
+        parser.add_argument("--dropout_o", type=float, default=DROPOUT_O)
+        parser.add_argument("--pos_embed_type", type=str, default=POS_EMBED_TYPE,
+                            choices=["no_pos_embed", "sinusoidal", "learned"])
+
+    def forward(self, x, x_len, image_features=None, image_feature_map=None):
+        attns = None
+        if self.embedding_type != "flat":
+            raise NotImplementedError("spatial embeddings are outside the contrastive hot path (SURVEY.md 8f4)")
+        if self.dropout_o and self.training:
+            raise NotImplementedError("output dropout > 0 is not used by any contrastive configuration")
+        if self.text_encoder == "embedding":
+            ret, raw_output = ops.embed_meanpool(self.embedding.weight, x, x_len, True)       # reference :496-503
+        elif self.text_encoder == "lstm":
+            if self.dropout_i and self.training:
+                raise NotImplementedError("train-mode LSTM input dropout needs the LSTM backward kernels (not in this build)")
+            ret, raw_output = ops.lstm_text(self.embedding.weight, self.lstm, x, x_len)      # reference :513-552
+        elif self.text_encoder == "transformer":
+            if self.training:
+                raise NotImplementedError("train-mode text transformer (dropout 0.1 + backward) is not in this build")
+            pos = self.pos_embed if self.pos_embed_type in ("sinusoidal", "learned") else None
+            ret, raw_output = ops.transformer_text(self.embedding.weight, self.transformer_encoder.layers[0], pos, x, x_len)
+        else:
+            raise NotImplementedError(f"text encoder {self.text_encoder!r} is outside the contrastive hot path")
+        return ret, raw_output, attns
+
+    @property
+    def vocab_size(self):
+        return len(self.vocab)
+
+    @property
+    def regressional(self):
+        return self.text_encoder == "lstm"
+
+    @property
+    def captioning(self):
+        return getattr(self, "_captioning", False)
+
+    @property
+    def has_attention(self):
+        return getattr(self, "_attention", False)
+
+    @property
+    def has_attention_gate(self):
+        return getattr(self, "_attention_gate", False)
+
+
+class MultiModalModel(nn.Module):
+    """encode_image / encode_text / forward / calculate_contrastive_loss (reference :691-822)."""
+
+    def __init__(self, vision_encoder, text_encoder, args):
+        super().__init__()
+        self.args = vars(args) if args is not None else {}
+        self.sim = self.args.get("sim", SIM)
+        self.embedding_type = self.args.get("embedding_type", EMBEDDING_TYPE)
+        self.normalize_features = self.args.get("normalize_features", NORMALIZE_FEATURES)
+        self.initial_temperature = self.args.get("temperature", TEMPERATURE)
+        self.fix_temperature = self.args.get("fix_temperature", FIX_TEMPERATURE)
+        self.global_negatives = not self.args.get("local_negatives", False)
+        self.image_embed = vision_encoder
+        self.text_embed = text_encoder
+        # reference :712-715 -- plain CPU tensor when fixed (not a buffer, not in the state_dict), Parameter otherwise
+        self.logit_neg_log_temperature = torch.ones([]) * -np.log(self.initial_temperature)
+        if not self.fix_temperature:
+            self.logit_neg_log_temperature = nn.Parameter(self.logit_neg_log_temperature)
+            self.logit_neg_log_temperature._cvcl_replicated_grad = True
+        self._temp_dev = None
+
+    @staticmethod
+    def add_to_argparse(parser):
+        parser.add_argument("--embedding_type", type=str, default=EMBEDDING_TYPE, choices=["spatial", "flat"])
+        parser.add_argument("--embedding_dim", type=int, default=EMBEDDING_DIM)
+        parser.add_argument("--normalize_features", action="store_true")
+        parser.add_argument("--sim", type=str, default=SIM, choices=["mean", "max"])
+        parser.add_argument("--temperature", type=float, default=TEMPERATURE)
+        parser.add_argument("--fix_temperature", action="store_true")
+        parser.add_argument("--local_negatives", action="store_true",
+                            help="data-parallel runs: per-rank B x B loss with averaged gradients (Lightning DDP "
+                                 "behaviour) instead of all-gathered global negatives")
+
+    def _temperature_on(self, device):
+        t = self.logit_neg_log_temperature
+        if isinstance(t, nn.Parameter) or t.device == device:
+            return t
+        if self._temp_dev is None or self._temp_dev.device != device:
+            self._temp_dev = t.to(device=device, dtype=torch.float32)       # one-time copy of the fixed scalar
+        return self._temp_dev
+
+    def encode_image(self, image):
+        image_features, image_feature_map = self.image_embed(image)
+        if self.normalize_features:
+            image_features = ops.l2_normalize(image_features)               # reference :736
+        return image_features, image_feature_map
+
+    def encode_text(self, text, text_length):
+        text_features, text_outputs, attns = self.text_embed(text, text_length)
+        if self.normalize_features:
+            text_features = ops.l2_normalize(text_features)                  # reference :743
+        return text_features, text_outputs
+
+    def forward(self, image, text, text_length, return_image_features=False, return_text_outputs=False):
+        image_features, image_feature_map = self.encode_image(image)
+        text_features, text_outputs = self.encode_text(text, text_length)
+        if self.embedding_type != "flat":
+            raise NotImplementedError("spatial similarity is outside the contrastive hot path (SURVEY.md 8f4)")
+        fi, ft = image_features, text_features
+        if self.training and self.global_negatives and parallel.is_distributed():
+            fi, ft = parallel.gather_features(fi, ft)                        # RCCL all-gather over xGMI
+        logits_per_image = ops.sim_logits(fi, ft, self._temperature_on(fi.device))   # reference :755, :783-786
+        logits_per_text = logits_per_image.t()                               # reference :787 (bitwise the same values)
+        ret = logits_per_image, logits_per_text
+        if return_image_features:
+            ret = ret + (image_features, image_feature_map)
+        if return_text_outputs:
+            ret = ret + (text_outputs,)
+        return ret
+
+    def calculate_contrastive_loss(self, x, y, y_len):
+        logits_per_image, logits_per_text, image_features, image_feature_map, text_outputs = self(
+            x, y, y_len, return_image_features=True, return_text_outputs=True)
+        infonce_loss, m = ops.infonce(logits_per_image)                      # reference :801-818 in one kernel pass
+        return infonce_loss, m[0], m[1], m[2], m[3], logits_per_image, logits_per_text, \
+            image_features, image_feature_map, text_outputs
+
+
+class LanguageModel(nn.Module):
+    """Parameter container for the tied output layer the reference always constructs
+    (multimodal_lit.py:65; multimodal.py:825-843).  Its loss branch is outside the contrastive path."""
+
+    def __init__(self, text_encoder, args):
+        super().__init__()
+        self.args = vars(args) if args is not None else {}
+        self.text_encoder = text_encoder
+        self.output_layer = nn.Linear(text_encoder.hidden_dim, text_encoder.vocab_size, bias=self.args.get("bias", True))
+        if self.args.get("tie", True):
+            self.output_layer.weight = self.text_encoder.embedding.weight
+
+    @staticmethod
+    def add_to_argparse(parser):
+        parser.add_argument("--tie", type=lambda s: bool(eval(s)), default=True)
+        parser.add_argument("--bias", type=lambda s: bool(eval(s)), default=True)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("the language-model loss (lambda_lm > 0) is outside the contrastive hot path")
+
+    calculate_ce_loss = forward
+    beam_search_decode = forward
+
+
+def calculate_attn_reg_loss(attns):
+    raise NotImplementedError("attention regularisation is outside the contrastive hot path")

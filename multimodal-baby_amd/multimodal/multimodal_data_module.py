@@ -1,0 +1,127 @@
+"""Batch contract of the reference data modules + a synthetic data module.
+
+Mirrors the constants, ``multiModalDataset_collate_fn`` and CLI flags of the reference
+(multimodal/multimodal_data_module.py:26-54, 98-109, 283-311; multimodal_saycam_data_module.py:93-124,
+142-150).  The SAYCam / COCO loaders themselves read a private dataset from hard-coded cluster paths and
+are out of scope; ``SyntheticDataModule`` produces batches of the same shape."""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+from torch.nn.utils.rnn import pad_sequence
+
+from .lightning import LightningDataModule
+
+BATCH_SIZE = 4
+VAL_BATCH_SIZE = 16
+NUM_WORKERS = 4
+EVAL_INCLUDE_SOS_EOS = False
+N_VAL_DATALOADERS_PER_SPLIT = 2
+TEST_WHILE_VAL = False
+EVAL_TYPE = "image"
+MAX_LEN_UTTERANCE = 25
+AUGMENT_FRAMES = False
+PAD_TOKEN, UNK_TOKEN, SOS_TOKEN, EOS_TOKEN = "<pad>", "<unk>", "<sos>", "<eos>"
+PAD_TOKEN_ID, UNK_TOKEN_ID, SOS_TOKEN_ID, EOS_TOKEN_ID = 0, 1, 2, 3
+IMAGE_H = IMAGE_W = 224
+IMAGENET_MEAN, IMAGENET_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+CLIP_EVAL = False
+VOCAB_FILENAME = os.path.join(os.path.dirname(os.path.abspath(__file__)), "vocab.json")
+
+
+def read_vocab(vocab_filename=VOCAB_FILENAME):
+    with open(vocab_filename) as f:
+        return json.load(f)
+
+
+def multiModalDataset_collate_fn(batch):
+    """(img, idxs, len, raw) items -> (img [B,3,H,W], idxs [B,Lmax<=25] pad 0, len [B] int64, raw list)."""
+    img, idxs, length, raw = zip(*batch)
+    img = torch.stack(img, 0)
+    idxs = pad_sequence(idxs, batch_first=True, padding_value=PAD_TOKEN_ID)
+    length = torch.tensor(length, dtype=torch.long)
+    if idxs.size(1) > MAX_LEN_UTTERANCE:
+        idxs = idxs[:, :MAX_LEN_UTTERANCE]
+        length = torch.clamp(length, max=MAX_LEN_UTTERANCE)
+    return img, idxs, length, list(raw)
+
+
+class MultiModalDataModule(LightningDataModule):
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = vars(args) if args is not None else {}
+        self.batch_size = self.args.get("batch_size", BATCH_SIZE)
+        self.drop_last = self.args.get("drop_last", False)
+        self.val_batch_size = self.args.get("val_batch_size", VAL_BATCH_SIZE)
+        self.num_workers = self.args.get("num_workers", NUM_WORKERS)
+
+    @staticmethod
+    def add_to_argparse(parser):
+        parser.add_argument("--batch_size", type=int, default=BATCH_SIZE)
+        parser.add_argument("--drop_last", action="store_true")
+        parser.add_argument("--val_batch_size", type=int, default=VAL_BATCH_SIZE)
+        parser.add_argument("--num_workers", type=int, default=NUM_WORKERS)
+        parser.add_argument("--augment_frames", action="store_true")
+        parser.add_argument("--eval_include_sos_eos", action="store_true")
+        parser.add_argument("--test_while_val", action="store_true")
+        parser.add_argument("--eval_type", type=str, default=EVAL_TYPE, choices=["image", "text"])
+        parser.add_argument("--eval_metadata_filename", type=str, default="eval_filtered_dev.json")
+        parser.add_argument("--clip_eval", action="store_true")
+        return parser
+
+    @staticmethod
+    def add_additional_to_argparse(parser):
+        parser.add_argument("--multiple_frames", action="store_true")
+        parser.add_argument("--shuffle_utterances", action="store_true")
+        parser.add_argument("--multiple_captions", action="store_true")
+        return parser
+
+    def read_vocab(self):
+        return read_vocab()
+
+
+class SyntheticPairs(torch.utils.data.Dataset):
+    """``rand -> ImageNet normalise`` frames and ``<sos> w1..wn <eos>`` utterances (reference item shape:
+    multimodal_saycam_data_module.py:93-124; image statistics: multimodal_data_module.py:57)."""
+
+    def __init__(self, n_items: int, vocab_size: int, n_words: int = 3, seed: int = 0):
+        self.n, self.vocab_size, self.n_words, self.seed = n_items, vocab_size, n_words, seed
+        self.mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
+        self.std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
+        img = (torch.rand(3, IMAGE_H, IMAGE_W, generator=g) - self.mean) / self.std
+        words = torch.randint(4, self.vocab_size, (self.n_words,), generator=g)
+        idxs = torch.cat([torch.tensor([SOS_TOKEN_ID]), words, torch.tensor([EOS_TOKEN_ID])]).long()
+        return img, idxs, int(idxs.numel()), [" ".join(f"w{int(w)}" for w in words)]
+
+
+class SyntheticDataModule(MultiModalDataModule):
+    """``--dataset synthetic``: same batch contract as the SAYCam module, no files needed."""
+
+    def __init__(self, args=None, n_items: int = 64):
+        super().__init__(args)
+        self.n_items = max(n_items, 2 * self.batch_size)
+        self.seed = self.args.get("seed", 0)
+
+    def prepare_data(self, *a, **k):
+        pass
+
+    def setup(self, *a, **k):
+        v = len(self.read_vocab())
+        self.train_set = SyntheticPairs(self.n_items, v, seed=self.seed)
+        self.val_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 1)
+
+    def train_dataloader(self):
+        return torch.utils.data.DataLoader(self.train_set, batch_size=self.batch_size, shuffle=False,
+                                           collate_fn=multiModalDataset_collate_fn, drop_last=self.drop_last)
+
+    def val_dataloader(self):
+        return [torch.utils.data.DataLoader(self.val_set, batch_size=self.val_batch_size, shuffle=False,
+                                            collate_fn=multiModalDataset_collate_fn)]

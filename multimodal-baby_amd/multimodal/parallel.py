@@ -1,0 +1,156 @@
+"""Data-parallel sharding of the contrastive step: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference has no distributed code; under Lightning DDP it would compute the loss on each rank's local
+B x B block and average gradients.  Two modes here:
+
+* global negatives (default when world > 1): the L2-normalised image and text features of every rank are
+  all-gathered (2 x [B,E] fp32 per rank -> [world*B, E]); every rank evaluates the full symmetric InfoNCE
+  on the replicated matrices (4.3 GFLOP at 2048 x 2048 x 512 -- cheaper than a second collective) and
+  back-propagates only through its own rows.  The full-batch gradient is then the SUM over ranks of the
+  per-rank parameter gradients (no division by world); parameters whose gradient is computed identically
+  on every rank from the replicated loss (the learned temperature) are flagged ``_cvcl_replicated_grad``
+  and averaged instead.  Parity definition: the reference's ``calculate_contrastive_loss`` math applied to
+  the concatenated feature matrices.
+* local negatives (``--local_negatives``): Lightning-DDP behaviour -- local loss, gradients averaged.
+
+Gradients are reduced in size-capped buckets launched from post-accumulate-grad hooks as soon as a bucket
+is complete, so the RCCL all-reduce of early buckets runs on RCCL's stream while the rest of backward is
+still executing; ``reduce_gradients`` waits and scatters the results back.  xGMI is point-to-point (7
+links of ~153 GB/s per GPU): few large buckets keep the ring per-link efficient; the frozen-CNN step has
+only ~9 MB of gradients, i.e. a single bucket.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size() -> int:
+    return dist.get_world_size() if is_distributed() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if is_distributed() else 0
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """cat_r(x_r) along dim 0; backward hands each rank the gradient rows of its own shard.
+    (Every rank evaluates the same replicated loss, so no reduction is needed here.)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        world = dist.get_world_size()
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x) if x.is_cuda else dist.all_gather(list(out.chunk(world, 0)), x)
+        ctx.rows = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        r = dist.get_rank()
+        return grad[r * ctx.rows:(r + 1) * ctx.rows].contiguous()
+
+
+def gather_features(image_features: torch.Tensor, text_features: torch.Tensor):
+    """[B,E] per rank -> [world*B, E] on every rank (rank-major row order)."""
+    if not is_distributed():
+        return image_features, text_features
+    return _AllGatherRows.apply(image_features), _AllGatherRows.apply(text_features)
+
+
+class DataParallelEngine:
+    """Bucketed gradient all-reduce over the trainable parameters of a module."""
+
+    def __init__(self, device, bucket_bytes: int = 32 << 20, global_negatives: bool = True):
+        self.device = device
+        self.bucket_bytes = bucket_bytes
+        self.global_negatives = global_negatives
+        self.buckets = []            # list of dict(params, buf, pending, handle)
+        self._hooks = []
+
+    @classmethod
+    def from_env(cls, device, **kw):
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1 and not dist.is_initialized():
+            backend = "nccl" if device.type == "cuda" else "gloo"     # "nccl" is RCCL on ROCm
+            if device.type == "cuda":
+                torch.cuda.set_device(device)
+            dist.init_process_group(backend=backend)
+        return cls(device, **kw)
+
+    def attach(self, module: torch.nn.Module):
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.buckets = [], []
+        if not is_distributed():
+            return self
+        params = [p for p in module.parameters() if p.requires_grad]
+        params.reverse()                                   # roughly the order gradients become ready
+        cur, cur_bytes = [], 0
+        for p in params:
+            nb = p.numel() * p.element_size()
+            if cur and cur_bytes + nb > self.bucket_bytes:
+                self._new_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self._new_bucket(cur)
+        return self
+
+    def _new_bucket(self, params):
+        total = sum(p.numel() for p in params)
+        b = {"params": list(params), "buf": torch.zeros(total, dtype=params[0].dtype, device=params[0].device),
+             "pending": len(params), "handle": None, "seen": set()}
+        self.buckets.append(b)
+        for p in params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+
+    def _make_hook(self, b):
+        def hook(p):
+            if id(p) in b["seen"]:
+                return
+            b["seen"].add(id(p))
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        off = 0
+        for p in b["params"]:
+            n = p.numel()
+            if p.grad is not None:
+                b["buf"][off:off + n].copy_(p.grad.reshape(-1))
+            else:
+                b["buf"][off:off + n].zero_()
+            off += n
+        b["handle"] = dist.all_reduce(b["buf"], op=dist.ReduceOp.SUM, async_op=True)
+
+    def reduce_gradients(self):
+        """Wait for (or launch) every bucket and write the reduced gradients back into ``.grad``."""
+        if not is_distributed():
+            return
+        world = dist.get_world_size()
+        for b in self.buckets:
+            if b["handle"] is None:                         # some parameter received no gradient this step
+                self._launch(b)
+            b["handle"].wait()
+            off = 0
+            for p in b["params"]:
+                n = p.numel()
+                g = b["buf"][off:off + n].view_as(p)
+                averaged = (not self.global_negatives) or getattr(p, "_cvcl_replicated_grad", False)
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(g / world if averaged else g)
+                off += n
+            b["pending"], b["handle"] = len(b["params"]), None
+            b["seen"].clear()
