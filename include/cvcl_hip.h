@@ -115,9 +115,9 @@ typedef struct {
     /* optional epilogue */
     const float* exp_scale; const float* bias; int act;
     const void* R; int ldr;
-    float* stats; int stats_rows;    /* stats_rows = capacity (>= grid_m returned by cvcl_gemm_grid_m) */
+    float* stats; int stats_rows;    /* stats_rows = capacity (>= cvcl_gemm_grid_m(dtype, M, N, a_scale != NULL)) */
 } cvcl_gemm_args;
-int cvcl_gemm_grid_m(int dtype, int M, int N);
+int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);
 
 /* out[c][r] = in[r][c], f32 (operand re-layout for the weight-gradient GEMMs). */

@@ -14,13 +14,19 @@
 //  * bf16 storage: v_mfma_f32_32x32x16_bf16; fp32 storage: v_mfma_f32_32x32x2_f32 (exact fp32, the
 //    parity mode).  Operands are "swapped" (MFMA-A = weight rows, MFMA-B = activation rows) so each
 //    lane ends up with 4 consecutive output channels of one output row.
-//  * workgroups are persistent over M tiles (grid.x = grid_m, grid.y = N tiles): the per-channel
-//    BatchNorm statistics of the output are accumulated in registers across tiles and written once
-//    per workgroup as a partial row (deterministic, no atomics).  Workgroups (i, j) and (i, j+1)
-//    have linear ids i and i+grid_m (grid_m % 8 == 0) -> same XCD -> the A tile they share is an L2 hit.
+//  * software pipeline over the flattened (M tile, K tile) sequence: while a tile is multiplied out of
+//    LDS, the next tile's global loads are already in flight in registers -- also across M-tile
+//    boundaries, so the epilogue of one tile overlaps the loads of the next.
+//  * workgroups are persistent over M tiles (grid.x = grid_m <= what is co-resident, grid.y = N tiles):
+//    the per-channel BatchNorm statistics of the output are accumulated in registers across tiles and
+//    written once per workgroup as a partial row (deterministic, no atomics).  Workgroups (i, j) and
+//    (i, j+1) have linear ids i and i+grid_m (grid_m % 8 == 0) -> same XCD -> the A tile they share is
+//    an L2 hit.
 //  * the epilogue goes through LDS so that C is written as full 128-byte row segments (16 B per lane).
 //  * the BatchNorm(+ReLU) of the *producer* layer is applied to A while it is staged (per-K scale /
 //    shift), so a normalised activation tensor is never written to HBM.
+#include <cstdlib>
+
 #include "cvcl_common.h"
 
 namespace {
@@ -69,8 +75,13 @@ template <typename T> constexpr int gemm_lds_bytes() {
     return (BM + BN) * ROWB > 4 * 64 * stage_rowb<T>() ? (BM + BN) * ROWB : 4 * 64 * stage_rowb<T>();
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
+// Operand tile held in registers between its global load and its LDS write (4 x 16 B per operand per thread).
+template <typename T> struct TileRegs {
+    Chunk<T> a[4], w[4];
+};
+
+template <typename T, bool PRO, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-B chunk
     constexpr int BK = 8 * EPC;
     constexpr int SROW = stage_rowb<T>();
@@ -90,18 +101,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
 
     const int kc = tid & 7, r0 = tid >> 3;          // staging role: chunk kc of rows r0 + 32 j
     const float out_scale = p.exp_scale ? expf(*p.exp_scale) : 1.f;
+    const int ktiles = (p.K + BK - 1) / BK;
 
     float st_sum[8], st_sq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
 
-    for (int mti = blockIdx.x; mti < p.num_m_tiles; mti += gridDim.x) {
-        const int m0 = mti * BM;
-        long a_off[4];
-        bool a_ok[4];
+    // ---- load side of the pipeline: position (l_mt, l_kt) of the tile whose loads are in flight ----------
+    int l_mt = blockIdx.x, l_kt = 0;
+    unsigned a_off[4];                              // element offsets (every operand here is < 2^31 elements)
+    bool a_ok[4];
+    unsigned w_off[4];
+    bool w_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        w_ok[j] = n < p.N;
+        w_off[j] = (unsigned)n * (unsigned)p.ldw;
+    }
+    auto set_rows = [&](int mt) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = m0 + r0 + 32 * j;
+            const int m = mt * BM + r0 + 32 * j;
             a_ok[j] = m < p.M;
             long row = m;
             if (p.g_s > 1 && a_ok[j]) {
@@ -110,8 +131,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
                 const int oy = r / p.g_wo, ox = r - oy * p.g_wo;
                 row = ((long)b * p.g_hi + (long)oy * p.g_s) * p.g_wi + (long)ox * p.g_s;
             }
-            a_off[j] = row * p.lda;
+            a_off[j] = (unsigned)(row * p.lda);
         }
+    };
+    TileRegs<T> t;
+    float sc[EPC], sh[EPC];
+    auto issue = [&]() {                            // global -> registers for tile (l_mt, l_kt); no waiting here
+        const int k = l_kt * BK + kc * EPC;
+        if (p.vec_in) {
+            const bool k_ok = k < p.K;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (a_ok[j] && k_ok) t.a[j].load(A + a_off[j] + k); else t.a[j].zero();
+                if (w_ok[j] && k_ok) t.w[j].load(W + w_off[j] + k); else t.w[j].zero();
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const bool ok = (k + e) < p.K;
+                    t.a[j].set(e, (a_ok[j] && ok) ? ElemTraits<T>::to_f(A[a_off[j] + k + e]) : 0.f);
+                    t.w[j].set(e, (w_ok[j] && ok) ? ElemTraits<T>::to_f(W[w_off[j] + k + e]) : 0.f);
+                }
+        }
+        if constexpr (PRO) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const bool ok = (k + e) < p.K;
+                sc[e] = ok ? p.a_scale[k + e] : 0.f;
+                sh[e] = ok ? p.a_shift[k + e] : 0.f;
+            }
+        }
+    };
+    bool l_live = l_mt < p.num_m_tiles;
+    if (l_live) { set_rows(l_mt); issue(); }
+
+    for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
+        const int m0 = cm * BM;
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -120,60 +177,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        for (int k0 = 0; k0 < p.K; k0 += BK) {
-            const int k = k0 + kc * EPC;
-            Chunk<T> ca[4], cw[4];
-            if (p.vec_in) {
-                const bool k_ok = k < p.K;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (a_ok[j] && k_ok) ca[j].load(A + a_off[j] + k); else ca[j].zero();
-                    const int n = n0 + r0 + 32 * j;
-                    if (n < p.N && k_ok) cw[j].load(W + (long)n * p.ldw + k); else cw[j].zero();
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + r0 + 32 * j;
-#pragma unroll
-                    for (int e = 0; e < EPC; ++e) {
-                        const bool ok = (k + e) < p.K;
-                        ca[j].set(e, (a_ok[j] && ok) ? ElemTraits<T>::to_f(A[a_off[j] + k + e]) : 0.f);
-                        cw[j].set(e, (n < p.N && ok) ? ElemTraits<T>::to_f(W[(long)n * p.ldw + k + e]) : 0.f);
-                    }
-                }
-            }
-            if (p.a_scale) {       // BatchNorm(+ReLU) of the producer, applied on the fly
-                float sc[EPC], sh[EPC];
-#pragma unroll
-                for (int e = 0; e < EPC; ++e) {
-                    const bool ok = (k + e) < p.K;
-                    sc[e] = ok ? p.a_scale[k + e] : 0.f;
-                    sh[e] = ok ? p.a_shift[k + e] : 0.f;
-                }
+        for (int kt = 0; kt < ktiles; ++kt) {
+            // registers hold tile (cm, kt): BatchNorm(+ReLU) of the producer on the fly, then into LDS
+            if constexpr (PRO) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
-                        float v = fmaf(ca[j].get(e), sc[e], sh[e]);
+                        float v = fmaf(t.a[j].get(e), sc[e], sh[e]);
                         if (p.a_relu) v = fmaxf(v, 0.f);
-                        ca[j].set(e, v);
+                        t.a[j].set(e, v);
                     }
             }
-            __syncthreads();                      // previous K tile fully consumed
+            __syncthreads();                      // LDS free: previous tile consumed / epilogue staging drained
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                ca[j].store((T*)(sA + (r0 + 32 * j) * ROWB + kc * 16));
-                cw[j].store((T*)(sW + (r0 + 32 * j) * ROWB + kc * 16));
+                t.a[j].store((T*)(sA + (r0 + 32 * j) * ROWB + kc * 16));
+                t.w[j].store((T*)(sW + (r0 + 32 * j) * ROWB + kc * 16));
             }
             __syncthreads();
+            // advance the load position and put the next tile's loads in flight under the MFMAs (and the epilogue)
+            if (++l_kt == ktiles) {
+                l_kt = 0;
+                l_mt += gridDim.x;
+                l_live = l_mt < p.num_m_tiles;
+                if (l_live) set_rows(l_mt);
+            }
+            if (l_live) issue();
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 Frag fw[2], fa[2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    fw[t] = *reinterpret_cast<const Frag*>(sW + (wn * 64 + t * 32 + l31) * ROWB + (g * 2 + h) * 16);
-                    fa[t] = *reinterpret_cast<const Frag*>(sA + (wm * 64 + t * 32 + l31) * ROWB + (g * 2 + h) * 16);
+                for (int q = 0; q < 2; ++q) {
+                    fw[q] = *reinterpret_cast<const Frag*>(sW + (wn * 64 + q * 32 + l31) * ROWB + (g * 2 + h) * 16);
+                    fa[q] = *reinterpret_cast<const Frag*>(sA + (wm * 64 + q * 32 + l31) * ROWB + (g * 2 + h) * 16);
                 }
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -183,7 +220,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
         }
 
         // ---- epilogue: registers -> (scale, bias, act, round) -> LDS -> full-row stores ----------
-        __syncthreads();
+        __syncthreads();                          // every wave is done reading the operand tiles
         char* stg = smem + wave * 64 * SROW;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -215,9 +252,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
             const T* src = (const T*)(stg + row * SROW) + colc;
             float v[8];
             if constexpr (sizeof(T) == 2) {
-                bf16x8 t = *reinterpret_cast<const bf16x8*>(src);
+                bf16x8 tt = *reinterpret_cast<const bf16x8*>(src);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+                for (int e = 0; e < 8; ++e) v[e] = (float)tt[e];
             } else {
                 f32x4 t0 = *reinterpret_cast<const f32x4*>(src), t1 = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
@@ -228,9 +265,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
                 if (R) {
                     if (full) {
                         if constexpr (sizeof(T) == 2) {
-                            bf16x8 t = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
+                            bf16x8 tt = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                            for (int e = 0; e < 8; ++e) v[e] += (float)tt[e];
                         } else {
                             f32x4 t0 = *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n);
                             f32x4 t1 = *reinterpret_cast<const f32x4*>(R + (long)m * p.ldr + n + 4);
@@ -248,9 +285,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
                 for (int e = 0; e < 8; ++e) {
                     o[e] = ElemTraits<T>::from_f(v[e]);
                     if (n + e < p.N) {                       // statistics of the tensor as stored
-                        const float s = ElemTraits<T>::to_f(o[e]);
-                        st_sum[e] += s;
-                        st_sq[e] = fmaf(s, s, st_sq[e]);
+                        const float sv = ElemTraits<T>::to_f(o[e]);
+                        st_sum[e] += sv;
+                        st_sq[e] = fmaf(sv, sv, st_sq[e]);
                     }
                 }
                 T* dst = C + (long)m * p.ldc + n;
@@ -268,7 +305,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmDev p) {
                 }
             }
         }
-        __syncthreads();       // staging region is about to be overwritten by the next tile's operands
     }
 
     if (p.stats) {
@@ -328,12 +364,86 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     if (s == 0 && n < N) out[n] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
 }
 
-int grid_m_for(int M, int N) {
+// Resident workgroups per CU of each kernel variant (queried once); the persistent grid never exceeds what is
+// co-resident, so there is no second "wave" of workgroups and no tail.
+// bf16: the register allocator is asked for 2 or 3 workgroups per CU ($CVCL_GEMM_MINW, default 2: at 3 the
+// 168-VGPR budget spills ~25 registers to scratch); fp32 (parity mode) runs one workgroup per CU.
+template <typename T> int min_waves() {
+    if (sizeof(T) != 2) return 1;
+    static int v = 0;
+    if (!v) { const char* e = getenv("CVCL_GEMM_MINW"); v = (e && e[0] == '3') ? 3 : 2; }
+    return v;
+}
+
+template <typename T, bool PRO, int MINW>
+int resident_per_cu_v() {
+    static int cached = 0;
+    if (cached) return cached;
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_kernel<T, PRO, MINW>, 256,
+                                                     gemm_lds_bytes<T>()) != hipSuccess || n < 1)
+        n = 1;
+    cached = n > 4 ? 4 : n;
+    return cached;
+}
+template <typename T, bool PRO>
+int resident_per_cu() {
+    if constexpr (sizeof(T) == 2) return min_waves<T>() == 3 ? resident_per_cu_v<T, PRO, 3>() : resident_per_cu_v<T, PRO, 2>();
+    else return resident_per_cu_v<T, PRO, 1>();
+}
+
+int num_cus() {
+    static int cached = 0;
+    if (cached) return cached;
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1)
+        n = 256;
+    cached = n;
+    return cached;
+}
+
+// persistent grid.x: minimise the tiles per workgroup; prefer multiples of 8 so that the workgroups (i, j) and
+// (i, j+1) -- linear ids i and i + grid_m -- share an XCD and therefore the A tile in L2
+int grid_m_for(int M, int N, int capacity) {
     const int tiles = cvcl_div_up(M, BM), ntn = cvcl_div_up(N, BN);
-    int target = 768 / ntn;                 // ~3 resident workgroups per CU over 256 CUs
-    if (target < 8) target = 8;
-    target &= ~7;                           // multiple of 8: (i, j) and (i, j+1) share an XCD
-    return tiles < target ? tiles : target;
+    int cap = capacity / ntn;
+    if (cap < 1) cap = 1;
+    if (tiles <= cap) return tiles;
+    int best = cap, best_cost = cvcl_div_up(tiles, cap);
+    for (int g = cap & ~7; g >= 8 && g > cap / 2; g -= 8) {
+        const int cost = cvcl_div_up(tiles, g);
+        if (cost < best_cost || (cost == best_cost && (best & 7) != 0)) { best = g; best_cost = cost; }
+    }
+    return best;
+}
+
+template <typename T, bool PRO, int MINW>
+int launch_gemm_w(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
+    const int gm = grid_m_for(a->M, a->N, resident_per_cu<T, PRO>() * num_cus());
+    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
+    static bool attr_set = false;
+    constexpr int lds = gemm_lds_bytes<T>();
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<T, PRO, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", lds);
+            return CVCL_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid(gm, cvcl_div_up(a->N, BN));
+    CvclProfScope prof(stream, sizeof(T) == 2 ? CVCL_K_GEMM : CVCL_K_GEMM_F32);
+    hipLaunchKernelGGL((gemm_kernel<T, PRO, MINW>), grid, dim3(256), lds, stream, d);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+template <typename T, bool PRO>
+int launch_gemm_v(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2)
+        return min_waves<T>() == 3 ? launch_gemm_w<T, PRO, 3>(a, d, stream) : launch_gemm_w<T, PRO, 2>(a, d, stream);
+    else
+        return launch_gemm_w<T, PRO, 1>(a, d, stream);
 }
 
 template <typename T>
@@ -351,29 +461,18 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.vec_in = (a->K % EPC == 0) && (a->lda % EPC == 0) && (a->ldw % EPC == 0) && al16(a->A) && al16(a->W);
     d.vec_out = (a->ldc % EPC == 0) && al16(a->C) && (!a->R || ((a->ldr % EPC == 0) && al16(a->R)));
     d.num_m_tiles = cvcl_div_up(a->M, BM);
-    const int gm = grid_m_for(a->M, a->N);
-    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
-    static bool attr_set = false;
-    constexpr int lds = gemm_lds_bytes<T>();
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", lds);
-            return CVCL_ELAUNCH;
-        }
-        attr_set = true;
-    }
-    dim3 grid(gm, cvcl_div_up(a->N, BN));
-    CvclProfScope prof(stream, sizeof(T) == 2 ? CVCL_K_GEMM : CVCL_K_GEMM_F32);
-    hipLaunchKernelGGL(gemm_kernel<T>, grid, dim3(256), lds, stream, d);
-    CVCL_LAUNCH_CHECK();
-    return CVCL_OK;
+    return a->a_scale ? launch_gemm_v<T, true>(a, d, stream) : launch_gemm_v<T, false>(a, d, stream);
+}
+
+template <typename T>
+int grid_m_query(int M, int N, bool pro) {
+    return grid_m_for(M, N, (pro ? resident_per_cu<T, true>() : resident_per_cu<T, false>()) * num_cus());
 }
 
 }  // namespace
 
-extern "C" int cvcl_gemm_grid_m(int dtype, int M, int N) {
-    (void)dtype;
-    return grid_m_for(M, N);
+extern "C" int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue) {
+    return dtype == CVCL_BF16 ? grid_m_query<bf16_t>(M, N, has_prologue != 0) : grid_m_query<float>(M, N, has_prologue != 0);
 }
 
 extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {

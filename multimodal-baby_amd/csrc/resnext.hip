@@ -24,16 +24,17 @@ constexpr int kMaxStatsRows = 1024;
 // ------------------------------------------------------------------------------------------------
 // stats [rows][2][C] partial sums -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale;
 // running_mean/var EMA with the unbiased variance (nn.BatchNorm2d train mode), num_batches_tracked += 1.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int rows, double count,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          int64_t* __restrict__ nbt, float momentum, float eps,
-                                                          float* __restrict__ scale, float* __restrict__ shift, int C) {
-    __shared__ double ps[4][64], pq[4][64];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int rows, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           int64_t* __restrict__ nbt, float momentum, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift, int C) {
+    // 64 channels x 16 row slices per workgroup; slices combined in a fixed order (deterministic)
+    __shared__ double ps[16][64], pq[16][64];
     const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, ch = blockIdx.x * 64 + c;
     double s = 0.0, q = 0.0;
     if (ch < C) {
-        for (int r = sl; r < rows; r += 4) {
+        for (int r = sl; r < rows; r += 16) {
             s += (double)stats[((long)r * 2 + 0) * C + ch];
             q += (double)stats[((long)r * 2 + 1) * C + ch];
         }
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     pq[sl][c] = q;
     __syncthreads();
     if (sl == 0 && ch < C) {
-        s = (ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c]);
-        q = (pq[0][c] + pq[1][c]) + (pq[2][c] + pq[3][c]);
+        s = 0.0; q = 0.0;
+        for (int i = 0; i < 16; ++i) { s += ps[i][c]; q += pq[i][c]; }
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -445,22 +446,45 @@ __global__ __launch_bounds__(256) void bn_add_relu_kernel(const T* __restrict__ 
                                                           const float* __restrict__ idn_scale,
                                                           const float* __restrict__ idn_shift, T* __restrict__ out,
                                                           long rows, int C) {
+    // The grid stride (gridDim * 256 chunks) is a multiple of the chunks per row (C / EPC divides 256 for every
+    // ResNeXt width), so a thread always lands on the same channel chunk: the per-channel affine is loaded once.
     constexpr int EPC = ElemTraits<T>::kPerChunk;
     const int CC = C / EPC;
     const long total = rows * CC;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CC) * EPC;
-        Chunk<T> a, d, o;
-        a.load(raw + i * EPC);
-        d.load(idn + i * EPC);
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % CC) * EPC;
+    float sc[EPC], sh[EPC], isc[EPC], ish[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = scale[c + e];
+        sh[e] = shift[c + e];
+        isc[e] = idn_scale ? idn_scale[c + e] : 1.f;
+        ish[e] = idn_scale ? idn_shift[c + e] : 0.f;
+    }
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = i0; i < total; i += 2 * stride) {          // two independent 16-B chunks in flight per thread
+        const long j = i + stride;
+        const bool has_j = j < total;
+        Chunk<T> a0, d0, a1, d1, o;
+        a0.load(raw + i * EPC);
+        d0.load(idn + i * EPC);
+        if (has_j) { a1.load(raw + j * EPC); d1.load(idn + j * EPC); }
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-            float v = fmaf(a.get(e), scale[c + e], shift[c + e]);
-            float r = d.get(e);
-            if (idn_scale) r = fmaf(r, idn_scale[c + e], idn_shift[c + e]);
+            const float v = fmaf(a0.get(e), sc[e], sh[e]);
+            const float r = idn_scale ? fmaf(d0.get(e), isc[e], ish[e]) : d0.get(e);
             o.set(e, fmaxf(v + r, 0.f));
         }
         o.store(out + i * EPC);
+        if (has_j) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float v = fmaf(a1.get(e), sc[e], sh[e]);
+                const float r = idn_scale ? fmaf(d1.get(e), isc[e], ish[e]) : d1.get(e);
+                o.set(e, fmaxf(v + r, 0.f));
+            }
+            o.store(out + j * EPC);
+        }
     }
 }
 
@@ -493,7 +517,7 @@ extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const 
                                 float eps, float* scale, float* shift, int C, void* stream) {
     CVCL_CHECK_ARG(stats && gamma && beta && scale && shift && rows > 0 && count > 0 && C > 0, "cvcl_bn_finalize: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 64)), dim3(256), 0, (hipStream_t)stream, stats, rows,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 64)), dim3(1024), 0, (hipStream_t)stream, stats, rows,
                        (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                        shift, C);
     CVCL_LAUNCH_CHECK();
@@ -686,12 +710,21 @@ extern "C" int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, 
     CVCL_CHECK_ARG(raw && scale && shift && idn && out && rows > 0 && C % 8 == 0, "cvcl_bn_add_relu: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_ADD_RELU);
     CVCL_CHECK_ARG((idn_scale == nullptr) == (idn_shift == nullptr), "cvcl_bn_add_relu: idn_scale/idn_shift pair");
+    const int epc = dtype == CVCL_F32 ? 4 : 8;
+    CVCL_CHECK_ARG(C % epc == 0, "cvcl_bn_add_relu: C must be a multiple of %d", epc);
     hipStream_t s = (hipStream_t)stream;
+    // the kernel needs (grid * 256) % (C / epc) == 0 so that a thread keeps its channel chunk across iterations
+    const int cc = C / epc;
+    int g256 = cc, t256 = 256;
+    while (t256) { const int r = g256 % t256; g256 = t256; t256 = r; }      // gcd(cc, 256)
+    const int mult = cc / g256;
+    int grid = grid_for(rows * (long)cc, 256 * 4, 16384);
+    grid = (grid + mult - 1) / mult * mult;
     if (dtype == CVCL_F32)
-        hipLaunchKernelGGL(bn_add_relu_kernel<float>, dim3(grid_for(rows * (C / 4), 256, 8192)), dim3(256), 0, s, (const float*)raw,
+        hipLaunchKernelGGL(bn_add_relu_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)raw,
                            scale, shift, (const float*)idn, idn_scale, idn_shift, (float*)out, rows, C);
     else
-        hipLaunchKernelGGL(bn_add_relu_kernel<bf16_t>, dim3(grid_for(rows * (C / 8), 256, 8192)), dim3(256), 0, s, (const bf16_t*)raw,
+        hipLaunchKernelGGL(bn_add_relu_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)raw,
                            scale, shift, (const bf16_t*)idn, idn_scale, idn_shift, (bf16_t*)out, rows, C);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -783,7 +816,7 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
                 a.M = (int)m_in; a.N = width; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = width;
                 a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
                 if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-                if ((rc = finalize(l1, cvcl_gemm_grid_m(dtype, a.M, a.N), m_in, width))) return rc;
+                if ((rc = finalize(l1, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_in, width))) return rc;
             }
             // conv2 grouped 3x3 (stride here): R1 -> R2 [m_out, width], BN1+ReLU fused into the load
             if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), layers[l2].w, R2, training ? stats : nullptr,
@@ -797,7 +830,7 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
                 a.a_scale = scale_of(l2); a.a_shift = shift_of(l2); a.a_relu = 1;
                 a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
                 if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N), m_out, outc))) return rc;
+                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N, 1), m_out, outc))) return rc;
             }
             char* dst = last ? (char*)layer4_out_nhwc : OUT;
             if (bi == 0) {
@@ -808,7 +841,7 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
                 if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
                 a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
                 if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-                if ((rc = finalize(ld, cvcl_gemm_grid_m(dtype, a.M, a.N), m_out, outc))) return rc;
+                if ((rc = finalize(ld, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_out, outc))) return rc;
                 if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), RD, scale_of(ld), shift_of(ld), dst, m_out,
                                            outc, stream))) return rc;
                 li += 4;

@@ -64,7 +64,7 @@ SIGNATURES = {
     "cvcl_infonce_fwd": (_I, [_P, _I, _P, _P, _P, _P, _SZ, _P]),
     "cvcl_infonce_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P]),
     "cvcl_row_entropy": (_I, [_P, _P, _I, _I, _P]),
-    "cvcl_gemm_grid_m": (_I, [_I, _I, _I]),
+    "cvcl_gemm_grid_m": (_I, [_I, _I, _I, _I]),
     "cvcl_gemm": (_I, [_I, C.POINTER(GemmArgs), _P]),
     "cvcl_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "cvcl_colsum_f32": (_I, [_P, _P, _I, _I, _P]),
@@ -182,8 +182,8 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
     return out
 
 
-def gemm_grid_m(dtype: int, M: int, N: int) -> int:
-    return lib().cvcl_gemm_grid_m(dtype, M, N)
+def gemm_grid_m(dtype: int, M: int, N: int, has_prologue: bool = False) -> int:
+    return lib().cvcl_gemm_grid_m(dtype, M, N, int(has_prologue))
 
 
 def prof_enable(on: bool):

@@ -43,7 +43,6 @@ def test_argument_validation_without_gpu(lib):
     assert b"null" in l.cvcl_last_error()
     assert l.cvcl_l2norm_fwd(None, None, None, 0, 0, 1e-12, None) == -1
     assert l.cvcl_infonce_workspace_bytes(256) == 6 * 256 * 4
-    assert l.cvcl_gemm_grid_m(lib.BF16, 802816, 256) % 8 == 0
 
 
 def test_no_cpu_fallback(lib):

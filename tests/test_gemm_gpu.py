@@ -70,7 +70,7 @@ def test_gemm_fused_everything(H, dev, dt):
     bias = torch.randn(N, generator=g)
     R = torch.randn(M, N, generator=g).to(tdt)
     for act in (0, 1, 2):
-        rows = H.gemm_grid_m(H.BF16 if bf else H.F32, M, N)
+        rows = H.gemm_grid_m(H.BF16 if bf else H.F32, M, N, True)
         stats = torch.full((rows, 2, N), float("nan"), device=dev)
         y = H.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act=act, residual=R.to(dev), a_scale=sc.to(dev),
                    a_shift=sh.to(dev), a_relu=True, stats=stats)
