@@ -41,7 +41,7 @@ const char* cvcl_last_error(void);
  * returns the summed device time and launch count per kernel class.  Off by default (zero overhead).  */
 enum { CVCL_K_GEMM = 0, CVCL_K_GCONV = 1, CVCL_K_STEM = 2, CVCL_K_BN_FINALIZE = 3, CVCL_K_BN_ADD_RELU = 4,
        CVCL_K_MAXPOOL = 5, CVCL_K_AVGPOOL = 6, CVCL_K_HEAD = 7, CVCL_K_OTHER = 8, CVCL_K_ATTENTION = 9,
-       CVCL_K_LAYERNORM = 10, CVCL_K_LSTM = 11, CVCL_K_GEMM_F32 = 12, CVCL_K_NCLASSES = 13 };
+       CVCL_K_LAYERNORM = 10, CVCL_K_LSTM = 11, CVCL_K_GEMM_F32 = 12, CVCL_K_BN_APPLY = 13, CVCL_K_NCLASSES = 14 };
 int cvcl_prof_enable(int on);
 int cvcl_prof_collect(double* ms_per_class, long* launches_per_class, int n_classes);
 
@@ -167,6 +167,9 @@ int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a
 /* out = relu(raw*scale+shift + (idn | idn*idn_scale+idn_shift)), [rows, C] */
 int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, const float* shift, const void* idn,
                      const float* idn_scale, const float* idn_shift, void* out, long rows, int C, void* stream);
+/* y = relu(x*scale+shift), [rows, C]; y may alias x */
+int cvcl_bn_relu_apply(int dtype, const void* x, const float* scale, const float* shift, void* y, long rows, int C,
+                       void* stream);
 /* adaptive avgpool to 1x1 + flatten: [B,HW,C] -> [B,C] f32 */
 int cvcl_avgpool(int dtype, const void* x, float* out, int B, int HW, int C, void* stream);
 

@@ -80,7 +80,10 @@ template <typename T> struct TileRegs {
     Chunk<T> a[4], w[4];
 };
 
-template <typename T, bool PRO, int MINW>
+// PRO: 0 = plain A, 1 = A*scale+shift, 2 = relu(A*scale+shift).
+// LEAN: the convolution fast path -- 16-byte aligned operands, N a multiple of 128, no bias / activation /
+// output scale / residual: the epilogue carries no per-element predicates.  !LEAN handles everything.
+template <typename T, int PRO, bool LEAN, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-B chunk
     constexpr int BK = 8 * EPC;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     const T* __restrict__ R = (const T*)p.R;
 
     const int kc = tid & 7, r0 = tid >> 3;          // staging role: chunk kc of rows r0 + 32 j
-    const float out_scale = p.exp_scale ? expf(*p.exp_scale) : 1.f;
+    const float out_scale = (!LEAN && p.exp_scale) ? expf(*p.exp_scale) : 1.f;
     const int ktiles = (p.K + BK - 1) / BK;
 
     float st_sum[8], st_sq[8];
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     float sc[EPC], sh[EPC];
     auto issue = [&]() {                            // global -> registers for tile (l_mt, l_kt); no waiting here
         const int k = l_kt * BK + kc * EPC;
-        if (p.vec_in) {
+        if (LEAN || p.vec_in) {
             const bool k_ok = k < p.K;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
                     t.w[j].set(e, (w_ok[j] && ok) ? ElemTraits<T>::to_f(W[w_off[j] + k + e]) : 0.f);
                 }
         }
-        if constexpr (PRO) {
+        if constexpr (PRO != 0) {
 #pragma unroll
             for (int e = 0; e < EPC; ++e) {
                 const bool ok = (k + e) < p.K;
@@ -179,13 +182,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
 
         for (int kt = 0; kt < ktiles; ++kt) {
             // registers hold tile (cm, kt): BatchNorm(+ReLU) of the producer on the fly, then into LDS
-            if constexpr (PRO) {
+            if constexpr (PRO != 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         float v = fmaf(t.a[j].get(e), sc[e], sh[e]);
-                        if (p.a_relu) v = fmaxf(v, 0.f);
+                        if constexpr (PRO == 2) v = fmaxf(v, 0.f);
                         t.a[j].set(e, v);
                     }
             }
@@ -233,9 +236,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
                     T q[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = acc[nt][mt][4 * g + e] * out_scale;
-                        if (p.bias && n_glob + e < p.N) v += p.bias[n_glob + e];
-                        q[e] = ElemTraits<T>::from_f(apply_act(v, p.act));
+                        if constexpr (LEAN) {
+                            q[e] = ElemTraits<T>::from_f(acc[nt][mt][4 * g + e]);
+                        } else {
+                            float v = acc[nt][mt][4 * g + e] * out_scale;
+                            if (p.bias && n_glob + e < p.N) v += p.bias[n_glob + e];
+                            q[e] = ElemTraits<T>::from_f(apply_act(v, p.act));
+                        }
                     }
                     T* dst = (T*)(stg + (mt * 32 + l31) * SROW) + n_local;
                     if constexpr (sizeof(T) == 2) {
@@ -260,6 +267,23 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
             }
+            if constexpr (LEAN) {
+                if (m < p.M) {
+                    // v[] already holds the values as stored (converted from the staged T)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        st_sum[e] += v[e];
+                        st_sq[e] = fmaf(v[e], v[e], st_sq[e]);
+                    }
+                    T* dst = C + (long)m * p.ldc + n;
+                    if constexpr (sizeof(T) == 2) {
+                        *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(src);
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    }
+                }
+            } else
             if (m < p.M && n < p.N) {
                 const bool full = (n + 8 <= p.N) && p.vec_out;
                 if (R) {
@@ -375,21 +399,23 @@ template <typename T> int min_waves() {
     return v;
 }
 
-template <typename T, bool PRO, int MINW>
+template <typename T, int PRO, bool LEAN, int MINW>
 int resident_per_cu_v() {
     static int cached = 0;
     if (cached) return cached;
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_kernel<T, PRO, MINW>, 256,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_kernel<T, PRO, LEAN, MINW>, 256,
                                                      gemm_lds_bytes<T>()) != hipSuccess || n < 1)
         n = 1;
     cached = n > 4 ? 4 : n;
     return cached;
 }
-template <typename T, bool PRO>
+template <typename T, int PRO, bool LEAN>
 int resident_per_cu() {
-    if constexpr (sizeof(T) == 2) return min_waves<T>() == 3 ? resident_per_cu_v<T, PRO, 3>() : resident_per_cu_v<T, PRO, 2>();
-    else return resident_per_cu_v<T, PRO, 1>();
+    if constexpr (sizeof(T) == 2)
+        return min_waves<T>() == 3 ? resident_per_cu_v<T, PRO, LEAN, 3>() : resident_per_cu_v<T, PRO, LEAN, 2>();
+    else
+        return resident_per_cu_v<T, PRO, LEAN, 1>();
 }
 
 int num_cus() {
@@ -418,14 +444,16 @@ int grid_m_for(int M, int N, int capacity) {
     return best;
 }
 
-template <typename T, bool PRO, int MINW>
+template <typename T> int grid_m_query(int M, int N);
+
+template <typename T, int PRO, bool LEAN, int MINW>
 int launch_gemm_w(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
-    const int gm = grid_m_for(a->M, a->N, resident_per_cu<T, PRO>() * num_cus());
+    const int gm = grid_m_query<T>(a->M, a->N);      // same capacity for every variant (see grid_m_query)
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
     static bool attr_set = false;
     constexpr int lds = gemm_lds_bytes<T>();
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<T, PRO, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<T, PRO, LEAN, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", lds);
             return CVCL_ELAUNCH;
         }
@@ -433,18 +461,23 @@ int launch_gemm_w(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     }
     dim3 grid(gm, cvcl_div_up(a->N, BN));
     CvclProfScope prof(stream, sizeof(T) == 2 ? CVCL_K_GEMM : CVCL_K_GEMM_F32);
-    hipLaunchKernelGGL((gemm_kernel<T, PRO, MINW>), grid, dim3(256), lds, stream, d);
+    hipLaunchKernelGGL((gemm_kernel<T, PRO, LEAN, MINW>), grid, dim3(256), lds, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
 
-template <typename T, bool PRO>
+template <typename T, int PRO, bool LEAN>
 int launch_gemm_v(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     if constexpr (sizeof(T) == 2)
-        return min_waves<T>() == 3 ? launch_gemm_w<T, PRO, 3>(a, d, stream) : launch_gemm_w<T, PRO, 2>(a, d, stream);
+        return min_waves<T>() == 3 ? launch_gemm_w<T, PRO, LEAN, 3>(a, d, stream) : launch_gemm_w<T, PRO, LEAN, 2>(a, d, stream);
     else
-        return launch_gemm_w<T, PRO, 1>(a, d, stream);
+        return launch_gemm_w<T, PRO, LEAN, 1>(a, d, stream);
 }
+
+inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
+    return d.vec_in && d.vec_out && !a->bias && !a->exp_scale && !a->R && a->act == CVCL_ACT_NONE && (a->N % BN) == 0;
+}
+inline int pro_kind(const cvcl_gemm_args* a) { return !a->a_scale ? 0 : (a->a_relu ? 2 : 1); }
 
 template <typename T>
 int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
@@ -461,18 +494,25 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.vec_in = (a->K % EPC == 0) && (a->lda % EPC == 0) && (a->ldw % EPC == 0) && al16(a->A) && al16(a->W);
     d.vec_out = (a->ldc % EPC == 0) && al16(a->C) && (!a->R || ((a->ldr % EPC == 0) && al16(a->R)));
     d.num_m_tiles = cvcl_div_up(a->M, BM);
-    return a->a_scale ? launch_gemm_v<T, true>(a, d, stream) : launch_gemm_v<T, false>(a, d, stream);
+    const bool lean = is_lean(a, d);
+    switch (pro_kind(a)) {
+        case 0: return lean ? launch_gemm_v<T, 0, true>(a, d, stream) : launch_gemm_v<T, 0, false>(a, d, stream);
+        case 1: return lean ? launch_gemm_v<T, 1, true>(a, d, stream) : launch_gemm_v<T, 1, false>(a, d, stream);
+        default: return lean ? launch_gemm_v<T, 2, true>(a, d, stream) : launch_gemm_v<T, 2, false>(a, d, stream);
+    }
 }
 
+// every variant of one dtype is compiled for the same occupancy target, so one query stands for all of them
 template <typename T>
-int grid_m_query(int M, int N, bool pro) {
-    return grid_m_for(M, N, (pro ? resident_per_cu<T, true>() : resident_per_cu<T, false>()) * num_cus());
+int grid_m_query(int M, int N) {
+    return grid_m_for(M, N, resident_per_cu<T, 0, true>() * num_cus());
 }
 
 }  // namespace
 
 extern "C" int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue) {
-    return dtype == CVCL_BF16 ? grid_m_query<bf16_t>(M, N, has_prologue != 0) : grid_m_query<float>(M, N, has_prologue != 0);
+    (void)has_prologue;
+    return dtype == CVCL_BF16 ? grid_m_query<bf16_t>(M, N) : grid_m_query<float>(M, N);
 }
 
 extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {

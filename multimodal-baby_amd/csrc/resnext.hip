@@ -488,6 +488,39 @@ __global__ __launch_bounds__(256) void bn_add_relu_kernel(const T* __restrict__ 
     }
 }
 
+// y = relu(x * scale + shift) over [rows, C] (may run in place).  Used ahead of conv3: applying BatchNorm in the
+// GEMM's operand load costs the affine once per 128-column tile of the output (2..16x redundant VALU work that
+// also stalls the MFMA pipe), while this pass touches the narrow tensor exactly once.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ y,
+                                                            long rows, int C) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int CC = C / EPC;
+    const long total = rows * CC;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % CC) * EPC;                 // fixed per thread: (grid * 256) % CC == 0 (see launcher)
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = i0; i < total; i += 2 * stride) {
+        const long j = i + stride;
+        const bool has_j = j < total;
+        Chunk<T> a0, a1, o;
+        a0.load(x + i * EPC);
+        if (has_j) a1.load(x + j * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, fmaxf(fmaf(a0.get(e), sc[e], sh[e]), 0.f));
+        o.store(y + i * EPC);
+        if (has_j) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) o.set(e, fmaxf(fmaf(a1.get(e), sc[e], sh[e]), 0.f));
+            o.store(y + j * EPC);
+        }
+    }
+}
+
 // global average pool: [B, HW, C] -> [B, C] fp32
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, int B, int HW, int C) {
@@ -730,6 +763,28 @@ extern "C" int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, 
     return CVCL_OK;
 }
 
+extern "C" int cvcl_bn_relu_apply(int dtype, const void* x, const float* scale, const float* shift, void* y, long rows,
+                                  int C, void* stream) {
+    CVCL_CHECK_ARG(x && scale && shift && y && rows > 0, "cvcl_bn_relu_apply: bad args");
+    CvclProfScope prof(stream, CVCL_K_BN_APPLY);
+    const int epc = dtype == CVCL_F32 ? 4 : 8;
+    CVCL_CHECK_ARG(C % epc == 0, "cvcl_bn_relu_apply: C must be a multiple of %d", epc);
+    const int cc = C / epc;
+    int g256 = cc, t256 = 256;
+    while (t256) { const int r = g256 % t256; g256 = t256; t256 = r; }
+    const int mult = cc / g256;
+    int grid = grid_for(rows * (long)cc, 256 * 4, 16384);
+    grid = (grid + mult - 1) / mult * mult;
+    if (dtype == CVCL_F32)
+        hipLaunchKernelGGL(bn_relu_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale,
+                           shift, (float*)y, rows, C);
+    else
+        hipLaunchKernelGGL(bn_relu_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           scale, shift, (bf16_t*)y, rows, C);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
 extern "C" int cvcl_avgpool(int dtype, const void* x, float* out, int B, int HW, int C, void* stream) {
     CVCL_CHECK_ARG(x && out && B > 0 && HW > 0 && C > 0, "cvcl_avgpool: bad args");
     CvclProfScope prof(stream, CVCL_K_AVGPOOL);
@@ -822,15 +877,16 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
             if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), layers[l2].w, R2, training ? stats : nullptr,
                                     kMaxStatsRows, B, h, wd, width, 32, stride, stream))) return rc;
             if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, stride), m_out, width))) return rc;
-            // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc]
+            // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  BN2+ReLU is applied to the narrow tensor in place first
+            // (one pass) instead of in the GEMM operand load (once per 128-column output tile): see bn_relu_apply_kernel.
+            if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
             {
                 cvcl_gemm_args a = {};
                 a.A = R2; a.W = layers[l3].w; a.C = R3;
                 a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
-                a.a_scale = scale_of(l2); a.a_shift = shift_of(l2); a.a_relu = 1;
                 a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
                 if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N, 1), m_out, outc))) return rc;
+                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_out, outc))) return rc;
             }
             char* dst = last ? (char*)layer4_out_nhwc : OUT;
             if (bi == 0) {

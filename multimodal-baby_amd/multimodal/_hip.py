@@ -20,7 +20,7 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ABI_VERSION = 1
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
-                  "other", "attention", "layernorm", "lstm", "gemm_f32")
+                  "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply")
 
 
 class CvclError(RuntimeError):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "cvcl_gconv3x3_stats_rows": (_I, [_I, _I, _I, _I, _I]),
     "cvcl_gconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cvcl_bn_add_relu": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _P]),
+    "cvcl_bn_relu_apply": (_I, [_I, _P, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_avgpool": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
