@@ -1,0 +1,113 @@
+"""CPU, world_size 2 over gloo: the data-parallel sharding logic (feature all-gather with own-rows backward,
+bucketed gradient reduction with SUM / replicated-average semantics).  The arithmetic of the loss is the
+oracle's (test infrastructure); what is under test is the host-side exchange in multimodal/parallel.py.
+
+Parity definition: global loss == reference calculate_contrastive_loss math applied to the
+concatenated feature matrices; full-batch gradient == SUM over ranks of per-rank gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, global_negatives, out):
+    for p in (os.path.join(ROOT, "multimodal-baby_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import cvcl_oracle as O
+    from multimodal import parallel
+    torch.manual_seed(0)
+    B, E, V = 6, 16, 40
+    # replicated trainable parameters (a projection, an embedding table, a learned temperature)
+    proj = torch.nn.Parameter(torch.randn(E, 24) * 0.2)
+    table = torch.nn.Parameter(torch.randn(V, E))
+    nlt = torch.nn.Parameter(torch.tensor(2.0))
+    nlt._cvcl_replicated_grad = True
+    mod = torch.nn.ParameterList([proj, table, nlt])
+    g = torch.Generator().manual_seed(123)
+    x_all = torch.randn(world * B, 24, generator=g)
+    tok_all = torch.randint(1, V, (world * B, 4), generator=g)
+    len_all = torch.full((world * B,), 4)
+
+    engine = parallel.DataParallelEngine.from_env(torch.device("cpu"), bucket_bytes=1 << 10,
+                                                  global_negatives=global_negatives).attach(mod)
+    assert parallel.world_size() == world and len(engine.buckets) >= 2      # several buckets -> exercises bucketing
+    sl = slice(rank * B, (rank + 1) * B)
+    fi = O.l2_normalize(x_all[sl] @ proj.t())
+    ft = O.l2_normalize(O.embedding_meanpool(table, tok_all[sl], len_all[sl])[0])
+    if global_negatives:
+        fi, ft = parallel.gather_features(fi, ft)
+        assert fi.shape == (world * B, E)
+    lpi, lpt = O.similarity_logits(fi, ft, nlt)
+    loss = O.contrastive_loss(lpi, lpt)[0]
+    loss.backward()
+    engine.reduce_gradients()
+    out.put((rank, float(loss), proj.grad.clone(), table.grad.clone(), nlt.grad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process_reference(world, global_negatives):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cvcl_oracle as O
+    torch.manual_seed(0)
+    B, E, V = 6, 16, 40
+    proj = torch.randn(E, 24) * 0.2
+    table = torch.randn(V, E)
+    nlt = torch.tensor(2.0)
+    proj.requires_grad_(True); table.requires_grad_(True); nlt.requires_grad_(True)
+    g = torch.Generator().manual_seed(123)
+    x_all = torch.randn(world * B, 24, generator=g)
+    tok_all = torch.randint(1, V, (world * B, 4), generator=g)
+    len_all = torch.full((world * B,), 4)
+    if global_negatives:
+        fi = O.l2_normalize(x_all @ proj.t())
+        ft = O.l2_normalize(O.embedding_meanpool(table, tok_all, len_all)[0])
+        loss = O.contrastive_loss(*O.similarity_logits(fi, ft, nlt))[0]
+    else:                                   # Lightning-DDP semantics: mean over ranks of the local losses
+        loss = 0
+        for r in range(world):
+            sl = slice(r * B, (r + 1) * B)
+            fi = O.l2_normalize(x_all[sl] @ proj.t())
+            ft = O.l2_normalize(O.embedding_meanpool(table, tok_all[sl], len_all[sl])[0])
+            loss = loss + O.contrastive_loss(*O.similarity_logits(fi, ft, nlt))[0] / world
+    loss.backward()
+    return float(loss), proj.grad, table.grad, nlt.grad
+
+
+@pytest.mark.parametrize("global_negatives", [True, False])
+def test_world2_gradients_equal_single_process(global_negatives):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, global_negatives, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_loss, g_proj, g_table, g_nlt = _single_process_reference(world, global_negatives)
+    res.sort(key=lambda t: t[0])
+    for rank, loss, gp, gt, gn in res:
+        if global_negatives:
+            assert abs(loss - ref_loss) < 1e-5           # every rank evaluates the same replicated loss
+        assert torch.allclose(gp, g_proj, atol=1e-5), rank
+        assert torch.allclose(gt, g_table, atol=1e-5), rank
+        assert torch.allclose(gn, g_nlt, atol=1e-5), rank
+    assert torch.equal(res[0][2], res[1][2])             # replicas stay bit-identical
