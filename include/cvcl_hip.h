@@ -182,6 +182,32 @@ int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float
                        const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
                        void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * DINO ViT image encoder (multimodal/vision_transformer_dino_mugs.py:87-250), the one-layer text
+ * transformer (multimodal/multimodal.py:553-573) and the LSTM text encoder (:513-552).  Linears run on
+ * cvcl_gemm; these are the non-GEMM pieces.                                                        */
+/* PatchEmbed unfold (vit:162,166): x NCHW f32 -> cols [B*np, Kpad] (k = c*p*p + ky*p + kx, zero padded) */
+int cvcl_im2col_patches(int dtype, const float* x_nchw, void* cols, int B, int H, int W, int patch, int Kpad,
+                        void* stream);
+/* prepare_tokens (vit:232-243): h[b,0] = cls + pos[0]; h[b,1+i] = tok[b,i] + pos[1+i]; h [B,T,D]     */
+int cvcl_vit_assemble_tokens(int dtype, const void* tok, const float* cls, const float* pos, void* h, int B, int T,
+                             int D, void* stream);
+/* nn.LayerNorm over the last dim; rows may be strided (x_row_stride elements); y is dtype or f32      */
+int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const float* gamma, const float* beta, float eps,
+                   void* y, int y_is_f32, long rows, int D, void* stream);
+/* softmax(q k^T * scale [+ key padding mask where key_tok == 0]) v;  qkv [B,T,3,heads,hd] -> out [B,T,heads*hd]
+ * (vit:119-127; nn.MultiheadAttention inside nn.TransformerEncoderLayer).  bf16, hd = 64, no mask -> MFMA kernel. */
+int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok, void* out, int B, int T, int heads, int head_dim,
+                   float scale, void* stream);
+/* x[b,l,:] = table[tok[b,l]] (+ pos[l]) (multimodal.py:496, 561-563) */
+int cvcl_embed_gather_pos(const float* table, const int64_t* tok, const float* pos, float* x, int B, int L, int E, int V,
+                          void* stream);
+/* ret[b,:] = sum over ALL L positions of x[b,l,:] / len[b] (multimodal.py:573) */
+int cvcl_seq_sum_div(const float* x, const int64_t* len, float* ret, int B, int L, int E, void* stream);
+/* one nn.LSTM step on precomputed gates [B,4H] (order i,f,g,o); rows with len <= t keep (h,c) and emit zeros */
+int cvcl_lstm_cell(const float* gates, const int64_t* len, int t, float* h, float* c, float* out, int B, int L, int Hd,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,6 +82,13 @@ SIGNATURES = {
     "cvcl_bn_add_relu": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_bn_relu_apply": (_I, [_I, _P, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_avgpool": (_I, [_I, _P, _P, _I, _I, _I, _P]),
+    "cvcl_im2col_patches": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "cvcl_vit_assemble_tokens": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_layernorm": (_I, [_I, _P, C.c_long, _P, _P, _F, _P, _I, C.c_long, _I, _P]),
+    "cvcl_attention": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "cvcl_embed_gather_pos": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_seq_sum_div": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_lstm_cell": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }

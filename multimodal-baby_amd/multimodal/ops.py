@@ -192,9 +192,71 @@ def linear_f32(x, weight, bias=None):
     return LinearF32.apply(x, weight, bias)
 
 
+def _embed_gather(table, tok, pos=None):
+    B, L = tok.shape
+    V, E = table.shape
+    x = torch.empty(B * L, E, dtype=_F, device=table.device)
+    H.check(H.lib().cvcl_embed_gather_pos(H.ptr(table.detach(), _F), H.ptr(tok, torch.int64), H.ptr(pos), H.ptr(x), B, L, E, V,
+                                         H.stream_ptr()), "cvcl_embed_gather_pos")
+    return x
+
+
 def lstm_text(table, lstm, tok, length):
-    raise NotImplementedError("the LSTM text-encoder kernels are not built yet")
+    """Embedding + one-layer uni-directional nn.LSTM over variable-length sequences, eval mode
+    (reference multimodal/multimodal.py:513-552).  -> (h at each sequence's last step [B,H], outputs [B,Lmax,H]).
+    x W_ih^T for all steps is one GEMM; each step is one recurrent GEMM (gates of the input added through the
+    residual epilogue) plus the cell kernel."""
+    if lstm.bidirectional or lstm.num_layers != 1:
+        raise NotImplementedError("only the one-layer uni-directional LSTM text encoder is on the contrastive path")
+    B, L = tok.shape
+    Hd = lstm.hidden_size
+    dev = table.device
+    with torch.no_grad():
+        x = _embed_gather(table, tok)
+        bias = (lstm.bias_ih_l0 + lstm.bias_hh_l0).detach().contiguous()
+        gx = H.gemm(x, lstm.weight_ih_l0.detach().contiguous(), bias=bias)             # [B*L, 4H]
+        w_hh = lstm.weight_hh_l0.detach().contiguous()
+        h = torch.zeros(B, Hd, dtype=_F, device=dev)                                   # init_hidden zeros (:671-688)
+        c = torch.zeros(B, Hd, dtype=_F, device=dev)
+        out = torch.empty(B, L, Hd, dtype=_F, device=dev)
+        gates = torch.empty(B, 4 * Hd, dtype=_F, device=dev)
+        lib, s = H.lib(), H.stream_ptr()
+        for t in range(L):
+            a = H.GemmArgs()
+            a.A, a.W, a.C = H.ptr(h), H.ptr(w_hh), H.ptr(gates)
+            a.M, a.N, a.K, a.lda, a.ldw, a.ldc = B, 4 * Hd, Hd, Hd, Hd, 4 * Hd
+            a.R, a.ldr = gx.data_ptr() + t * 4 * Hd * 4, L * 4 * Hd                   # row b of step t inside gx
+            H.check(lib.cvcl_gemm(H.F32, a, s), "cvcl_gemm")
+            H.check(lib.cvcl_lstm_cell(H.ptr(gates), H.ptr(length, torch.int64), t, H.ptr(h), H.ptr(c), H.ptr(out), B, L, Hd, s),
+                    "cvcl_lstm_cell")
+        lmax = int(length.max())              # pad_packed_sequence trims to the longest sequence (the reference syncs here too)
+    return h, out[:, :lmax]
 
 
 def transformer_text(table, layer, pos_embed, tok, length):
-    raise NotImplementedError("the text-transformer kernels are not built yet")
+    """Embedding (+pos) + one post-norm nn.TransformerEncoderLayer with key-padding mask + sum/len, eval mode
+    (reference multimodal/multimodal.py:553-573).  -> (ret [B,E], outputs [B,L,E])."""
+    B, L = tok.shape
+    E = table.shape[1]
+    nh = layer.self_attn.num_heads
+    lib, s = H.lib(), H.stream_ptr()
+    with torch.no_grad():
+        pos = None if pos_embed is None else pos_embed.detach()[:L, 0].contiguous().float()
+        x = _embed_gather(table, tok, pos)                                              # [B*L, E]
+        sa = layer.self_attn
+        qkv = H.gemm(x, sa.in_proj_weight.detach().contiguous(), bias=sa.in_proj_bias.detach().contiguous())
+        att = torch.empty(B * L, E, dtype=_F, device=x.device)
+        H.check(lib.cvcl_attention(H.F32, H.ptr(qkv), H.ptr(tok, torch.int64), H.ptr(att), B, L, nh, E // nh,
+                                   float((E // nh) ** -0.5), s), "cvcl_attention")
+        y = H.gemm(att, sa.out_proj.weight.detach().contiguous(), bias=sa.out_proj.bias.detach().contiguous(), residual=x)
+        h1 = torch.empty_like(y)
+        H.check(lib.cvcl_layernorm(H.F32, H.ptr(y), E, H.ptr(layer.norm1.weight.detach()), H.ptr(layer.norm1.bias.detach()),
+                                   layer.norm1.eps, H.ptr(h1), 1, B * L, E, s), "cvcl_layernorm")
+        f = H.gemm(h1, layer.linear1.weight.detach().contiguous(), bias=layer.linear1.bias.detach().contiguous(), act=H.ACT_RELU)
+        y2 = H.gemm(f, layer.linear2.weight.detach().contiguous(), bias=layer.linear2.bias.detach().contiguous(), residual=h1)
+        h2 = torch.empty_like(y2)
+        H.check(lib.cvcl_layernorm(H.F32, H.ptr(y2), E, H.ptr(layer.norm2.weight.detach()), H.ptr(layer.norm2.bias.detach()),
+                                   layer.norm2.eps, H.ptr(h2), 1, B * L, E, s), "cvcl_layernorm")
+        ret = torch.empty(B, E, dtype=_F, device=x.device)
+        H.check(lib.cvcl_seq_sum_div(H.ptr(h2), H.ptr(length, torch.int64), H.ptr(ret), B, L, E, s), "cvcl_seq_sum_div")
+    return ret, h2.view(B, L, E)

@@ -1,0 +1,91 @@
+"""ViT forward on libcvcl_hip (reference multimodal/vision_transformer_dino_mugs.py:232-250).
+
+prepare_tokens -> depth x [LN, qkv GEMM(+bias), attention, proj GEMM(+bias, +residual), LN, fc1 GEMM(+bias, GELU),
+fc2 GEMM(+bias, +residual)] -> LN of the cls rows -> [B, D] fp32.  Weights are cast once per weight version into
+the compute dtype (bf16 perf mode / fp32 parity mode).  Inference-only (the DINO ViT is frozen in every CVCL
+configuration; ``--finetune_cnn`` with a ViT raises)."""
+from __future__ import annotations
+
+import torch
+
+from . import _hip as H
+
+
+def _packed(model, dt, device):
+    key = (str(dt), str(device)) + tuple((p.data_ptr(), p._version) for p in model.parameters())
+    hit = model._cache.get("w")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    D, p = model.embed_dim, model.patch_size
+    K = 3 * p * p
+    Kpad = (K + 7) // 8 * 8
+    w = {}
+    pe = model.patch_embed.proj.weight.detach().reshape(D, K)
+    wp = torch.zeros(D, Kpad, dtype=torch.float32, device=device)
+    wp[:, :K] = pe
+    w["pe_w"], w["Kpad"] = wp.to(dt).contiguous(), Kpad
+    w["pe_b"] = model.patch_embed.proj.bias.detach().float().contiguous()
+    w["cls"] = model.cls_token.detach().reshape(-1).float().contiguous()
+    w["pos"] = model.pos_embed.detach().reshape(-1, D).float().contiguous()
+    w["blocks"] = []
+    for blk in model.blocks:
+        w["blocks"].append({
+            "n1w": blk.norm1.weight.detach().float().contiguous(), "n1b": blk.norm1.bias.detach().float().contiguous(),
+            "qkv_w": blk.attn.qkv.weight.detach().to(dt).contiguous(),
+            "qkv_b": None if blk.attn.qkv.bias is None else blk.attn.qkv.bias.detach().float().contiguous(),
+            "proj_w": blk.attn.proj.weight.detach().to(dt).contiguous(), "proj_b": blk.attn.proj.bias.detach().float().contiguous(),
+            "n2w": blk.norm2.weight.detach().float().contiguous(), "n2b": blk.norm2.bias.detach().float().contiguous(),
+            "fc1_w": blk.mlp.fc1.weight.detach().to(dt).contiguous(), "fc1_b": blk.mlp.fc1.bias.detach().float().contiguous(),
+            "fc2_w": blk.mlp.fc2.weight.detach().to(dt).contiguous(), "fc2_b": blk.mlp.fc2.bias.detach().float().contiguous(),
+            "eps": blk.norm1.eps, "scale": float(blk.attn.scale), "heads": blk.attn.num_heads})
+    w["nw"], w["nb"], w["neps"] = model.norm.weight.detach().float().contiguous(), model.norm.bias.detach().float().contiguous(), model.norm.eps
+    model._cache["w"] = (key, w)
+    return w
+
+
+def _ln(cd, x, stride, g, b, eps, out, out_f32, rows, D):
+    H.check(H.lib().cvcl_layernorm(cd, H.ptr(x), stride, H.ptr(g), H.ptr(b), eps, H.ptr(out), int(out_f32), rows, D,
+                                   H.stream_ptr()), "cvcl_layernorm")
+
+
+def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
+    if torch.is_grad_enabled() and any(p.requires_grad for n, p in model.named_parameters() if not n.startswith("head.")):
+        raise NotImplementedError("fine-tuning the ViT trunk needs its backward kernels, which this build does not ship "
+                                  "(frozen-ViT configurations only)")
+    if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+        raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
+    x = x.contiguous()
+    B, _, Hh, Ww = x.shape
+    p, D = model.patch_size, model.embed_dim
+    dt = model.compute_dtype
+    cd = H.cvcl_dtype(dt)
+    lib, s = H.lib(), H.stream_ptr()
+    n_p = (Hh // p) * (Ww // p)
+    T = n_p + 1
+    if T != model.pos_embed.shape[1]:
+        raise NotImplementedError("positional-embedding interpolation (non-native resolution) is not on the hot path")
+    with torch.no_grad():
+        w = _packed(model, dt, x.device)
+        dev = x.device
+        cols = torch.empty(B * n_p, w["Kpad"], dtype=dt, device=dev)
+        H.check(lib.cvcl_im2col_patches(cd, H.ptr(x), H.ptr(cols), B, Hh, Ww, p, w["Kpad"], s), "cvcl_im2col_patches")
+        tok = H.gemm(cols, w["pe_w"], bias=w["pe_b"])
+        h = torch.empty(B * T, D, dtype=dt, device=dev)
+        H.check(lib.cvcl_vit_assemble_tokens(cd, H.ptr(tok), H.ptr(w["cls"]), H.ptr(w["pos"]), H.ptr(h), B, T, D, s),
+                "cvcl_vit_assemble_tokens")
+        y = torch.empty_like(h)
+        att = torch.empty_like(h)
+        qkv = torch.empty(B * T, 3 * D, dtype=dt, device=dev)
+        mid = torch.empty(B * T, w["blocks"][0]["fc1_w"].shape[0], dtype=dt, device=dev) if w["blocks"] else None
+        for bw in w["blocks"]:
+            _ln(cd, h, D, bw["n1w"], bw["n1b"], bw["eps"], y, False, B * T, D)
+            H.gemm(y, bw["qkv_w"], out=qkv, bias=bw["qkv_b"])
+            H.check(lib.cvcl_attention(cd, H.ptr(qkv), None, H.ptr(att), B, T, bw["heads"], D // bw["heads"], bw["scale"], s),
+                    "cvcl_attention")
+            H.gemm(att, bw["proj_w"], out=h, bias=bw["proj_b"], residual=h)          # h = h + proj(att)   (vit:146)
+            _ln(cd, h, D, bw["n2w"], bw["n2b"], bw["eps"], y, False, B * T, D)
+            H.gemm(y, bw["fc1_w"], out=mid, bias=bw["fc1_b"], act=H.ACT_GELU)
+            H.gemm(mid, bw["fc2_w"], out=h, bias=bw["fc2_b"], residual=h)            # h = h + mlp(...)     (vit:147)
+        cls = torch.empty(B, D, dtype=torch.float32, device=dev)
+        _ln(cd, h, T * D, w["nw"], w["nb"], w["neps"], cls, True, B, D)              # norm(x)[:, 0]        (vit:249-250)
+    return cls

@@ -1,0 +1,167 @@
+"""GPU parity: ViT, LSTM and transformer text encoders through the C ABI vs golden vectors generated from the
+reference (tests/golden) and vs the oracle.  fp32 mode is the parity mode (tolerance 1e-4 rel or tighter);
+bf16 mode is compared with the oracle's storage-point emulation."""
+import argparse
+import contextlib
+import io
+from functools import partial
+
+import pytest
+import torch
+
+import cvcl_oracle as O
+from conftest import load_golden, maxrel
+
+pytestmark = pytest.mark.gpu
+
+
+def _w(g):
+    return {k[2:]: v for k, v in g.items() if k.startswith("w.")}
+
+
+def _text_encoder(kind, pos, E, vocab_n):
+    from multimodal.multimodal import TextEncoder
+    vocab = {f"w{i}": i for i in range(vocab_n)}
+    args = argparse.Namespace(text_encoder=kind, embedding_type="flat", embedding_dim=E, crange=1, dropout_i=0.0,
+                              dropout_o=0.0, pos_embed_type=pos)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return TextEncoder(vocab, 2048, args)
+
+
+def test_lstm_text_golden(dev):
+    g = load_golden("text_lstm")
+    w = _w(g)
+    te = _text_encoder("lstm", "no_pos_embed", w["embedding.weight"].shape[1], w["embedding.weight"].shape[0])
+    te.load_state_dict(w)
+    te = te.to(dev).eval()
+    ret, out, _ = te(g["x"].to(dev), g["x_len"].to(dev))
+    assert out.shape == g["output"].shape
+    assert maxrel(ret, g["ret"]) < 2e-5 and maxrel(out, g["output"]) < 2e-5
+
+
+@pytest.mark.parametrize("pos", ["learned", "sinusoidal", "no_pos_embed"])
+def test_transformer_text_golden(dev, pos):
+    g = load_golden(f"text_transformer_{pos}")
+    w = _w(load_golden("text_transformer_weights"))
+    w.update(_w(g))
+    te = _text_encoder("transformer", pos, w["embedding.weight"].shape[1], w["embedding.weight"].shape[0])
+    sd = te.state_dict()
+    for k in sd:                                   # the dead duplicate `encoder_layer.*` keeps its own init
+        if k in w:
+            sd[k].copy_(w[k])
+    te = te.to(dev).eval()
+    ret, out, _ = te(g["x"].to(dev), g["x_len"].to(dev))
+    assert maxrel(ret, g["ret"]) < 2e-5 and maxrel(out, g["output"]) < 2e-5
+
+
+@pytest.mark.parametrize("B,L,E", [(256, 5, 512), (8, 25, 512)])
+def test_text_encoders_oracle_config_size(dev, B, L, E):
+    """BASELINE config sizes (E=512; L=5 training utterances, L=25 tokenizer padding) vs the oracle."""
+    g = torch.Generator().manual_seed(L)
+    lens = torch.randint(3, L + 1, (B,), generator=g)
+    lens[0] = L
+    tok = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        n = int(lens[b])
+        tok[b, :n] = torch.randint(4, 2350, (n,), generator=g)
+    for kind, pos in (("lstm", "no_pos_embed"), ("transformer", "learned")):
+        torch.manual_seed(1)
+        te = _text_encoder(kind, pos, E, 2350).eval()
+        if pos == "learned":
+            with torch.no_grad():
+                te.pos_embed.normal_(0, 0.3)
+        sd = {k: v.clone() for k, v in te.state_dict().items()}
+        if kind == "lstm":
+            r_o, o_o = O.lstm_text(sd, tok, lens)
+        else:
+            r_o, o_o = O.transformer_text(sd, tok, lens, pos)
+        ret, out, _ = te.to(dev)(tok.to(dev), lens.to(dev))
+        assert maxrel(ret, r_o) < 5e-5 and maxrel(out, o_o) < 5e-5, kind
+
+
+def _tiny_vit():
+    from multimodal import vision_transformer_dino_mugs as vits
+    import torch.nn as nn
+    return vits.VisionTransformer(img_size=[32], patch_size=8, embed_dim=32, depth=2, num_heads=2, mlp_ratio=4,
+                                  qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6))
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_vit_tiny_golden(dev, dt):
+    g = load_golden("vit_tiny")
+    m = _tiny_vit()
+    m.load_state_dict(_w(g))
+    m = m.to(dev).eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    m.compute_dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    y = m(g["x"].to(dev))
+    if dt == "f32":
+        assert maxrel(y, g["cls"]) < 2e-5
+    else:
+        yo = O.vit_forward(_w(g), g["x"], 8, 2, quant=O.bf16_round)
+        assert maxrel(y, yo) < 3e-2 and maxrel(y, g["cls"]) < 6e-2
+
+
+@pytest.mark.parametrize("patch", [16, 14])
+def test_vit_base_golden(dev, patch):
+    """Full-size DINO ViT-B/16 (BASELINE configs 4-5) and ViT-B/14 (the reference's hard-coded model) at B=1 with
+    formula-filled weights: fp32 vs the reference's own output (golden), bf16 vs the emulating oracle."""
+    import gen_golden as G
+    from multimodal import vision_transformer_dino_mugs as vits
+    g = load_golden(f"vit_b{patch}")
+    m = vits.vit_base(patch_size=patch, num_classes=0)
+    sd = G.vit_formula_state(m.state_dict())
+    assert sorted(sd.keys()) == [str(k) for k in g["keys"]]
+    m.load_state_dict(sd)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(int(g["x_seed"][0])))
+    m = m.to(dev).eval()
+    y = m(x.to(dev))
+    e = maxrel(y, g["cls"])
+    print(f"vit_b{patch} fp32 vs reference golden: rel err {e:.2e}")
+    assert e < 1e-4                                           # BASELINE gate is 1e-3
+    m.compute_dtype = torch.bfloat16
+    yb = m(x.to(dev))
+    yo = O.vit_forward(sd, x, patch, 12, quant=O.bf16_round)
+    eb = maxrel(yb, yo)
+    print(f"vit_b{patch} bf16 vs emulating oracle: rel err {eb:.2e}; vs fp32 golden {maxrel(yb, g['cls']):.2e}")
+    assert eb < 4e-2
+
+
+def test_vit_transformer_model_end_to_end(dev):
+    """saycam_contrastive_transformer shape (C4): ViT-B/16 + transformer text encoder, eval forward, vs the oracle."""
+    import gen_golden as G
+    from multimodal import vision_transformer_dino_mugs as vits
+    from multimodal.multimodal import MultiModalModel, TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import read_vocab
+    import multimodal.multimodal as mm
+    args = argparse.Namespace(embedding_type="flat", embedding_dim=512, pretrained_cnn=False, cnn_dino=False, vit_dino=True,
+                              finetune_cnn=False, text_encoder="transformer", crange=1, dropout_i=0.0, dropout_o=0.0,
+                              pos_embed_type="learned", normalize_features=True, sim="max", temperature=0.07,
+                              fix_temperature=True)
+    orig = mm.load_model
+    mm.load_model = lambda name, pretrained: vits.vit_base(patch_size=16, num_classes=0)   # BASELINE names ViT-B/16
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            torch.manual_seed(0)
+            ve = VisionEncoder(args)
+            te = TextEncoder(read_vocab(), 768, args)
+            model = MultiModalModel(ve, te, args)
+    finally:
+        mm.load_model = orig
+    with torch.no_grad():
+        te.pos_embed.normal_(0, 0.3)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd["logit_neg_log_temperature"] = model.logit_neg_log_temperature.clone()
+    img, tok, ln = O.synthetic_batch(4, seed=3, pad_to=7)
+    lpi_o, lpt_o, *_ = O.cvcl_forward(sd, img, tok, ln, vision="vit", text_encoder="transformer", normalize_features=True,
+                                      training=False, vit_patch=16, pos_embed_type="learned")
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        lpi, lpt = model(img.to(dev), tok.to(dev), ln.to(dev))
+    e = maxrel(lpi, lpi_o)
+    print(f"C4 logits fp32 vs oracle rel err {e:.2e}")
+    assert e < 1e-3 and maxrel(lpt, lpt_o) < 1e-3             # the BASELINE gate
+    assert e < 1e-4
