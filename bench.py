@@ -113,15 +113,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus > 1 and world != a.gpus:
+    if a.gpus != world and not (a.gpus == 1 and world == 1):
         raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the CVCL hot path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")           # RCCL on ROCm
+        # "nccl" is RCCL on ROCm; CVCL_DIST_BACKEND=gloo lets two ranks share one GPU to smoke-test the N>1 path
+        dist.init_process_group(backend=os.environ.get("CVCL_DIST_BACKEND", "nccl"))
 
     from multimodal import _hip as H
     from multimodal import parallel

@@ -48,7 +48,10 @@ class _AllGatherRows(torch.autograd.Function):
         x = x.contiguous()
         world = dist.get_world_size()
         out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x) if x.is_cuda else dist.all_gather(list(out.chunk(world, 0)), x)
+        if dist.get_backend() == "nccl":                   # RCCL: one fused all-gather into the output buffer
+            dist.all_gather_into_tensor(out, x)
+        else:                                              # gloo (CPU tests, single-GPU smoke of the N>1 path)
+            dist.all_gather(list(out.chunk(world, 0)), x)
         ctx.rows = x.shape[0]
         return out
 
@@ -79,7 +82,7 @@ class DataParallelEngine:
     def from_env(cls, device, **kw):
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if world > 1 and not dist.is_initialized():
-            backend = "nccl" if device.type == "cuda" else "gloo"     # "nccl" is RCCL on ROCm
+            backend = os.environ.get("CVCL_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")   # "nccl" = RCCL
             if device.type == "cuda":
                 torch.cuda.set_device(device)
             dist.init_process_group(backend=backend)
@@ -125,6 +128,7 @@ class DataParallelEngine:
 
     def _launch(self, b):
         off = 0
+        b["had_grad"] = [p.grad is not None for p in b["params"]]
         for p in b["params"]:
             n = p.numel()
             if p.grad is not None:
@@ -144,13 +148,12 @@ class DataParallelEngine:
                 self._launch(b)
             b["handle"].wait()
             off = 0
-            for p in b["params"]:
+            for p, had in zip(b["params"], b["had_grad"]):
                 n = p.numel()
-                g = b["buf"][off:off + n].view_as(p)
-                averaged = (not self.global_negatives) or getattr(p, "_cvcl_replicated_grad", False)
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(g / world if averaged else g)
+                if had:      # a parameter no rank produced a gradient for keeps grad=None (the optimizer skips it,
+                    g = b["buf"][off:off + n].view_as(p)        # as in the single-process reference)
+                    averaged = (not self.global_negatives) or getattr(p, "_cvcl_replicated_grad", False)
+                    p.grad.copy_(g / world if averaged else g)
                 off += n
             b["pending"], b["handle"] = len(b["params"]), None
             b["seen"].clear()
