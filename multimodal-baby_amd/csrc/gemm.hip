@@ -362,6 +362,192 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant for the convolution fast path (bf16, no operand prologue, K % 64 == 0, N % 128 == 0).
+//
+// Both operand tiles are fetched with global_load_lds_dwordx4 (no VGPR round trip, no ds_write): each wave
+// instruction lands 64 x 16 B = 8 consecutive 128-byte rows.  The destination must be lane-linear, so LDS rows are
+// unpadded and bank conflicts are avoided by an XOR swizzle applied on the *source* address: the 16-byte chunk c of
+// row r lives at chunk position c ^ ((r >> 1) & 7), which makes the 16 rows touched by a ds_read_b128 lane group
+// hit 16 different 16-byte slots.  Two LDS buffers; per K tile: wait for this wave's loads, one barrier, issue the
+// next tile's loads into the other buffer, multiply the current one.  The epilogue stages C through the buffer
+// that was just consumed (same swizzle idea) and writes full 128-byte rows.
+// ------------------------------------------------------------------------------------------------
+constexpr int GL_OPER = 128 * 128;          // bytes of one operand tile (128 rows x 64 bf16)
+constexpr int GL_BUF = 2 * GL_OPER;         // A tile + W tile
+constexpr int GL_LDS = 2 * GL_BUF;          // double buffered: 64 KiB
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const bf16_t* __restrict__ A = (const bf16_t*)p.A;
+    const bf16_t* __restrict__ W = (const bf16_t*)p.W;
+    bf16_t* __restrict__ C = (bf16_t*)p.C;
+    const int ktiles = p.K / 64;
+
+    // staging role: wave w issues instructions j = 0..3 per operand; instruction (w, j) covers tile rows
+    // (4w + j) * 8 .. + 7; this lane supplies row (4w + j) * 8 + lane / 8, chunk position lane % 8
+    int s_row[4];
+    unsigned w_off[4], a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);          // logical chunk that belongs at this position
+        s_row[j] = r;
+        w_off[j] = (unsigned)(n0 + r) * (unsigned)p.ldw + c * 8;
+    }
+    auto set_rows = [&](int mt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = mt * BM + s_row[j];
+            if (m >= p.M) m = p.M - 1;                         // tail rows: any valid row, masked at the store
+            long row = m;
+            if (p.g_s > 1) {
+                const int hw = p.g_ho * p.g_wo;
+                const int b = m / hw, r = m - b * hw;
+                const int oy = r / p.g_wo, ox = r - oy * p.g_wo;
+                row = ((long)b * p.g_hi + (long)oy * p.g_s) * p.g_wi + (long)ox * p.g_s;
+            }
+            const int c = (lane & 7) ^ ((s_row[j] >> 1) & 7);
+            a_off[j] = (unsigned)(row * p.lda) + c * 8;
+        }
+    };
+    auto issue = [&](int buf, int kt) {
+        char* base = smem + buf * GL_BUF + wave * 4 * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(A + a_off[j] + kt * 64, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(W + w_off[j] + kt * 64, base + GL_OPER + j * 1024);
+    };
+
+    float st_sum[8], st_sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+
+    // fragment read offsets inside a buffer (rows fixed per lane, swizzle per row)
+    int fw_off[2], fa_off[2], fw_sw[2], fa_sw[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rw = wn * 64 + q * 32 + l31, ra = wm * 64 + q * 32 + l31;
+        fw_off[q] = GL_OPER + rw * 128; fw_sw[q] = (rw >> 1) & 7;
+        fa_off[q] = ra * 128;           fa_sw[q] = (ra >> 1) & 7;
+    }
+
+    int l_mt = blockIdx.x, l_kt = 0, buf = 0;
+    bool l_live = l_mt < p.num_m_tiles;
+    if (l_live) { set_rows(l_mt); issue(0, 0); }
+
+    for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
+        const int m0 = cm * BM;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        for (int kt = 0; kt < ktiles; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the current tile has landed
+            __builtin_amdgcn_s_barrier();                        // ... and everybody's; buffer buf^1 is free again
+            if (++l_kt == ktiles) {
+                l_kt = 0;
+                l_mt += gridDim.x;
+                l_live = l_mt < p.num_m_tiles;
+                if (l_live) set_rows(l_mt);
+            }
+            if (l_live) issue(buf ^ 1, l_kt);
+            const char* cur = smem + buf * GL_BUF;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = g * 2 + h;
+                bf16x8 fw[2], fa[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    fw[q] = *reinterpret_cast<const bf16x8*>(cur + fw_off[q] + ((c ^ fw_sw[q]) << 4));
+                    fa[q] = *reinterpret_cast<const bf16x8*>(cur + fa_off[q] + ((c ^ fa_sw[q]) << 4));
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+
+        // ---- epilogue: stage C through the buffer just consumed (buf ^ 1), 8 KiB per wave, rows of 128 B with the
+        // 16-byte chunks XOR-swizzled by the row; then full-row 16-byte stores + BN partial sums
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // every wave finished reading that buffer
+        char* stg = smem + (buf ^ 1) * GL_BUF + wave * 8192;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = mt * 32 + l31;
+                    const int chunk = nt * 4 + g;                // 8 channels per 16-B chunk; this lane owns half h
+                    bf16x4 q = {(bf16_t)acc[nt][mt][4 * g + 0], (bf16_t)acc[nt][mt][4 * g + 1],
+                                (bf16_t)acc[nt][mt][4 * g + 2], (bf16_t)acc[nt][mt][4 * g + 3]};
+                    *reinterpret_cast<bf16x4*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4) + h * 8) = q;
+                }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = j * 8 + (lane >> 3), chunk = lane & 7;
+            const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4));
+            if (m < p.M) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    st_sum[e] += f;
+                    st_sq[e] = fmaf(f, f, st_sq[e]);
+                }
+                *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = v;
+            }
+        }
+        // the next loop iteration's vmcnt(0) + barrier orders these staging reads before the buffer is refilled
+    }
+
+    if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int o = 8; o <= 32; o <<= 1) {
+                st_sum[e] += __shfl_xor(st_sum[e], o, 64);
+                st_sq[e] += __shfl_xor(st_sq[e], o, 64);
+            }
+        }
+        __syncthreads();
+        float* red = (float*)smem;                  // [4 waves][2][64]
+        if (lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * 64 + lane * 8 + e] = st_sum[e];
+                red[(wave * 2 + 1) * 64 + lane * 8 + e] = st_sq[e];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wn_ = tid >> 6, c = tid & 63, n = n0 + tid;
+            const float sv = red[((0 + 2 * wn_) * 2 + 0) * 64 + c] + red[((1 + 2 * wn_) * 2 + 0) * 64 + c];
+            const float qv = red[((0 + 2 * wn_) * 2 + 1) * 64 + c] + red[((1 + 2 * wn_) * 2 + 1) * 64 + c];
+            p.stats[((long)blockIdx.x * 2 + 0) * p.N + n] = sv;
+            p.stats[((long)blockIdx.x * 2 + 1) * p.N + n] = qv;
+        }
+    }
+}
+
 __global__ void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
@@ -479,6 +665,24 @@ inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
 }
 inline int pro_kind(const cvcl_gemm_args* a) { return !a->a_scale ? 0 : (a->a_relu ? 2 : 1); }
 
+int launch_gemm_glds(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
+    const int gm = grid_m_query<bf16_t>(a->M, a->N);
+    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS) != hipSuccess) {
+            cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", GL_LDS);
+            return CVCL_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    dim3 grid(gm, a->N / BN);
+    CvclProfScope prof(stream, CVCL_K_GEMM);
+    hipLaunchKernelGGL(gemm_glds_kernel, grid, dim3(256), GL_LDS, stream, d);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
 template <typename T>
 int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     constexpr int EPC = ElemTraits<T>::kPerChunk;
@@ -495,6 +699,10 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.vec_out = (a->ldc % EPC == 0) && al16(a->C) && (!a->R || ((a->ldr % EPC == 0) && al16(a->R)));
     d.num_m_tiles = cvcl_div_up(a->M, BM);
     const bool lean = is_lean(a, d);
+    if constexpr (sizeof(T) == 2) {
+        static const bool use_glds = [] { const char* e = getenv("CVCL_GEMM_GLDS"); return !(e && e[0] == '0'); }();
+        if (use_glds && lean && pro_kind(a) == 0 && a->K % 64 == 0) return launch_gemm_glds(a, d, stream);
+    }
     switch (pro_kind(a)) {
         case 0: return lean ? launch_gemm_v<T, 0, true>(a, d, stream) : launch_gemm_v<T, 0, false>(a, d, stream);
         case 1: return lean ? launch_gemm_v<T, 1, true>(a, d, stream) : launch_gemm_v<T, 1, false>(a, d, stream);

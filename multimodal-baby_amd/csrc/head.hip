@@ -28,15 +28,17 @@ __global__ __launch_bounds__(128) void embed_meanpool_fwd_kernel(const float* __
     }
 }
 
-// one workgroup per vocabulary row: scan the B*L tokens in (b,l) order, 128 at a time (ballot), and
-// accumulate the matching utterances' d_ret[b]/len[b] in registers.  Deterministic, no atomics,
+// one workgroup per vocabulary row: the B*L token ids are staged into LDS once (independent coalesced loads),
+// then each wave scans them 64 at a time (ballot) in (b,l) order and accumulates the matching utterances'
+// d_ret[b]/len[b] for its own slice of E in registers.  Deterministic, no atomics, no barrier inside the scan;
 // writes every row (zeros where the word does not occur; row 0 = padding_idx gets no gradient).
+constexpr int EMB_CHUNK = 8192;
 __global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __restrict__ d_ret,
                                                                  const int64_t* __restrict__ tok,
                                                                  const int64_t* __restrict__ len,
                                                                  float* __restrict__ d_table, int B, int L, int E) {
-    __shared__ unsigned long long masks[2][2];
-    const int v = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    __shared__ int stok[EMB_CHUNK];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int total = B * L;
     constexpr int MAXR = 8;                        // E <= 128 * MAXR handled in registers per pass
     for (int ebase = 0; ebase < E; ebase += 128 * MAXR) {
@@ -44,25 +46,45 @@ __global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) acc[i] = 0.f;
         if (v != 0) {
-            int par = 0;
-            for (int c = 0; c < total; c += 128, par ^= 1) {
-                const int idx = c + tid;
-                const bool hit = idx < total && tok[idx] == (int64_t)v;
-                const unsigned long long m = __ballot(hit);
-                if ((tid & 63) == 0) masks[par][wave] = m;
+            for (int c0 = 0; c0 < total; c0 += EMB_CHUNK) {
+                const int n = min(EMB_CHUNK, total - c0);
                 __syncthreads();
-                for (int w = 0; w < 2; ++w) {
-                    unsigned long long mm = masks[par][w];
+                for (int i = tid; i < n; i += 128) stok[i] = (int)tok[c0 + i];
+                __syncthreads();
+                for (int base = 0; base < n; base += 64) {
+                    const bool hit = (base + lane) < n && stok[base + lane] == v;
+                    unsigned long long mm = __ballot(hit);
+                    // frequent words (<sos>, <eos> occur in every utterance) have hundreds of matches: fetch the
+                    // operands of up to 8 matches at once, then accumulate them in (b,l) order
                     while (mm) {
-                        const int bit = __ffsll((long long)mm) - 1;
-                        mm &= mm - 1;
-                        const int bb = (c + w * 64 + bit) / L;
-                        const float den = (float)len[bb];
+                        int bbs[8];
+                        int nb = 0;
 #pragma unroll
-                        for (int i = 0; i < MAXR; ++i) {
-                            const int e = ebase + tid + 128 * i;
-                            if (e < E) acc[i] += d_ret[(long)bb * E + e] / den;
+                        for (int k = 0; k < 8; ++k) {
+                            bbs[k] = 0;
+                            if (mm) {
+                                const int bit = __ffsll((long long)mm) - 1;
+                                mm &= mm - 1;
+                                bbs[k] = (c0 + base + bit) / L;
+                                nb = k + 1;
+                            }
                         }
+                        float den[8], val[8][MAXR];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            den[k] = (float)len[bbs[k]];
+#pragma unroll
+                            for (int i = 0; i < MAXR; ++i) {
+                                const int e = ebase + tid + 128 * i;
+                                val[k][i] = (k < nb && e < E) ? d_ret[(long)bbs[k] * E + e] : 0.f;
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (k < nb) {
+#pragma unroll
+                                for (int i = 0; i < MAXR; ++i) acc[i] += val[k][i] / den[k];
+                            }
                     }
                 }
             }
@@ -72,7 +94,6 @@ __global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __
             const int e = ebase + tid + 128 * i;
             if (e < E) d_table[(long)v * E + e] = acc[i];
         }
-        __syncthreads();
     }
 }
 

@@ -13,6 +13,8 @@
 //                          channels per group, one tap x 32 channels per step for 32 per group),
 //                          input band staged in LDS with BN+ReLU applied on the way in
 //   fp32 (parity mode)   : direct VALU kernels with identical semantics + a column-statistics pass
+#include <cstdlib>
+
 #include "cvcl_common.h"
 
 namespace {
@@ -168,21 +170,41 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         for (int b = 0; b < 4; ++b) { ssum[a][b] = 0.f; ssq[a][b] = 0.f; }
 
     const int mtiles_per_row = cvcl_div_up(Wo, 16);
+    for (int i = tid; i < 3 * STEM_ROWS * STEM_PITCH; i += 256) patch[i] = 0u;       // pad columns stay zero for good
     for (int item = blockIdx.x; item < B * bands; item += gridDim.x) {
         const int b = item / bands, band = item - b * bands;
         const int oy0 = band * STEM_TH;
         __syncthreads();
-        // stage: rows (c, iy) <- x[b][c][2*oy0 - 3 + iy][*], bf16, with 3 zero columns of padding on the left
-        for (int r = 0; r < 3 * STEM_ROWS; ++r) {
-            const int c = r / STEM_ROWS, iy = r - c * STEM_ROWS;
-            const int yin = 2 * oy0 - 3 + iy;
-            const bool row_ok = yin >= 0 && yin < Hin;
-            const float* src = x + (((long)b * 3 + c) * Hin + (row_ok ? yin : 0)) * Win;
-            bf16_t* dst = (bf16_t*)(patch + r * STEM_PITCH);
-            for (int col = tid; col < 2 * STEM_PITCH; col += 256) {
-                const int xin = col - 3;
-                const float v = (row_ok && xin >= 0 && xin < Win) ? src[xin] : 0.f;
-                dst[col] = (bf16_t)v;
+        // stage: rows (c, iy) <- x[b][c][2*oy0 - 3 + iy][*] as bf16 at columns x + 3 (the 3 + slack pad columns on
+        // either side were zeroed once and are never written).  All of a thread's 16-byte loads are issued before
+        // the first LDS write so they overlap instead of paying one memory round trip each.
+        {
+            const int vec_per_row = Win / 4, nvec = 3 * STEM_ROWS * vec_per_row;
+            constexpr int NV = 10;                                   // ceil(39 * 56 / 256) for 224-wide inputs
+            f32x4 v[NV];
+            bool ok[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int idx = tid + 256 * i;
+                ok[i] = idx < nvec;
+                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ok[i]) {
+                    const int r = idx / vec_per_row, j = idx - r * vec_per_row;
+                    const int c = r / STEM_ROWS, iy = r - c * STEM_ROWS;
+                    const int yin = 2 * oy0 - 3 + iy;
+                    if (yin >= 0 && yin < Hin)
+                        v[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + yin) * Win + 4 * j);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                if (ok[i]) {
+                    const int idx = tid + 256 * i;
+                    const int r = idx / vec_per_row, j = idx - r * vec_per_row;
+                    bf16_t* dst = (bf16_t*)(patch + r * STEM_PITCH) + 4 * j + 3;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[e] = (bf16_t)v[i][e];
+                }
             }
         }
         __syncthreads();
@@ -311,6 +333,7 @@ constexpr int GC_PIXB = 144;               // LDS bytes per staged pixel (128 B 
 struct GconvDev {
     const void* x; const float* a_scale; const float* a_shift; const void* w; void* y; float* stats;
     int B, H, W, C, cg, stride, Ho, Wo, TH, bands, rows_in;
+    int ablate;      // debug only ($CVCL_GCONV_ABLATE): 1 skip BN math, 2 skip MFMA loop, 4 skip stores, 8 skip LDS staging writes
 };
 
 __global__ __launch_bounds__(256) void gconv_mfma_kernel(GconvDev p) {
@@ -345,53 +368,100 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GconvDev p) {
 
     const int npix_in = p.rows_in * Wp;
     const int n_out = p.TH * p.Wo, n_mt = cvcl_div_up(n_out, 16);
-    for (int item = blockIdx.x; item < p.B * p.bands; item += gridDim.x) {
+    // per-lane constants of the compute loop: LDS byte offset of each K step's tap (+ this lane's channel block),
+    // first pixel's (row, column), output channel
+    int tap_off[9];
+#pragma unroll
+    for (int ks = 0; ks < 9; ++ks) {
+        int tap = wide ? ks : 2 * ks + (kb >> 1);
+        if (tap > 8) tap = 8;                                          // padded tap: its weights are zero
+        const int ky = tap / 3, kx = tap - ky * 3;
+        tap_off[ks] = (ky * Wp + kx) * GC_PIXB + in_ch_off * 2;
+    }
+    const int ty_init = pix / p.Wo, ox_init = pix - ty_init * p.Wo;
+    const int out_ch = c0 + wave * 16 + kb * 4;
+    // software pipeline over work items: the next band's pixels are loaded into registers (raw, no waiting) before
+    // the current band is multiplied out of LDS; BN+ReLU and the LDS write happen one iteration later.
+    constexpr int NPF = 11;                          // >= ceil(max staged pixels / 32) = ceil(6 * 58 / 32)
+    bf16x8 pf[NPF];
+    bool pf_in[NPF];
+    auto prefetch = [&](int item) {
+        const int b = item / p.bands, band = item - b * p.bands;
+        const int iy0 = band * p.TH * p.stride - 1;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int pi = s_pix0 + 32 * i;
+            pf_in[i] = false;
+            if (pi < npix_in) {
+                const int ry = pi / Wp, rx = pi - ry * Wp;
+                const int yin = iy0 + ry, xin = rx - 1;
+                if (yin >= 0 && yin < p.H && xin >= 0 && xin < p.W) {
+                    pf_in[i] = true;
+                    pf[i] = *reinterpret_cast<const bf16x8*>(x + (((long)b * p.H + yin) * p.W + xin) * p.C + c0 + s_chunk * 8);
+                }
+            }
+        }
+    };
+    const int n_items = p.B * p.bands;
+    if ((int)blockIdx.x < n_items) prefetch(blockIdx.x);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = item / p.bands, band = item - b * p.bands;
         const int oy0 = band * p.TH;
-        const int iy0 = oy0 * p.stride - 1;                       // first staged input row
         __syncthreads();
-        for (int pi = s_pix0; pi < npix_in; pi += 32) {
-            const int ry = pi / Wp, rx = pi - ry * Wp;
-            const int yin = iy0 + ry, xin = rx - 1;
-            bf16x8 v;
-            if (yin >= 0 && yin < p.H && xin >= 0 && xin < p.W) {
-                const bf16x8 raw = *reinterpret_cast<const bf16x8*>(x + (((long)b * p.H + yin) * p.W + xin) * p.C + c0 + s_chunk * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)raw[e], sc[e], sh[e]), 0.f);
-            } else {
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                v = __builtin_bit_cast(bf16x8, z);               // zero padding lives in the post-activation domain
+        for (int i = 0; i < NPF; ++i) {
+            const int pi = s_pix0 + 32 * i;
+            if (pi < npix_in) {
+                bf16x8 v;
+                if (pf_in[i] && (p.ablate & 1)) {
+                    v = pf[i];
+                } else if (pf_in[i]) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)pf[i][e], sc[e], sh[e]), 0.f);
+                } else {
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+                    v = __builtin_bit_cast(bf16x8, z);           // zero padding lives in the post-activation domain
+                }
+                if (!(p.ablate & 8)) *reinterpret_cast<bf16x8*>(smem + pi * GC_PIXB + s_chunk * 16) = v;
             }
-            *reinterpret_cast<bf16x8*>(smem + pi * GC_PIXB + s_chunk * 16) = v;
         }
         __syncthreads();
-        for (int mt = 0; mt < n_mt; ++mt) {
-            const int q = mt * 16 + pix;
-            const bool ok_q = q < n_out;
-            const int ty = ok_q ? q / p.Wo : 0, ox = ok_q ? q - ty * p.Wo : 0;
-            const int base = ((ty * p.stride) * Wp + ox * p.stride);           // staged pixel of tap (0,0)
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
+        if (p.ablate & 2) continue;
+        // two independent m-tiles (16 output pixels each) in flight per wave: their LDS reads and MFMA chains
+        // interleave.  Pixel coordinates advance incrementally (no divisions in the loop).
+        int q0 = pix, ty0 = ty_init, ox0 = ox_init;
+        for (int mt = 0; mt < n_mt; mt += 2) {
+            int q1 = q0 + 16, ty1 = ty0, ox1 = ox0 + 16;
+            while (ox1 >= p.Wo) { ox1 -= p.Wo; ++ty1; }
+            const bool ok0 = q0 < n_out, ok1 = (mt + 1 < n_mt) && q1 < n_out;
+            const int base0 = ok0 ? ((ty0 * p.stride) * Wp + ox0 * p.stride) * GC_PIXB : 0;
+            const int base1 = ok1 ? ((ty1 * p.stride) * Wp + ox1 * p.stride) * GC_PIXB : 0;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 9; ++ks) {
                 if (ks < KS) {
-                    int tap = wide ? ks : 2 * ks + (kb >> 1);
-                    if (tap > 8) tap = 8;                                      // padded tap: zero weights
-                    const int ky = tap / 3, kx = tap - ky * 3;
-                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + (base + ky * Wp + kx) * GC_PIXB + in_ch_off * 2);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a, acc, 0, 0, 0);
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(smem + base0 + tap_off[ks]);
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(smem + base1 + tap_off[ks]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a1, acc1, 0, 0, 0);
                 }
             }
-            const int oy = oy0 + ty;
-            if (ok_q && oy < p.Ho) {
-                bf16x4 o = {(bf16_t)acc[0], (bf16_t)acc[1], (bf16_t)acc[2], (bf16_t)acc[3]};
-                *reinterpret_cast<bf16x4*>(y + (((long)b * p.Ho + oy) * p.Wo + ox) * p.C + c0 + wave * 16 + kb * 4) = o;
+            if (p.ablate & 4) { asm volatile("" :: "v"(acc0[0]), "v"(acc1[0])); q0 = q1 + 16; ty0 = ty1; ox0 = ox1 + 16; while (ox0 >= p.Wo) { ox0 -= p.Wo; ++ty0; } continue; }
+            if (ok0 && oy0 + ty0 < p.Ho) {
+                bf16x4 o = {(bf16_t)acc0[0], (bf16_t)acc0[1], (bf16_t)acc0[2], (bf16_t)acc0[3]};
+                *reinterpret_cast<bf16x4*>(y + (((long)b * p.Ho + oy0 + ty0) * p.Wo + ox0) * p.C + out_ch) = o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float s = (float)o[e];
-                    ssum[e] += s;
-                    ssq[e] = fmaf(s, s, ssq[e]);
-                }
+                for (int e = 0; e < 4; ++e) { const float sv = (float)o[e]; ssum[e] += sv; ssq[e] = fmaf(sv, sv, ssq[e]); }
             }
+            if (ok1 && oy0 + ty1 < p.Ho) {
+                bf16x4 o = {(bf16_t)acc1[0], (bf16_t)acc1[1], (bf16_t)acc1[2], (bf16_t)acc1[3]};
+                *reinterpret_cast<bf16x4*>(y + (((long)b * p.Ho + oy0 + ty1) * p.Wo + ox1) * p.C + out_ch) = o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float sv = (float)o[e]; ssum[e] += sv; ssq[e] = fmaf(sv, sv, ssq[e]); }
+            }
+            q0 = q1 + 16; ty0 = ty1; ox0 = ox1 + 16;
+            while (ox0 >= p.Wo) { ox0 -= p.Wo; ++ty0; }
         }
     }
     // per-channel partial sums: reduce over the 16 pixel lanes; channel = c0 + wave*16 + kb*4 + e
@@ -637,7 +707,8 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
     CVCL_CHECK_ARG(x_nchw && w_packed && y_nhwc && B > 0 && H % 2 == 0 && W % 2 == 0, "cvcl_stem_conv7x7: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16) {
-        CVCL_CHECK_ARG(W + 6 + 8 <= 2 * STEM_PITCH, "cvcl_stem_conv7x7: width %d too large for the staged patch", W);
+        CVCL_CHECK_ARG(W + 6 + 8 <= 2 * STEM_PITCH && W % 4 == 0 && 3 * STEM_ROWS * (W / 4) <= 10 * 256,
+                       "cvcl_stem_conv7x7: width %d not supported by the staged patch", W);
         const int g = stem_grid(B, H);
         CVCL_CHECK_ARG(!stats || stats_rows >= g, "cvcl_stem_conv7x7: stats_rows %d < %d", stats_rows, g);
         const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4;
@@ -681,7 +752,9 @@ GconvPlan gconv_plan(int B, int H, int W, int stride) {
     const int Ho = (H - 1) / stride + 1, Wp = W + 2;
     // output rows per work item: keep the staged band under ~60 KiB so two workgroups fit a CU
     int TH = Ho;
-    while (TH > 1 && (size_t)((TH - 1) * stride + 3) * Wp * GC_PIXB > 60 * 1024) TH = (TH + 1) / 2;
+    // ... and its pixel count within the 11 x 32 register-prefetch slots of the kernel
+    while (TH > 1 && ((size_t)((TH - 1) * stride + 3) * Wp * GC_PIXB > 60 * 1024 || ((TH - 1) * stride + 3) * Wp > 11 * 32))
+        TH = (TH + 1) / 2;
     g.TH = TH;
     g.bands = cvcl_div_up(Ho, TH);
     g.rows_in = (TH - 1) * stride + 3;
@@ -710,12 +783,14 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         CVCL_CHECK_ARG((cg == 4 || cg == 8 || cg == 16 || cg == 32) && C % GC_CS == 0,
                        "cvcl_gconv3x3: unsupported channels-per-group %d (C=%d)", cg, C);
         const GconvPlan g = gconv_plan(B, H, W, stride);
-        CVCL_CHECK_ARG(g.lds <= 160 * 1024, "cvcl_gconv3x3: feature map too wide for one LDS band (%zu B)", g.lds);
+        CVCL_CHECK_ARG(g.lds <= 160 * 1024 && g.rows_in * (W + 2) <= 11 * 32,
+                       "cvcl_gconv3x3: feature map too wide for one staged band (%zu B, %d pixels)", g.lds, g.rows_in * (W + 2));
         CVCL_CHECK_ARG(!stats || stats_rows >= g.grid_x, "cvcl_gconv3x3: stats_rows %d < %d", stats_rows, g.grid_x);
         GconvDev d;
         d.x = x; d.a_scale = a_scale; d.a_shift = a_shift; d.w = w_packed; d.y = y; d.stats = stats;
         d.B = B; d.H = H; d.W = W; d.C = C; d.cg = cg; d.stride = stride; d.Ho = Ho; d.Wo = Wo;
         d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
+        { const char* e = getenv("CVCL_GCONV_ABLATE"); d.ablate = e ? atoi(e) : 0; }
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)gconv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
