@@ -161,7 +161,7 @@ int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void
 int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int B, int H, int W,
                          int C, void* stream);
 /* grouped 3x3 conv pad 1 stride 1|2 on relu(x*a_scale+a_shift): [B,H,W,C] -> raw [B,Ho,Wo,C] (+stats) */
-int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int stride);
+int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int C, int stride);
 int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed, void* y,
                   float* stats, int stats_rows, int B, int H, int W, int C, int groups, int stride, void* stream);
 /* out = relu(raw*scale+shift + (idn | idn*idn_scale+idn_shift)), [rows, C] */

@@ -336,7 +336,8 @@ struct GconvDev {
     int ablate;      // debug only ($CVCL_GCONV_ABLATE): 1 skip BN math, 2 skip MFMA loop, 4 skip stores, 8 skip LDS staging writes
 };
 
-__global__ __launch_bounds__(256) void gconv_mfma_kernel(GconvDev p) {
+template <bool WIDE>
+__global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bf16_t* __restrict__ x = (const bf16_t*)p.x;
     bf16_t* __restrict__ y = (bf16_t*)p.y;
@@ -344,16 +345,15 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GconvDev p) {
     const int pix = lane & 15, kb = lane >> 4;
     const int slab = blockIdx.y, c0 = slab * GC_CS;
     const int Wp = p.W + 2;                                       // staged row width incl. halo columns
-    const bool wide = p.cg == 32;
-    const int KS = wide ? 9 : 5;
+    constexpr bool wide = WIDE;                                   // 32 channels per group (layer4) vs 4/8/16
+    constexpr int KS = WIDE ? 9 : 5;
     // this wave's unit: 16 output channels [c0 + 16*wave, +16); for cg == 32 the unit's inputs are the
     // 32 channels of its group, else the same 16 channels (block-diagonal weights)
     const int unit = c0 / 16 + wave;
     const bf16_t* wu = (const bf16_t*)p.w + (long)unit * KS * 512;
-    bf16x8 wf[9];
+    bf16x8 wf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 9; ++ks)
-        if (ks < KS) wf[ks] = *reinterpret_cast<const bf16x8*>(wu + (ks * 16 + pix) * 32 + kb * 8);
+    for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const bf16x8*>(wu + (ks * 16 + pix) * 32 + kb * 8);
     const int in_ch_off = wide ? ((wave >> 1) * 32 + kb * 8) : (wave * 16 + (kb & 1) * 8);   // within the slab
 
     // staging role: 8 chunks (of 8 channels) per pixel, 32 pixels per pass
@@ -370,19 +370,19 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GconvDev p) {
     const int n_out = p.TH * p.Wo, n_mt = cvcl_div_up(n_out, 16);
     // per-lane constants of the compute loop: LDS byte offset of each K step's tap (+ this lane's channel block),
     // first pixel's (row, column), output channel
-    int tap_off[9];
+    int tap_off[KS];
 #pragma unroll
-    for (int ks = 0; ks < 9; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         int tap = wide ? ks : 2 * ks + (kb >> 1);
         if (tap > 8) tap = 8;                                          // padded tap: its weights are zero
         const int ky = tap / 3, kx = tap - ky * 3;
         tap_off[ks] = (ky * Wp + kx) * GC_PIXB + in_ch_off * 2;
     }
     const int ty_init = pix / p.Wo, ox_init = pix - ty_init * p.Wo;
-    const int out_ch = c0 + wave * 16 + kb * 4;
+    char* s_out = smem + npix_in * GC_PIXB;                            // output band [TH * Wo pixels][GC_PIXB]
     // software pipeline over work items: the next band's pixels are loaded into registers (raw, no waiting) before
     // the current band is multiplied out of LDS; BN+ReLU and the LDS write happen one iteration later.
-    constexpr int NPF = 11;                          // >= ceil(max staged pixels / 32) = ceil(6 * 58 / 32)
+    constexpr int NPF = 10;                          // >= ceil(max staged pixels / 32) (see gconv_plan)
     bf16x8 pf[NPF];
     bool pf_in[NPF];
     auto prefetch = [&](int item) {
@@ -439,29 +439,39 @@ __global__ __launch_bounds__(256) void gconv_mfma_kernel(GconvDev p) {
             const int base1 = ok1 ? ((ty1 * p.stride) * Wp + ox1 * p.stride) * GC_PIXB : 0;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 9; ++ks) {
-                if (ks < KS) {
-                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(smem + base0 + tap_off[ks]);
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(smem + base1 + tap_off[ks]);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a1, acc1, 0, 0, 0);
-                }
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(smem + base0 + tap_off[ks]);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(smem + base1 + tap_off[ks]);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a1, acc1, 0, 0, 0);
             }
-            if (p.ablate & 4) { asm volatile("" :: "v"(acc0[0]), "v"(acc1[0])); q0 = q1 + 16; ty0 = ty1; ox0 = ox1 + 16; while (ox0 >= p.Wo) { ox0 -= p.Wo; ++ty0; } continue; }
             if (ok0 && oy0 + ty0 < p.Ho) {
                 bf16x4 o = {(bf16_t)acc0[0], (bf16_t)acc0[1], (bf16_t)acc0[2], (bf16_t)acc0[3]};
-                *reinterpret_cast<bf16x4*>(y + (((long)b * p.Ho + oy0 + ty0) * p.Wo + ox0) * p.C + out_ch) = o;
+                *reinterpret_cast<bf16x4*>(s_out + q0 * GC_PIXB + wave * 32 + kb * 8) = o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float sv = (float)o[e]; ssum[e] += sv; ssq[e] = fmaf(sv, sv, ssq[e]); }
             }
             if (ok1 && oy0 + ty1 < p.Ho) {
                 bf16x4 o = {(bf16_t)acc1[0], (bf16_t)acc1[1], (bf16_t)acc1[2], (bf16_t)acc1[3]};
-                *reinterpret_cast<bf16x4*>(y + (((long)b * p.Ho + oy0 + ty1) * p.Wo + ox1) * p.C + out_ch) = o;
+                *reinterpret_cast<bf16x4*>(s_out + q1 * GC_PIXB + wave * 32 + kb * 8) = o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float sv = (float)o[e]; ssum[e] += sv; ssq[e] = fmaf(sv, sv, ssq[e]); }
             }
             q0 = q1 + 16; ty0 = ty1; ox0 = ox1 + 16;
             while (ox0 >= p.Wo) { ox0 -= p.Wo; ++ty0; }
+        }
+        // the band's output sits in LDS as [pixel][64 channels]: write it out as full 128-byte pixel rows
+        // (16 B per lane).  Scattered 8-byte stores straight from the MFMA layout cost more than the whole
+        // load + compute phases together (ablation in DESIGN.md).
+        __syncthreads();
+        if (!(p.ablate & 4)) {
+            const int valid_rows = min(p.TH, p.Ho - oy0);
+            const int n_chunks = valid_rows * p.Wo * 8;
+            for (int i = tid; i < n_chunks; i += 256) {
+                const int px = i >> 3, ch = i & 7;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(s_out + px * GC_PIXB + ch * 16);
+                *reinterpret_cast<bf16x8*>(y + (((long)b * p.Ho + oy0) * p.Wo + px) * p.C + c0 + ch * 8) = v;
+            }
         }
     }
     // per-channel partial sums: reduce over the 16 pixel lanes; channel = c0 + wave*16 + kb*4 + e
@@ -747,26 +757,34 @@ extern "C" int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale
 
 namespace {
 struct GconvPlan { int TH, bands, rows_in, grid_x; size_t lds; };
-GconvPlan gconv_plan(int B, int H, int W, int stride) {
+GconvPlan gconv_plan(int B, int H, int W, int C, int stride) {
     GconvPlan g;
-    const int Ho = (H - 1) / stride + 1, Wp = W + 2;
-    // output rows per work item: keep the staged band under ~60 KiB so two workgroups fit a CU
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, Wp = W + 2;
+    // output rows per work item: staged input band + output band within ~52 KiB (3 workgroups per CU) and the
+    // input pixel count within the 10 x 32 register-prefetch slots of the kernel
+    auto bytes = [&](int th) { return (size_t)(((th - 1) * stride + 3) * Wp + th * Wo) * GC_PIXB; };
     int TH = Ho;
-    // ... and its pixel count within the 11 x 32 register-prefetch slots of the kernel
-    while (TH > 1 && ((size_t)((TH - 1) * stride + 3) * Wp * GC_PIXB > 60 * 1024 || ((TH - 1) * stride + 3) * Wp > 11 * 32))
-        TH = (TH + 1) / 2;
+    while (TH > 1 && (bytes(TH) > 52 * 1024 || ((TH - 1) * stride + 3) * Wp > 10 * 32)) TH = (TH + 1) / 2;
     g.TH = TH;
     g.bands = cvcl_div_up(Ho, TH);
     g.rows_in = (TH - 1) * stride + 3;
-    g.lds = (size_t)g.rows_in * Wp * GC_PIXB;
+    g.lds = bytes(TH);
+    // persistent grid = what is co-resident (no second round of workgroups): LDS- and register-limited to 3 per CU
+    int per_cu = (int)((160 * 1024) / g.lds);
+    const int reg_limit = (C / 32 == 32) ? 2 : 3;                     // launch bounds of the two kernel variants
+    if (per_cu > reg_limit) per_cu = reg_limit;
+    if (per_cu < 1) per_cu = 1;
+    const int slabs = C / GC_CS;
+    int gx = per_cu * 256 / slabs;
+    if (gx < 1) gx = 1;
     const int items = B * g.bands;
-    g.grid_x = items < 256 ? items : 256;
+    g.grid_x = items < gx ? items : gx;
     return g;
 }
 }  // namespace
 
-extern "C" int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int stride) {
-    if (dtype == CVCL_BF16) return gconv_plan(B, H, W, stride).grid_x;
+extern "C" int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int C, int stride) {
+    if (dtype == CVCL_BF16) return gconv_plan(B, H, W, C, stride).grid_x;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     return cvcl_col_stats_rows((long)B * Ho * Wo);
 }
@@ -782,8 +800,8 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
     if (dtype == CVCL_BF16) {
         CVCL_CHECK_ARG((cg == 4 || cg == 8 || cg == 16 || cg == 32) && C % GC_CS == 0,
                        "cvcl_gconv3x3: unsupported channels-per-group %d (C=%d)", cg, C);
-        const GconvPlan g = gconv_plan(B, H, W, stride);
-        CVCL_CHECK_ARG(g.lds <= 160 * 1024 && g.rows_in * (W + 2) <= 11 * 32,
+        const GconvPlan g = gconv_plan(B, H, W, C, stride);
+        CVCL_CHECK_ARG(g.lds <= 160 * 1024 && g.rows_in * (W + 2) <= 10 * 32,
                        "cvcl_gconv3x3: feature map too wide for one staged band (%zu B, %d pixels)", g.lds, g.rows_in * (W + 2));
         CVCL_CHECK_ARG(!stats || stats_rows >= g.grid_x, "cvcl_gconv3x3: stats_rows %d < %d", stats_rows, g.grid_x);
         GconvDev d;
@@ -793,14 +811,18 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         { const char* e = getenv("CVCL_GCONV_ABLATE"); d.ablate = e ? atoi(e) : 0; }
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)gconv_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            if (hipFuncSetAttribute((const void*)gconv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)gconv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
                 return CVCL_ELAUNCH;
             }
             attr_set = true;
         }
         CvclProfScope prof(stream, CVCL_K_GCONV);
-        hipLaunchKernelGGL(gconv_mfma_kernel, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
+        if (cg == 32)
+            hipLaunchKernelGGL(gconv_mfma_kernel<true>, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
+        else
+            hipLaunchKernelGGL(gconv_mfma_kernel<false>, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }
@@ -951,7 +973,7 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
             // conv2 grouped 3x3 (stride here): R1 -> R2 [m_out, width], BN1+ReLU fused into the load
             if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), layers[l2].w, R2, training ? stats : nullptr,
                                     kMaxStatsRows, B, h, wd, width, 32, stride, stream))) return rc;
-            if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, stride), m_out, width))) return rc;
+            if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, width, stride), m_out, width))) return rc;
             // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  BN2+ReLU is applied to the narrow tensor in place first
             // (one pass) instead of in the GEMM operand load (once per 128-column output tile): see bn_relu_apply_kernel.
             if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;

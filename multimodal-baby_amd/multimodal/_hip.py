@@ -77,7 +77,7 @@ SIGNATURES = {
     "cvcl_stem_conv_stats_rows": (_I, [_I, _I, _I, _I]),
     "cvcl_stem_conv7x7": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_bn_relu_maxpool": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "cvcl_gconv3x3_stats_rows": (_I, [_I, _I, _I, _I, _I]),
+    "cvcl_gconv3x3_stats_rows": (_I, [_I, _I, _I, _I, _I, _I]),
     "cvcl_gconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cvcl_bn_add_relu": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_bn_relu_apply": (_I, [_I, _P, _P, _P, _P, C.c_long, _I, _P]),

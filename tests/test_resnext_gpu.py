@@ -131,7 +131,7 @@ def test_gconv(H, dev, dt, C_, S, stride, B):
     wp = pack(H, dt, H.PACK_GCONV3, w, dev)
     So = (S - 1) // stride + 1
     y = torch.empty(B, So, So, C_, dtype=_t(dt), device=dev)
-    rows = H.lib().cvcl_gconv3x3_stats_rows(cd, B, S, S, stride)
+    rows = H.lib().cvcl_gconv3x3_stats_rows(cd, B, S, S, C_, stride)
     st = stats_tensor(rows, C_, dev)
     xd, scd, shd = nhwc(xq).to(_t(dt)).to(dev), sc.to(dev), sh.to(dev)      # keep device operands alive
     H.check(H.lib().cvcl_gconv3x3(cd, H.ptr(xd), H.ptr(scd), H.ptr(shd), H.ptr(wp),

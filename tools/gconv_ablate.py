@@ -14,7 +14,7 @@ def run(B, S, C, stride):
     sc, sh = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     So = (S - 1) // stride + 1
     y = torch.empty(B, So, So, C, dtype=torch.bfloat16, device=dev)
-    rows = H.lib().cvcl_gconv3x3_stats_rows(H.BF16, B, S, S, stride)
+    rows = H.lib().cvcl_gconv3x3_stats_rows(H.BF16, B, S, S, C, stride)
     st = torch.empty(rows, 2, C, device=dev)
     def call():
         H.check(H.lib().cvcl_gconv3x3(H.BF16, H.ptr(x), H.ptr(sc), H.ptr(sh), H.ptr(wp), H.ptr(y), H.ptr(st), rows, B, S, S, C, 32, stride, H.stream_ptr()), "gconv")
