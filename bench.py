@@ -191,9 +191,19 @@ def main():
         avg_s = g_ms / max(g_n, 1) * 1e-3
         per_launch_bytes = nbytes / launches
         achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        roofline = {"kernel": "gemm_kernel<bf16> (1x1-conv MFMA GEMM, fused BN-apply prologue + BN-stats epilogue)",
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3
+        # --pmc passes of this same command: tools/pmc_bench.sh -> profiles/r01_pmc_hbm_traffic.json)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                pm = json.load(f)["gemm_glds_kernel"]
+            traffic = int((pm["hbm_read_bytes_per_step_corrected_x2"] + pm["hbm_write_bytes_per_step"]) / pm["launches_per_step"])
+        except Exception:
+            pass
+        roofline = {"kernel": "gemm_glds_kernel (bf16 1x1-conv MFMA GEMM, direct-to-LDS operand loads, BN-stats epilogue)",
                     "dominant_class_by_time": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_note": "PMC HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)",
                     "launches_per_step": g_n // nprof, "avg_launch_us": round(avg_s * 1e6, 2),
                     "algorithmic_bytes_per_launch": int(per_launch_bytes),
                     "mfma_tflops": round(flops / launches / avg_s / 1e12, 1) if avg_s > 0 else 0.0,

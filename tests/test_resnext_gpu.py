@@ -159,6 +159,10 @@ def test_bn_add_relu_and_avgpool(H, dev, dt):
                                          H.ptr(s2d) if with_ds else None, H.ptr(b2d) if with_ds else None, H.ptr(out),
                                          rows, Cn, H.stream_ptr()), "bn_add_relu")
         assert maxrel(out.float(), q(ref)) < (5e-3 if dt == "bf16" else 1e-6)
+    # relu(bn(x)) in place (the pass that runs ahead of conv3)
+    buf = rawd.clone()
+    H.check(H.lib().cvcl_bn_relu_apply(cd, H.ptr(buf), H.ptr(s1d), H.ptr(b1d), H.ptr(buf), rows, Cn, H.stream_ptr()), "bn_relu_apply")
+    assert maxrel(buf.float(), q(torch.relu(raw * s1 + b1))) < (5e-3 if dt == "bf16" else 1e-6)
     pooled = torch.empty(2, Cn, device=dev)
     H.check(H.lib().cvcl_avgpool(cd, H.ptr(out), H.ptr(pooled), 2, 49, Cn, H.stream_ptr()), "avgpool")
     assert maxrel(pooled, out.float().reshape(2, 49, Cn).mean(dim=1)) < 1e-5
