@@ -208,6 +208,31 @@ int cvcl_seq_sum_div(const float* x, const int64_t* len, float* ret, int B, int 
 int cvcl_lstm_cell(const float* gates, const int64_t* len, int t, float* h, float* c, float* out, int B, int L, int Hd,
                    void* stream);
 
+/* Training side of the text encoders (the reference trains them under Lightning's .train(): dropout 0.1 in
+ * nn.TransformerEncoderLayer, LockedDropout(dropout_i) ahead of the LSTM; multimodal/multimodal.py:46-53,513-573).
+ * All f32, deterministic.  Dropout uses a counter-based hash of (seed, element index): the same call is the
+ * backward.  shared_period > 0 shares the mask along a dimension of that extent (LockedDropout's [B,1,E] mask).  */
+int cvcl_dropout(const float* x, const float* residual, float* y, long n, float p, unsigned long long seed,
+                 long shared_period, long inner, void* stream);      /* y = dropout(x) (+ residual) */
+/* LayerNorm backward: dx, plus dy*xhat per element (column-summed by cvcl_colsum_f32 into dgamma; dbeta = colsum(dy)) */
+int cvcl_layernorm_bwd(const float* x, const float* gamma, const float* dy, float eps, float* dx, float* dy_xhat, long rows,
+                       int D, void* stream);
+int cvcl_relu_bwd(const float* y, const float* dy, float* dx, long n, void* stream);
+/* d_table[v] = sum of dx rows whose token is v, in position order; row 0 (padding_idx) = 0; fully overwritten */
+int cvcl_embed_rows_bwd(const float* dx, const int64_t* tok, float* d_table, int n_pos, int E, int V, void* stream);
+int cvcl_seq_sum_div_bwd(const float* d_ret, const int64_t* len, float* dx, int B, int L, int E, void* stream);
+/* nn.MultiheadAttention core for short sequences (T <= 32) with key padding mask and probability dropout:
+ * forward when out != NULL, backward when d_qkv != NULL (P is recomputed).  qkv [B,T,3,heads,hd] f32.            */
+int cvcl_attention_small(const float* qkv, const int64_t* key_tok, const float* d_out, float* out, float* d_qkv, int B,
+                         int T, int heads, int head_dim, float scale, float dropout_p, unsigned long long seed,
+                         void* stream);
+/* nn.LSTM step t that saves, in [B,L,.] layout (row b*L+t), the gate activations, c_t and h_{t-1} for BPTT; and the
+ * BPTT step: d_gates rows b*L+t of [B,L,4H], dc updated in place, dh_carry = dh where the step was masked        */
+int cvcl_lstm_cell_train(const float* gates, const int64_t* len, int t, float* h, float* c, float* out /*[B,L,H] or NULL*/,
+                         float* gates_act, float* c_save, float* h_prev_save, int B, int L, int Hd, void* stream);
+int cvcl_lstm_cell_bwd(const float* gates_act, const float* c_save, const int64_t* len, int t, const float* dh, float* dc,
+                       float* d_gates, float* dh_carry, int B, int L, int Hd, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

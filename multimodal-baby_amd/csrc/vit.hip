@@ -399,3 +399,368 @@ extern "C" int cvcl_lstm_cell(const float* gates, const int64_t* len, int t, flo
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
+
+// ================================================================================================
+// Training side of the text encoders (reference multimodal/multimodal.py:513-573 run under Lightning's
+// .train()): backward kernels + dropout.  All fp32, deterministic (no atomics).
+// ================================================================================================
+namespace {
+
+// counter-based hash RNG (one draw per element): keep iff u >= p.  Same (seed, index) -> same mask in fwd and bwd.
+__device__ inline float hash_uniform(unsigned long long seed, unsigned long long idx) {
+    unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);          // 24 random bits -> [0, 1)
+}
+
+// y = x * keep / (1 - p); the same kernel is the backward (dx = dy * keep / (1 - p)).
+// period > 0: the mask index is (i / (period * inner)) * inner + i % inner, i.e. shared along one dimension
+// (LockedDropout, multimodal.py:46-53: mask shape [B,1,E] shared over time).
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                      float* __restrict__ y, long n, float p, unsigned long long seed,
+                                                      long period, long inner) {
+    const float scale = 1.f / (1.f - p);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long mi = period > 0 ? (i / (period * inner)) * inner + (i % inner) : i;
+        float v = (p <= 0.f || hash_uniform(seed, (unsigned long long)mi) >= p) ? x[i] * scale : 0.f;
+        if (res) v += res[i];
+        y[i] = v;
+    }
+}
+
+// LayerNorm backward, one wave per row: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma.
+// Per-row partial products for dgamma / dbeta are written as dy*xhat and dy (reduced by cvcl_colsum_f32).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, float eps, float* __restrict__ dx,
+                                                            float* __restrict__ dyxhat, long rows, int D) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * D;
+    const float* gr = dy + row * D;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += xr[d];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int d = lane; d < D; d += 64) { const float c = xr[d] - mean; q = fmaf(c, c, q); }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        const float xh = (xr[d] - mean) * rstd, g = gr[d] * gamma[d];
+        sg += g;
+        sgx = fmaf(g, xh, sgx);
+    }
+    sg = wave_sum(sg) / (float)D;
+    sgx = wave_sum(sgx) / (float)D;
+    for (int d = lane; d < D; d += 64) {
+        const float xh = (xr[d] - mean) * rstd, g = gr[d] * gamma[d];
+        dx[row * D + d] = rstd * (g - sg - xh * sgx);
+        dyxhat[row * D + d] = gr[d] * xh;
+    }
+}
+
+// dx = dy where y > 0 (ReLU backward from the saved output)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+// d_table[v] = sum over positions (b,l) with tok == v of dx[b,l,:], in (b,l) order; padding row 0 -> 0.
+// Same deterministic per-vocabulary-row scan as embed_meanpool_bwd_kernel (head.hip), without the /len.
+__global__ __launch_bounds__(128) void embed_rows_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tok,
+                                                             float* __restrict__ d_table, int total, int E) {
+    __shared__ int stok[8192];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    constexpr int MAXR = 8;
+    for (int ebase = 0; ebase < E; ebase += 128 * MAXR) {
+        float acc[MAXR];
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) acc[i] = 0.f;
+        if (v != 0) {
+            for (int c0 = 0; c0 < total; c0 += 8192) {
+                const int n = min(8192, total - c0);
+                __syncthreads();
+                for (int i = tid; i < n; i += 128) stok[i] = (int)tok[c0 + i];
+                __syncthreads();
+                for (int base = 0; base < n; base += 64) {
+                    const bool hit = (base + lane) < n && stok[base + lane] == v;
+                    unsigned long long mm = __ballot(hit);
+                    while (mm) {
+                        int pos[8];
+                        int nb = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            pos[k] = 0;
+                            if (mm) { const int bit = __ffsll((long long)mm) - 1; mm &= mm - 1; pos[k] = c0 + base + bit; nb = k + 1; }
+                        }
+                        float val[8][MAXR];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+#pragma unroll
+                            for (int i = 0; i < MAXR; ++i) {
+                                const int e = ebase + tid + 128 * i;
+                                val[k][i] = (k < nb && e < E) ? dx[(long)pos[k] * E + e] : 0.f;
+                            }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (k < nb) {
+#pragma unroll
+                                for (int i = 0; i < MAXR; ++i) acc[i] += val[k][i];
+                            }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int e = ebase + tid + 128 * i;
+            if (e < E) d_table[(long)v * E + e] = acc[i];
+        }
+    }
+}
+
+// dx[b,l,:] = d_ret[b,:] / len[b] for every l (backward of seq_sum_div: pads included, as in the forward)
+__global__ __launch_bounds__(256) void seq_sum_div_bwd_kernel(const float* __restrict__ d_ret, const int64_t* __restrict__ len,
+                                                              float* __restrict__ dx, int B, int L, int E) {
+    const long total = (long)B * L * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const long b = i / ((long)L * E);
+        dx[i] = d_ret[b * E + e] / (float)len[b];
+    }
+}
+
+// Small-sequence attention forward+backward with key padding mask and probability dropout (training).
+// One workgroup (64 threads = 1 wave) per (b, head); T <= 32, hd <= 128.  P is recomputed in the backward.
+//   S = q k^T * scale (+mask) ; P = softmax(S) ; Pd = dropout(P) ; O = Pd v
+//   dPd = dO v^T ; dP = dropout'(dPd) ; dS = P * (dP - sum_j dP P) ; dq = dS k * scale ; dk = dS^T q * scale ; dv = Pd^T dO
+constexpr int SA_T = 32;
+__global__ __launch_bounds__(64) void attn_small_kernel(const float* __restrict__ qkv, const int64_t* __restrict__ key_tok,
+                                                        const float* __restrict__ d_out, float* __restrict__ out,
+                                                        float* __restrict__ d_qkv, int B, int T, int heads, int hd,
+                                                        float scale, float p, unsigned long long seed) {
+    __shared__ float sP[SA_T][SA_T + 1], sPd[SA_T][SA_T + 1], sdS[SA_T][SA_T + 1];
+    const int lane = threadIdx.x;
+    const int hh = blockIdx.x % heads, b = blockIdx.x / heads;
+    const int D = heads * hd;
+    const float* base = qkv + (long)b * T * 3 * D;
+    const float keep_scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    // scores: lane handles pairs (i, j) = idx / T, idx % T
+    for (int idx = lane; idx < T * T; idx += 64) {
+        const int i = idx / T, j = idx - i * T;
+        const float* qp = base + (long)i * 3 * D + hh * hd;
+        const float* kp = base + (long)j * 3 * D + D + hh * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(qp[d], kp[d], s);
+        s *= scale;
+        if (key_tok && key_tok[(long)b * T + j] == 0) s = -INFINITY;
+        sP[i][j] = s;
+    }
+    __syncthreads();
+    if (lane < T) {                                       // row softmax + dropout mask
+        const int i = lane;
+        float mx = -INFINITY;
+        for (int j = 0; j < T; ++j) mx = fmaxf(mx, sP[i][j]);
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { const float e = expf(sP[i][j] - mx); sP[i][j] = e; sum += e; }
+        for (int j = 0; j < T; ++j) {
+            const float pr = sP[i][j] / sum;
+            sP[i][j] = pr;
+            float keep = 1.f;
+            if (p > 0.f) keep = hash_uniform(seed, (((unsigned long long)b * heads + hh) * T + i) * T + j) >= p ? keep_scale : 0.f;
+            sPd[i][j] = pr * keep;
+        }
+    }
+    __syncthreads();
+    if (out) {
+        for (int idx = lane; idx < T * hd; idx += 64) {
+            const int i = idx / hd, d = idx - i * hd;
+            float acc = 0.f;
+            for (int j = 0; j < T; ++j) acc = fmaf(sPd[i][j], base[(long)j * 3 * D + 2 * D + hh * hd + d], acc);
+            out[((long)b * T + i) * D + hh * hd + d] = acc;
+        }
+    }
+    if (!d_qkv) return;
+    const float* dO = d_out + (long)b * T * D;
+    float* dbase = d_qkv + (long)b * T * 3 * D;
+    // dPd[i][j] = dO[i] . v[j]; dP = dPd * keep
+    for (int idx = lane; idx < T * T; idx += 64) {
+        const int i = idx / T, j = idx - i * T;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(dO[(long)i * D + hh * hd + d], base[(long)j * 3 * D + 2 * D + hh * hd + d], s);
+        float keep = 1.f;
+        if (p > 0.f) keep = hash_uniform(seed, (((unsigned long long)b * heads + hh) * T + i) * T + j) >= p ? keep_scale : 0.f;
+        sdS[i][j] = s * keep;
+    }
+    __syncthreads();
+    if (lane < T) {
+        const int i = lane;
+        float dot = 0.f;
+        for (int j = 0; j < T; ++j) dot = fmaf(sdS[i][j], sP[i][j], dot);
+        for (int j = 0; j < T; ++j) sdS[i][j] = sP[i][j] * (sdS[i][j] - dot);
+    }
+    __syncthreads();
+    for (int idx = lane; idx < T * hd; idx += 64) {
+        const int i = idx / hd, d = idx - i * hd;
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+        for (int j = 0; j < T; ++j) {
+            dq = fmaf(sdS[i][j], base[(long)j * 3 * D + D + hh * hd + d], dq);       // dS[i][j] * k[j]
+            dk = fmaf(sdS[j][i], base[(long)j * 3 * D + hh * hd + d], dk);           // dS[j][i] * q[j]
+            dv = fmaf(sPd[j][i], dO[(long)j * D + hh * hd + d], dv);                 // Pd[j][i] * dO[j]
+        }
+        dbase[(long)i * 3 * D + hh * hd + d] = dq * scale;
+        dbase[(long)i * 3 * D + D + hh * hd + d] = dk * scale;
+        dbase[(long)i * 3 * D + 2 * D + hh * hd + d] = dv;
+    }
+}
+
+// LSTM training step t (gate order i,f,g,o).  Saved for BPTT in [B, L, .] layout (row b*L + t, matching the rows of the
+// input-projection GEMM): gate activations, c_t, h_{t-1}.  Rows with len <= t keep their state (packed-sequence semantics).
+__global__ __launch_bounds__(256) void lstm_cell_train_kernel(const float* __restrict__ gates, const int64_t* __restrict__ len,
+                                                              int t, float* __restrict__ h, float* __restrict__ c,
+                                                              float* __restrict__ out, float* __restrict__ gates_act,
+                                                              float* __restrict__ c_save, float* __restrict__ h_prev_save,
+                                                              int B, int L, int Hd) {
+    const long total = (long)B * Hd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Hd);
+        const long b = i / Hd;
+        const long row = b * L + t;
+        h_prev_save[row * Hd + j] = h[i];
+        float* ga = gates_act + row * 4 * Hd;
+        float ho = 0.f;
+        if (len[b] > t) {
+            const float* gp = gates + b * 4 * Hd;
+            const float ig = 1.f / (1.f + expf(-gp[j]));
+            const float fg = 1.f / (1.f + expf(-gp[Hd + j]));
+            const float gg = tanhf(gp[2 * Hd + j]);
+            const float og = 1.f / (1.f + expf(-gp[3 * Hd + j]));
+            const float cn = fg * c[i] + ig * gg;
+            ga[j] = ig; ga[Hd + j] = fg; ga[2 * Hd + j] = gg; ga[3 * Hd + j] = og;
+            c[i] = cn;
+            ho = og * tanhf(cn);
+            h[i] = ho;
+        }
+        c_save[row * Hd + j] = c[i];
+        if (out) out[row * Hd + j] = ho;
+    }
+}
+
+// BPTT step t.  In: dh (gradient wrt h_t), dc (gradient wrt c_t, updated in place to the gradient wrt c_{t-1}).
+// Out: d_gates rows b*L + t of the [B, L, 4H] buffer (pre-activation gate gradients), dh_carry = dh for rows whose
+// step was not taken (their h_t = h_{t-1}), 0 otherwise.
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const float* __restrict__ gates_act, const float* __restrict__ c_save,
+                                                            const int64_t* __restrict__ len, int t, const float* __restrict__ dh,
+                                                            float* __restrict__ dc, float* __restrict__ d_gates,
+                                                            float* __restrict__ dh_carry, int B, int L, int Hd) {
+    const long total = (long)B * Hd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % Hd);
+        const long b = i / Hd;
+        const long row = b * L + t;
+        float* dg = d_gates + row * 4 * Hd;
+        if (len[b] <= t) {
+            dg[j] = 0.f; dg[Hd + j] = 0.f; dg[2 * Hd + j] = 0.f; dg[3 * Hd + j] = 0.f;
+            dh_carry[i] = dh[i];
+            continue;
+        }
+        dh_carry[i] = 0.f;
+        const float* ga = gates_act + row * 4 * Hd;
+        const float ig = ga[j], fg = ga[Hd + j], gg = ga[2 * Hd + j], og = ga[3 * Hd + j];
+        const float c_t = c_save[row * Hd + j];
+        const float c_prev = t > 0 ? c_save[(row - 1) * Hd + j] : 0.f;
+        const float tc = tanhf(c_t);
+        const float dho = dh[i];
+        const float dct = dc[i] + dho * og * (1.f - tc * tc);
+        dg[j] = dct * gg * ig * (1.f - ig);
+        dg[Hd + j] = dct * c_prev * fg * (1.f - fg);
+        dg[2 * Hd + j] = dct * ig * (1.f - gg * gg);
+        dg[3 * Hd + j] = dho * tc * og * (1.f - og);
+        dc[i] = dct * fg;
+    }
+}
+
+}  // namespace
+
+extern "C" int cvcl_dropout(const float* x, const float* residual, float* y, long n, float p, unsigned long long seed,
+                            long shared_period, long inner, void* stream) {
+    CVCL_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "cvcl_dropout: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, residual, y, n, p, seed,
+                       shared_period, inner > 0 ? inner : 1);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_layernorm_bwd(const float* x, const float* gamma, const float* dy, float eps, float* dx, float* dy_xhat,
+                                  long rows, int D, void* stream) {
+    CVCL_CHECK_ARG(x && gamma && dy && dx && dy_xhat && rows > 0 && D > 0, "cvcl_layernorm_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_LAYERNORM);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(cvcl_div_up(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, dy, eps, dx,
+                       dy_xhat, rows, D);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_relu_bwd(const float* y, const float* dy, float* dx, long n, void* stream) {
+    CVCL_CHECK_ARG(y && dy && dx && n > 0, "cvcl_relu_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_embed_rows_bwd(const float* dx, const int64_t* tok, float* d_table, int n_pos, int E, int V, void* stream) {
+    CVCL_CHECK_ARG(dx && tok && d_table && n_pos > 0 && E > 0 && V > 0, "cvcl_embed_rows_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(embed_rows_bwd_kernel, dim3(V), dim3(128), 0, (hipStream_t)stream, dx, tok, d_table, n_pos, E);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_seq_sum_div_bwd(const float* d_ret, const int64_t* len, float* dx, int B, int L, int E, void* stream) {
+    CVCL_CHECK_ARG(d_ret && len && dx && B > 0 && L > 0 && E > 0, "cvcl_seq_sum_div_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(seq_sum_div_bwd_kernel, dim3(grid_for((long)B * L * E)), dim3(256), 0, (hipStream_t)stream, d_ret, len, dx,
+                       B, L, E);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_attention_small(const float* qkv, const int64_t* key_tok, const float* d_out, float* out, float* d_qkv,
+                                    int B, int T, int heads, int head_dim, float scale, float dropout_p,
+                                    unsigned long long seed, void* stream) {
+    CVCL_CHECK_ARG(qkv && (out || d_qkv) && B > 0 && T > 0 && T <= SA_T && heads > 0 && head_dim > 0,
+                   "cvcl_attention_small: bad args (T <= %d)", SA_T);
+    CVCL_CHECK_ARG(!d_qkv || d_out, "cvcl_attention_small: d_out needed for the backward");
+    CvclProfScope prof(stream, CVCL_K_ATTENTION);
+    hipLaunchKernelGGL(attn_small_kernel, dim3(B * heads), dim3(64), 0, (hipStream_t)stream, qkv, key_tok, d_out, out, d_qkv, B, T,
+                       heads, head_dim, scale, dropout_p, seed);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_lstm_cell_train(const float* gates, const int64_t* len, int t, float* h, float* c, float* out,
+                                    float* gates_act, float* c_save, float* h_prev_save, int B, int L, int Hd, void* stream) {
+    CVCL_CHECK_ARG(gates && len && h && c && gates_act && c_save && h_prev_save && B > 0 && L > 0 && Hd > 0 && t >= 0 && t < L,
+                   "cvcl_lstm_cell_train: bad args");
+    CvclProfScope prof(stream, CVCL_K_LSTM);
+    hipLaunchKernelGGL(lstm_cell_train_kernel, dim3(grid_for((long)B * Hd)), dim3(256), 0, (hipStream_t)stream, gates, len, t, h, c,
+                       out, gates_act, c_save, h_prev_save, B, L, Hd);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_lstm_cell_bwd(const float* gates_act, const float* c_save, const int64_t* len, int t, const float* dh,
+                                  float* dc, float* d_gates, float* dh_carry, int B, int L, int Hd, void* stream) {
+    CVCL_CHECK_ARG(gates_act && c_save && len && dh && dc && d_gates && dh_carry && B > 0 && L > 0 && Hd > 0 && t >= 0 && t < L,
+                   "cvcl_lstm_cell_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_LSTM);
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((long)B * Hd)), dim3(256), 0, (hipStream_t)stream, gates_act, c_save, len,
+                       t, dh, dc, d_gates, dh_carry, B, L, Hd);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}

@@ -89,6 +89,14 @@ SIGNATURES = {
     "cvcl_embed_gather_pos": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_seq_sum_div": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "cvcl_lstm_cell": (_I, [_P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_dropout": (_I, [_P, _P, _P, C.c_long, _F, C.c_ulonglong, C.c_long, C.c_long, _P]),
+    "cvcl_layernorm_bwd": (_I, [_P, _P, _P, _F, _P, _P, C.c_long, _I, _P]),
+    "cvcl_relu_bwd": (_I, [_P, _P, _P, C.c_long, _P]),
+    "cvcl_embed_rows_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_seq_sum_div_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_attention_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, C.c_ulonglong, _P]),
+    "cvcl_lstm_cell_train": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_lstm_cell_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }

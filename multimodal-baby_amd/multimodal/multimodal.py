@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops, parallel, resnext
+from . import ops, parallel, resnext, text_train
 from .attention_maps import Hook
 from .multimodal_data_module import MAX_LEN_UTTERANCE, PAD_TOKEN_ID
 from .utils import load_model
@@ -130,7 +130,11 @@ class LockedDropout(nn.Module):
     def forward(self, x, dropout, dim=1):
         if not (self.training and dropout):
             return x
-        raise NotImplementedError("train-mode locked dropout needs the LSTM backward kernels (not in this build)")
+        if dim != 1 or x.dim() != 3:
+            raise NotImplementedError("LockedDropout is used with [B, L, E] inputs and dim=1 on the contrastive path")
+        B, L, E = x.shape
+        y = text_train.DropoutAdd.apply(x.reshape(B * L, E), None, float(dropout), text_train._seed(), L, E)
+        return y.view(B, L, E)
 
 
 class TextEncoder(nn.Module):
@@ -202,15 +206,20 @@ class TextEncoder(nn.Module):
             raise NotImplementedError("output dropout > 0 is not used by any contrastive configuration")
         if self.text_encoder == "embedding":
             ret, raw_output = ops.embed_meanpool(self.embedding.weight, x, x_len, True)       # reference :496-503
-        elif self.text_encoder == "lstm":
-            if self.dropout_i and self.training:
-                raise NotImplementedError("train-mode LSTM input dropout needs the LSTM backward kernels (not in this build)")
-            ret, raw_output = ops.lstm_text(self.embedding.weight, self.lstm, x, x_len)      # reference :513-552
-        elif self.text_encoder == "transformer":
-            if self.training:
-                raise NotImplementedError("train-mode text transformer (dropout 0.1 + backward) is not in this build")
+        elif self.text_encoder == "lstm":                                                    # reference :513-552
+            if self.training or torch.is_grad_enabled():
+                # differentiable path: embedding -> LockedDropout(dropout_i) -> LSTM (BPTT in the backward)
+                ret, raw_output = text_train.lstm_text_train(self.embedding.weight, self.lstm, x, x_len, self.dropout_i,
+                                                             self.training)
+            else:
+                ret, raw_output = ops.lstm_text(self.embedding.weight, self.lstm, x, x_len)
+        elif self.text_encoder == "transformer":                                             # reference :553-573
             pos = self.pos_embed if self.pos_embed_type in ("sinusoidal", "learned") else None
-            ret, raw_output = ops.transformer_text(self.embedding.weight, self.transformer_encoder.layers[0], pos, x, x_len)
+            layer = self.transformer_encoder.layers[0]
+            if self.training or torch.is_grad_enabled():
+                ret, raw_output = text_train.transformer_text_train(self.embedding.weight, layer, pos, x, x_len, self.training)
+            else:
+                ret, raw_output = ops.transformer_text(self.embedding.weight, layer, pos, x, x_len)
         else:
             raise NotImplementedError(f"text encoder {self.text_encoder!r} is outside the contrastive hot path")
         return ret, raw_output, attns

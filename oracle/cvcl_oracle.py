@@ -64,7 +64,7 @@ def embedding_meanpool(table: Tensor, x: Tensor, x_len: Tensor) -> Tuple[Tensor,
     pad positions contribute row 0 of the table (zero at init, zero grad: padding_idx=0,
     multimodal.py:311-312).
     """
-    emb = table[x]                                   # (B, L, E)
+    emb = F.embedding(x, table, padding_idx=PAD_TOKEN_ID)   # (B, L, E); row 0 receives no gradient (:311-312)
     ret = emb.sum(dim=1) / x_len.unsqueeze(1)        # int64 length promotes like the reference
     return ret, emb
 
@@ -102,7 +102,7 @@ def lstm_text(p: Dict[str, Tensor], x: Tensor, x_len: Tensor, prefix: str = "") 
     b = p[prefix + "lstm.bias_ih_l0"] + p[prefix + "lstm.bias_hh_l0"]
     B, L = x.shape
     H = w_hh.shape[1]
-    emb = table[x]
+    emb = F.embedding(x, table, padding_idx=PAD_TOKEN_ID)
     h = torch.zeros(B, H, dtype=table.dtype)
     c = torch.zeros(B, H, dtype=table.dtype)
     Lmax = int(x_len.max())
@@ -142,7 +142,7 @@ def transformer_text(p: Dict[str, Tensor], x: Tensor, x_len: Tensor, pos_embed_t
     B, L = x.shape
     E = table.shape[1]
     hd = E // nhead
-    h = table[x]                                            # (B, L, E)
+    h = F.embedding(x, table, padding_idx=PAD_TOKEN_ID)    # (B, L, E)
     if pos_embed_type in ("sinusoidal", "learned"):
         h = h + p[prefix + "pos_embed"][:L, 0].unsqueeze(0)
     pad = (x == PAD_TOKEN_ID)                               # (B, L) keys to ignore
