@@ -382,6 +382,9 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+// EPI = false: convolution epilogue (round, BN partial sums).  EPI = true: + bias, activation, residual (the ViT /
+// nn.Linear epilogue: out = round(round(act(acc + bias)) + R)), no statistics.
+template <bool EPI>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
     const bf16_t* __restrict__ A = (const bf16_t*)p.A;
     const bf16_t* __restrict__ W = (const bf16_t*)p.W;
     bf16_t* __restrict__ C = (bf16_t*)p.C;
+    const bf16_t* __restrict__ R = (const bf16_t*)p.R;
     const int ktiles = p.K / 64;
 
     // staging role: wave w issues instructions j = 0..3 per operand; instruction (w, j) covers tile rows
@@ -497,21 +501,38 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                 for (int g = 0; g < 4; ++g) {
                     const int row = mt * 32 + l31;
                     const int chunk = nt * 4 + g;                // 8 channels per 16-B chunk; this lane owns half h
-                    bf16x4 q = {(bf16_t)acc[nt][mt][4 * g + 0], (bf16_t)acc[nt][mt][4 * g + 1],
-                                (bf16_t)acc[nt][mt][4 * g + 2], (bf16_t)acc[nt][mt][4 * g + 3]};
+                    bf16x4 q;
+                    if constexpr (EPI) {
+                        const int n_glob = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h;
+                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n_glob);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q[e] = (bf16_t)apply_act(acc[nt][mt][4 * g + e] + bv[e], p.act);
+                    } else {
+                        q = bf16x4{(bf16_t)acc[nt][mt][4 * g + 0], (bf16_t)acc[nt][mt][4 * g + 1],
+                                   (bf16_t)acc[nt][mt][4 * g + 2], (bf16_t)acc[nt][mt][4 * g + 3]};
+                    }
                     *reinterpret_cast<bf16x4*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4) + h * 8) = q;
                 }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int row = j * 8 + (lane >> 3), chunk = lane & 7;
             const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4));
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4));
             if (m < p.M) {
+                if constexpr (EPI) {
+                    if (R) {
+                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
-                    st_sum[e] += f;
-                    st_sq[e] = fmaf(f, f, st_sq[e]);
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float f = (float)v[e];
+                        st_sum[e] += f;
+                        st_sq[e] = fmaf(f, f, st_sq[e]);
+                    }
                 }
                 *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = v;
             }
@@ -519,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
         // the next loop iteration's vmcnt(0) + barrier orders these staging reads before the buffer is refilled
     }
 
-    if (p.stats) {
+    if (!EPI && p.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -665,12 +686,13 @@ inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
 }
 inline int pro_kind(const cvcl_gemm_args* a) { return !a->a_scale ? 0 : (a->a_relu ? 2 : 1); }
 
+template <bool EPI>
 int launch_gemm_glds(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     const int gm = grid_m_query<bf16_t>(a->M, a->N);
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_glds_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS) != hipSuccess) {
             cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", GL_LDS);
             return CVCL_ELAUNCH;
         }
@@ -678,7 +700,7 @@ int launch_gemm_glds(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     }
     dim3 grid(gm, a->N / BN);
     CvclProfScope prof(stream, CVCL_K_GEMM);
-    hipLaunchKernelGGL(gemm_glds_kernel, grid, dim3(256), GL_LDS, stream, d);
+    hipLaunchKernelGGL(gemm_glds_kernel<EPI>, grid, dim3(256), GL_LDS, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
@@ -701,7 +723,12 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
         static const bool use_glds = [] { const char* e = getenv("CVCL_GEMM_GLDS"); return !(e && e[0] == '0'); }();
-        if (use_glds && lean && pro_kind(a) == 0 && a->K % 64 == 0) return launch_gemm_glds(a, d, stream);
+        if (use_glds && lean && pro_kind(a) == 0 && a->K % 64 == 0) return launch_gemm_glds<false>(a, d, stream);
+        // ViT / nn.Linear shapes: bias, activation, residual, no statistics
+        const bool al = ((uintptr_t)a->bias & 15) == 0;
+        if (use_glds && d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && !a->exp_scale &&
+            !a->stats && al && !(a->gather_stride > 1))
+            return launch_gemm_glds<true>(a, d, stream);
     }
     switch (pro_kind(a)) {
         case 0: return lean ? launch_gemm_v<T, 0, true>(a, d, stream) : launch_gemm_v<T, 0, false>(a, d, stream);
