@@ -151,3 +151,32 @@ def test_linear_f32(ops, dev):
     y.backward(dy.to(dev))
     assert maxrel(y, yo) < TOL
     assert maxrel(wd.grad, wo.grad) < TOL and maxrel(bd.grad, bo.grad) < TOL and maxrel(xd.grad, xo.grad) < TOL
+
+
+def test_edge_cases(ops, dev):
+    """Ragged / degenerate inputs the reference accepts: single pair, maximum utterance length 25, single-token
+    utterances, out-of-range token ids (reported as NaN), ties in the arg-max."""
+    # B = 1: loss of a 1x1 logit matrix is 0, accuracy 1, entropy 0
+    one = ops.sim_logits(ops.l2_normalize(torch.randn(1, 16, device=dev)), ops.l2_normalize(torch.randn(1, 16, device=dev)),
+                         torch.tensor(2.0, device=dev))
+    loss, m = ops.infonce(one)
+    assert abs(float(loss)) < 1e-6 and float(m[0]) == 1.0 and abs(float(m[2])) < 1e-6
+    # L = 25 (MAX_LEN_UTTERANCE) and length-1 utterances
+    table = torch.randn(50, 32)
+    table[0] = 0
+    tok = torch.randint(1, 50, (4, 25))
+    ln = torch.tensor([25, 1, 13, 2])
+    for b in range(4):
+        tok[b, int(ln[b]):] = 0
+    ret, _ = ops.embed_meanpool(table.to(dev), tok.to(dev), ln.to(dev), True)
+    assert maxrel(ret, O.embedding_meanpool(table, tok, ln)[0]) < 1e-6
+    # out-of-range id -> NaN row (the reference raises an index error)
+    bad = tok.clone()
+    bad[2, 0] = 50
+    ret2, _ = ops.embed_meanpool(table.to(dev), bad.to(dev), ln.to(dev), False)
+    assert torch.isnan(ret2[2]).all() and torch.isfinite(ret2[0]).all()
+    # ties: identical rows -> torch.argmax picks the first maximum
+    f = torch.ones(4, 8, device=dev)
+    lg = ops.sim_logits(f, f, torch.tensor(0.0, device=dev))
+    loss, m = ops.infonce(lg)
+    assert abs(float(loss) - math.log(4)) < 1e-5 and abs(float(m[0]) - 0.25) < 1e-6 and abs(float(m[1]) - 0.25) < 1e-6

@@ -252,3 +252,45 @@ def test_trunk_properties_full_batch(H, dev):
     p4, _ = model.trunk(x)
     p5, _ = model.trunk(x)
     assert torch.equal(p4, p5)                      # train-mode statistics are deterministic (no atomics)
+
+
+@pytest.mark.parametrize("B,Hh,Ww", [(1, 224, 224), (5, 160, 160), (2, 256, 192)])
+def test_trunk_other_shapes(H, dev, B, Hh, Ww):
+    """Edge shapes: a single image (BN over one sample's pixels), odd batch, non-square / non-224 resolutions
+    (multiples of 32), fp32 parity mode in both BN modes and bf16 eval vs the emulating oracle."""
+    from multimodal.resnext import ResNet
+    p = O.resnext50_random_params(seed=3)
+    x = torch.randn(B, 3, Hh, Ww, generator=torch.Generator().manual_seed(B + Hh))
+    model = ResNet()
+    _load_oracle_params_into(model, p)
+    model = model.to(dev)
+    for prm in model.parameters():
+        prm.requires_grad_(False)
+    for training in (False, True):
+        model.load_state_dict({k: v for k, v in p.items()}, strict=False)       # reset running statistics
+        model.train(training)
+        model.compute_dtype = torch.float32
+        pooled_o, fmap_o = O.resnext50_forward(p, x, training)
+        pooled, fmap = model.trunk(x.to(dev))
+        assert fmap.shape == fmap_o.shape == (B, 2048, Hh // 32, Ww // 32)
+        assert maxrel(pooled, pooled_o) < 5e-4 and maxrel(fmap.float(), fmap_o) < 5e-4, training
+    model.eval()
+    model.load_state_dict({k: v for k, v in p.items()}, strict=False)
+    model.compute_dtype = torch.bfloat16
+    pooled_b, _ = model.trunk(x.to(dev))
+    pooled_q, _ = O.resnext50_forward(p, x, False, O.bf16_round)
+    assert maxrel(pooled_b, pooled_q) < 3e-2
+
+
+def test_trunk_rejects_bad_inputs(H, dev):
+    from multimodal.resnext import ResNet
+    model = ResNet().to(dev).eval()
+    for prm in model.parameters():
+        prm.requires_grad_(False)
+    with pytest.raises(H.CvclError):
+        model.trunk(torch.zeros(1, 3, 224, 224, device=dev, dtype=torch.float16))
+    with pytest.raises(H.CvclError):
+        model.trunk(torch.zeros(1, 3, 100, 100, device=dev))            # not a multiple of 32
+    model.layer1[0].conv1.weight.requires_grad_(True)
+    with pytest.raises(NotImplementedError):                             # fine-tuning needs the trunk backward
+        model.trunk(torch.zeros(1, 3, 224, 224, device=dev))
