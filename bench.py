@@ -58,8 +58,10 @@ def synthetic_batch_on_device(batch, seed, device, vocab=2350):
 
 
 def gemm_algorithmic_work(B):
-    """Algorithmic bytes / flops of the 52 bf16 1x1-conv GEMM launches of one ResNeXt-50 forward at batch B:
-    every operand element moved once (A rows actually used, W, C), 2 bytes each; 2*M*N*K flops."""
+    """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode):
+    every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
+    enqueues: conv1 and downsample (A + W + C); conv3 of layers 3-4 (A + W + C); conv3 of layers 1-2 twice -- a
+    statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C)."""
     nbytes = flops = launches = 0
     inplanes, h = 64, 56
     for stage, blocks in enumerate((3, 4, 6, 3)):
@@ -69,13 +71,20 @@ def gemm_algorithmic_work(B):
             stride = 2 if (stage > 0 and bi == 0) else 1
             ho = h // stride
             m_in, m_out = B * h * h, B * ho * ho
-            convs = [(m_in, width, inplanes), (m_out, outc, width)]
+            plain = [(m_in, width, inplanes)]                       # conv1
             if bi == 0:
-                convs.append((m_out, outc, inplanes))
-            for (m, n, k) in convs:
+                plain.append((m_out, outc, inplanes))               # downsample
+            if stage >= 2:
+                plain.append((m_out, outc, width))                  # conv3, raw output materialised
+            for (m, n, k) in plain:
                 nbytes += 2 * (m * k + n * k + m * n)
                 flops += 2 * m * n * k
                 launches += 1
+            if stage < 2:                                           # conv3 as statistics pass + fused tail pass
+                m, n, k = m_out, outc, width
+                nbytes += 2 * (m * k + n * k) + 2 * (m * k + n * k + 2 * m * n)
+                flops += 2 * (2 * m * n * k)
+                launches += 2
             h, inplanes = ho, outc
     return nbytes, flops, launches
 
@@ -200,7 +209,8 @@ def main():
             traffic = int((pm["hbm_read_bytes_per_step_corrected_x2"] + pm["hbm_write_bytes_per_step"]) / pm["launches_per_step"])
         except Exception:
             pass
-        roofline = {"kernel": "gemm_glds_kernel (bf16 1x1-conv MFMA GEMM, direct-to-LDS operand loads, BN-stats epilogue)",
+        roofline = {"kernel": "gemm_glds_kernel (bf16 1x1-conv MFMA GEMM, direct-to-LDS operand loads; epilogues: BN statistics / "
+                              "fused BN3+identity+ReLU Bottleneck tail)",
                     "dominant_class_by_time": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_note": "PMC HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)",

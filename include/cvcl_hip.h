@@ -116,6 +116,9 @@ typedef struct {
     const float* exp_scale; const float* bias; int act;
     const void* R; int ldr;
     float* stats; int stats_rows;    /* stats_rows = capacity (>= cvcl_gemm_grid_m(dtype, M, N, a_scale != NULL)) */
+    /* Bottleneck tail (bf16): C = relu(round(A'W^T) * c_scale[N] + c_shift[N] + (R | R * r_scale[N] + r_shift[N])).
+     * With C == NULL and stats != NULL the product is not stored, only its column statistics (same rounding). */
+    const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);

@@ -38,6 +38,7 @@ struct GemmDev {
     int g_ho, g_wo, g_hi, g_wi, g_s;
     const float* exp_scale; const float* bias; int act;
     const void* R; int ldr;
+    const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;   // BN-apply epilogue
     float* stats;
     int vec_in;    // A/W rows are 16-byte aligned and K is a whole number of chunks
     int vec_out;   // C/R rows are 16-byte aligned
@@ -382,9 +383,11 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-// EPI = false: convolution epilogue (round, BN partial sums).  EPI = true: + bias, activation, residual (the ViT /
-// nn.Linear epilogue: out = round(round(act(acc + bias)) + R)), no statistics.
-template <bool EPI>
+// EPI = 0: convolution epilogue (round, BN partial sums; C may be NULL = statistics only).
+// EPI = 1: + bias, activation, residual (the ViT / nn.Linear epilogue: out = round(round(act(acc + bias)) + R)).
+// EPI = 2: Bottleneck tail: out = relu(round(acc) * c_scale[n] + c_shift[n] + (R | R * r_scale[n] + r_shift[n])) --
+//          BatchNorm of this conv's (rounded) output + identity / normalised downsample branch + ReLU, no statistics.
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -435,6 +438,16 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
     float st_sum[8], st_sq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+    // EPI 2: this lane always handles the same 8 output channels in the read-back phase: load their affines once
+    float cs[8], cb[8], rs[8], rb[8];
+    if constexpr (EPI == 2) {
+        const int nn = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cs[e] = p.c_scale[nn + e]; cb[e] = p.c_shift[nn + e];
+            rs[e] = p.r_scale ? p.r_scale[nn + e] : 1.f; rb[e] = p.r_scale ? p.r_shift[nn + e] : 0.f;
+        }
+    }
 
     // fragment read offsets inside a buffer (rows fixed per lane, swizzle per row)
     int fw_off[2], fa_off[2], fw_sw[2], fa_sw[2];
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                     const int row = mt * 32 + l31;
                     const int chunk = nt * 4 + g;                // 8 channels per 16-B chunk; this lane owns half h
                     bf16x4 q;
-                    if constexpr (EPI) {
+                    if constexpr (EPI == 1) {
                         const int n_glob = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h;
                         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                         if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n_glob);
@@ -520,11 +533,19 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
             const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4));
             if (m < p.M) {
-                if constexpr (EPI) {
+                if constexpr (EPI == 1) {
                     if (R) {
                         const bf16x8 r = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
+                    }
+                } else if constexpr (EPI == 2) {
+                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float y = fmaf((float)v[e], cs[e], cb[e]);
+                        const float idv = p.r_scale ? fmaf((float)r[e], rs[e], rb[e]) : (float)r[e];
+                        v[e] = (bf16_t)fmaxf(y + idv, 0.f);
                     }
                 } else {
 #pragma unroll
@@ -534,13 +555,13 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                         st_sq[e] = fmaf(f, f, st_sq[e]);
                     }
                 }
-                *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = v;
+                if (EPI != 0 || C) *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = v;
             }
         }
         // the next loop iteration's vmcnt(0) + barrier orders these staging reads before the buffer is refilled
     }
 
-    if (!EPI && p.stats) {
+    if (EPI == 0 && p.stats) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -686,7 +707,7 @@ inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
 }
 inline int pro_kind(const cvcl_gemm_args* a) { return !a->a_scale ? 0 : (a->a_relu ? 2 : 1); }
 
-template <bool EPI>
+template <int EPI>
 int launch_gemm_glds(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     const int gm = grid_m_query<bf16_t>(a->M, a->N);
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
@@ -716,6 +737,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.g_s = a->gather_stride;
     d.exp_scale = a->exp_scale; d.bias = a->bias; d.act = a->act;
     d.R = a->R; d.ldr = a->ldr; d.stats = a->stats;
+    d.c_scale = a->c_scale; d.c_shift = a->c_shift; d.r_scale = a->r_scale; d.r_shift = a->r_shift;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     d.vec_in = (a->K % EPC == 0) && (a->lda % EPC == 0) && (a->ldw % EPC == 0) && al16(a->A) && al16(a->W);
     d.vec_out = (a->ldc % EPC == 0) && al16(a->C) && (!a->R || ((a->ldr % EPC == 0) && al16(a->R)));
@@ -723,13 +745,20 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
         static const bool use_glds = [] { const char* e = getenv("CVCL_GEMM_GLDS"); return !(e && e[0] == '0'); }();
-        if (use_glds && lean && pro_kind(a) == 0 && a->K % 64 == 0) return launch_gemm_glds<false>(a, d, stream);
+        if (use_glds && a->c_scale) {                // Bottleneck tail epilogue: only the direct-to-LDS kernel implements it
+            CVCL_CHECK_ARG(d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && a->R && a->c_shift &&
+                               !a->bias && !a->exp_scale && !a->stats && (a->r_scale == nullptr) == (a->r_shift == nullptr),
+                           "cvcl_gemm: the c_scale epilogue needs bf16, K %% 64 == 0, N %% 128 == 0, a residual and no bias/stats");
+            return launch_gemm_glds<2>(a, d, stream);
+        }
+        if (use_glds && lean && pro_kind(a) == 0 && a->K % 64 == 0) return launch_gemm_glds<0>(a, d, stream);
         // ViT / nn.Linear shapes: bias, activation, residual, no statistics
         const bool al = ((uintptr_t)a->bias & 15) == 0;
         if (use_glds && d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && !a->exp_scale &&
             !a->stats && al && !(a->gather_stride > 1))
-            return launch_gemm_glds<true>(a, d, stream);
+            return launch_gemm_glds<1>(a, d, stream);
     }
+    CVCL_CHECK_ARG(a->C && !a->c_scale, "cvcl_gemm: statistics-only / BN-tail epilogues need the direct-to-LDS bf16 path");
     switch (pro_kind(a)) {
         case 0: return lean ? launch_gemm_v<T, 0, true>(a, d, stream) : launch_gemm_v<T, 0, false>(a, d, stream);
         case 1: return lean ? launch_gemm_v<T, 1, true>(a, d, stream) : launch_gemm_v<T, 1, false>(a, d, stream);
@@ -751,7 +780,8 @@ extern "C" int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue) {
 }
 
 extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {
-    CVCL_CHECK_ARG(a && a->A && a->W && a->C, "cvcl_gemm: null operand");
+    CVCL_CHECK_ARG(a && a->A && a->W && (a->C || a->stats), "cvcl_gemm: null operand");
+    CVCL_CHECK_ARG(!a->c_scale || dtype == CVCL_BF16, "cvcl_gemm: the c_scale epilogue exists for bf16 only");
     CVCL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "cvcl_gemm: bad shape %d %d %d", a->M, a->N, a->K);
     CVCL_CHECK_ARG((a->a_scale == nullptr) == (a->a_shift == nullptr), "cvcl_gemm: a_scale/a_shift must come together");
     if (dtype == CVCL_F32) return launch_gemm<float>(a, (hipStream_t)stream);

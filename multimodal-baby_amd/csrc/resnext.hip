@@ -977,15 +977,27 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
             // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  BN2+ReLU is applied to the narrow tensor in place first
             // (one pass) instead of in the GEMM operand load (once per 128-column output tile): see bn_relu_apply_kernel.
             if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
-            {
-                cvcl_gemm_args a = {};
-                a.A = R2; a.W = layers[l3].w; a.C = R3;
-                a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
-                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
-                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_out, outc))) return rc;
-            }
             char* dst = last ? (char*)layer4_out_nhwc : OUT;
+            // Layers 1-2 in bf16: conv3 is HBM-bound and cheap, so it runs twice -- a statistics-only pass (reads only
+            // the narrow operand), then a pass whose epilogue applies BN3 + identity / normalised downsample + ReLU
+            // and writes the block output -- instead of materialising raw3 and re-reading it in bn_add_relu
+            // (saves one write and one read of the wide tensor; results are bit-identical).
+            const bool fused_tail = dtype == CVCL_BF16 && stage < 2;
+            auto conv3_args = [&]() {
+                cvcl_gemm_args a = {};
+                a.A = R2; a.W = layers[l3].w;
+                a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
+                return a;
+            };
+            if (!fused_tail || training) {
+                cvcl_gemm_args a = conv3_args();
+                a.C = fused_tail ? nullptr : R3;
+                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+                if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
+                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_out, outc))) return rc;
+            } else {
+                if ((rc = finalize(l3, 0, m_out, outc))) return rc;              // eval mode: affine from the running stats
+            }
             if (bi == 0) {
                 // downsample 1x1 stride s: X -> RD [m_out, outc]
                 cvcl_gemm_args a = {};
@@ -995,14 +1007,22 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
                 a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
                 if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
                 if ((rc = finalize(ld, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_out, outc))) return rc;
+            }
+            if (fused_tail) {
+                cvcl_gemm_args a = conv3_args();
+                a.C = dst; a.act = CVCL_ACT_RELU;
+                a.c_scale = scale_of(l3); a.c_shift = shift_of(l3);
+                a.R = bi == 0 ? RD : X; a.ldr = outc;
+                if (bi == 0) { a.r_scale = scale_of(ld); a.r_shift = shift_of(ld); }
+                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
+            } else if (bi == 0) {
                 if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), RD, scale_of(ld), shift_of(ld), dst, m_out,
                                            outc, stream))) return rc;
-                li += 4;
             } else {
                 if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), X, nullptr, nullptr, dst, m_out, outc,
                                            stream))) return rc;
-                li += 3;
             }
+            li += bi == 0 ? 4 : 3;
             char* t = X; X = dst; OUT = (t == (char*)layer4_out_nhwc) ? OUT : t;
             h = ho; wd = wo; inplanes = outc;
         }

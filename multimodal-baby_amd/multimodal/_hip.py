@@ -37,6 +37,7 @@ class GemmArgs(C.Structure):
         ("exp_scale", C.c_void_p), ("bias", C.c_void_p), ("act", C.c_int),
         ("R", C.c_void_p), ("ldr", C.c_int),
         ("stats", C.c_void_p), ("stats_rows", C.c_int),
+        ("c_scale", C.c_void_p), ("c_shift", C.c_void_p), ("r_scale", C.c_void_p), ("r_shift", C.c_void_p),
     ]
 
 
