@@ -49,10 +49,11 @@ class LightningModule(nn.Module):
         self.trainer = None
 
     def save_hyperparameters(self, *args, **kwargs):
+        """Record the constructor arguments of the calling ``__init__`` (what Lightning stores as hyper_parameters)."""
         import inspect
-        frame = inspect.currentframe().f_back
-        local = frame.f_locals
-        self.hparams = {k: v for k, v in local.items() if k not in ("self", "__class__")}
+        local = inspect.currentframe().f_back.f_locals
+        names = [n for n in inspect.signature(type(self).__init__).parameters if n != "self"]
+        self.hparams = {k: local[k] for k in names if k in local}
 
     def log(self, name, value, *args, **kwargs):
         self._logged[name] = value
@@ -68,10 +69,22 @@ class LightningModule(nn.Module):
 
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
+        """Lightning ckpt layout: ``state_dict`` + ``hyper_parameters`` (the constructor arguments, which for
+        MultiModalLitModel include the pickled encoder modules: reference multimodal_lit.py:74,139)."""
+        from . import resnext
+        resnext.register_torchvision_alias()
         ckpt = torch.load(checkpoint_path, map_location=map_location or "cpu", weights_only=False)
-        model = cls(**ckpt["hyper_parameters"])
+        hp = dict(ckpt["hyper_parameters"])
+        hp.update(kwargs)
+        model = cls(**hp)
         model.load_state_dict(ckpt["state_dict"])
         return model
+
+    def checkpoint_dict(self, trainer=None, optimizer=None):
+        return {"state_dict": self.state_dict(), "hyper_parameters": dict(self.hparams),
+                "epoch": getattr(trainer, "current_epoch", 0), "global_step": getattr(trainer, "global_step", 0),
+                "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
+                "pytorch-lightning_version": "1.6.0-shim"}
 
 
 def _move(batch, device):
@@ -116,6 +129,10 @@ class Trainer:
         self.callbacks = callbacks or []
         self.logged_metrics = {}
         self.global_step = 0
+        self.current_epoch = 0
+        # `--checkpoint_callback` is the pre-1.7 alias of enable_checkpointing (reference train.py:97)
+        self.enable_checkpointing = bool(checkpoint_callback if enable_checkpointing is None else enable_checkpointing) \
+            and not fast_dev_run
 
     def _device(self):
         if self.gpus and self.gpus > 0:
@@ -138,11 +155,16 @@ class Trainer:
         sched = None
         if isinstance(opt, dict):
             sched, opt = opt.get("lr_scheduler"), opt["optimizer"]
+        start_epoch = 0
         if ckpt_path is not None and os.path.exists(str(ckpt_path)):
             ckpt = torch.load(str(ckpt_path), map_location="cpu", weights_only=False)
             model.load_state_dict(ckpt["state_dict"])
+            if ckpt.get("optimizer_states"):
+                opt.load_state_dict(ckpt["optimizer_states"][0])
+            start_epoch, self.global_step = int(ckpt.get("epoch", -1)) + 1, int(ckpt.get("global_step", 0))
         engine.attach(model)
-        for epoch in range(self.max_epochs):
+        for epoch in range(start_epoch, self.max_epochs):
+            self.current_epoch = epoch
             model.train()
             outs = []
             for bi, batch in enumerate(datamodule.train_dataloader()):
@@ -161,4 +183,25 @@ class Trainer:
             self.logged_metrics.update(model._logged)
             if sched is not None and "val_loss" in self.logged_metrics:
                 sched["scheduler"].step(float(self.logged_metrics["val_loss"]))
+            if self.enable_checkpointing and parallel.rank() == 0:
+                for cb in self.callbacks:
+                    if hasattr(cb, "save"):
+                        cb.save(self, model, opt)
         return self
+
+
+class ModelCheckpoint:
+    """``save_last`` / ``{epoch}.ckpt`` files in ``dirpath`` (the subset of pl.callbacks.ModelCheckpoint that
+    reference train.py:84-89 configures; top-k selection on val_loss needs the private validation data)."""
+
+    def __init__(self, monitor=None, save_last=True, save_top_k=1, dirpath="checkpoints", filename="{epoch}"):
+        self.monitor, self.save_last, self.save_top_k = monitor, save_last, save_top_k
+        self.dirpath, self.filename = str(dirpath), filename
+
+    def save(self, trainer, model, optimizer):
+        os.makedirs(self.dirpath, exist_ok=True)
+        ckpt = model.checkpoint_dict(trainer, optimizer)
+        if self.save_top_k != 0:
+            torch.save(ckpt, os.path.join(self.dirpath, self.filename.format(epoch=f"epoch={trainer.current_epoch}") + ".ckpt"))
+        if self.save_last:
+            torch.save(ckpt, os.path.join(self.dirpath, "last.ckpt"))

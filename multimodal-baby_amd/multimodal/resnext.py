@@ -147,12 +147,47 @@ class ResNet(nn.Module):
                     "cvcl_resnext50_fwd")
         return pooled, fmap.permute(0, 3, 1, 2)
 
+    # caches hold ctypes arrays / device buffers: never pickled (save_hyperparameters pickles whole encoder modules)
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_pack_cache"], d["_ws_cache"] = {}, {}
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.__dict__.setdefault("compute_dtype", torch.float32)      # objects pickled by torchvision lack these
+        self.__dict__.setdefault("_pack_cache", {})
+        self.__dict__.setdefault("_ws_cache", {})
+
     def forward(self, x):
         pooled, fmap = self.trunk(x)
-        self.layer4(fmap)                                # fires forward hooks registered on layer4
+        # fire the forward hooks registered on layer4 (the reference's Hook(model.layer4)); done by hand so that it
+        # also works when layer4 is a plain nn.Sequential unpickled from a torchvision-built checkpoint
+        for hook in list(self.layer4._forward_hooks.values()):
+            hook(self.layer4, (fmap,), fmap)
         if isinstance(self.fc, nn.Linear):
             return ops.linear_f32(pooled, self.fc.weight, self.fc.bias)
         return self.fc(pooled)                           # e.g. nn.Identity (utils.build_dino_mugs)
+
+
+def register_torchvision_alias():
+    """Make ``torchvision.models.resnet.{ResNet,Bottleneck}`` resolvable when torchvision is absent, so that the
+    reference's Lightning checkpoints (whose ``hyper_parameters`` pickle the whole VisionEncoder, i.e. a torchvision
+    ResNet object: multimodal_lit.py:74,139 of the reference) can be unpickled onto these classes."""
+    import sys
+    import types
+    try:
+        import torchvision  # noqa: F401  (a real torchvision wins)
+        return False
+    except Exception:
+        pass
+    tv = sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    models = sys.modules.setdefault("torchvision.models", types.ModuleType("torchvision.models"))
+    resnet = sys.modules.setdefault("torchvision.models.resnet", types.ModuleType("torchvision.models.resnet"))
+    resnet.ResNet, resnet.Bottleneck = ResNet, Bottleneck
+    models.resnet, models.resnext50_32x4d = resnet, resnext50_32x4d
+    tv.models = models
+    return True
 
 
 def resnext50_32x4d(pretrained: bool = False, **kwargs) -> ResNet:

@@ -90,6 +90,16 @@ class VisionTransformer(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_cache"] = {}
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.__dict__.setdefault("compute_dtype", torch.float32)
+        self.__dict__.setdefault("_cache", {})
+
     def forward(self, x):
         """-> cls token after the final LayerNorm, [B, D] fp32 (reference :245-250)."""
         from . import vit_hip

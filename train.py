@@ -55,7 +55,10 @@ def main(argv=None):
     vision_encoder = VisionEncoder(args=args)
     text_encoder = TextEncoder(vocab, image_feature_map_dim=vision_encoder.last_cnn_out_dim, args=args)
     lit_model = MultiModalLitModel(vision_encoder, text_encoder, args)
-    trainer = pl.Trainer.from_argparse_args(args)
+    checkpoint_callback = pl.ModelCheckpoint(monitor="val_loss", save_last=True, save_top_k=args.save_top_k,
+                                             dirpath=ckpt_dir, filename="{epoch}")
+    trainer = pl.Trainer.from_argparse_args(args, enable_checkpointing=args.checkpoint_callback,
+                                            callbacks=[checkpoint_callback])
     print(args)
     trainer.fit(lit_model, data, ckpt_path=args.resume_ckpt)
     return trainer, lit_model
