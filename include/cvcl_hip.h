@@ -163,7 +163,8 @@ int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void
 /* relu(bn(x)) then maxpool 3x3/2 pad 1: [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
 int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int B, int H, int W,
                          int C, void* stream);
-/* grouped 3x3 conv pad 1 stride 1|2 on relu(x*a_scale+a_shift): [B,H,W,C] -> raw [B,Ho,Wo,C] (+stats) */
+/* grouped 3x3 conv pad 1 stride 1|2 on relu(x*a_scale+a_shift): [B,H,W,C] -> raw [B,Ho,Wo,C] (+stats).
+ * a_scale == a_shift == NULL: plain convolution of x (no affine, no ReLU) -- the data-gradient form. */
 int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int C, int stride);
 int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed, void* y,
                   float* stats, int stats_rows, int B, int H, int W, int C, int groups, int stride, void* stream);
@@ -235,6 +236,35 @@ int cvcl_lstm_cell_train(const float* gates, const int64_t* len, int t, float* h
                          float* gates_act, float* c_save, float* h_prev_save, int B, int L, int Hd, void* stream);
 int cvcl_lstm_cell_bwd(const float* gates_act, const float* c_save, const int64_t* len, int t, const float* dh, float* dc,
                        float* d_gates, float* dh_carry, int B, int L, int Hd, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward side of the ResNeXt trunk for --finetune_cnn (multimodal/multimodal.py:175-179: the CNN's parameters keep
+ * requires_grad, so autograd runs through torchvision's Bottlenecks).  Used by the autograd-composed fine-tuning
+ * path; [rows, C] = NHWC activations flattened over pixels.                                              */
+int cvcl_bn_apply(int dtype, const void* x, const float* scale, const float* shift, void* y, long rows, int C, int relu,
+                  void* stream);
+/* train-mode BatchNorm backward (optionally through a following ReLU, masked by y > 0):
+ *   g = dy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;  dx = gamma * rstd * (g - dbeta/n - xhat * dgamma/n)
+ * partial: scratch [partial_rows >= min(256, ceil(rows/256))][2][C] f32                                  */
+int cvcl_bn_bwd(int dtype, const void* x, const void* y, const void* dy, const float* mean, const float* rstd,
+                const float* gamma, float* dgamma, float* dbeta, void* dx, long rows, int C, int relu, float* partial,
+                int partial_rows, void* stream);
+/* batch mean and 1/sqrt(var_biased + eps) from the forward statistics rows (what bn_finalize normalised with) */
+int cvcl_bn_batch_moments(const float* stats, int stats_rows, long count, float eps, float* mean, float* rstd, int C,
+                          void* stream);
+/* OIHW f32 weight of the convolution that computes the data gradient of a grouped 3x3 conv (flip + in/out swap per group) */
+int cvcl_gconv_weight_dgrad(const float* w, float* out, int C, int cin_per_group, void* stream);
+int cvcl_transpose(int dtype, const void* in, void* out, long rows, int cols, void* stream);     /* out[c][r] = in[r][c] */
+int cvcl_add(int dtype, const void* a, const void* b, void* y, long n, void* stream);
+int cvcl_relu_mask(int dtype, const void* y, const void* dy, void* dx, long n, void* stream);    /* dx = dy where y > 0 */
+/* max pool 3x3/2 pad 1, NHWC: dy == NULL -> forward (out = pooled); else backward (out = dx, first arg-max wins) */
+int cvcl_maxpool3x3s2(int dtype, const void* x, const void* dy, void* out, int B, int H, int W, int C, void* stream);
+int cvcl_avgpool_bwd(int dtype, const float* d_pooled, void* dx, int B, int HW, int C, void* stream);
+/* z[b,2oy,2ox,:] = dy[b,oy,ox,:], zeros elsewhere ([B,2Ho,2Wo,C]): data gradient of a stride-2 conv = stride-1 conv of z */
+int cvcl_zero_stuff2(int dtype, const void* dy, void* z, int B, int Ho, int Wo, int C, void* stream);
+/* dW[co][ci][ky][kx] (f32, reference OIHW layout) of a k x k (grouped) convolution, direct form */
+int cvcl_conv_wgrad_direct(int dtype, const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                           int cin_per_group, int k, int stride, int pad, int x_is_nchw_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -333,6 +333,7 @@ constexpr int GC_PIXB = 144;               // LDS bytes per staged pixel (128 B 
 struct GconvDev {
     const void* x; const float* a_scale; const float* a_shift; const void* w; void* y; float* stats;
     int B, H, W, C, cg, stride, Ho, Wo, TH, bands, rows_in;
+    float act_floor; // 0 = ReLU after the affine; -inf = none (a_scale == NULL: plain convolution of x, used by the data gradient)
     int ablate;      // debug only ($CVCL_GCONV_ABLATE): 1 skip BN math, 2 skip MFMA loop, 4 skip stores, 8 skip LDS staging writes
 };
 
@@ -361,8 +362,8 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        sc[e] = p.a_scale[c0 + s_chunk * 8 + e];
-        sh[e] = p.a_shift[c0 + s_chunk * 8 + e];
+        sc[e] = p.a_scale ? p.a_scale[c0 + s_chunk * 8 + e] : 1.f;
+        sh[e] = p.a_scale ? p.a_shift[c0 + s_chunk * 8 + e] : 0.f;
     }
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
                     v = pf[i];
                 } else if (pf_in[i]) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)pf[i][e], sc[e], sh[e]), 0.f);
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)pf[i][e], sc[e], sh[e]), p.act_floor);
                 } else {
                     const u32x4 z = {0u, 0u, 0u, 0u};
                     v = __builtin_bit_cast(bf16x8, z);           // zero padding lives in the post-activation domain
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
 __global__ __launch_bounds__(256) void gconv_direct_f32_kernel(const float* __restrict__ x, const float* __restrict__ a_scale,
                                                                const float* __restrict__ a_shift, const float* __restrict__ w,
                                                                float* __restrict__ y, int B, int H, int W, int C, int cg,
-                                                               int stride, int Ho, int Wo) {
+                                                               int stride, int Ho, int Wo, float act_floor) {
     const long total = (long)B * Ho * Wo * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int co = (int)(i % C);
@@ -501,14 +502,14 @@ __global__ __launch_bounds__(256) void gconv_direct_f32_kernel(const float* __re
         const int g0 = (co / cg) * cg;
         float acc = 0.f;
         for (int ci = 0; ci < cg; ++ci) {
-            const float sc = a_scale[g0 + ci], sh = a_shift[g0 + ci];
+            const float sc = a_scale ? a_scale[g0 + ci] : 1.f, sh = a_scale ? a_shift[g0 + ci] : 0.f;
             for (int ky = 0; ky < 3; ++ky) {
                 const int yin = oy * stride - 1 + ky;
                 if (yin < 0 || yin >= H) continue;
                 for (int kx = 0; kx < 3; ++kx) {
                     const int xin = ox * stride - 1 + kx;
                     if (xin < 0 || xin >= W) continue;
-                    const float v = fmaxf(fmaf(x[(((long)b * H + yin) * W + xin) * C + g0 + ci], sc, sh), 0.f);
+                    const float v = fmaxf(fmaf(x[(((long)b * H + yin) * W + xin) * C + g0 + ci], sc, sh), act_floor);
                     acc = fmaf(v, w[((long)co * cg + ci) * 9 + ky * 3 + kx], acc);
                 }
             }
@@ -792,7 +793,8 @@ extern "C" int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int C, i
 extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed,
                              void* y, float* stats, int stats_rows, int B, int H, int W, int C, int groups, int stride,
                              void* stream) {
-    CVCL_CHECK_ARG(x && a_scale && a_shift && w_packed && y, "cvcl_gconv3x3: null pointer");
+    CVCL_CHECK_ARG(x && w_packed && y && (!a_scale == !a_shift), "cvcl_gconv3x3: null pointer");
+    const float act_floor = a_scale ? 0.f : -INFINITY;
     CVCL_CHECK_ARG(B > 0 && (stride == 1 || stride == 2) && groups > 0 && C % groups == 0, "cvcl_gconv3x3: bad shape");
     const int cg = C / groups;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -808,6 +810,7 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         d.x = x; d.a_scale = a_scale; d.a_shift = a_shift; d.w = w_packed; d.y = y; d.stats = stats;
         d.B = B; d.H = H; d.W = W; d.C = C; d.cg = cg; d.stride = stride; d.Ho = Ho; d.Wo = Wo;
         d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
+        d.act_floor = act_floor;
         { const char* e = getenv("CVCL_GCONV_ABLATE"); d.ablate = e ? atoi(e) : 0; }
         static bool attr_set = false;
         if (!attr_set) {
@@ -829,7 +832,7 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
     const long total = (long)B * Ho * Wo * C;
     { CvclProfScope prof(stream, CVCL_K_GCONV);
     hipLaunchKernelGGL(gconv_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, (const float*)x, a_scale,
-                       a_shift, (const float*)w_packed, (float*)y, B, H, W, C, cg, stride, Ho, Wo); }
+                       a_shift, (const float*)w_packed, (float*)y, B, H, W, C, cg, stride, Ho, Wo, act_floor); }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y, (long)B * Ho * Wo, C, stats, stats_rows, stream);
     return CVCL_OK;

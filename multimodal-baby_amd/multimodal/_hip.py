@@ -98,6 +98,17 @@ SIGNATURES = {
     "cvcl_attention_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, C.c_ulonglong, _P]),
     "cvcl_lstm_cell_train": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cvcl_lstm_cell_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_bn_apply": (_I, [_I, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
+    "cvcl_bn_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _P, _I, _P]),
+    "cvcl_bn_batch_moments": (_I, [_P, _I, C.c_long, C.c_float, _P, _P, _I, _P]),
+    "cvcl_gconv_weight_dgrad": (_I, [_P, _P, _I, _I, _P]),
+    "cvcl_transpose": (_I, [_I, _P, _P, C.c_long, _I, _P]),
+    "cvcl_add": (_I, [_I, _P, _P, _P, C.c_long, _P]),
+    "cvcl_relu_mask": (_I, [_I, _P, _P, _P, C.c_long, _P]),
+    "cvcl_maxpool3x3s2": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_avgpool_bwd": (_I, [_I, _P, _P, _I, _I, _I, _P]),
+    "cvcl_zero_stuff2": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_conv_wgrad_direct": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }

@@ -123,9 +123,9 @@ class ResNet(nn.Module):
 
     def trunk(self, x: torch.Tensor):
         """conv1 .. layer4 + avgpool.  -> (pooled [B,2048] f32, layer4 map as a logical NCHW view)."""
-        if any(p.requires_grad for c, b, _ in self.conv_bn_pairs() for p in (c.weight, b.weight, b.bias)) and torch.is_grad_enabled():
-            raise NotImplementedError("fine-tuning the ResNeXt trunk needs its backward kernels, which this build does "
-                                      "not ship yet (frozen-CNN configurations only); see DESIGN.md")
+        if torch.is_grad_enabled() and any(p.requires_grad for c, b, _ in self.conv_bn_pairs() for p in (c.weight, b.weight, b.bias)):
+            from .trunk_train import trunk_train       # --finetune_cnn: differentiable twin (saves activations)
+            return trunk_train(self, x)
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
             raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
         x = x.contiguous()

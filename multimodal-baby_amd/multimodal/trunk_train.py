@@ -1,0 +1,288 @@
+"""Fine-tuning path of the ResNeXt-50 trunk (``--finetune_cnn``): forward + backward as autograd-composed HIP kernels.
+
+Reference behaviour: with ``finetune_cnn`` the CNN's parameters keep ``requires_grad`` (multimodal/multimodal.py:175-179),
+so the contrastive loss back-propagates through torchvision's ``Bottleneck`` blocks (conv1x1 -> BN -> ReLU -> grouped
+3x3 -> BN -> ReLU -> conv1x1 -> BN -> (+identity | downsample) -> ReLU) in train mode.
+
+The frozen-CNN fast path (``ResNet.trunk`` -> ``cvcl_resnext50_fwd``) saves nothing for backward; this module is the
+differentiable twin: one ``torch.autograd.Function`` per operator, each a thin wrapper over libcvcl_hip kernels, with
+autograd only doing the bookkeeping (which tensors to keep, where gradients add).  Activations are NHWC, stored in the
+trunk's compute dtype (fp32 parity mode / bf16); parameter gradients are returned in fp32.
+
+  conv 1x1        fwd  cvcl_gemm                          dX  cvcl_gemm(dY, W^T)     dW  cvcl_gemm(dY^T, X^T)
+  grouped 3x3     fwd  cvcl_gconv3x3 (identity prologue)  dX  cvcl_gconv3x3 on (zero-stuffed) dY with the flipped,
+                                                              group-transposed weight   dW  cvcl_conv_wgrad_direct
+  stem 7x7        fwd  cvcl_stem_conv7x7                  dW  cvcl_conv_wgrad_direct (images need no gradient)
+  BatchNorm(+ReLU) fwd col_stats -> bn_finalize (running stats) -> bn_apply;   bwd  cvcl_bn_bwd
+  max / avg pool, residual add + ReLU: cvcl_maxpool3x3s2, cvcl_avgpool(_bwd), cvcl_bn_add_relu / cvcl_relu_mask
+
+There is no PyTorch-op fallback: CPU tensors raise in ``_hip.ptr``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip as H
+
+_F = torch.float32
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _cd(t: torch.Tensor) -> int:
+    return H.cvcl_dtype(t.dtype)
+
+
+def _transpose(t2d: torch.Tensor) -> torch.Tensor:
+    rows, cols = t2d.shape
+    out = torch.empty(cols, rows, dtype=t2d.dtype, device=t2d.device)
+    H.check(H.lib().cvcl_transpose(_cd(t2d), H.ptr(t2d), H.ptr(out), rows, cols, H.stream_ptr()), "cvcl_transpose")
+    return out
+
+
+def _pack(w: torch.Tensor, kind: int, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 OIHW master weight -> kernel operand layout in the compute dtype (cvcl_pack_conv_weight)."""
+    cout, cing, k, _ = w.shape
+    dt = H.cvcl_dtype(dtype)
+    nb = H.lib().cvcl_packed_weight_bytes(dt, kind, cout, cing, k)
+    buf = torch.empty(nb, dtype=torch.uint8, device=w.device)
+    H.check(H.lib().cvcl_pack_conv_weight(dt, kind, H.ptr(w.detach().contiguous(), _F), H.ptr(buf), cout, cing, k,
+                                          H.stream_ptr()), "cvcl_pack_conv_weight")
+    return buf
+
+
+def _zero_stuff(dy: torch.Tensor) -> torch.Tensor:
+    B, Ho, Wo, Cn = dy.shape
+    z = torch.empty(B, 2 * Ho, 2 * Wo, Cn, dtype=dy.dtype, device=dy.device)
+    H.check(H.lib().cvcl_zero_stuff2(_cd(dy), H.ptr(dy), H.ptr(z), B, Ho, Wo, Cn, H.stream_ptr()), "cvcl_zero_stuff2")
+    return z
+
+
+class Conv1x1(torch.autograd.Function):
+    """nn.Conv2d(cin, cout, 1, stride, bias=False) on NHWC: x [B,H,W,K] -> raw [B,Ho,Wo,N]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride: int):
+        B, Hh, Ww, K = x.shape
+        N = weight.shape[0]
+        wq = _pack(weight, H.PACK_DENSE, x.dtype).view(x.dtype).view(N, K)
+        Ho, Wo = (Hh - 1) // stride + 1, (Ww - 1) // stride + 1
+        out = torch.empty(B, Ho, Wo, N, dtype=x.dtype, device=x.device)
+        gather = (Ho, Wo, Hh, Ww, stride) if stride > 1 else None
+        H.gemm(x, wq, out=out, gather=gather, M=B * Ho * Wo, lda=K)
+        ctx.save_for_backward(x, wq)
+        ctx.stride = stride
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        B, Hh, Ww, K = x.shape
+        N = wq.shape[0]
+        dy = dy.contiguous()
+        if ctx.stride > 1:                               # rows of the skipped pixels get zero gradient / contribute nothing
+            dy = _zero_stuff(dy)
+        M = B * Hh * Ww
+        dy2, x2 = dy.view(M, N), x.view(M, K)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = H.gemm(dy2, _transpose(wq)).view(B, Hh, Ww, K)
+        if ctx.needs_input_grad[1]:
+            dw = H.gemm(_transpose(dy2), _transpose(x2)).float().view(N, K, 1, 1)
+        return dx, dw, None
+
+
+class GroupedConv3x3(torch.autograd.Function):
+    """nn.Conv2d(C, C, 3, stride, 1, groups=32, bias=False) on NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride: int):
+        B, Hh, Ww, Cn = x.shape
+        wp = _pack(weight, H.PACK_GCONV3, x.dtype)
+        Ho, Wo = (Hh - 1) // stride + 1, (Ww - 1) // stride + 1
+        out = torch.empty(B, Ho, Wo, Cn, dtype=x.dtype, device=x.device)
+        H.check(H.lib().cvcl_gconv3x3(_cd(x), H.ptr(x), None, None, H.ptr(wp), H.ptr(out), None, 0, B, Hh, Ww, Cn, 32,
+                                      stride, H.stream_ptr()), "cvcl_gconv3x3")
+        ctx.save_for_backward(x, weight)
+        ctx.stride = stride
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, Hh, Ww, Cn = x.shape
+        cg = weight.shape[1]
+        dy = dy.contiguous()
+        dx = dw = None
+        lib, s = H.lib(), H.stream_ptr()
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, dtype=_F)
+            H.check(lib.cvcl_conv_wgrad_direct(_cd(x), H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, Cn, Cn, cg, 3, ctx.stride, 1, 0, s),
+                    "cvcl_conv_wgrad_direct")
+        if ctx.needs_input_grad[0]:
+            wf = torch.empty_like(weight, dtype=_F)
+            H.check(lib.cvcl_gconv_weight_dgrad(H.ptr(weight.detach().contiguous(), _F), H.ptr(wf), Cn, cg, s), "cvcl_gconv_weight_dgrad")
+            wp = _pack(wf, H.PACK_GCONV3, x.dtype)
+            z = _zero_stuff(dy) if ctx.stride > 1 else dy
+            dx = torch.empty_like(x)
+            H.check(lib.cvcl_gconv3x3(_cd(x), H.ptr(z), None, None, H.ptr(wp), H.ptr(dx), None, 0, B, Hh, Ww, Cn, 32, 1, s),
+                    "cvcl_gconv3x3")
+        return dx, dw, None
+
+
+class StemConv(torch.autograd.Function):
+    """conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False) on the NCHW fp32 images -> raw NHWC."""
+
+    @staticmethod
+    def forward(ctx, x, weight, dtype):
+        B, _, Hh, Ww = x.shape
+        dt = H.cvcl_dtype(dtype)
+        wp = _pack(weight, H.PACK_STEM7, dtype)
+        out = torch.empty(B, Hh // 2, Ww // 2, 64, dtype=dtype, device=x.device)
+        rows = H.lib().cvcl_stem_conv_stats_rows(dt, B, Hh, Ww)
+        st = torch.empty(rows, 2, 64, dtype=_F, device=x.device)
+        H.check(H.lib().cvcl_stem_conv7x7(dt, H.ptr(x, _F), H.ptr(wp), H.ptr(out), H.ptr(st), rows, B, Hh, Ww, H.stream_ptr()),
+                "cvcl_stem_conv7x7")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, _, Hh, Ww = x.shape
+        dy = dy.contiguous()
+        dw = torch.empty(64, 3, 7, 7, dtype=_F, device=x.device)
+        H.check(H.lib().cvcl_conv_wgrad_direct(_cd(dy), H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, 3, 64, 3, 7, 2, 3, 1,
+                                               H.stream_ptr()), "cvcl_conv_wgrad_direct")
+        return None, dw, None
+
+
+class BatchNormTrain(torch.autograd.Function):
+    """nn.BatchNorm2d in train mode (+ optional fused ReLU) on raw [.., C]; updates the running statistics in place."""
+
+    @staticmethod
+    def forward(ctx, raw, gamma, beta, running_mean, running_var, num_batches_tracked, relu: bool):
+        Cn = raw.shape[-1]
+        rows = raw.numel() // Cn
+        lib, s, dt = H.lib(), H.stream_ptr(), _cd(raw)
+        dev = raw.device
+        srows = lib.cvcl_col_stats_rows(rows)
+        st = torch.empty(srows, 2, Cn, dtype=_F, device=dev)
+        H.check(lib.cvcl_col_stats(dt, H.ptr(raw), rows, Cn, H.ptr(st), srows, s), "cvcl_col_stats")
+        scale, shift = torch.empty(Cn, dtype=_F, device=dev), torch.empty(Cn, dtype=_F, device=dev)
+        H.check(lib.cvcl_bn_finalize(H.ptr(st), srows, rows, H.ptr(gamma.detach(), _F), H.ptr(beta.detach(), _F),
+                                     H.ptr(running_mean, _F), H.ptr(running_var, _F), H.ptr(num_batches_tracked, torch.int64),
+                                     BN_MOMENTUM, BN_EPS, H.ptr(scale), H.ptr(shift), Cn, s), "cvcl_bn_finalize")
+        mean, rstd = torch.empty(Cn, dtype=_F, device=dev), torch.empty(Cn, dtype=_F, device=dev)
+        H.check(lib.cvcl_bn_batch_moments(H.ptr(st), srows, rows, BN_EPS, H.ptr(mean), H.ptr(rstd), Cn, s), "cvcl_bn_batch_moments")
+        y = torch.empty_like(raw)
+        H.check(lib.cvcl_bn_apply(dt, H.ptr(raw), H.ptr(scale), H.ptr(shift), H.ptr(y), rows, Cn, int(relu), s), "cvcl_bn_apply")
+        ctx.save_for_backward(raw, y if relu else None, mean, rstd, gamma)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        raw, y, mean, rstd, gamma = ctx.saved_tensors
+        Cn = raw.shape[-1]
+        rows = raw.numel() // Cn
+        dev = raw.device
+        dy = dy.contiguous()
+        dgamma, dbeta = torch.empty(Cn, dtype=_F, device=dev), torch.empty(Cn, dtype=_F, device=dev)
+        prow = min(256, (rows + 255) // 256)
+        partial = torch.empty(prow, 2, Cn, dtype=_F, device=dev)
+        dx = torch.empty_like(raw)
+        H.check(H.lib().cvcl_bn_bwd(_cd(raw), H.ptr(raw), H.ptr(y), H.ptr(dy), H.ptr(mean), H.ptr(rstd),
+                                    H.ptr(gamma.detach().contiguous(), _F), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dx), rows, Cn,
+                                    int(ctx.relu), H.ptr(partial), prow, H.stream_ptr()), "cvcl_bn_bwd")
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+class MaxPool3x3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, Hh, Ww, Cn = x.shape
+        out = torch.empty(B, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cn, dtype=x.dtype, device=x.device)
+        H.check(H.lib().cvcl_maxpool3x3s2(_cd(x), H.ptr(x), None, H.ptr(out), B, Hh, Ww, Cn, H.stream_ptr()), "cvcl_maxpool3x3s2")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, Hh, Ww, Cn = x.shape
+        dx = torch.empty_like(x)
+        H.check(H.lib().cvcl_maxpool3x3s2(_cd(x), H.ptr(x), H.ptr(dy.contiguous()), H.ptr(dx), B, Hh, Ww, Cn, H.stream_ptr()),
+                "cvcl_maxpool3x3s2")
+        return dx
+
+
+class AddRelu(torch.autograd.Function):
+    """out = relu(a + b): the Bottleneck tail (torchvision resnet.py: ``out += identity; out = self.relu(out)``)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out = torch.empty_like(a)
+        n = a.numel()
+        s = H.stream_ptr()
+        H.check(H.lib().cvcl_add(_cd(a), H.ptr(a), H.ptr(b), H.ptr(out), n, s), "cvcl_add")
+        H.check(H.lib().cvcl_relu_mask(_cd(a), H.ptr(out), H.ptr(out), H.ptr(out), n, s), "cvcl_relu_mask")   # out = out where out > 0
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (out,) = ctx.saved_tensors
+        g = torch.empty_like(out)
+        H.check(H.lib().cvcl_relu_mask(_cd(out), H.ptr(out), H.ptr(dy.contiguous()), H.ptr(g), out.numel(), H.stream_ptr()),
+                "cvcl_relu_mask")
+        return g, g
+
+
+class AvgPool(torch.autograd.Function):
+    """AdaptiveAvgPool2d((1,1)) + flatten: [B,H,W,C] -> [B,C] fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, Hh, Ww, Cn = x.shape
+        out = torch.empty(B, Cn, dtype=_F, device=x.device)
+        H.check(H.lib().cvcl_avgpool(_cd(x), H.ptr(x), H.ptr(out), B, Hh * Ww, Cn, H.stream_ptr()), "cvcl_avgpool")
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        B, Hh, Ww, Cn = ctx.shape
+        dx = torch.empty(ctx.shape, dtype=ctx.dtype, device=d_pooled.device)
+        H.check(H.lib().cvcl_avgpool_bwd(H.cvcl_dtype(ctx.dtype), H.ptr(d_pooled.contiguous(), _F), H.ptr(dx), B, Hh * Ww, Cn,
+                                         H.stream_ptr()), "cvcl_avgpool_bwd")
+        return dx
+
+
+def _bn(raw, bn, relu):
+    return BatchNormTrain.apply(raw, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, relu)
+
+
+def trunk_train(model, x: torch.Tensor):
+    """Differentiable conv1 .. layer4 + avgpool of ``resnext.ResNet`` in train mode.
+    -> (pooled [B,2048] fp32, layer4 map as a logical NCHW view)."""
+    if not model.training:
+        raise NotImplementedError("gradients through the ResNeXt trunk are implemented for train-mode BatchNorm only "
+                                  "(the reference fine-tunes in train mode); eval-mode runs use the no-grad fast path")
+    if x.dtype != _F or x.dim() != 4 or x.shape[1] != 3:
+        raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
+    x = x.contiguous()
+    cdt = model.compute_dtype
+    h = StemConv.apply(x, model.conv1.weight, cdt)
+    h = _bn(h, model.bn1, True)
+    h = MaxPool3x3s2.apply(h)
+    for li in (1, 2, 3, 4):
+        for blk in getattr(model, f"layer{li}"):
+            idn = h
+            o = _bn(Conv1x1.apply(h, blk.conv1.weight, 1), blk.bn1, True)
+            o = _bn(GroupedConv3x3.apply(o, blk.conv2.weight, blk.conv2.stride[0]), blk.bn2, True)
+            o = _bn(Conv1x1.apply(o, blk.conv3.weight, 1), blk.bn3, False)
+            if blk.downsample is not None:
+                idn = _bn(Conv1x1.apply(h, blk.downsample[0].weight, blk.downsample[0].stride[0]), blk.downsample[1], False)
+            h = AddRelu.apply(o, idn)
+    pooled = AvgPool.apply(h)
+    return pooled, h.permute(0, 3, 1, 2)
