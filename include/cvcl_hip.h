@@ -266,6 +266,21 @@ int cvcl_zero_stuff2(int dtype, const void* dy, void* z, int B, int Ho, int Wo, 
 int cvcl_conv_wgrad_direct(int dtype, const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                            int cin_per_group, int k, int stride, int pad, int x_is_nchw_f32, void* stream);
 
+/* Weight-gradient ("TN") GEMM: C[n][k] = sum_m A[m][n] * B[m][k], A [M, lda >= N], B [M, ldb >= K] row-major in the
+ * run dtype, C [N, k_keep] f32 (k_keep <= K drops trailing padded columns).  1x1-conv weight gradient with A = dY,
+ * B = X (NHWC, no transposed copies); the contraction is split over M with a fixed-order reduction (deterministic).
+ * workspace >= cvcl_gemm_tn_workspace_bytes(dtype, M, N, K).                                             */
+size_t cvcl_gemm_tn_workspace_bytes(int dtype, long M, int N, int K);
+int cvcl_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, long M, int N, int K, float* C, int k_keep,
+                 void* workspace, size_t workspace_bytes, void* stream);
+/* grouped 3x3 (pad 1, stride 1|2) weight gradient, bf16 activations: dW [C][C/groups][3][3] f32 (reference OIHW) */
+size_t cvcl_gconv3x3_wgrad_workspace_bytes(int B, int H, int W, int C, int stride);
+int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int groups, int stride,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* bf16 patch matrix of the 7x7/2 stem: col [B*H/2*W/2][160] (147 = 3*7*7 columns (c, ky, kx), zero-padded to 160);
+ * stem weight gradient = cvcl_gemm_tn(A = dY [P,64], B = col, k_keep = 147)                              */
+int cvcl_stem_im2col(const float* x_nchw, void* col_bf16, int B, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,374 @@
+// Weight-gradient GEMMs of the fine-tuning path (--finetune_cnn; reference: autograd through torchvision's Conv2d,
+// call sites multimodal/multimodal.py:155-158,175-179):
+//
+//     C[n][k] = sum_m A[m][n] * B[m][k]            ("TN" GEMM: the contraction runs over the ROWS of both operands)
+//
+// A = dY [pixels, Cout], B = X [pixels, Cin] as they sit in HBM (NHWC, channel-contiguous) -- no transposed copies.
+// bf16 kernel: 128 x 128 output tile per workgroup (4 waves, 64 x 64 each = 2 x 2 MFMA 32x32x16 tiles), 64 rows of both
+// operands staged per step into a row-major LDS image (pitch 320 B); the MFMA fragments need 8 consecutive m for a
+// fixed column, i.e. the transpose of what is stored, and are read with gfx950's ds_read_b64_tr_b16 (two per
+// fragment).  Pitch 320 B = 80 dwords puts the 4 rows x 2 column groups that the first 32 lanes touch on disjoint
+// banks.  The pixel dimension is split S ways (deterministic: fp32 partials [S][N][K], then a fixed-order reduction);
+// workgroups of one split land on one XCD (linear id % 8 == s % 8) so that the operand rows they share are fetched into
+// that XCD's L2 once.
+//
+// conv-tap mode (grouped 3x3 weight gradient): grid.z = tap (ky, kx); row m = (b, oy, ox) of B is taken from pixel
+// (b, oy*stride + ky - 1, ox*stride + kx - 1) (zeros outside the image) and only the diagonal tiles (same 128-channel
+// slab of A and B) are computed: every group of <= 32 channels lies inside one slab; the reduction kernel picks the
+// block-diagonal out.  The dense 128 x 128 products waste MFMA work (x4 .. x32), which is cheap; HBM traffic is what counts.
+#include "cvcl_common.h"
+
+namespace {
+
+constexpr int TN_T = 128;            // output tile edge
+constexpr int TN_BM = 64;            // rows (pixels) per step
+constexpr int TN_PITCH = 320;        // LDS bytes per staged row (256 B of data + 64 B pad)
+constexpr int TN_TILE_BYTES = TN_BM * TN_PITCH;
+
+struct TnDev {
+    const bf16_t* A; const bf16_t* B; float* P;
+    long M;                   // rows of A (contraction length)
+    int N, K, lda, ldb;
+    int S; long chunk;        // split count, rows per split (multiple of TN_BM)
+    int tiles_n, tiles_k, diag;
+    int taps, Ho, Wo, Hi, Wi, stride;      // conv-tap gather on B (taps == 9) -- else taps == 1
+};
+
+typedef __bf16 tr_bf16x4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+
+__device__ inline bf16x4 lds_tr_read(const char* p) {
+    auto lp = reinterpret_cast<__attribute__((address_space(3))) tr_bf16x4*>(
+        (__attribute__((address_space(3))) char*)(p));
+    tr_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(lp);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnDev p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TN_TILE_BYTES];
+    char* sA = smem;
+    char* sB = smem + TN_TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    // linear id -> (split s, tile): id % 8 = s % 8 (XCD), then tiles of one split adjacent
+    const int ntile = p.diag ? p.tiles_n : p.tiles_n * p.tiles_k;
+    int id = blockIdx.x, s, tile;
+    if (p.S % 8 == 0) { s = (id & 7) + 8 * ((id >> 3) / ntile); tile = (id >> 3) % ntile; }
+    else { s = id / ntile; tile = id % ntile; }
+    const int tn = p.diag ? tile : tile / p.tiles_k, tk = p.diag ? tile : tile % p.tiles_k;
+    const int tap = blockIdx.y;
+    const int n0 = tn * TN_T, k0 = tk * TN_T;
+    const long m_begin = (long)s * p.chunk;
+    long m_end = m_begin + p.chunk;
+    if (m_end > p.M) m_end = p.M;
+
+    // staging role: 16 chunks (16 B = 8 channels) per row, 16 rows per pass, 4 passes per operand
+    const int s_chunk = tid & 15, s_row0 = tid >> 4;
+    const bool a_col_ok = n0 + s_chunk * 8 < p.N, b_col_ok = k0 + s_chunk * 8 < p.K;
+    const int ky = tap / 3 - 1, kx = tap % 3 - 1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    u32x4 ra[4], rb[4];
+    auto load_step = [&](long m0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = m0 + s_row0 + 16 * i;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            ra[i] = z; rb[i] = z;
+            if (m < m_end) {
+                if (a_col_ok) ra[i] = *reinterpret_cast<const u32x4*>(p.A + m * p.lda + n0 + s_chunk * 8);
+                if (b_col_ok) {
+                    if (p.taps == 1) {
+                        rb[i] = *reinterpret_cast<const u32x4*>(p.B + m * p.ldb + k0 + s_chunk * 8);
+                    } else {
+                        const int ox = (int)(m % p.Wo);
+                        const long t = m / p.Wo;
+                        const int oy = (int)(t % p.Ho);
+                        const long b = t / p.Ho;
+                        const int yi = oy * p.stride + ky, xi = ox * p.stride + kx;
+                        if (yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
+                            rb[i] = *reinterpret_cast<const u32x4*>(p.B + ((b * p.Hi + yi) * p.Wi + xi) * p.ldb + k0 + s_chunk * 8);
+                    }
+                }
+            }
+        }
+    };
+    auto write_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = (s_row0 + 16 * i) * TN_PITCH + s_chunk * 16;
+            *reinterpret_cast<u32x4*>(sA + off) = ra[i];
+            *reinterpret_cast<u32x4*>(sB + off) = rb[i];
+        }
+    };
+
+    // fragment addressing: 16-lane group g4 reads a [4 m][16 col] block; lane q supplies row q/4, cols 4*(q%4)..+3
+    const int g4 = lane >> 4, q = lane & 15;
+    const int frag_row = (g4 >> 1) * 8 + (q >> 2);                 // + kk*16 + h*4
+    const int frag_col = (g4 & 1) * 16 + (q & 3) * 4;              // + wave/tile column base
+    const char* fa = sA + frag_row * TN_PITCH + (wn * 64 + frag_col) * 2;
+    const char* fb = sB + frag_row * TN_PITCH + (wk * 64 + frag_col) * 2;
+
+    if (m_begin < m_end) {
+        load_step(m_begin);
+        write_step();
+        __syncthreads();
+        for (long m0 = m_begin; m0 < m_end; m0 += TN_BM) {
+            const bool more = m0 + TN_BM < m_end;
+            if (more) load_step(m0 + TN_BM);
+#pragma unroll
+            for (int kk = 0; kk < TN_BM / 16; ++kk) {
+                bf16x8 af[2], bfr[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16x4 a0 = lds_tr_read(fa + (kk * 16) * TN_PITCH + t * 64);
+                    const bf16x4 a1 = lds_tr_read(fa + (kk * 16 + 4) * TN_PITCH + t * 64);
+                    const bf16x4 b0 = lds_tr_read(fb + (kk * 16) * TN_PITCH + t * 64);
+                    const bf16x4 b1 = lds_tr_read(fb + (kk * 16 + 4) * TN_PITCH + t * 64);
+                    af[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bfr[t] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                write_step();
+                __syncthreads();
+            }
+        }
+    }
+
+    // partial tile -> P[tap][s][...]: full [N][K] matrix per (tap, s), or the stack of diagonal tiles
+    float* out;
+    long ldo;
+    if (p.diag) { out = p.P + (((long)tap * p.S + s) * p.tiles_n + tn) * TN_T * TN_T; ldo = TN_T; }
+    else { out = p.P + ((long)tap * p.S + s) * p.N * p.K + (long)n0 * p.K + k0; ldo = p.K; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wk * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wn * 64 + i * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+                if (p.diag || (n0 + row < p.N && k0 + col < p.K)) out[(long)row * ldo + col] = acc[i][j][r];
+            }
+        }
+}
+
+// fp32 parity mode: plain LDS-tiled VALU kernel, 64 x 64 tile, 4 x 4 outputs per thread, same split / partial layout
+struct TnF32Dev { const float* A; const float* B; float* P; long M; int N, K, lda, ldb, S; long chunk; int tiles_k; };
+
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(TnF32Dev p) {
+    __shared__ float sA[16][64 + 4], sB[16][64 + 4];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, s = blockIdx.y;
+    const int n0 = (tile / p.tiles_k) * 64, k0 = (tile % p.tiles_k) * 64;
+    const long m_begin = (long)s * p.chunk;
+    long m_end = m_begin + p.chunk;
+    if (m_end > p.M) m_end = p.M;
+    const int tr = tid >> 4, tc = tid & 15;          // thread's 4 x 4 block: rows tr*4.., cols tc*4..
+    float acc[4][4] = {};
+    for (long m0 = m_begin; m0 < m_end; m0 += 16) {
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const long m = m0 + r;
+            sA[r][c] = (m < m_end && n0 + c < p.N) ? p.A[m * p.lda + n0 + c] : 0.f;
+            sB[r][c] = (m < m_end && k0 + c < p.K) ? p.B[m * p.ldb + k0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sA[r][tr * 4 + i]; b[i] = sB[r][tc * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* out = p.P + (long)s * p.N * p.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tr * 4 + i, k = k0 + tc * 4 + j;
+            if (n < p.N && k < p.K) out[(long)n * p.K + k] = acc[i][j];
+        }
+}
+
+// C[n][k] = sum_s P[s][n][k]   (fixed order -> deterministic); ldc/col_limit let the stem drop its padded columns
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ P, float* __restrict__ C, int S, int N, int K,
+                                                        int k_keep) {
+    const long total = (long)N * k_keep;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / k_keep), k = (int)(i % k_keep);
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += P[((long)s * N + n) * K + k];
+        C[i] = a;
+    }
+}
+
+// grouped 3x3: dW[co][ci][tap] = sum_s P[tap][s][co / 128][co % 128][(co / cg * cg + ci) % 128]
+__global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ P, float* __restrict__ dw, int S, int C,
+                                                                 int cg) {
+    const long total = (long)C * cg * 9;
+    const int tiles = C / TN_T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 9), ci = (int)((i / 9) % cg), co = (int)(i / (9 * cg));
+        const int cin = (co / cg) * cg + ci;
+        const float* src = P + (((long)tap * S * tiles) + co / TN_T) * TN_T * TN_T + (long)(co % TN_T) * TN_T + (cin % TN_T);
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += src[(long)s * tiles * TN_T * TN_T];
+        dw[i] = a;
+    }
+}
+
+// stem 7x7/2 pad 3: bf16 patch matrix col[p][(c*7 + ky)*7 + kx] (147 columns padded to 160 with zeros), p = (b, oy, ox)
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, bf16_t* __restrict__ col, int B, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo * 20;                 // 20 chunks of 8 columns per pixel
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % 20);
+        const long pix = i / 20;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+        const long b = pix / ((long)Wo * Ho);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = ch * 8 + e;
+            float f = 0.f;
+            if (j < 147) {
+                const int c = j / 49, kyy = (j / 7) % 7, kxx = j % 7;
+                const int yi = 2 * oy - 3 + kyy, xi = 2 * ox - 3 + kxx;
+                if (yi >= 0 && yi < H && xi >= 0 && xi < W) f = x[((b * 3 + c) * H + yi) * W + xi];
+            }
+            v[e] = (bf16_t)f;
+        }
+        *reinterpret_cast<bf16x8*>(col + pix * 160 + ch * 8) = v;
+    }
+}
+
+struct TnPlan { int S; long chunk; int tiles_n, tiles_k, ntile; };
+
+TnPlan tn_plan(long M, int N, int K, int taps, bool diag, int tile) {
+    TnPlan pl;
+    pl.tiles_n = cvcl_div_up(N, tile);
+    pl.tiles_k = cvcl_div_up(K, tile);
+    pl.ntile = diag ? pl.tiles_n : pl.tiles_n * pl.tiles_k;
+    long want = cvcl_div_up(1024, (long)pl.ntile * taps);            // ~4 workgroups per CU in total
+    const long max_s = cvcl_div_up(M, 1024);                         // >= 1024 rows per split
+    if (want > max_s) want = max_s;
+    if (want < 1) want = 1;
+    if (want >= 8) want = (want + 7) / 8 * 8;
+    pl.chunk = (cvcl_div_up(M, want) + TN_BM - 1) / TN_BM * TN_BM;
+    pl.S = cvcl_div_up(M, pl.chunk);
+    if (pl.S >= 8 && pl.S % 8) {                                     // keep the XCD mapping exact: pad with empty splits
+        pl.S = (pl.S + 7) / 8 * 8;
+    }
+    return pl;
+}
+
+size_t tn_ws_bytes(const TnPlan& pl, int N, int K, int taps, bool diag) {
+    return diag ? (size_t)taps * pl.S * pl.tiles_n * TN_T * TN_T * 4 : (size_t)taps * pl.S * N * K * 4;
+}
+
+int reduce_grid(long total) {
+    long g = (total + 255) / 256;
+    return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" size_t cvcl_gemm_tn_workspace_bytes(int dtype, long M, int N, int K) {
+    const TnPlan pl = tn_plan(M, N, K, 1, false, dtype == CVCL_BF16 ? TN_T : 64);
+    return tn_ws_bytes(pl, N, K, 1, false);
+}
+
+extern "C" int cvcl_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, long M, int N, int K, float* C,
+                            int k_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    CVCL_CHECK_ARG(A && B && C && workspace && M > 0 && N > 0 && K > 0 && lda >= N && ldb >= K && k_keep > 0 && k_keep <= K,
+                   "cvcl_gemm_tn: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const bool bf = dtype == CVCL_BF16;
+    const TnPlan pl = tn_plan(M, N, K, 1, false, bf ? TN_T : 64);
+    if (workspace_bytes < tn_ws_bytes(pl, N, K, 1, false)) {
+        cvcl_set_error("cvcl_gemm_tn: workspace too small");
+        return CVCL_EWORKSPACE;
+    }
+    CvclProfScope prof(stream, CVCL_K_GEMM);
+    if (bf) {
+        CVCL_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+                       "cvcl_gemm_tn: bf16 operands need 16-byte aligned rows (N, K, lda, ldb multiples of 8)");
+        TnDev d = {};
+        d.A = (const bf16_t*)A; d.B = (const bf16_t*)B; d.P = (float*)workspace;
+        d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.S = pl.S; d.chunk = pl.chunk;
+        d.tiles_n = pl.tiles_n; d.tiles_k = pl.tiles_k; d.diag = 0; d.taps = 1;
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(pl.ntile * pl.S, 1), dim3(256), 0, st, d);
+    } else {
+        TnF32Dev d = {(const float*)A, (const float*)B, (float*)workspace, M, N, K, lda, ldb, pl.S, pl.chunk, pl.tiles_k};
+        hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(pl.ntile, pl.S), dim3(256), 0, st, d);
+    }
+    CVCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(reduce_grid((long)N * k_keep)), dim3(256), 0, st, (const float*)workspace, C, pl.S, N, K,
+                       k_keep);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" size_t cvcl_gconv3x3_wgrad_workspace_bytes(int B, int H, int W, int C, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const TnPlan pl = tn_plan((long)B * Ho * Wo, C, C, 9, true, TN_T);
+    return tn_ws_bytes(pl, C, C, 9, true);
+}
+
+// bf16 only (the fp32 parity mode uses cvcl_conv_wgrad_direct)
+extern "C" int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int groups, int stride,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    CVCL_CHECK_ARG(x && dy && dw && workspace && B > 0 && (stride == 1 || stride == 2) && groups > 0 && C % groups == 0,
+                   "cvcl_gconv3x3_wgrad: bad args");
+    const int cg = C / groups;
+    CVCL_CHECK_ARG(C % TN_T == 0 && cg <= TN_T && TN_T % cg == 0, "cvcl_gconv3x3_wgrad: unsupported C=%d groups=%d", C, groups);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long M = (long)B * Ho * Wo;
+    const TnPlan pl = tn_plan(M, C, C, 9, true, TN_T);
+    if (workspace_bytes < tn_ws_bytes(pl, C, C, 9, true)) {
+        cvcl_set_error("cvcl_gconv3x3_wgrad: workspace too small");
+        return CVCL_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    CvclProfScope prof(stream, CVCL_K_GCONV);
+    TnDev d = {};
+    d.A = (const bf16_t*)dy; d.B = (const bf16_t*)x; d.P = (float*)workspace;
+    d.M = M; d.N = C; d.K = C; d.lda = C; d.ldb = C; d.S = pl.S; d.chunk = pl.chunk;
+    d.tiles_n = pl.tiles_n; d.tiles_k = pl.tiles_k; d.diag = 1;
+    d.taps = 9; d.Ho = Ho; d.Wo = Wo; d.Hi = H; d.Wi = W; d.stride = stride;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(pl.ntile * pl.S, 9), dim3(256), 0, st, d);
+    CVCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3(reduce_grid((long)C * cg * 9)), dim3(256), 0, st, (const float*)workspace, dw,
+                       pl.S, C, cg);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_stem_im2col(const float* x_nchw, void* col_bf16, int B, int H, int W, void* stream) {
+    CVCL_CHECK_ARG(x_nchw && col_bf16 && B > 0 && H % 2 == 0 && W % 2 == 0, "cvcl_stem_im2col: bad args");
+    CvclProfScope prof(stream, CVCL_K_STEM);
+    const long total = (long)B * (H / 2) * (W / 2) * 20;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(reduce_grid(total) * 2), dim3(256), 0, (hipStream_t)stream, x_nchw, (bf16_t*)col_bf16, B, H, W);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}

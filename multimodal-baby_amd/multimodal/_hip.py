@@ -109,6 +109,11 @@ SIGNATURES = {
     "cvcl_avgpool_bwd": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "cvcl_zero_stuff2": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_conv_wgrad_direct": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cvcl_gemm_tn_workspace_bytes": (C.c_size_t, [_I, C.c_long, _I, _I]),
+    "cvcl_gemm_tn": (_I, [_I, _P, _I, _P, _I, C.c_long, _I, _I, _P, _I, _P, C.c_size_t, _P]),
+    "cvcl_gconv3x3_wgrad_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
+    "cvcl_gconv3x3_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, C.c_size_t, _P]),
+    "cvcl_stem_im2col": (_I, [_P, _P, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }

@@ -9,10 +9,10 @@ differentiable twin: one ``torch.autograd.Function`` per operator, each a thin w
 autograd only doing the bookkeeping (which tensors to keep, where gradients add).  Activations are NHWC, stored in the
 trunk's compute dtype (fp32 parity mode / bf16); parameter gradients are returned in fp32.
 
-  conv 1x1        fwd  cvcl_gemm                          dX  cvcl_gemm(dY, W^T)     dW  cvcl_gemm(dY^T, X^T)
+  conv 1x1        fwd  cvcl_gemm                          dX  cvcl_gemm(dY, W^T)     dW  cvcl_gemm_tn(dY, X)
   grouped 3x3     fwd  cvcl_gconv3x3 (identity prologue)  dX  cvcl_gconv3x3 on (zero-stuffed) dY with the flipped,
-                                                              group-transposed weight   dW  cvcl_conv_wgrad_direct
-  stem 7x7        fwd  cvcl_stem_conv7x7                  dW  cvcl_conv_wgrad_direct (images need no gradient)
+                                                              group-transposed weight   dW  cvcl_gconv3x3_wgrad (bf16) / cvcl_conv_wgrad_direct (fp32)
+  stem 7x7        fwd  cvcl_stem_conv7x7                  dW  cvcl_stem_im2col + cvcl_gemm_tn (bf16) / cvcl_conv_wgrad_direct (fp32)
   BatchNorm(+ReLU) fwd col_stats -> bn_finalize (running stats) -> bn_apply;   bwd  cvcl_bn_bwd
   max / avg pool, residual add + ReLU: cvcl_maxpool3x3s2, cvcl_avgpool(_bwd), cvcl_bn_add_relu / cvcl_relu_mask
 
@@ -48,6 +48,21 @@ def _pack(w: torch.Tensor, kind: int, dtype: torch.dtype) -> torch.Tensor:
     H.check(H.lib().cvcl_pack_conv_weight(dt, kind, H.ptr(w.detach().contiguous(), _F), H.ptr(buf), cout, cing, k,
                                           H.stream_ptr()), "cvcl_pack_conv_weight")
     return buf
+
+
+def _gemm_tn(a2d: torch.Tensor, b2d: torch.Tensor, k_keep: int | None = None) -> torch.Tensor:
+    """C[n][k] = sum_m a[m][n] * b[m][k] -> fp32 [N, k_keep] (cvcl_gemm_tn: weight-gradient GEMM, no transposed copies)."""
+    M, N = a2d.shape
+    K = b2d.shape[1]
+    k_keep = K if k_keep is None else k_keep
+    dt = _cd(a2d)
+    lib = H.lib()
+    nb = lib.cvcl_gemm_tn_workspace_bytes(dt, M, N, K)
+    ws = torch.empty(nb, dtype=torch.uint8, device=a2d.device)
+    out = torch.empty(N, k_keep, dtype=_F, device=a2d.device)
+    H.check(lib.cvcl_gemm_tn(dt, H.ptr(a2d), N, H.ptr(b2d, a2d.dtype), K, M, N, K, H.ptr(out), k_keep, H.ptr(ws), nb, H.stream_ptr()),
+            "cvcl_gemm_tn")
+    return out
 
 
 def _zero_stuff(dy: torch.Tensor) -> torch.Tensor:
@@ -87,7 +102,7 @@ class Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = H.gemm(dy2, _transpose(wq)).view(B, Hh, Ww, K)
         if ctx.needs_input_grad[1]:
-            dw = H.gemm(_transpose(dy2), _transpose(x2)).float().view(N, K, 1, 1)
+            dw = _gemm_tn(dy2, x2).view(N, K, 1, 1)
         return dx, dw, None
 
 
@@ -116,8 +131,14 @@ class GroupedConv3x3(torch.autograd.Function):
         lib, s = H.lib(), H.stream_ptr()
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(weight, dtype=_F)
-            H.check(lib.cvcl_conv_wgrad_direct(_cd(x), H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, Cn, Cn, cg, 3, ctx.stride, 1, 0, s),
-                    "cvcl_conv_wgrad_direct")
+            if x.dtype == torch.bfloat16:                 # 9 tap-shifted TN GEMMs on the diagonal channel slabs (MFMA)
+                nb = lib.cvcl_gconv3x3_wgrad_workspace_bytes(B, Hh, Ww, Cn, ctx.stride)
+                ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                H.check(lib.cvcl_gconv3x3_wgrad(H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, Cn, 32, ctx.stride, H.ptr(ws), nb, s),
+                        "cvcl_gconv3x3_wgrad")
+            else:
+                H.check(lib.cvcl_conv_wgrad_direct(_cd(x), H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, Cn, Cn, cg, 3, ctx.stride, 1, 0, s),
+                        "cvcl_conv_wgrad_direct")
         if ctx.needs_input_grad[0]:
             wf = torch.empty_like(weight, dtype=_F)
             H.check(lib.cvcl_gconv_weight_dgrad(H.ptr(weight.detach().contiguous(), _F), H.ptr(wf), Cn, cg, s), "cvcl_gconv_weight_dgrad")
@@ -150,6 +171,11 @@ class StemConv(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         B, _, Hh, Ww = x.shape
         dy = dy.contiguous()
+        if dy.dtype == torch.bfloat16:                    # patch matrix (bf16, 147 -> 160 columns) + TN GEMM on MFMA
+            P = B * (Hh // 2) * (Ww // 2)
+            col = torch.empty(P, 160, dtype=torch.bfloat16, device=x.device)
+            H.check(H.lib().cvcl_stem_im2col(H.ptr(x, _F), H.ptr(col), B, Hh, Ww, H.stream_ptr()), "cvcl_stem_im2col")
+            return None, _gemm_tn(dy.view(P, 64), col, 147).view(64, 3, 7, 7), None
         dw = torch.empty(64, 3, 7, 7, dtype=_F, device=x.device)
         H.check(H.lib().cvcl_conv_wgrad_direct(_cd(dy), H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, 3, 64, 3, 7, 2, 3, 1,
                                                H.stream_ptr()), "cvcl_conv_wgrad_direct")

@@ -30,6 +30,43 @@ def _tol(dt, f32, bf16):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K,k_keep", [(1000, 64, 256, 256), (5000, 128, 64, 64), (77, 256, 512, 512), (20000, 64, 160, 147),
+                                          (300000, 128, 256, 256), (4096, 1024, 512, 512)])
+def test_gemm_tn_exact_on_small_integers(dev, dt, M, N, K, k_keep):
+    """Weight-gradient GEMM C = A^T B (contraction over rows, split + fixed-order reduction): with small-integer operands
+    every product and partial sum is exact in fp32, so the result must equal the float64 reference bit for bit --
+    this pins the ds_read_b64_tr_b16 fragment layout (any row/column mix-up changes the answer) and the split logic."""
+    from multimodal.trunk_train import _gemm_tn
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randint(-3, 4, (M, N), generator=g).float()
+    b = torch.randint(-3, 4, (M, K), generator=g).float()
+    ref = (a.double().t() @ b.double())[:, :k_keep].float()
+    ad, bd = a.to(_cdt(dt)).to(dev), b.to(_cdt(dt)).to(dev)
+    out = _gemm_tn(ad, bd, k_keep)
+    out2 = _gemm_tn(ad, bd, k_keep)
+    assert out.shape == (N, k_keep) and torch.equal(out.cpu(), ref) and torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("B,S,C_,stride", [(2, 8, 128, 1), (2, 16, 256, 2), (3, 14, 1024, 2), (4, 28, 512, 1)])
+def test_gconv_wgrad_exact_on_small_integers(dev, B, S, C_, stride):
+    """bf16 grouped-conv weight gradient (tap-shifted TN GEMMs on diagonal slabs) is exact on small integers."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(C_ + S)
+    cg = C_ // 32
+    x = torch.randint(-2, 3, (B, C_, S, S), generator=g).float().requires_grad_(False)
+    w = torch.zeros(C_, cg, 3, 3, requires_grad=True)
+    y = F.conv2d(x.double(), w.double(), None, stride, 1, 1, 32)
+    dy = torch.randint(-2, 3, y.shape, generator=g).float()
+    (gw,) = torch.autograd.grad(y, w, dy.double())
+    xd, dyd = nhwc(x).bfloat16().to(dev), nhwc(dy).bfloat16().to(dev)
+    dw = torch.empty(C_, cg, 3, 3, device=dev)
+    nb = H.lib().cvcl_gconv3x3_wgrad_workspace_bytes(B, S, S, C_, stride)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    H.check(H.lib().cvcl_gconv3x3_wgrad(H.ptr(xd), H.ptr(dyd), H.ptr(dw), B, S, S, C_, 32, stride, H.ptr(ws), nb, H.stream_ptr()), "wgrad")
+    assert torch.equal(dw.cpu(), gw.float())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("B,S,K,N,stride", [(2, 8, 64, 128, 1), (3, 7, 256, 64, 1), (2, 8, 256, 512, 2), (1, 14, 1024, 2048, 2)])
 def test_conv1x1_grads(dev, dt, B, S, K, N, stride):
     from multimodal.trunk_train import Conv1x1
