@@ -41,7 +41,8 @@ const char* cvcl_last_error(void);
  * returns the summed device time and launch count per kernel class.  Off by default (zero overhead).  */
 enum { CVCL_K_GEMM = 0, CVCL_K_GCONV = 1, CVCL_K_STEM = 2, CVCL_K_BN_FINALIZE = 3, CVCL_K_BN_ADD_RELU = 4,
        CVCL_K_MAXPOOL = 5, CVCL_K_AVGPOOL = 6, CVCL_K_HEAD = 7, CVCL_K_OTHER = 8, CVCL_K_ATTENTION = 9,
-       CVCL_K_LAYERNORM = 10, CVCL_K_LSTM = 11, CVCL_K_GEMM_F32 = 12, CVCL_K_BN_APPLY = 13, CVCL_K_NCLASSES = 14 };
+       CVCL_K_LAYERNORM = 10, CVCL_K_LSTM = 11, CVCL_K_GEMM_F32 = 12, CVCL_K_BN_APPLY = 13, CVCL_K_BN_BWD = 14,
+       CVCL_K_WGRAD = 15, CVCL_K_NCLASSES = 16 };
 int cvcl_prof_enable(int on);
 int cvcl_prof_collect(double* ms_per_class, long* launches_per_class, int n_classes);
 
@@ -243,19 +244,22 @@ int cvcl_lstm_cell_bwd(const float* gates_act, const float* c_save, const int64_
  * path; [rows, C] = NHWC activations flattened over pixels.                                              */
 int cvcl_bn_apply(int dtype, const void* x, const float* scale, const float* shift, void* y, long rows, int C, int relu,
                   void* stream);
-/* train-mode BatchNorm backward (optionally through a following ReLU, masked by y > 0):
- *   g = dy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;  dx = gamma * rstd * (g - dbeta/n - xhat * dgamma/n)
- * partial: scratch [partial_rows >= min(256, ceil(rows/256))][2][C] f32                                  */
-int cvcl_bn_bwd(int dtype, const void* x, const void* y, const void* dy, const float* mean, const float* rstd,
-                const float* gamma, float* dgamma, float* dbeta, void* dx, long rows, int C, int relu, float* partial,
-                int partial_rows, void* stream);
+/* train-mode BatchNorm backward, g = dy * mask:
+ *   mode 0: no mask | mode 1: [x*scale+shift > 0] (ReLU right after the BN; recomputed, y is not read) |
+ *   mode 2: [out > 0], out = relu(bn(x) + identity) the Bottleneck output; g_out (optional) receives g = d identity.
+ *   dbeta = sum g;  dgamma = sum g * xhat;  dx = gamma * rstd * (g - dbeta/n - xhat * dgamma/n)
+ * partial: scratch [partial_rows >= cvcl_bn_bwd_partial_rows(dtype, rows, C)][2][C] f32;  coef: scratch [3][C] f32 */
+int cvcl_bn_bwd_partial_rows(int dtype, long rows, int C);
+int cvcl_bn_bwd(int dtype, int mode, const void* x, const void* out, const void* dy, const float* scale, const float* shift,
+                const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, void* dx, void* g_out,
+                long rows, int C, float* partial, int partial_rows, float* coef, void* stream);
 /* batch mean and 1/sqrt(var_biased + eps) from the forward statistics rows (what bn_finalize normalised with) */
 int cvcl_bn_batch_moments(const float* stats, int stats_rows, long count, float eps, float* mean, float* rstd, int C,
                           void* stream);
 /* OIHW f32 weight of the convolution that computes the data gradient of a grouped 3x3 conv (flip + in/out swap per group) */
 int cvcl_gconv_weight_dgrad(const float* w, float* out, int C, int cin_per_group, void* stream);
 int cvcl_transpose(int dtype, const void* in, void* out, long rows, int cols, void* stream);     /* out[c][r] = in[r][c] */
-int cvcl_add(int dtype, const void* a, const void* b, void* y, long n, void* stream);
+int cvcl_add(int dtype, const void* a, const void* b, void* y, long n, int relu, void* stream);  /* y = a + b (ReLU if relu) */
 int cvcl_relu_mask(int dtype, const void* y, const void* dy, void* dx, long n, void* stream);    /* dx = dy where y > 0 */
 /* max pool 3x3/2 pad 1, NHWC: dy == NULL -> forward (out = pooled); else backward (out = dx, first arg-max wins) */
 int cvcl_maxpool3x3s2(int dtype, const void* x, const void* dy, void* out, int B, int H, int W, int C, void* stream);

@@ -14,78 +14,156 @@ int grid_for(long total, int per_block = 256, int cap = 8192) {
     return (int)(g > cap ? cap : g);
 }
 
-// ---- BatchNorm (train mode) forward apply without ReLU:  y = x * scale + shift  (relu optional) -------------------
+// All elementwise / reduction kernels below work on 16-byte chunks (8 bf16 / 4 fp32 channels) with the channel chunk
+// fixed per thread (grid * 256 is a multiple of the chunks per row), so per-channel vectors are loaded once per thread.
+
+// ---- BatchNorm forward apply:  y = x * scale + shift (+ReLU) ---------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, T* __restrict__ y, long rows, int C,
                                                        int relu) {
-    const long total = rows * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        float v = fmaf(ElemTraits<T>::to_f(x[i]), scale[c], shift[c]);
-        if (relu) v = fmaxf(v, 0.f);
-        y[i] = ElemTraits<T>::from_f(v);
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int CC = C / EPC;
+    const long total = rows * CC;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % CC) * EPC;
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+    const float floor_ = relu ? 0.f : -INFINITY;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = i0; i < total; i += stride) {
+        Chunk<T> a, o;
+        a.load(x + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, fmaxf(fmaf(a.get(e), sc[e], sh[e]), floor_));
+        o.store(y + i * EPC);
     }
 }
 
-// ---- BatchNorm backward, pass 1: per-channel partial sums of g and g * xhat, g = dy * (y > 0 if relu) ---------------
-// xhat = (x - mean) * rstd.  partial rows [gridDim.x][2][C] (same layout as the forward statistics).
+// ---- BatchNorm backward ---------------------------------------------------------------------------------------------
+// g = dy * mask, mask: mode 0 none | mode 1 [x*scale+shift > 0] (ReLU right after the BN, recomputed -- no read of y) |
+// mode 2 [out > 0] with `out` the block output relu(bn(x) + identity).
+// pass 1: per-channel partial sums of g and g * xhat, xhat = (x - mean) * rstd;  partial rows [gridDim.x][2][C]
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
-                                                            const T* __restrict__ dy, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, long rows, int C, int relu,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ out,
+                                                            const T* __restrict__ dy, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, long rows, int C, int mode,
                                                             float* __restrict__ partial) {
-    __shared__ float ps[4][64], pq[4][64];
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, ch = blockIdx.y * 64 + c;
-    float s = 0.f, q = 0.f;
-    if (ch < C) {
-        const float mu = mean[ch], rs = rstd[ch];
-        for (long r = (long)blockIdx.x * 4 + sl; r < rows; r += (long)gridDim.x * 4) {
-            float g = ElemTraits<T>::to_f(dy[r * C + ch]);
-            if (relu && !(ElemTraits<T>::to_f(y[r * C + ch]) > 0.f)) g = 0.f;
-            const float xh = (ElemTraits<T>::to_f(x[r * C + ch]) - mu) * rs;
-            s += g;
-            q = fmaf(g, xh, q);
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    __shared__ float red[256 * EPC * 2];
+    const int CC = C / EPC;
+    const int ccb = CC < 256 ? CC : 256;               // chunk columns handled by this block
+    const int RL = 256 / ccb;                          // row lanes
+    const int cc = blockIdx.y * ccb + threadIdx.x % ccb, rl = threadIdx.x / ccb;
+    const int c = cc * EPC;
+    float sc[EPC], sh[EPC], mu[EPC], rs[EPC], s[EPC], q[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = mode == 1 ? scale[c + e] : 0.f; sh[e] = mode == 1 ? shift[c + e] : 0.f;
+        mu[e] = mean[c + e]; rs[e] = rstd[c + e]; s[e] = 0.f; q[e] = 0.f;
+    }
+    for (long r = (long)blockIdx.x * RL + rl; r < rows; r += (long)gridDim.x * RL) {
+        const long off = r * C + c;
+        Chunk<T> xv, gv, ov;
+        xv.load(x + off);
+        gv.load(dy + off);
+        if (mode == 2) ov.load(out + off);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float xe = xv.get(e);
+            float g = gv.get(e);
+            if (mode == 1 && !(fmaf(xe, sc[e], sh[e]) > 0.f)) g = 0.f;
+            if (mode == 2 && !(ov.get(e) > 0.f)) g = 0.f;
+            s[e] += g;
+            q[e] = fmaf(g, (xe - mu[e]) * rs[e], q[e]);
         }
     }
-    ps[sl][c] = s;
-    pq[sl][c] = q;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        red[(threadIdx.x * EPC + e) * 2 + 0] = s[e];
+        red[(threadIdx.x * EPC + e) * 2 + 1] = q[e];
+    }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            float ts = 0.f, tq = 0.f;
+            for (int l = 0; l < RL; ++l) {
+                ts += red[((l * ccb + threadIdx.x) * EPC + e) * 2 + 0];
+                tq += red[((l * ccb + threadIdx.x) * EPC + e) * 2 + 1];
+            }
+            partial[((long)blockIdx.x * 2 + 0) * C + c + e] = ts;
+            partial[((long)blockIdx.x * 2 + 1) * C + c + e] = tq;
+        }
+    }
+}
+
+// reduce the partial rows (fp64, fixed order): dbeta = sum g, dgamma = sum g*xhat, and the apply-pass coefficients
+//   dx = gamma*rstd*(g - dbeta/n - xhat*dgamma/n) = k1*g + k2*x + k3
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int prow, int C, long n,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double ss[8][32], sq[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, ch = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (ch < C)
+        for (int r = sl; r < prow; r += 8) {
+            s += (double)partial[((long)r * 2 + 0) * C + ch];
+            q += (double)partial[((long)r * 2 + 1) * C + ch];
+        }
+    ss[sl][cl] = s;
+    sq[sl][cl] = q;
     __syncthreads();
     if (sl == 0 && ch < C) {
-        partial[((long)blockIdx.x * 2 + 0) * C + ch] = (ps[0][c] + ps[1][c]) + (ps[2][c] + ps[3][c]);
-        partial[((long)blockIdx.x * 2 + 1) * C + ch] = (pq[0][c] + pq[1][c]) + (pq[2][c] + pq[3][c]);
+        for (int l = 1; l < 8; ++l) { s += ss[l][cl]; q += sq[l][cl]; }
+        const float db = (float)s, dg = (float)q;
+        dbeta[ch] = db;
+        dgamma[ch] = dg;
+        const float inv_n = 1.f / (float)n, gr = gamma[ch] * rstd[ch];
+        const float k2 = -gr * rstd[ch] * dg * inv_n;
+        coef[ch] = gr;
+        coef[C + ch] = k2;
+        coef[2 * C + ch] = -gr * db * inv_n - k2 * mean[ch];
     }
 }
 
-// reduce partial rows -> dbeta = sum g, dgamma = sum g*xhat (fp64 accumulation, fixed order)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int prow, int C,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int r = 0; r < prow; ++r) {
-        s += (double)partial[((long)r * 2 + 0) * C + ch];
-        q += (double)partial[((long)r * 2 + 1) * C + ch];
-    }
-    dbeta[ch] = (float)s;
-    dgamma[ch] = (float)q;
-}
-
-// ---- BatchNorm backward, pass 2: dx = gamma * rstd * (g - dbeta / n - xhat * dgamma / n) ------------------------------
+// pass 2: dx = k1*g + k2*x + k3; optionally also stores g (the gradient of the residual identity, mode 2)
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y,
-                                                           const T* __restrict__ dy, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                           T* __restrict__ dx, long rows, int C, int relu) {
-    const long total = rows * C;
-    const float inv_n = 1.f / (float)rows;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        float g = ElemTraits<T>::to_f(dy[i]);
-        if (relu && !(ElemTraits<T>::to_f(y[i]) > 0.f)) g = 0.f;
-        const float xh = (ElemTraits<T>::to_f(x[i]) - mean[c]) * rstd[c];
-        dx[i] = ElemTraits<T>::from_f(gamma[c] * rstd[c] * (g - dbeta[c] * inv_n - xh * dgamma[c] * inv_n));
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ out,
+                                                           const T* __restrict__ dy, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ coef,
+                                                           T* __restrict__ dx, T* __restrict__ g_out, long rows, int C, int mode) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int CC = C / EPC;
+    const long total = rows * CC;
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % CC) * EPC;
+    float sc[EPC], sh[EPC], k1[EPC], k2[EPC], k3[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+        sc[e] = mode == 1 ? scale[c + e] : 0.f; sh[e] = mode == 1 ? shift[c + e] : 0.f;
+        k1[e] = coef[c + e]; k2[e] = coef[C + c + e]; k3[e] = coef[2 * C + c + e];
+    }
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = i0; i < total; i += stride) {
+        Chunk<T> xv, gv, ov, o, go;
+        xv.load(x + i * EPC);
+        gv.load(dy + i * EPC);
+        if (mode == 2) ov.load(out + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+            const float xe = xv.get(e);
+            float g = gv.get(e);
+            if (mode == 1 && !(fmaf(xe, sc[e], sh[e]) > 0.f)) g = 0.f;
+            if (mode == 2 && !(ov.get(e) > 0.f)) g = 0.f;
+            go.set(e, g);
+            o.set(e, fmaf(k1[e], g, fmaf(k2[e], xe, k3[e])));
+        }
+        o.store(dx + i * EPC);
+        if (g_out) go.store(g_out + i * EPC);
     }
 }
 
@@ -108,18 +186,32 @@ __global__ void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, 
     }
 }
 
-// ---- y = relu(a + b) and its backward mask are served by bn_add_relu / relu_bwd; elementwise add for gradients --------
+// ---- y = a + b (optionally ReLU), dx = dy * [y > 0]: 16-byte chunks; n is a multiple of the chunk size -----------------
 template <typename T>
-__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        y[i] = ElemTraits<T>::from_f(ElemTraits<T>::to_f(a[i]) + ElemTraits<T>::to_f(b[i]));
+__global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long n, int relu) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const float floor_ = relu ? 0.f : -INFINITY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / EPC; i += (long)gridDim.x * blockDim.x) {
+        Chunk<T> av, bv, o;
+        av.load(a + i * EPC);
+        bv.load(b + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, fmaxf(av.get(e) + bv.get(e), floor_));
+        o.store(y + i * EPC);
+    }
 }
 
-// dx = dy where y > 0 (typed)
 template <typename T>
-__global__ __launch_bounds__(256) void relu_mask_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dx[i] = ElemTraits<T>::to_f(y[i]) > 0.f ? dy[i] : ElemTraits<T>::from_f(0.f);
+__global__ __launch_bounds__(256) void relu_mask_kernel(const T* y, const T* dy, T* dx, long n) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / EPC; i += (long)gridDim.x * blockDim.x) {
+        Chunk<T> yv, gv, o;
+        yv.load(y + i * EPC);
+        gv.load(dy + i * EPC);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, yv.get(e) > 0.f ? gv.get(e) : 0.f);
+        o.store(dx + i * EPC);
+    }
 }
 
 // ---- max pool 3x3 / 2 pad 1 (NHWC) forward on an already-activated tensor, and backward (first arg-max wins) -----------
@@ -146,39 +238,54 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 }
 
 // gather form of the backward (deterministic, no atomics): dx[in] = sum over the <= 4 windows containing `in` of
-// dy[window] where `in` is that window's first arg-max
+// dy[window] where `in` is that window's first arg-max (row-major scan order, like torch).  One 16-byte channel chunk
+// per thread; the 3x3 neighbourhoods of the candidate windows overlap in a 5x5 patch that is loaded once.
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                           int B, int H, int W, int C) {
-    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)B * H * W * C;
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, CC = C / EPC;
+    const long total = (long)B * H * W * CC;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long p = i / C;
+        const int c = (int)(i % CC) * EPC;
+        const long p = i / CC;
         const int xi = (int)(p % W), yi = (int)((p / W) % H), b = (int)(p / ((long)W * H));
-        const float v = ElemTraits<T>::to_f(x[i]);
-        float acc = 0.f;
+        Chunk<T> v, o;
+        v.load(x + p * C + c);
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
         for (int oy = (yi + 1) / 2 - 1; oy <= (yi + 1) / 2; ++oy) {         // windows with 2*oy - 1 <= yi <= 2*oy + 1
             if (oy < 0 || oy >= Ho || 2 * oy - 1 > yi || 2 * oy + 1 < yi) continue;
             for (int ox = (xi + 1) / 2 - 1; ox <= (xi + 1) / 2; ++ox) {
                 if (ox < 0 || ox >= Wo || 2 * ox - 1 > xi || 2 * ox + 1 < xi) continue;
-                // is (yi, xi) the first arg-max of window (oy, ox)?  (row-major scan order, like torch)
-                bool first = true;
-                for (int ky = 0; ky < 3 && first; ++ky) {
+                bool first[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) first[e] = true;
+                for (int ky = 0; ky < 3; ++ky) {
                     const int yy = 2 * oy - 1 + ky;
                     if (yy < 0 || yy >= H) continue;
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = 2 * ox - 1 + kx;
-                        if (xx < 0 || xx >= W) continue;
-                        const float u = ElemTraits<T>::to_f(x[(((long)b * H + yy) * W + xx) * C + c]);
+                        if (xx < 0 || xx >= W || (yy == yi && xx == xi)) continue;
+                        Chunk<T> u;
+                        u.load(x + (((long)b * H + yy) * W + xx) * C + c);
                         const bool before = (yy < yi) || (yy == yi && xx < xi);
-                        if (u > v || (before && u == v)) { first = false; break; }
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e)
+                            if (u.get(e) > v.get(e) || (before && u.get(e) == v.get(e))) first[e] = false;
                     }
                 }
-                if (first) acc += ElemTraits<T>::to_f(dy[(((long)b * Ho + oy) * Wo + ox) * C + c]);
+                Chunk<T> g;
+                g.load(dy + (((long)b * Ho + oy) * Wo + ox) * C + c);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (first[e]) acc[e] += g.get(e);
             }
         }
-        dx[i] = ElemTraits<T>::from_f(acc);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, acc[e]);
+        o.store(dx + p * C + c);
     }
 }
 
@@ -234,21 +341,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const void* __re
     if (threadIdx.x == 0) dw[widx] = acc;
 }
 
-// batch mean / rstd from the forward statistics rows [prow][2][C] (same fp64 reduction order as bn_finalize, biased variance)
+// batch mean / rstd from the forward statistics rows [prow][2][C] (fp64, biased variance: what bn_finalize normalised with)
 __global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict__ stats, int prow, long count, float eps, int C,
                                                          float* __restrict__ mean, float* __restrict__ rstd) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= C) return;
+    __shared__ double ss[8][32], sq[8][32];
+    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, ch = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
-    for (int r = 0; r < prow; ++r) {
-        s += (double)stats[((long)r * 2 + 0) * C + ch];
-        q += (double)stats[((long)r * 2 + 1) * C + ch];
+    if (ch < C)
+        for (int r = sl; r < prow; r += 8) {
+            s += (double)stats[((long)r * 2 + 0) * C + ch];
+            q += (double)stats[((long)r * 2 + 1) * C + ch];
+        }
+    ss[sl][cl] = s;
+    sq[sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && ch < C) {
+        for (int l = 1; l < 8; ++l) { s += ss[l][cl]; q += sq[l][cl]; }
+        const double m = s / (double)count;
+        double var = q / (double)count - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[ch] = (float)m;
+        rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    const double m = s / (double)count;
-    double var = q / (double)count - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[ch] = (float)m;
-    rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
 // weight of the data-gradient convolution of a grouped 3x3 conv with as many outputs as inputs per group:
@@ -270,44 +384,75 @@ __global__ __launch_bounds__(256) void gconv_wflip_kernel(const float* __restric
         else hipLaunchKernelGGL(KERNEL<bf16_t>, GRID, BLOCK, 0, (hipStream_t)(STREAM), __VA_ARGS__);        \
     } while (0)
 
+namespace {
+// grid for the chunk kernels whose threads keep a fixed channel chunk: (grid * 256) % chunks_per_row == 0
+int chunk_grid(long total_chunks, int cc, int per_thread) {
+    int mult = 1;
+    while ((mult * 256) % cc) ++mult;
+    long g = (total_chunks + 256L * per_thread - 1) / (256L * per_thread);
+    if (g < 1) g = 1;
+    if (g > 16384) g = 16384;
+    return (int)((g + mult - 1) / mult * mult);
+}
+int epc_of(int dtype) { return dtype == CVCL_BF16 ? 8 : 4; }
+int bn_bwd_rows(int dtype, long rows, int C) {
+    const int cc = C / epc_of(dtype), ccb = cc < 256 ? cc : 256, rl = 256 / ccb, ny = cc / ccb;
+    long g = (rows + (long)rl * 8 - 1) / ((long)rl * 8);           // >= 8 rows per row lane
+    const long cap = 2048 / ny > 0 ? 2048 / ny : 1;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+}  // namespace
+
 extern "C" int cvcl_bn_apply(int dtype, const void* x, const float* scale, const float* shift, void* y, long rows, int C, int relu,
                              void* stream) {
-    CVCL_CHECK_ARG(x && scale && shift && y && rows > 0 && C > 0, "cvcl_bn_apply: bad args");
+    CVCL_CHECK_ARG(x && scale && shift && y && rows > 0 && C > 0 && C % epc_of(dtype) == 0, "cvcl_bn_apply: bad args");
+    const int cc = C / epc_of(dtype);
+    CVCL_CHECK_ARG((cc & (cc - 1)) == 0 || 256 % cc == 0 || cc % 256 == 0, "cvcl_bn_apply: unsupported channel count %d", C);
     CvclProfScope prof(stream, CVCL_K_BN_APPLY);
+    const int grid = chunk_grid(rows * cc, cc, 4);
     if (dtype == CVCL_F32)
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale,
-                           shift, (float*)y, rows, C, relu);
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift,
+                           (float*)y, rows, C, relu);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                           scale, shift, (bf16_t*)y, rows, C, relu);
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift,
+                           (bf16_t*)y, rows, C, relu);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
 
-extern "C" int cvcl_bn_bwd(int dtype, const void* x, const void* y, const void* dy, const float* mean, const float* rstd,
-                           const float* gamma, float* dgamma, float* dbeta, void* dx, long rows, int C, int relu, float* partial,
-                           int partial_rows, void* stream) {
-    CVCL_CHECK_ARG(x && dy && mean && rstd && gamma && dgamma && dbeta && dx && partial && rows > 0 && C > 0 && (!relu || y),
-                   "cvcl_bn_bwd: bad args");
-    int g = (int)((rows + 255) / 256);
-    if (g < 1) g = 1;
-    if (g > 256) g = 256;
+extern "C" int cvcl_bn_bwd_partial_rows(int dtype, long rows, int C) { return bn_bwd_rows(dtype, rows, C); }
+
+extern "C" int cvcl_bn_bwd(int dtype, int mode, const void* x, const void* out, const void* dy, const float* scale,
+                           const float* shift, const float* mean, const float* rstd, const float* gamma, float* dgamma,
+                           float* dbeta, void* dx, void* g_out, long rows, int C, float* partial, int partial_rows, float* coef,
+                           void* stream) {
+    CVCL_CHECK_ARG(x && dy && mean && rstd && gamma && dgamma && dbeta && dx && partial && coef && rows > 0 && C > 0,
+                   "cvcl_bn_bwd: null pointer");
+    CVCL_CHECK_ARG(mode >= 0 && mode <= 2 && (mode != 1 || (scale && shift)) && (mode != 2 || out), "cvcl_bn_bwd: bad mode %d", mode);
+    const int epc = epc_of(dtype), cc = C / epc;
+    CVCL_CHECK_ARG(C % epc == 0 && (cc & (cc - 1)) == 0, "cvcl_bn_bwd: channel count %d must be a power of two >= %d", C, epc);
+    const int g = bn_bwd_rows(dtype, rows, C);
     CVCL_CHECK_ARG(partial_rows >= g, "cvcl_bn_bwd: partial_rows %d < %d", partial_rows, g);
-    CvclProfScope prof(stream, CVCL_K_OTHER);
+    CvclProfScope prof(stream, CVCL_K_BN_BWD);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(g, cvcl_div_up(C, 64));
+    const int ccb = cc < 256 ? cc : 256;
+    dim3 rgrid(g, cc / ccb);
+    const int agrid = chunk_grid(rows * cc, cc, 4);
     if (dtype == CVCL_F32) {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)y, (const float*)dy, mean,
-                           rstd, rows, C, relu, partial);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 256)), dim3(256), 0, s, partial, g, C, dgamma, dbeta);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(rows * C)), dim3(256), 0, s, (const float*)x, (const float*)y,
-                           (const float*)dy, mean, rstd, gamma, dgamma, dbeta, (float*)dx, rows, C, relu);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, s, (const float*)x, (const float*)out, (const float*)dy,
+                           scale, shift, mean, rstd, rows, C, mode, partial);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 32)), dim3(256), 0, s, partial, g, C, rows, mean, rstd, gamma,
+                           dgamma, dbeta, coef);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(agrid), dim3(256), 0, s, (const float*)x, (const float*)out,
+                           (const float*)dy, scale, shift, coef, (float*)dx, (float*)g_out, rows, C, mode);
     } else {
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y, (const bf16_t*)dy,
-                           mean, rstd, rows, C, relu, partial);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 256)), dim3(256), 0, s, partial, g, C, dgamma, dbeta);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid_for(rows * C)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)y,
-                           (const bf16_t*)dy, mean, rstd, gamma, dgamma, dbeta, (bf16_t*)dx, rows, C, relu);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)out,
+                           (const bf16_t*)dy, scale, shift, mean, rstd, rows, C, mode, partial);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 32)), dim3(256), 0, s, partial, g, C, rows, mean, rstd, gamma,
+                           dgamma, dbeta, coef);
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(agrid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)out,
+                           (const bf16_t*)dy, scale, shift, coef, (bf16_t*)dx, (bf16_t*)g_out, rows, C, mode);
     }
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -317,7 +462,7 @@ extern "C" int cvcl_bn_batch_moments(const float* stats, int stats_rows, long co
                                      void* stream) {
     CVCL_CHECK_ARG(stats && mean && rstd && stats_rows > 0 && count > 0 && C > 0, "cvcl_bn_batch_moments: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
-    hipLaunchKernelGGL(bn_moments_kernel, dim3(cvcl_div_up(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, stats_rows, count, eps, C,
+    hipLaunchKernelGGL(bn_moments_kernel, dim3(cvcl_div_up(C, 32)), dim3(256), 0, (hipStream_t)stream, stats, stats_rows, count, eps, C,
                        mean, rstd);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -344,19 +489,19 @@ extern "C" int cvcl_transpose(int dtype, const void* in, void* out, long rows, i
     return CVCL_OK;
 }
 
-extern "C" int cvcl_add(int dtype, const void* a, const void* b, void* y, long n, void* stream) {
-    CVCL_CHECK_ARG(a && b && y && n > 0, "cvcl_add: bad args");
+extern "C" int cvcl_add(int dtype, const void* a, const void* b, void* y, long n, int relu, void* stream) {
+    CVCL_CHECK_ARG(a && b && y && n > 0 && n % epc_of(dtype) == 0, "cvcl_add: bad args");
     CvclProfScope prof(stream, CVCL_K_OTHER);
     if (dtype == CVCL_F32)
-        hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)y, n);
+        hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)a, (const float*)b, (float*)y, n, relu);
     else
-        hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n);
+        hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n, relu);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
 
 extern "C" int cvcl_relu_mask(int dtype, const void* y, const void* dy, void* dx, long n, void* stream) {
-    CVCL_CHECK_ARG(y && dy && dx && n > 0, "cvcl_relu_mask: bad args");
+    CVCL_CHECK_ARG(y && dy && dx && n > 0 && n % epc_of(dtype) == 0, "cvcl_relu_mask: bad args");
     CvclProfScope prof(stream, CVCL_K_OTHER);
     if (dtype == CVCL_F32)
         hipLaunchKernelGGL(relu_mask_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)y, (const float*)dy, (float*)dx, n);
@@ -367,7 +512,7 @@ extern "C" int cvcl_relu_mask(int dtype, const void* y, const void* dy, void* dx
 }
 
 extern "C" int cvcl_maxpool3x3s2(int dtype, const void* x, const void* dy, void* out, int B, int H, int W, int C, void* stream) {
-    CVCL_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && C > 0, "cvcl_maxpool3x3s2: bad args");
+    CVCL_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && C > 0 && C % epc_of(dtype) == 0, "cvcl_maxpool3x3s2: bad args");
     CvclProfScope prof(stream, CVCL_K_MAXPOOL);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     hipStream_t s = (hipStream_t)stream;
@@ -375,8 +520,8 @@ extern "C" int cvcl_maxpool3x3s2(int dtype, const void* x, const void* dy, void*
         if (dtype == CVCL_F32) hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for((long)B * Ho * Wo * C)), dim3(256), 0, s, (const float*)x, (float*)out, B, H, W, C);
         else hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid_for((long)B * Ho * Wo * C)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B, H, W, C);
     } else {         // backward: out = dx [B,H,W,C]
-        if (dtype == CVCL_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)out, B, H, W, C);
-        else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, B, H, W, C);
+        if (dtype == CVCL_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for((long)B * H * W * C / 4)), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)out, B, H, W, C);
+        else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for((long)B * H * W * C / 8)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, B, H, W, C);
     }
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;

@@ -309,7 +309,7 @@ extern "C" int cvcl_gemm_tn(int dtype, const void* A, int lda, const void* B, in
         cvcl_set_error("cvcl_gemm_tn: workspace too small");
         return CVCL_EWORKSPACE;
     }
-    CvclProfScope prof(stream, CVCL_K_GEMM);
+    CvclProfScope prof(stream, CVCL_K_WGRAD);
     if (bf) {
         CVCL_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
                        "cvcl_gemm_tn: bf16 operands need 16-byte aligned rows (N, K, lda, ldb multiples of 8)");
@@ -350,7 +350,7 @@ extern "C" int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int
         return CVCL_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    CvclProfScope prof(stream, CVCL_K_GCONV);
+    CvclProfScope prof(stream, CVCL_K_WGRAD);
     TnDev d = {};
     d.A = (const bf16_t*)dy; d.B = (const bf16_t*)x; d.P = (float*)workspace;
     d.M = M; d.N = C; d.K = C; d.lda = C; d.ldb = C; d.S = pl.S; d.chunk = pl.chunk;

@@ -20,7 +20,7 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ABI_VERSION = 1
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
-                  "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply")
+                  "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply", "bn_bwd", "wgrad")
 
 
 class CvclError(RuntimeError):
@@ -99,11 +99,12 @@ SIGNATURES = {
     "cvcl_lstm_cell_train": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cvcl_lstm_cell_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cvcl_bn_apply": (_I, [_I, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
-    "cvcl_bn_bwd": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _I, _P, _I, _P]),
+    "cvcl_bn_bwd_partial_rows": (_I, [_I, C.c_long, _I]),
+    "cvcl_bn_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _P, _I, _P, _P]),
     "cvcl_bn_batch_moments": (_I, [_P, _I, C.c_long, C.c_float, _P, _P, _I, _P]),
     "cvcl_gconv_weight_dgrad": (_I, [_P, _P, _I, _I, _P]),
     "cvcl_transpose": (_I, [_I, _P, _P, C.c_long, _I, _P]),
-    "cvcl_add": (_I, [_I, _P, _P, _P, C.c_long, _P]),
+    "cvcl_add": (_I, [_I, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_relu_mask": (_I, [_I, _P, _P, _P, C.c_long, _P]),
     "cvcl_maxpool3x3s2": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_avgpool_bwd": (_I, [_I, _P, _P, _I, _I, _I, _P]),

@@ -13,7 +13,8 @@ trunk's compute dtype (fp32 parity mode / bf16); parameter gradients are returne
   grouped 3x3     fwd  cvcl_gconv3x3 (identity prologue)  dX  cvcl_gconv3x3 on (zero-stuffed) dY with the flipped,
                                                               group-transposed weight   dW  cvcl_gconv3x3_wgrad (bf16) / cvcl_conv_wgrad_direct (fp32)
   stem 7x7        fwd  cvcl_stem_conv7x7                  dW  cvcl_stem_im2col + cvcl_gemm_tn (bf16) / cvcl_conv_wgrad_direct (fp32)
-  BatchNorm(+ReLU) fwd col_stats -> bn_finalize (running stats) -> bn_apply;   bwd  cvcl_bn_bwd
+  BatchNorm(+ReLU) fwd statistics from the conv epilogues -> bn_finalize (running stats) -> bn_apply;  bwd  cvcl_bn_bwd
+  Bottleneck tail  fwd cvcl_bn_add_relu (BN3 + identity + ReLU in one pass);  bwd  cvcl_bn_bwd mode 2 (mask from the output)
   max / avg pool, residual add + ReLU: cvcl_maxpool3x3s2, cvcl_avgpool(_bwd), cvcl_bn_add_relu / cvcl_relu_mask
 
 There is no PyTorch-op fallback: CPU tensors raise in ``_hip.ptr``.
@@ -83,13 +84,16 @@ class Conv1x1(torch.autograd.Function):
         Ho, Wo = (Hh - 1) // stride + 1, (Ww - 1) // stride + 1
         out = torch.empty(B, Ho, Wo, N, dtype=x.dtype, device=x.device)
         gather = (Ho, Wo, Hh, Ww, stride) if stride > 1 else None
-        H.gemm(x, wq, out=out, gather=gather, M=B * Ho * Wo, lda=K)
+        M = B * Ho * Wo
+        st = torch.empty(H.gemm_grid_m(_cd(x), M, N), 2, N, dtype=_F, device=x.device)      # BN statistics from the epilogue
+        H.gemm(x, wq, out=out, gather=gather, M=M, lda=K, stats=st)
         ctx.save_for_backward(x, wq)
         ctx.stride = stride
-        return out
+        ctx.mark_non_differentiable(st)
+        return out, st
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dst):
         x, wq = ctx.saved_tensors
         B, Hh, Ww, K = x.shape
         N = wq.shape[0]
@@ -115,14 +119,17 @@ class GroupedConv3x3(torch.autograd.Function):
         wp = _pack(weight, H.PACK_GCONV3, x.dtype)
         Ho, Wo = (Hh - 1) // stride + 1, (Ww - 1) // stride + 1
         out = torch.empty(B, Ho, Wo, Cn, dtype=x.dtype, device=x.device)
-        H.check(H.lib().cvcl_gconv3x3(_cd(x), H.ptr(x), None, None, H.ptr(wp), H.ptr(out), None, 0, B, Hh, Ww, Cn, 32,
+        srows = H.lib().cvcl_gconv3x3_stats_rows(_cd(x), B, Hh, Ww, Cn, stride)
+        st = torch.empty(srows, 2, Cn, dtype=_F, device=x.device)
+        H.check(H.lib().cvcl_gconv3x3(_cd(x), H.ptr(x), None, None, H.ptr(wp), H.ptr(out), H.ptr(st), srows, B, Hh, Ww, Cn, 32,
                                       stride, H.stream_ptr()), "cvcl_gconv3x3")
         ctx.save_for_backward(x, weight)
         ctx.stride = stride
-        return out
+        ctx.mark_non_differentiable(st)
+        return out, st
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dst):
         x, weight = ctx.saved_tensors
         B, Hh, Ww, Cn = x.shape
         cg = weight.shape[1]
@@ -164,10 +171,11 @@ class StemConv(torch.autograd.Function):
         H.check(H.lib().cvcl_stem_conv7x7(dt, H.ptr(x, _F), H.ptr(wp), H.ptr(out), H.ptr(st), rows, B, Hh, Ww, H.stream_ptr()),
                 "cvcl_stem_conv7x7")
         ctx.save_for_backward(x)
-        return out
+        ctx.mark_non_differentiable(st)
+        return out, st
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dst):
         (x,) = ctx.saved_tensors
         B, _, Hh, Ww = x.shape
         dy = dy.contiguous()
@@ -182,45 +190,86 @@ class StemConv(torch.autograd.Function):
         return None, dw, None
 
 
+def _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked):
+    """statistics rows (from the producing conv's epilogue, or a cvcl_col_stats pass) -> scale/shift (+ running-stat EMA),
+    batch mean and rstd."""
+    Cn = raw.shape[-1]
+    rows = raw.numel() // Cn
+    lib, s, dev = H.lib(), H.stream_ptr(), raw.device
+    if stats is None:
+        srows = lib.cvcl_col_stats_rows(rows)
+        stats = torch.empty(srows, 2, Cn, dtype=_F, device=dev)
+        H.check(lib.cvcl_col_stats(_cd(raw), H.ptr(raw), rows, Cn, H.ptr(stats), srows, s), "cvcl_col_stats")
+    srows = stats.shape[0]
+    vec = torch.empty(4, Cn, dtype=_F, device=dev)                 # scale, shift, mean, rstd
+    scale, shift, mean, rstd = vec[0], vec[1], vec[2], vec[3]
+    H.check(lib.cvcl_bn_finalize(H.ptr(stats), srows, rows, H.ptr(gamma.detach(), _F), H.ptr(beta.detach(), _F),
+                                 H.ptr(running_mean, _F), H.ptr(running_var, _F), H.ptr(num_batches_tracked, torch.int64),
+                                 BN_MOMENTUM, BN_EPS, H.ptr(scale), H.ptr(shift), Cn, s), "cvcl_bn_finalize")
+    H.check(lib.cvcl_bn_batch_moments(H.ptr(stats), srows, rows, BN_EPS, H.ptr(mean), H.ptr(rstd), Cn, s), "cvcl_bn_batch_moments")
+    return scale, shift, mean, rstd
+
+
+def _bn_backward(mode, raw, out, dy, scale, shift, mean, rstd, gamma, want_g):
+    Cn = raw.shape[-1]
+    rows = raw.numel() // Cn
+    dev, dt = raw.device, _cd(raw)
+    lib = H.lib()
+    prow = lib.cvcl_bn_bwd_partial_rows(dt, rows, Cn)
+    scratch = torch.empty(prow * 2 + 5, Cn, dtype=_F, device=dev)  # partial rows | coef[3] | dgamma | dbeta
+    partial, coef = scratch[:prow * 2], scratch[prow * 2:prow * 2 + 3]
+    dgamma, dbeta = scratch[prow * 2 + 3], scratch[prow * 2 + 4]
+    dx = torch.empty_like(raw)
+    g = torch.empty_like(raw) if want_g else None
+    H.check(lib.cvcl_bn_bwd(dt, mode, H.ptr(raw), H.ptr(out), H.ptr(dy), H.ptr(scale), H.ptr(shift), H.ptr(mean), H.ptr(rstd),
+                            H.ptr(gamma.detach().contiguous(), _F), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dx), H.ptr(g), rows, Cn,
+                            H.ptr(partial), prow, H.ptr(coef), H.stream_ptr()), "cvcl_bn_bwd")
+    return dx, dgamma, dbeta, g
+
+
 class BatchNormTrain(torch.autograd.Function):
-    """nn.BatchNorm2d in train mode (+ optional fused ReLU) on raw [.., C]; updates the running statistics in place."""
+    """nn.BatchNorm2d in train mode (+ optional fused ReLU) on raw [.., C]; updates the running statistics in place.
+    ``stats``: the per-channel (sum, sumsq) rows the producing convolution emitted, or None (computed here)."""
 
     @staticmethod
-    def forward(ctx, raw, gamma, beta, running_mean, running_var, num_batches_tracked, relu: bool):
+    def forward(ctx, raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, relu: bool):
         Cn = raw.shape[-1]
         rows = raw.numel() // Cn
-        lib, s, dt = H.lib(), H.stream_ptr(), _cd(raw)
-        dev = raw.device
-        srows = lib.cvcl_col_stats_rows(rows)
-        st = torch.empty(srows, 2, Cn, dtype=_F, device=dev)
-        H.check(lib.cvcl_col_stats(dt, H.ptr(raw), rows, Cn, H.ptr(st), srows, s), "cvcl_col_stats")
-        scale, shift = torch.empty(Cn, dtype=_F, device=dev), torch.empty(Cn, dtype=_F, device=dev)
-        H.check(lib.cvcl_bn_finalize(H.ptr(st), srows, rows, H.ptr(gamma.detach(), _F), H.ptr(beta.detach(), _F),
-                                     H.ptr(running_mean, _F), H.ptr(running_var, _F), H.ptr(num_batches_tracked, torch.int64),
-                                     BN_MOMENTUM, BN_EPS, H.ptr(scale), H.ptr(shift), Cn, s), "cvcl_bn_finalize")
-        mean, rstd = torch.empty(Cn, dtype=_F, device=dev), torch.empty(Cn, dtype=_F, device=dev)
-        H.check(lib.cvcl_bn_batch_moments(H.ptr(st), srows, rows, BN_EPS, H.ptr(mean), H.ptr(rstd), Cn, s), "cvcl_bn_batch_moments")
+        scale, shift, mean, rstd = _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked)
         y = torch.empty_like(raw)
-        H.check(lib.cvcl_bn_apply(dt, H.ptr(raw), H.ptr(scale), H.ptr(shift), H.ptr(y), rows, Cn, int(relu), s), "cvcl_bn_apply")
-        ctx.save_for_backward(raw, y if relu else None, mean, rstd, gamma)
+        H.check(H.lib().cvcl_bn_apply(_cd(raw), H.ptr(raw), H.ptr(scale), H.ptr(shift), H.ptr(y), rows, Cn, int(relu),
+                                      H.stream_ptr()), "cvcl_bn_apply")
+        ctx.save_for_backward(raw, scale, shift, mean, rstd, gamma)
         ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        raw, y, mean, rstd, gamma = ctx.saved_tensors
+        raw, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta, _ = _bn_backward(1 if ctx.relu else 0, raw, None, dy.contiguous(), scale, shift, mean, rstd, gamma, False)
+        return dx, None, dgamma, dbeta, None, None, None, None
+
+
+class BnAddRelu(torch.autograd.Function):
+    """Bottleneck tail: out = relu(bn3(raw) + identity) in one pass (cvcl_bn_add_relu); the backward masks with out > 0,
+    hands g = dy * mask to the identity branch and runs the BatchNorm backward on g."""
+
+    @staticmethod
+    def forward(ctx, raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, identity):
         Cn = raw.shape[-1]
         rows = raw.numel() // Cn
-        dev = raw.device
-        dy = dy.contiguous()
-        dgamma, dbeta = torch.empty(Cn, dtype=_F, device=dev), torch.empty(Cn, dtype=_F, device=dev)
-        prow = min(256, (rows + 255) // 256)
-        partial = torch.empty(prow, 2, Cn, dtype=_F, device=dev)
-        dx = torch.empty_like(raw)
-        H.check(H.lib().cvcl_bn_bwd(_cd(raw), H.ptr(raw), H.ptr(y), H.ptr(dy), H.ptr(mean), H.ptr(rstd),
-                                    H.ptr(gamma.detach().contiguous(), _F), H.ptr(dgamma), H.ptr(dbeta), H.ptr(dx), rows, Cn,
-                                    int(ctx.relu), H.ptr(partial), prow, H.stream_ptr()), "cvcl_bn_bwd")
-        return dx, dgamma, dbeta, None, None, None, None
+        scale, shift, mean, rstd = _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked)
+        out = torch.empty_like(raw)
+        H.check(H.lib().cvcl_bn_add_relu(_cd(raw), H.ptr(raw), H.ptr(scale), H.ptr(shift), H.ptr(identity.contiguous(), raw.dtype),
+                                         None, None, H.ptr(out), rows, Cn, H.stream_ptr()), "cvcl_bn_add_relu")
+        ctx.save_for_backward(raw, out, mean, rstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        raw, out, mean, rstd, gamma = ctx.saved_tensors
+        dx, dgamma, dbeta, g = _bn_backward(2, raw, out, dy.contiguous(), None, None, mean, rstd, gamma, True)
+        return dx, None, dgamma, dbeta, None, None, None, g
 
 
 class MaxPool3x3s2(torch.autograd.Function):
@@ -250,8 +299,7 @@ class AddRelu(torch.autograd.Function):
         out = torch.empty_like(a)
         n = a.numel()
         s = H.stream_ptr()
-        H.check(H.lib().cvcl_add(_cd(a), H.ptr(a), H.ptr(b), H.ptr(out), n, s), "cvcl_add")
-        H.check(H.lib().cvcl_relu_mask(_cd(a), H.ptr(out), H.ptr(out), H.ptr(out), n, s), "cvcl_relu_mask")   # out = out where out > 0
+        H.check(H.lib().cvcl_add(_cd(a), H.ptr(a), H.ptr(b), H.ptr(out), n, 1, s), "cvcl_add")
         ctx.save_for_backward(out)
         return out
 
@@ -284,8 +332,9 @@ class AvgPool(torch.autograd.Function):
         return dx
 
 
-def _bn(raw, bn, relu):
-    return BatchNormTrain.apply(raw, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, relu)
+def _bn(raw_and_stats, bn, relu):
+    raw, st = raw_and_stats
+    return BatchNormTrain.apply(raw, st, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, relu)
 
 
 def trunk_train(model, x: torch.Tensor):
@@ -306,9 +355,10 @@ def trunk_train(model, x: torch.Tensor):
             idn = h
             o = _bn(Conv1x1.apply(h, blk.conv1.weight, 1), blk.bn1, True)
             o = _bn(GroupedConv3x3.apply(o, blk.conv2.weight, blk.conv2.stride[0]), blk.bn2, True)
-            o = _bn(Conv1x1.apply(o, blk.conv3.weight, 1), blk.bn3, False)
             if blk.downsample is not None:
                 idn = _bn(Conv1x1.apply(h, blk.downsample[0].weight, blk.downsample[0].stride[0]), blk.downsample[1], False)
-            h = AddRelu.apply(o, idn)
+            raw3, st3 = Conv1x1.apply(o, blk.conv3.weight, 1)
+            b3 = blk.bn3
+            h = BnAddRelu.apply(raw3, st3, b3.weight, b3.bias, b3.running_mean, b3.running_var, b3.num_batches_tracked, idn)
     pooled = AvgPool.apply(h)
     return pooled, h.permute(0, 3, 1, 2)

@@ -79,7 +79,8 @@ def test_conv1x1_grads(dev, dt, B, S, K, N, stride):
     y.backward(dy)
     xd = nhwc(x.detach()).to(_cdt(dt)).to(dev).requires_grad_()
     wd = w.detach().to(dev).requires_grad_()
-    yd = Conv1x1.apply(xd, wd, stride)
+    yd, st = Conv1x1.apply(xd, wd, stride)
+    assert maxrel(st.double().sum(0)[0].float(), yd.detach().float().reshape(-1, N).sum(0)) < (2e-2 if dt == 'bf16' else 1e-4)
     dyd = nhwc(dy).to(_cdt(dt)).to(dev)
     yd.backward(dyd)
     assert maxrel(yd.float(), nhwc(y.detach())) < _tol(dt, 2e-5, 8e-3)
@@ -101,7 +102,7 @@ def test_gconv_grads(dev, dt, B, S, C_, stride):
     y.backward(dy)
     xd = nhwc(x.detach()).to(_cdt(dt)).to(dev).requires_grad_()
     wd = w.detach().to(dev).requires_grad_()
-    yd = GroupedConv3x3.apply(xd, wd, stride)
+    yd, _st = GroupedConv3x3.apply(xd, wd, stride)
     dyd = nhwc(dy).to(_cdt(dt)).to(dev)
     yd.backward(dyd)
     assert maxrel(yd.float(), nhwc(y.detach())) < _tol(dt, 2e-5, 8e-3)
@@ -120,7 +121,7 @@ def test_stem_maxpool_avgpool_addrelu_grads(dev, dt):
     dy = q(torch.randn(y.shape, generator=g))
     y.backward(dy)
     xd, wd = x.to(dev), w.detach().to(dev).requires_grad_()
-    yd = StemConv.apply(xd, wd, _cdt(dt))
+    yd, _st = StemConv.apply(xd, wd, _cdt(dt))
     dyd = nhwc(dy).to(_cdt(dt)).to(dev)
     yd.backward(dyd)
     assert maxrel(yd.float(), nhwc(y.detach())) < _tol(dt, 2e-5, 8e-3)
@@ -169,13 +170,44 @@ def test_batchnorm_train_grads(dev, dt, relu, rows_shape, C_):
     xd = nhwc(x.detach()).to(_cdt(dt)).to(dev).requires_grad_()
     gd, bd = gamma.detach().to(dev).requires_grad_(), beta.detach().to(dev).requires_grad_()
     rmd, rvd, nbt = rm.to(dev), rv.to(dev), torch.zeros((), dtype=torch.int64, device=dev)
-    yd = BatchNormTrain.apply(xd, gd, bd, rmd, rvd, nbt, relu)
+    yd = BatchNormTrain.apply(xd, None, gd, bd, rmd, rvd, nbt, relu)
     dyd = nhwc(dy).to(_cdt(dt)).to(dev)
     yd.backward(dyd)
     assert maxrel(yd.float(), nhwc(y.detach())) < _tol(dt, 2e-5, 1e-2)
     assert maxrel(rmd, rm_o) < 1e-5 and maxrel(rvd, rv_o) < 1e-5 and int(nbt) == 1
     if dt == "f32":          # in bf16 the ReLU mask comes from the rounded y: compare only where unambiguous
         assert maxrel(xd.grad, nhwc(x.grad)) < 2e-4
+        assert maxrel(gd.grad, gamma.grad) < 1e-4 and maxrel(bd.grad, beta.grad) < 1e-4
+    else:
+        assert maxrel(gd.grad, gamma.grad) < 3e-2 and maxrel(bd.grad, beta.grad) < 3e-2
+        assert maxrel(xd.grad.float(), nhwc(x.grad)) < 5e-2
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("rows_shape,C_", [((2, 9, 9), 256), ((3, 14, 14), 1024), ((5, 2, 2), 2048)])
+def test_bn_add_relu_tail_grads(dev, dt, rows_shape, C_):
+    """Fused Bottleneck tail out = relu(bn3(raw) + identity): output and the gradients of raw, identity, gamma, beta."""
+    from multimodal.trunk_train import BnAddRelu
+    g = torch.Generator().manual_seed(C_ + 1)
+    q = O.bf16_round if dt == "bf16" else (lambda t: t)
+    B, Hh, Ww = rows_shape
+    x = q(torch.randn(B, C_, Hh, Ww, generator=g) * 1.5 + 0.3).requires_grad_()
+    idn = q(torch.randn(B, C_, Hh, Ww, generator=g)).requires_grad_()
+    gamma = (torch.rand(C_, generator=g) + 0.5).requires_grad_()
+    beta = (torch.randn(C_, generator=g) * 0.3).requires_grad_()
+    rm, rv = torch.zeros(C_), torch.ones(C_)
+    y = torch.relu(F.batch_norm(x, rm.clone(), rv.clone(), gamma, beta, True, 0.1, 1e-5) + idn)
+    dy = q(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    xd, idd = (nhwc(t.detach()).to(_cdt(dt)).to(dev).requires_grad_() for t in (x, idn))
+    gd, bd = gamma.detach().to(dev).requires_grad_(), beta.detach().to(dev).requires_grad_()
+    rmd, rvd, nbt = rm.to(dev), rv.to(dev), torch.zeros((), dtype=torch.int64, device=dev)
+    yd = BnAddRelu.apply(xd, None, gd, bd, rmd, rvd, nbt, idd)
+    dyd = nhwc(dy).to(_cdt(dt)).to(dev)
+    yd.backward(dyd)
+    assert maxrel(yd.float(), nhwc(y.detach())) < _tol(dt, 2e-5, 1e-2)
+    if dt == "f32":
+        assert maxrel(xd.grad, nhwc(x.grad)) < 2e-4 and maxrel(idd.grad, nhwc(idn.grad)) < 1e-6
         assert maxrel(gd.grad, gamma.grad) < 1e-4 and maxrel(bd.grad, beta.grad) < 1e-4
     else:
         assert maxrel(gd.grad, gamma.grad) < 3e-2 and maxrel(bd.grad, beta.grad) < 3e-2

@@ -23,7 +23,7 @@ opt = opt["optimizer"] if isinstance(opt, dict) else opt
 batch = synthetic_batch_on_device(a.batch, 0, dev) + (None,)
 def step():
     opt.zero_grad(set_to_none=True); out = lit.training_step(batch, 0); out["loss"].backward(); opt.step(); return out
-out = step()
+out = step(); out = step(); out = step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): out = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
@@ -31,3 +31,9 @@ H.prof_enable(True); step(); torch.cuda.synchronize(); prof = H.prof_collect(); 
 print(f"C2 --finetune_cnn B={a.batch} {a.dtype}: {dt*1e3:.1f} ms/step, {a.batch/dt:.0f} pairs/s, loss {float(out['loss']):.4f}, "
       f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
 print({k: round(v[0], 2) for k, v in prof.items() if v[1] > 0})
+if os.environ.get("FT_CPROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(3): step()
+    torch.cuda.synchronize(); pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)

@@ -9,5 +9,5 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows[:22]:
-    print(f'{float(r["TotalDurationNs"])/1e6/4:9.2f} ms/step {int(r["Calls"])//4:5d} calls/step {100*float(r["TotalDurationNs"])/tot:5.1f}%  {r["Name"][:110]}')
+    print(f'{float(r["TotalDurationNs"])/1e6/6:9.2f} ms/step {int(r["Calls"])//6:5d} calls/step {100*float(r["TotalDurationNs"])/tot:5.1f}%  {r["Name"][:110]}')
 PY
