@@ -303,13 +303,17 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
 // ---- zero-stuffing for the data gradient of a stride-2 convolution: z[b, 2*oy, 2*ox, :] = dy[b, oy, ox, :], 0 elsewhere ---
 template <typename T>
 __global__ __launch_bounds__(256) void zero_stuff_kernel(const T* __restrict__ dy, T* __restrict__ z, int B, int Ho, int Wo, int C) {
-    const int H = 2 * Ho, W = 2 * Wo;
-    const long total = (long)B * H * W * C;
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int H = 2 * Ho, W = 2 * Wo, CC = C / EPC;
+    const long total = (long)B * H * W * CC;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const long p = i / C;
+        const int c = (int)(i % CC) * EPC;
+        const long p = i / CC;
         const int xi = (int)(p % W), yi = (int)((p / W) % H), b = (int)(p / ((long)W * H));
-        z[i] = (!(yi & 1) && !(xi & 1)) ? dy[(((long)b * Ho + (yi >> 1)) * Wo + (xi >> 1)) * C + c] : ElemTraits<T>::from_f(0.f);
+        Chunk<T> v;
+        if (!(yi & 1) && !(xi & 1)) v.load(dy + (((long)b * Ho + (yi >> 1)) * Wo + (xi >> 1)) * C + c);
+        else v.zero();
+        v.store(z + p * C + c);
     }
 }
 
@@ -398,7 +402,7 @@ int epc_of(int dtype) { return dtype == CVCL_BF16 ? 8 : 4; }
 int bn_bwd_rows(int dtype, long rows, int C) {
     const int cc = C / epc_of(dtype), ccb = cc < 256 ? cc : 256, rl = 256 / ccb, ny = cc / ccb;
     long g = (rows + (long)rl * 8 - 1) / ((long)rl * 8);           // >= 8 rows per row lane
-    const long cap = 2048 / ny > 0 ? 2048 / ny : 1;
+    const long cap = 512 / ny > 0 ? 512 / ny : 1;
     if (g > cap) g = cap;
     return (int)(g < 1 ? 1 : g);
 }
@@ -537,9 +541,9 @@ extern "C" int cvcl_avgpool_bwd(int dtype, const float* d_pooled, void* dx, int 
 }
 
 extern "C" int cvcl_zero_stuff2(int dtype, const void* dy, void* z, int B, int Ho, int Wo, int C, void* stream) {
-    CVCL_CHECK_ARG(dy && z && B > 0 && Ho > 0 && Wo > 0 && C > 0, "cvcl_zero_stuff2: bad args");
+    CVCL_CHECK_ARG(dy && z && B > 0 && Ho > 0 && Wo > 0 && C > 0 && C % epc_of(dtype) == 0, "cvcl_zero_stuff2: bad args");
     CvclProfScope prof(stream, CVCL_K_OTHER);
-    const long total = (long)B * 4 * Ho * Wo * C;
+    const long total = (long)B * 4 * Ho * Wo * C / epc_of(dtype);
     if (dtype == CVCL_F32) hipLaunchKernelGGL(zero_stuff_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)dy, (float*)z, B, Ho, Wo, C);
     else hipLaunchKernelGGL(zero_stuff_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (bf16_t*)z, B, Ho, Wo, C);
     CVCL_LAUNCH_CHECK();
