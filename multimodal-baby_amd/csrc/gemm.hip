@@ -702,6 +702,58 @@ int launch_gemm_v(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
         return launch_gemm_w<T, PRO, LEAN, 1>(a, d, stream);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small fp32 GEMMs (fc 2048->E on 256 pooled rows, the B x B similarity logits and their gradients): a 128 x 128 MFMA
+// tiling would leave a handful of workgroups walking the whole K (8 workgroups for the fc layer = 160 us).  Here a
+// workgroup owns a 16 x 16 output tile and splits K over 16 thread slices (float4 loads straight from L2, 4 x 4
+// register micro-tiles), then reduces the 16 partial tiles through LDS in a fixed order -- deterministic, no scratch.
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __restrict__ A, const float* __restrict__ W,
+                                                             float* __restrict__ C, int M, int N, int K, int lda, int ldw,
+                                                             int ldc, const float* __restrict__ exp_scale,
+                                                             const float* __restrict__ bias) {
+    __shared__ float red[16][16 * 16 + 4];
+    const int tid = threadIdx.x, kl = tid & 15, tc = (tid >> 4) & 3, tr = tid >> 6;
+    const int m0 = blockIdx.y * 16 + tr * 4, n0 = blockIdx.x * 16 + tc * 4;
+    const float* ap[4];
+    const float* wp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ap[i] = A + (long)min(m0 + i, M - 1) * lda;          // rows past the edge are clamped; their results are not stored
+        wp[i] = W + (long)min(n0 + i, N - 1) * ldw;
+    }
+    float acc[4][4] = {};
+    for (int k = kl * 4; k < K; k += 64) {
+        f32x4 a[4], w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = *reinterpret_cast<const f32x4*>(ap[i] + k);
+            w[i] = *reinterpret_cast<const f32x4*>(wp[i] + k);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j] = fmaf(a[i][e], w[j][e], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[kl][(tr * 4 + i) * 16 + tc * 4 + j] = acc[i][j];
+    __syncthreads();
+    const int r = tid >> 4, c = tid & 15;
+    float v = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) v += red[l][r * 16 + c];
+    const int m = blockIdx.y * 16 + r, n = blockIdx.x * 16 + c;
+    if (m < M && n < N) {
+        if (exp_scale) v *= expf(*exp_scale);
+        if (bias) v += bias[n];
+        C[(long)m * ldc + n] = v;
+    }
+}
+
+
 inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
     return d.vec_in && d.vec_out && !a->bias && !a->exp_scale && !a->R && a->act == CVCL_ACT_NONE && (a->N % BN) == 0;
 }
@@ -759,6 +811,19 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
             return launch_gemm_glds<1>(a, d, stream);
     }
     CVCL_CHECK_ARG(a->C && !a->c_scale, "cvcl_gemm: statistics-only / BN-tail epilogues need the direct-to-LDS bf16 path");
+    if constexpr (sizeof(T) == 4) {
+        auto al16p = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        if (pro_kind(a) == 0 && !(a->gather_stride > 1) && !a->stats && !a->R && a->act == CVCL_ACT_NONE && a->K % 4 == 0 &&
+            a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) &&
+            (long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN) <= 64) {
+            CvclProfScope prof(stream, CVCL_K_GEMM_F32);
+            hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cvcl_div_up(a->N, 16), cvcl_div_up(a->M, 16)), dim3(256), 0, stream,
+                               (const float*)a->A, (const float*)a->W, (float*)a->C, a->M, a->N, a->K, a->lda, a->ldw, a->ldc,
+                               a->exp_scale, a->bias);
+            CVCL_LAUNCH_CHECK();
+            return CVCL_OK;
+        }
+    }
     switch (pro_kind(a)) {
         case 0: return lean ? launch_gemm_v<T, 0, true>(a, d, stream) : launch_gemm_v<T, 0, false>(a, d, stream);
         case 1: return lean ? launch_gemm_v<T, 1, true>(a, d, stream) : launch_gemm_v<T, 1, false>(a, d, stream);

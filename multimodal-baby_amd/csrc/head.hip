@@ -33,14 +33,16 @@ __global__ __launch_bounds__(128) void embed_meanpool_fwd_kernel(const float* __
 // d_ret[b]/len[b] for its own slice of E in registers.  Deterministic, no atomics, no barrier inside the scan;
 // writes every row (zeros where the word does not occur; row 0 = padding_idx gets no gradient).
 constexpr int EMB_CHUNK = 8192;
-__global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __restrict__ d_ret,
+constexpr int EMB_GROUPS = 4;                      // match batches are dealt round-robin to 4 groups of 128 threads
+__global__ __launch_bounds__(128 * EMB_GROUPS) void embed_meanpool_bwd_kernel(const float* __restrict__ d_ret,
                                                                  const int64_t* __restrict__ tok,
                                                                  const int64_t* __restrict__ len,
                                                                  float* __restrict__ d_table, int B, int L, int E) {
     __shared__ int stok[EMB_CHUNK];
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int total = B * L;
     constexpr int MAXR = 8;                        // E <= 128 * MAXR handled in registers per pass
+    __shared__ float part[EMB_GROUPS][128 * MAXR];
+    const int v = blockIdx.x, grp = threadIdx.x >> 7, tid = threadIdx.x & 127, lane = tid & 63;
+    const int total = B * L;
     for (int ebase = 0; ebase < E; ebase += 128 * MAXR) {
         float acc[MAXR];
 #pragma unroll
@@ -49,8 +51,9 @@ __global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __
             for (int c0 = 0; c0 < total; c0 += EMB_CHUNK) {
                 const int n = min(EMB_CHUNK, total - c0);
                 __syncthreads();
-                for (int i = tid; i < n; i += 128) stok[i] = (int)tok[c0 + i];
+                for (int i = threadIdx.x; i < n; i += 128 * EMB_GROUPS) stok[i] = (int)tok[c0 + i];
                 __syncthreads();
+                int batch = 0;
                 for (int base = 0; base < n; base += 64) {
                     const bool hit = (base + lane) < n && stok[base + lane] == v;
                     unsigned long long mm = __ballot(hit);
@@ -69,6 +72,7 @@ __global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __
                                 nb = k + 1;
                             }
                         }
+                        if ((batch++ & (EMB_GROUPS - 1)) != grp) continue;      // this batch belongs to another group
                         float den[8], val[8][MAXR];
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
@@ -89,10 +93,17 @@ __global__ __launch_bounds__(128) void embed_meanpool_bwd_kernel(const float* __
                 }
             }
         }
+        // combine the groups' partial sums in a fixed order (deterministic)
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const int e = ebase + tid + 128 * i;
-            if (e < E) d_table[(long)v * E + e] = acc[i];
+        for (int i = 0; i < MAXR; ++i) part[grp][tid + 128 * i] = acc[i];
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < MAXR; ++i) {
+                const int e = ebase + tid + 128 * i;
+                if (e < E) d_table[(long)v * E + e] = (part[0][tid + 128 * i] + part[1][tid + 128 * i]) + (part[2][tid + 128 * i] + part[3][tid + 128 * i]);
+            }
         }
     }
 }
@@ -300,7 +311,7 @@ extern "C" int cvcl_embed_meanpool_bwd(const float* d_ret, const int64_t* tok, c
     CVCL_CHECK_ARG(d_ret && tok && len && d_table, "cvcl_embed_meanpool_bwd: null pointer");
     CvclProfScope prof(stream, CVCL_K_HEAD);
     CVCL_CHECK_ARG(B > 0 && L > 0 && E > 0 && V > 0, "cvcl_embed_meanpool_bwd: bad shape");
-    hipLaunchKernelGGL(embed_meanpool_bwd_kernel, dim3(V), dim3(128), 0, (hipStream_t)stream, d_ret, tok, len, d_table,
+    hipLaunchKernelGGL(embed_meanpool_bwd_kernel, dim3(V), dim3(128 * EMB_GROUPS), 0, (hipStream_t)stream, d_ret, tok, len, d_table,
                        B, L, E);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
