@@ -472,6 +472,18 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+        // EPI 2: the residual rows this lane will need in the read-back phase are fetched now, so that their latency
+        // hides behind the K loop instead of sitting between the last MFMA and the stores
+        bf16x8 rpre[8];
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int m = m0 + wm * 64 + j * 8 + (lane >> 3);
+                if (m >= p.M) m = p.M - 1;
+                rpre[j] = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n0 + wn * 64 + (lane & 7) * 8);
+            }
+        }
+
         for (int kt = 0; kt < ktiles; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the current tile has landed
             __builtin_amdgcn_s_barrier();                        // ... and everybody's; buffer buf^1 is free again
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                         for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                     }
                 } else if constexpr (EPI == 2) {
-                    const bf16x8 r = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
+                    const bf16x8 r = rpre[j];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float y = fmaf((float)v[e], cs[e], cb[e]);

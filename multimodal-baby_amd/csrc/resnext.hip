@@ -903,6 +903,12 @@ namespace {
 struct Spec { int cin, cout, k, stride, groups; };
 constexpr int kLayers[4] = {3, 4, 6, 3};
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+// scratch of the Gram-matrix BN3 statistics (conv3 of layers 1 and 2: K = 128 at H/4 x W/4, K = 256 at H/8 x W/8)
+inline size_t gram_ws_bytes(int B, int H, int W) {
+    const size_t a = cvcl_conv1x1_bn_stats_gram_workspace_bytes((long)B * (H / 4) * (W / 4), 128);
+    const size_t b = cvcl_conv1x1_bn_stats_gram_workspace_bytes((long)B * (H / 8) * (W / 8), 256);
+    return al256(a > b ? a : b);
+}
 inline size_t act_elems(int B, int H, int W) {
     // largest activation: stem output [B, H/2, W/2, 64] == layer1 tensors [B, H/4, W/4, 256]
     return (size_t)B * (H / 2) * (W / 2) * 64;
@@ -911,7 +917,8 @@ inline size_t act_elems(int B, int H, int W) {
 
 extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W) {
     const size_t es = dtype == CVCL_BF16 ? 2 : 4;
-    return 5 * al256(act_elems(B, H, W) * es) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)53 * 2 * 2048 * 4);
+    return 5 * al256(act_elems(B, H, W) * es) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)53 * 2 * 2048 * 4) +
+           gram_ws_bytes(B, H, W);
 }
 
 extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
@@ -929,7 +936,9 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
     char* buf[5];
     for (int i = 0; i < 5; ++i) { buf[i] = w; w += al256(act_elems(B, H, W) * es); }
     float* stats = (float*)w; w += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
-    float* affine = (float*)w;
+    float* affine = (float*)w; w += al256((size_t)53 * 2 * 2048 * 4);
+    char* gram_ws = w;
+    const size_t gram_bytes = gram_ws_bytes(B, H, W);
     int rc, li = 0;
 
     // (scale, shift) of layer l live at affine + l * 4096
@@ -992,7 +1001,16 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
                 a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
                 return a;
             };
-            if (!fused_tail || training) {
+            // opt-in ($CVCL_BN3_GRAM=1): measured SLOWER than the statistics-only GEMM pass on MI355X at B=256 (8.14 vs 7.74
+            // ms/step: the Gram TN GEMM runs at ~400 TFLOP/s and needs two small follow-up kernels), kept as an experiment
+            static const bool use_gram = [] { const char* e = getenv("CVCL_BN3_GRAM"); return e && e[0] == '1'; }();
+            if (fused_tail && training && use_gram) {
+                // BN3 statistics from the Gram matrix of conv3's (narrow) input: one read of R2 instead of a statistics-only
+                // GEMM pass (the conv is linear: sum_y = W colsum(R2), sum_y2[n] = w_n^T (R2^T R2) w_n)
+                if ((rc = cvcl_conv1x1_bn_stats_gram(R2, width, layers[l3].w, width, m_out, outc, width, stats, gram_ws,
+                                                     gram_bytes, stream))) return rc;
+                if ((rc = finalize(l3, 1, m_out, outc))) return rc;
+            } else if (!fused_tail || training) {
                 cvcl_gemm_args a = conv3_args();
                 a.C = fused_tail ? nullptr : R3;
                 a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
