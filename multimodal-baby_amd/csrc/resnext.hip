@@ -31,12 +31,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            int64_t* __restrict__ nbt, float momentum, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift, int C) {
-    // 64 channels x 16 row slices per workgroup; slices combined in a fixed order (deterministic)
-    __shared__ double ps[16][64], pq[16][64];
-    const int c = threadIdx.x & 63, sl = threadIdx.x >> 6, ch = blockIdx.x * 64 + c;
+    // 16 channels x 64 row slices per workgroup (short dependent-load chains: the early layers have 512 partial rows and
+    // only 64-256 channels); slices combined in a fixed order (deterministic)
+    constexpr int NS = 64, NC = 16;
+    __shared__ double ps[NS][NC], pq[NS][NC];
+    const int c = threadIdx.x & (NC - 1), sl = threadIdx.x / NC, ch = blockIdx.x * NC + c;
     double s = 0.0, q = 0.0;
     if (ch < C) {
-        for (int r = sl; r < rows; r += 16) {
+        for (int r = sl; r < rows; r += NS) {
             s += (double)stats[((long)r * 2 + 0) * C + ch];
             q += (double)stats[((long)r * 2 + 1) * C + ch];
         }
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     __syncthreads();
     if (sl == 0 && ch < C) {
         s = 0.0; q = 0.0;
-        for (int i = 0; i < 16; ++i) { s += ps[i][c]; q += pq[i][c]; }
+        for (int i = 0; i < NS; ++i) { s += ps[i][c]; q += pq[i][c]; }
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -631,7 +633,7 @@ extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const 
                                 float eps, float* scale, float* shift, int C, void* stream) {
     CVCL_CHECK_ARG(stats && gamma && beta && scale && shift && rows > 0 && count > 0 && C > 0, "cvcl_bn_finalize: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 64)), dim3(1024), 0, (hipStream_t)stream, stats, rows,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 16)), dim3(1024), 0, (hipStream_t)stream, stats, rows,
                        (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                        shift, C);
     CVCL_LAUNCH_CHECK();
