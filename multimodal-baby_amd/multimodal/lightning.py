@@ -56,7 +56,18 @@ class LightningModule(nn.Module):
         self.hparams = {k: local[k] for k in names if k in local}
 
     def log(self, name, value, *args, **kwargs):
-        self._logged[name] = value
+        """Last value wins for step-level logs; ``on_step=False, on_epoch=True`` logs (the evaluation loops) are
+        averaged over the epoch like Lightning's default mean reduction."""
+        if kwargs.get("on_epoch") and kwargs.get("on_step") is False:
+            acc = self.__dict__.setdefault("_log_accum", {}).setdefault(name, [0.0, 0])
+            acc[0] += float(value)
+            acc[1] += 1
+            self._logged[name] = acc[0] / acc[1]
+        else:
+            self._logged[name] = value
+
+    def _reset_epoch_logs(self):
+        self.__dict__["_log_accum"] = {}
 
     @property
     def device(self):
@@ -100,7 +111,8 @@ class Trainer:
 
     FLAGS = (("gpus", int, 0), ("max_epochs", int, 1), ("check_val_every_n_epoch", int, 1),
              ("checkpoint_callback", _str2bool, True), ("logger", _str2bool, True), ("fast_dev_run", None, False),
-             ("strategy", str, None), ("devices", int, None), ("precision", str, "32"), ("limit_train_batches", int, None))
+             ("strategy", str, None), ("devices", int, None), ("precision", str, "32"), ("limit_train_batches", int, None),
+             ("limit_val_batches", int, None))
 
     @classmethod
     def add_argparse_args(cls, parser):
@@ -119,11 +131,13 @@ class Trainer:
 
     def __init__(self, gpus=0, max_epochs=1, check_val_every_n_epoch=1, checkpoint_callback=True, logger=True,
                  fast_dev_run=False, strategy=None, devices=None, precision="32", limit_train_batches=None,
-                 callbacks=None, enable_checkpointing=None, **_ignored):
+                 limit_val_batches=None, callbacks=None, enable_checkpointing=None, **_ignored):
         self.gpus, self.max_epochs = gpus or 0, max_epochs
         self.fast_dev_run = fast_dev_run
         self.precision = str(precision)
         self.limit_train_batches = 1 if fast_dev_run else limit_train_batches
+        self.limit_val_batches = 1 if fast_dev_run else limit_val_batches
+        self.check_val_every_n_epoch = max(int(check_val_every_n_epoch or 1), 1)
         if fast_dev_run:
             self.max_epochs = 1
         self.callbacks = callbacks or []
@@ -140,6 +154,50 @@ class Trainer:
                 raise RuntimeError("--gpus > 0 but no GPU is visible")
             return torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
         return torch.device("cpu")
+
+    def _eval_loop(self, model, loaders, step_name, epoch_end_name, device):
+        """Lightning's evaluation loop: eval mode (BatchNorm on running statistics, no dropout), no autograd, one pass
+        over every dataloader with its ``dataloader_idx``, then the ``*_epoch_end`` hook on the per-loader output lists."""
+        if loaders is None:
+            return {}
+        if not isinstance(loaders, (list, tuple)):
+            loaders = [loaders]
+        was_training = model.training
+        model.eval()
+        model._reset_epoch_logs()
+        outputs = []
+        with torch.no_grad():
+            for di, dl in enumerate(loaders):
+                outs = []
+                for bi, batch in enumerate(dl):
+                    if self.limit_val_batches is not None and bi >= self.limit_val_batches:
+                        break
+                    out = getattr(model, step_name)(_move(batch, device), bi, dataloader_idx=di)
+                    outs.append({k: (v.detach() if torch.is_tensor(v) else v) for k, v in (out or {}).items()})
+                outputs.append(outs)
+            if hasattr(model, epoch_end_name) and outputs and outputs[0]:
+                getattr(model, epoch_end_name)(outputs)
+        self.logged_metrics.update({k: (float(v.detach()) if torch.is_tensor(v) and v.numel() == 1 else v) for k, v in model._logged.items()})
+        model.train(was_training)
+        return dict(self.logged_metrics)
+
+    def _prepare(self, model, datamodule):
+        device = self._device()
+        model.trainer = self
+        datamodule.prepare_data()
+        datamodule.setup()
+        model.to(device)
+        if hasattr(model, "set_precision"):
+            model.set_precision(self.precision)
+        return device
+
+    def validate(self, model, datamodule=None):
+        device = self._prepare(model, datamodule)
+        return [self._eval_loop(model, datamodule.val_dataloader(), "validation_step", "validation_epoch_end", device)]
+
+    def test(self, model, datamodule=None):
+        device = self._prepare(model, datamodule)
+        return [self._eval_loop(model, datamodule.test_dataloader(), "test_step", "test_epoch_end", device)]
 
     def fit(self, model, datamodule=None, ckpt_path=None):
         from . import parallel
@@ -181,6 +239,9 @@ class Trainer:
             if hasattr(model, "training_epoch_end") and outs:
                 model.training_epoch_end(outs)
             self.logged_metrics.update(model._logged)
+            if (epoch + 1) % self.check_val_every_n_epoch == 0 and hasattr(datamodule, "val_dataloader") \
+                    and hasattr(model, "validation_step"):
+                self._eval_loop(model, datamodule.val_dataloader(), "validation_step", "validation_epoch_end", device)
             if sched is not None and "val_loss" in self.logged_metrics:
                 sched["scheduler"].step(float(self.logged_metrics["val_loss"]))
             if self.enable_checkpointing and parallel.rank() == 0:
@@ -199,9 +260,23 @@ class ModelCheckpoint:
         self.dirpath, self.filename = str(dirpath), filename
 
     def save(self, trainer, model, optimizer):
+        """``last.ckpt`` every epoch; ``epoch=N.ckpt`` kept for the ``save_top_k`` best values of ``monitor`` (min mode, as
+        for val_loss; every epoch counts as best when the monitored metric was not logged)."""
         os.makedirs(self.dirpath, exist_ok=True)
         ckpt = model.checkpoint_dict(trainer, optimizer)
         if self.save_top_k != 0:
-            torch.save(ckpt, os.path.join(self.dirpath, self.filename.format(epoch=f"epoch={trainer.current_epoch}") + ".ckpt"))
+            score = trainer.logged_metrics.get(self.monitor) if self.monitor else None
+            score = float(score) if score is not None else float(-trainer.current_epoch)     # no metric: newest wins
+            path = os.path.join(self.dirpath, self.filename.format(epoch=f"epoch={trainer.current_epoch}") + ".ckpt")
+            best = self.__dict__.setdefault("best_k", [])
+            if self.save_top_k < 0 or len(best) < self.save_top_k or score < max(b[0] for b in best):
+                torch.save(ckpt, path)
+                best.append((score, path))
+                best.sort(key=lambda t: t[0])
+                while 0 < self.save_top_k < len(best):
+                    _s, worst = best.pop()
+                    if os.path.exists(worst) and worst != path:
+                        os.remove(worst)
+                self.best_model_path, self.best_model_score = best[0][1], best[0][0]
         if self.save_last:
             torch.save(ckpt, os.path.join(self.dirpath, "last.ckpt"))

@@ -102,6 +102,28 @@ class SyntheticPairs(torch.utils.data.Dataset):
         return img, idxs, int(idxs.numel()), [" ".join(f"w{int(w)}" for w in words)]
 
 
+class SyntheticEvalTrials(torch.utils.data.Dataset):
+    """4-way evaluation trials with the item layout of the reference's LabeledSEvalDataset
+    (multimodal_data_module.py:112-160): (imgs [4,3,H,W] target first, label ids, label length, [raw category])."""
+
+    def __init__(self, n_trials, vocab_size, seed=0, eval_include_sos_eos=False, n_images=4):
+        self.n, self.v, self.seed, self.sos_eos, self.n_images = n_trials, vocab_size, seed, eval_include_sos_eos, n_images
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, idx):
+        g = torch.Generator().manual_seed(self.seed * 7919 + idx)
+        mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        imgs = (torch.rand(self.n_images, 3, IMAGE_H, IMAGE_W, generator=g) - mean) / std
+        word = int(torch.randint(4, self.v, (1,), generator=g))
+        label = [word]
+        if self.sos_eos:
+            label = [SOS_TOKEN_ID] + label + [EOS_TOKEN_ID]
+        return imgs, torch.tensor(label, dtype=torch.long), len(label), [f"w{word}"]
+
+
 class SyntheticDataModule(MultiModalDataModule):
     """``--dataset synthetic``: same batch contract as the SAYCam module, no files needed."""
 
@@ -117,11 +139,23 @@ class SyntheticDataModule(MultiModalDataModule):
         v = len(self.read_vocab())
         self.train_set = SyntheticPairs(self.n_items, v, seed=self.seed)
         self.val_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 1)
+        self.test_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 2)
+        sos_eos = bool(self.args.get("eval_include_sos_eos", False))
+        self.eval_sets = {"val": SyntheticEvalTrials(4, v, seed=self.seed + 3, eval_include_sos_eos=sos_eos),
+                          "test": SyntheticEvalTrials(4, v, seed=self.seed + 4, eval_include_sos_eos=sos_eos)}
 
     def train_dataloader(self):
         return torch.utils.data.DataLoader(self.train_set, batch_size=self.batch_size, shuffle=False,
                                            collate_fn=multiModalDataset_collate_fn, drop_last=self.drop_last)
 
+    def _val_test(self, pairs, trials):
+        """reference val_test_dataloader (:378-403): [pair batches, one evaluation trial per batch]"""
+        return [torch.utils.data.DataLoader(pairs, batch_size=self.val_batch_size, shuffle=False,
+                                            collate_fn=multiModalDataset_collate_fn),
+                torch.utils.data.DataLoader(trials, batch_size=1, shuffle=False, collate_fn=multiModalDataset_collate_fn)]
+
     def val_dataloader(self):
-        return [torch.utils.data.DataLoader(self.val_set, batch_size=self.val_batch_size, shuffle=False,
-                                            collate_fn=multiModalDataset_collate_fn)]
+        return self._val_test(self.val_set, self.eval_sets["val"])
+
+    def test_dataloader(self):
+        return self._val_test(self.test_set, self.eval_sets["test"])

@@ -42,3 +42,42 @@ def test_checkpoint_and_resume_c2_bf16(dev, tmp_path, monkeypatch):
     assert trainer2.global_step == 4                                              # resumed at epoch 1, ran one more epoch
     assert not torch.equal(lit2.vision_encoder.model.fc.weight.detach().cpu(), w1.cpu())
     assert int(lit2.vision_encoder.model.bn1.num_batches_tracked) == 4
+
+
+def test_validation_and_four_way_trials(dev, tmp_path, monkeypatch):
+    """Lightning's evaluation loop through train.py's objects: val pairs (eval-mode BN on running statistics, no grad)
+    + one 4-way trial per batch (reference multimodal_lit.py:466-511: logits_per_text[0] over the 4 images, target at
+    index 0), val_loss/val_accuracy logged, trial logits equal to an explicit encode_image/encode_text evaluation."""
+    import contextlib, io
+    import train
+    monkeypatch.chdir(tmp_path)
+    argv = ("--dataset synthetic --batch_size 4 --val_batch_size 4 --gpus 1 --text_encoder embedding --embedding_dim 32 "
+            "--lambda_lm 0 --optimize_unused --max_epochs 1 --limit_train_batches 2 --normalize_features "
+            "--checkpoint_callback True --logger False --exp_name evaltest").split()
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer, lit = train.main(argv)
+    m = trainer.logged_metrics
+    for k in ("val_loss", "val_infonce_loss", "val_image_accuracy", "val_accuracy", "val_entropy"):
+        assert k in m, (k, sorted(m))
+    assert 0.0 <= float(m["val_accuracy"]) <= 1.0 and float(m["val_loss"]) > 0
+    assert (tmp_path / "checkpoints" / "evaltest" / "epoch=0.ckpt").exists()
+    # a trial by hand: image features of the 4 candidates vs the label's text feature
+    from multimodal.multimodal_data_module import SyntheticDataModule
+    dm = SyntheticDataModule(train._setup_parser().parse_args(argv))
+    dm.setup()
+    x, y, y_len, raw = next(iter(dm.val_dataloader()[1]))
+    lit.eval()
+    with torch.no_grad():
+        xi = x.view(-1, 3, 224, 224).to(dev)
+        img = lit.encode_image(xi)
+        txt = lit.encode_text(y.to(dev), y_len.to(dev))
+        lpi, lpt = lit.model(xi, y.to(dev), y_len.to(dev))
+    assert lpt.shape == (1, 4) and lpi.shape == (4, 1)
+    scale = float(lit.model.logit_neg_log_temperature.exp())
+    assert torch.allclose(lpt[0], (txt @ img.t())[0] * scale, rtol=1e-4, atol=1e-5)
+    out = lit.validation_step((xi.view(1, 4, 3, 224, 224), y.to(dev), y_len.to(dev), raw), 0, dataloader_idx=1)
+    assert out["accuracy"] == int(int(torch.argmax(lpt[0])) == 0)
+    # test loop: same machinery under the test_ prefix
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = trainer.test(lit, dm)[0]
+    assert "test_loss" in res and "test_accuracy" in res
