@@ -75,6 +75,21 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
     }
 }
 
+// eval mode of the whole trunk: all 53 (scale, shift) pairs from the running statistics in ONE launch (the layer table
+// travels by value in the kernel argument block), instead of 53 dependent 4-us launches on the latency path
+struct EvalAffineAll {
+    const float* gamma[53]; const float* beta[53]; const float* rm[53]; const float* rv[53];
+    int C[53];
+};
+__global__ __launch_bounds__(256) void bn_eval_affine_all_kernel(EvalAffineAll t, float eps, float* __restrict__ affine) {
+    const int l = blockIdx.x;
+    for (int ch = threadIdx.x; ch < t.C[l]; ch += 256) {
+        const float sc = t.gamma[l][ch] / sqrtf(t.rv[l][ch] + eps);
+        affine[(size_t)l * 4096 + ch] = sc;
+        affine[(size_t)l * 4096 + 2048 + ch] = t.beta[l][ch] - t.rm[l][ch] * sc;
+    }
+}
+
 // per-column sum / sumsq partial rows of a stored [rows, C] tensor (fp32 parity path + tests)
 template <typename T>
 __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ x, long rows, int C, float* __restrict__ stats) {
@@ -951,8 +966,28 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
         if (training)
             return cvcl_bn_finalize(stats, rows, count, L.gamma, L.beta, L.running_mean, L.running_var,
                                     L.num_batches_tracked, momentum, eps, scale_of(l), shift_of(l), C, stream);
-        return cvcl_bn_eval_affine(L.gamma, L.beta, L.running_mean, L.running_var, eps, scale_of(l), shift_of(l), C, stream);
+        return CVCL_OK;                                   // eval mode: every layer's affine was produced up front
     };
+    if (!training) {
+        EvalAffineAll t;
+        int l = 0;
+        auto put = [&](int C) {
+            t.gamma[l] = layers[l].gamma; t.beta[l] = layers[l].beta; t.rm[l] = layers[l].running_mean; t.rv[l] = layers[l].running_var;
+            t.C[l] = C; ++l;
+        };
+        put(64);
+        for (int st = 0; st < 4; ++st)
+            for (int b = 0; b < kLayers[st]; ++b) {
+                const int pl = 64 << st;
+                put(pl * 2); put(pl * 2); put(pl * 4);
+                if (b == 0) put(pl * 4);
+            }
+        for (int i = 0; i < 53; ++i)
+            CVCL_CHECK_ARG(t.gamma[i] && t.beta[i] && t.rm[i] && t.rv[i], "cvcl_resnext50_fwd: layer %d lacks BatchNorm tensors", i);
+        CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
+        hipLaunchKernelGGL(bn_eval_affine_all_kernel, dim3(53), dim3(256), 0, (hipStream_t)stream, t, eps, affine);
+        CVCL_LAUNCH_CHECK();
+    }
 
     // ---- stem ----
     int h = H / 2, wd = W / 2;
@@ -996,7 +1031,8 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
             // the narrow operand), then a pass whose epilogue applies BN3 + identity / normalised downsample + ReLU
             // and writes the block output -- instead of materialising raw3 and re-reading it in bn_add_relu
             // (saves one write and one read of the wide tensor; results are bit-identical).
-            const bool fused_tail = dtype == CVCL_BF16 && stage < 2;
+            // In eval mode there is no statistics pass at all, so the fused tail is used in every stage.
+            const bool fused_tail = dtype == CVCL_BF16 && (stage < 2 || !training);
             auto conv3_args = [&]() {
                 cvcl_gemm_args a = {};
                 a.A = R2; a.W = layers[l3].w;
