@@ -118,104 +118,137 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Attention, bf16 MFMA, head_dim 64 (ViT-B: 12 x 64): one workgroup per (b, head, 64 queries); each wave owns
-// 16 queries.  S^T = K.Q^T on v_mfma_f32_16x16x32_bf16 with K fragments read straight from global (L2 resident),
-// softmax in registers, P staged through LDS into the A-operand layout, V staged transposed in LDS for P.V.
+// Attention, bf16 MFMA, head_dim 64 (ViT-B: 12 x 64): ONE workgroup per (image, head) -- K and V of the head are staged
+// into LDS once (coalesced 16-byte rows, no transposed copy) and every wave walks 16-query tiles over them:
+//   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K rows from LDS (ds_read_b128, pitch 144 B), B = Q^T from global
+//   softmax       in registers (a lane holds 4 keys of every 16-key tile for one query; 2 shuffles finish the row)
+//   O = P V       P goes through a wave-private LDS strip into the A layout; the B operand needs 8 keys of one d per
+//                 lane, i.e. the transpose of the row-major V image: gfx950 ds_read_b64_tr_b16 (pitch 160 B keeps the
+//                 8 rows x 32 B that 32 lanes touch on disjoint banks).  The k index of a lane's block is
+//                 {32ks + 4g + e} U {32ks + 16 + 4g + e} in BOTH operands (any fixed permutation of k is valid).
+//   out           staged through the P strip, written as 16-byte row pieces.
+// (The first version ran one workgroup per 64 queries: V^T was rebuilt 4x per head with 2-byte LDS scatters, 4-way
+//  bank conflicted, and K was re-read from L2 by every wave: 440 us per ViT-B/16 layer at B = 256.)
 // ------------------------------------------------------------------------------------------------
 constexpr int ATT_TPAD_MAX = 288;      // keys padded to a multiple of 32 (T <= 288 covers ViT-B/14 at 224: 257)
+constexpr int ATT_KP = 144;            // LDS bytes per K row (128 + 16)
+constexpr int ATT_VP = 160;            // LDS bytes per V row (128 + 32)
 
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B,
-                                                             int Tn, int heads, float scale, int Tpad) {
+typedef __bf16 att_tr4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
+__device__ inline bf16x4 att_tr_read(const char* p) {
+    auto lp = reinterpret_cast<__attribute__((address_space(3))) att_tr4*>((__attribute__((address_space(3))) char*)(p));
+    return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(lp));
+}
+
+__global__ __launch_bounds__(512) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B,
+                                                             int Tn, int heads, float scale, int Tpad, int nwaves) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int VT_PITCH = Tpad + 8;                                  // bf16 elements per transposed-V row
-    bf16_t* sVt = (bf16_t*)smem;                                    // [64 d][VT_PITCH]
-    bf16_t* sP = sVt + 64 * VT_PITCH;                               // [4 waves][16 q][Tpad + 8]
+    const int PP = (Tpad + 8) * 2;                                  // bytes per P row
+    char* sK = smem;                                                // [Tpad][ATT_KP]
+    char* sV = sK + Tpad * ATT_KP;                                  // [Tpad][ATT_VP]
+    char* sP = sV + Tpad * ATT_VP;                                  // [nwaves][16 q][PP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int qblocks = (Tn + 63) / 64;
-    const int qb = blockIdx.x % qblocks, hh = (blockIdx.x / qblocks) % heads, b = blockIdx.x / (qblocks * heads);
+    const int hh = blockIdx.x % heads, b = blockIdx.x / heads;
     const int D = heads * 64;
     const bf16_t* base = qkv + (long)b * Tn * 3 * D;
 
-    // stage V^T (zeros beyond Tn) -- coalesced 16-B reads along d, scattered 2-B LDS writes
-    for (int i = tid; i < Tpad * 8; i += 256) {
-        const int j = i >> 3, dc = (i & 7) * 8;
-        bf16x8 v;
-        if (j < Tn) v = *reinterpret_cast<const bf16x8*>(base + (long)j * 3 * D + 2 * D + hh * 64 + dc);
-        else { const u32x4 z = {0u, 0u, 0u, 0u}; v = __builtin_bit_cast(bf16x8, z); }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sVt[(dc + e) * VT_PITCH + j] = v[e];
+    // stage K and V rows of this head (zeros beyond Tn): 8 chunks of 16 B per row
+    for (int i = tid; i < Tpad * 8; i += blockDim.x) {
+        const int j = i >> 3, c = i & 7;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (j < Tn) {
+            kv = *reinterpret_cast<const u32x4*>(base + (long)j * 3 * D + D + hh * 64 + c * 8);
+            vv = *reinterpret_cast<const u32x4*>(base + (long)j * 3 * D + 2 * D + hh * 64 + c * 8);
+        }
+        *reinterpret_cast<u32x4*>(sK + j * ATT_KP + c * 16) = kv;
+        *reinterpret_cast<u32x4*>(sV + j * ATT_VP + c * 16) = vv;
     }
-    // this wave's 16 queries as the MFMA B operand (cols = query, k = d): lane (query l15, d block g)
-    const int q0 = qb * 64 + wave * 16;
-    const int qrow = min(q0 + l15, Tn - 1);
-    bf16x8 qf[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * 3 * D + hh * 64 + ks * 32 + g * 8);
+    __syncthreads();
+    if (wave >= nwaves) return;
 
-    // S^T tiles: rows = keys (16 per tile), cols = queries; lane holds keys 4g..4g+3 of each tile for query l15
-    const int ntile = Tpad / 16;
-    f32x4 s[ATT_TPAD_MAX / 16];
-    float mx = -INFINITY;
+    const int ntile = Tpad / 16, nqt = (Tn + 15) / 16;
+    const float scale2 = scale * 1.4426950408889634f;
+    char* myP = sP + wave * 16 * PP;
+    // tr-read lane addressing inside a [4 keys][16 d] block: row (lane & 15) >> 2, d columns 4 * (lane & 3)
+    const int v_lane_off = (4 * g + (l15 >> 2)) * ATT_VP + (l15 & 3) * 8;
+
+    for (int qt = wave; qt < nqt; qt += nwaves) {
+        const int q0 = qt * 16;
+        const int qrow = min(q0 + l15, Tn - 1);
+        bf16x8 qf[2];
 #pragma unroll
-    for (int t = 0; t < ATT_TPAD_MAX / 16; ++t) {
-        if (t < ntile) {
-            const int krow = min(t * 16 + l15, Tn - 1);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * 3 * D + hh * 64 + ks * 32 + g * 8);
+
+        // S^T tiles: rows = keys (16 per tile), cols = queries; lane holds keys 4g..4g+3 of each tile for query l15
+        f32x4 s[ATT_TPAD_MAX / 16];
+        float mx = -INFINITY;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(base + (long)krow * 3 * D + D + hh * 64 + ks * 32 + g * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+        for (int t = 0; t < ATT_TPAD_MAX / 16; ++t) {
+            if (t < ntile) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + l15) * ATT_KP + ks * 64 + g * 16);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = t * 16 + g * 4 + e;
+                    acc[e] = key < Tn ? acc[e] * scale2 : -INFINITY;       // logits in units of log2(e): exp(x) = 2^(x log2 e)
+                    mx = fmaxf(mx, acc[e]);
+                }
+                s[t] = acc;
             }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = t * 16 + g * 4 + e;
-                acc[e] = key < Tn ? acc[e] * scale : -INFINITY;
-                mx = fmaxf(mx, acc[e]);
+        for (int t = 0; t < ATT_TPAD_MAX / 16; ++t)
+            if (t < ntile) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_amdgcn_exp2f(s[t][e] - mx); sum += s[t][e]; }   // v_exp_f32
             }
-            s[t] = acc;
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        // P (bf16) -> wave-private LDS strip [q][key]
+#pragma unroll
+        for (int t = 0; t < ATT_TPAD_MAX / 16; ++t)
+            if (t < ntile) {
+                bf16x4 pv = {(bf16_t)(s[t][0] * inv), (bf16_t)(s[t][1] * inv), (bf16_t)(s[t][2] * inv), (bf16_t)(s[t][3] * inv)};
+                *reinterpret_cast<bf16x4*>(myP + l15 * PP + (t * 16 + g * 4) * 2) = pv;
+            }
+        // O[16 q][64 d] = P V over 32-key steps; lane's k block = keys {32ks + 4g + e} U {32ks + 16 + 4g + e}
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < Tpad / 32; ++ks) {
+            const bf16x4 p0 = *reinterpret_cast<const bf16x4*>(myP + l15 * PP + (ks * 32 + g * 4) * 2);
+            const bf16x4 p1 = *reinterpret_cast<const bf16x4*>(myP + l15 * PP + (ks * 32 + 16 + g * 4) * 2);
+            const bf16x8 pf = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const char* vb = sV + (ks * 32) * ATT_VP + v_lane_off;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x4 v0 = att_tr_read(vb + dt * 32);
+                const bf16x4 v1 = att_tr_read(vb + 16 * ATT_VP + dt * 32);
+                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
+            }
         }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float sum = 0.f;
+        // D[row = query 4g+e][col = d 16dt + l15] -> strip as [q][64 d] (pitch 144 B) -> 16-byte row pieces
 #pragma unroll
-    for (int t = 0; t < ATT_TPAD_MAX / 16; ++t)
-        if (t < ntile) {
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s[t][e] = expf(s[t][e] - mx); sum += s[t][e]; }
-        }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.f / sum;
-    // P (bf16) -> LDS [q][key] so it can be re-read as the A operand (8 consecutive keys per lane)
-    bf16_t* myP = sP + wave * 16 * (Tpad + 8);
+            for (int dt = 0; dt < 4; ++dt)
+                *reinterpret_cast<bf16_t*>(myP + (g * 4 + e) * ATT_KP + (dt * 16 + l15) * 2) = (bf16_t)o[dt][e];
 #pragma unroll
-    for (int t = 0; t < ATT_TPAD_MAX / 16; ++t)
-        if (t < ntile) {
-            bf16x4 pv = {(bf16_t)(s[t][0] * inv), (bf16_t)(s[t][1] * inv), (bf16_t)(s[t][2] * inv), (bf16_t)(s[t][3] * inv)};
-            *reinterpret_cast<bf16x4*>(myP + l15 * (Tpad + 8) + t * 16 + g * 4) = pv;
-        }
-    __syncthreads();                                                 // V^T complete (and P visible to its own wave)
-    // O[16 q][64 d] = P[16 x Tpad] . V[Tpad x 64]: A = P rows (query l15, keys g*8..), B = V^T rows (d l15, keys g*8..)
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < Tpad / 32; ++ks) {
-        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(myP + l15 * (Tpad + 8) + ks * 32 + g * 8);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sVt + (dt * 16 + l15) * VT_PITCH + ks * 32 + g * 8);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
-        }
-    }
-    // D[row = query 4g+e][col = d l15]
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int q = q0 + g * 4 + e;
-        if (q < Tn) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) out[((long)b * Tn + q) * D + hh * 64 + dt * 16 + l15] = (bf16_t)o[dt][e];
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lane + 64 * i, q = idx >> 3, c = idx & 7;
+            if (q0 + q < Tn)
+                *reinterpret_cast<u32x4*>(out + ((long)b * Tn + q0 + q) * D + hh * 64 + c * 8) =
+                    *reinterpret_cast<const u32x4*>(myP + q * ATT_KP + c * 16);
         }
     }
 }
@@ -342,9 +375,15 @@ extern "C" int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok
     CVCL_CHECK_ARG(qkv && out && B > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim <= 128, "cvcl_attention: bad args");
     CvclProfScope prof(stream, CVCL_K_ATTENTION);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == CVCL_BF16 && head_dim == 64 && !key_tok && T <= ATT_TPAD_MAX) {
+    if (dtype == CVCL_BF16 && head_dim == 64 && !key_tok && T > 32 && T <= ATT_TPAD_MAX) {   // T <= 32: generic kernel below
         const int Tpad = (T + 31) / 32 * 32;
-        const size_t lds = (size_t)(64 * (Tpad + 8) + 4 * 16 * (Tpad + 8)) * 2;
+        const size_t fixed = (size_t)Tpad * (ATT_KP + ATT_VP), strip = (size_t)16 * (Tpad + 8) * 2;
+        int nwaves = (int)((160 * 1024 - fixed) / strip);
+        if (nwaves > 8) nwaves = 8;
+        const int nqt = (T + 15) / 16;
+        if (nwaves > nqt) nwaves = nqt;
+        CVCL_CHECK_ARG(nwaves >= 1 && strip >= (size_t)16 * ATT_KP, "cvcl_attention: sequence too long for the MFMA kernel (%d)", T);
+        const size_t lds = fixed + nwaves * strip;
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -353,9 +392,9 @@ extern "C" int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok
             }
             attr_set = true;
         }
-        const int grid = B * heads * ((T + 63) / 64);
-        hipLaunchKernelGGL(attention_mfma_kernel, dim3(grid), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, T, heads,
-                           scale, Tpad);
+        const int threads = nwaves <= 4 ? 256 : 512;
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * heads), dim3(threads), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, T, heads,
+                           scale, Tpad, nwaves);
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }

@@ -165,3 +165,24 @@ def test_vit_transformer_model_end_to_end(dev):
     print(f"C4 logits fp32 vs oracle rel err {e:.2e}")
     assert e < 1e-3 and maxrel(lpt, lpt_o) < 1e-3             # the BASELINE gate
     assert e < 1e-4
+
+
+@pytest.mark.parametrize("B,T,heads", [(2, 197, 12), (1, 257, 12), (3, 50, 4), (2, 33, 2), (2, 64, 3), (1, 288, 1), (2, 17, 2)])
+def test_attention_bf16_mfma_vs_float64(dev, B, T, heads):
+    """cvcl_attention (bf16, head_dim 64: per-head workgroup, K/V in LDS, transposed V reads) vs softmax(q k^T / 8) v in
+    float64 on the same bf16-rounded operands.  Asymmetric random data: a wrong key permutation between the P and V
+    operands, a transposed tile or a padding leak changes the result at O(1)."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(T * 7 + heads)
+    D = heads * 64
+    qkv = (torch.randn(B, T, 3, heads, 64, generator=g) * 1.5).bfloat16()
+    q, k, v = (qkv[:, :, i].double().permute(0, 2, 1, 3) for i in range(3))            # [B, heads, T, 64]
+    p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, T, D)
+    qd = qkv.to(dev).contiguous()
+    out = torch.full((B, T, D), float("nan"), dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().cvcl_attention(H.BF16, H.ptr(qd), None, H.ptr(out), B, T, heads, 64, 0.125, H.stream_ptr()), "attention")
+    got = out.double().cpu()
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 2e-2, err
