@@ -70,6 +70,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// bf16 rows held in registers: one wave per row, up to 4 chunks of 16 B per lane (D <= 2048, D % 8 == 0, 16-byte aligned
+// rows); the row is read once (the scalar kernel above walks it three times with 2-byte loads)
+template <typename TO>
+__global__ __launch_bounds__(256) void layernorm_bf16_vec_kernel(const bf16_t* __restrict__ x, long x_row_stride,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float eps, TO* __restrict__ y, long rows, int D) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const bf16_t* xr = x + row * x_row_stride;
+    const int nch = D >> 3;
+    bf16x8 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            v[i] = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = (float)v[i][e] - mean; q = fmaf(c, c, q); }
+        }
+    const float rstd = 1.f / sqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = ((float)v[i][e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+            if constexpr (sizeof(TO) == 2) {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)o[e];
+                *reinterpret_cast<bf16x8*>(y + row * D + c * 8) = ov;
+            } else {
+                *reinterpret_cast<f32x4*>(y + row * D + c * 8) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(y + row * D + c * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention, generic (any head_dim <= 128, any T, optional key padding mask): one wave per (b, head, query).
 // qkv [B, T, 3, heads, hd] -> out [B, T, heads*hd].  P is rounded to the storage type before P.V.
@@ -360,12 +413,22 @@ extern "C" int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const
     if (dtype == CVCL_F32)
         hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, dim3(256), 0, s, (const float*)x, x_row_stride, gamma, beta,
                            eps, (float*)y, rows, D);
-    else if (y_is_f32)
-        hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
-                           eps, (float*)y, rows, D);
-    else
-        hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
-                           eps, (bf16_t*)y, rows, D);
+    else {
+        const bool vec = D % 8 == 0 && D <= 2048 && x_row_stride % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                         ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0;
+        if (vec && y_is_f32)
+            hipLaunchKernelGGL((layernorm_bf16_vec_kernel<float>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
+                               eps, (float*)y, rows, D);
+        else if (vec)
+            hipLaunchKernelGGL((layernorm_bf16_vec_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
+                               eps, (bf16_t*)y, rows, D);
+        else if (y_is_f32)
+            hipLaunchKernelGGL((layernorm_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
+                               eps, (float*)y, rows, D);
+        else
+            hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
+                               eps, (bf16_t*)y, rows, D);
+    }
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
