@@ -123,6 +123,15 @@ typedef struct {
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);
+/* exact number of statistics rows cvcl_gemm writes for these arguments when given a buffer of at least that many rows
+ * (args->stats / stats_rows are ignored).  With a smaller buffer sized by cvcl_gemm_grid_m the 128-tile kernel runs and
+ * writes cvcl_gemm_grid_m rows.                                                                          */
+int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* args);
+/* the 256 x 256 phase-interleaved bf16 kernel behind cvcl_gemm's dispatcher (epi 0: conv + statistics, 1: bias /
+ * activation / residual); exposed for tests and tuning                                                   */
+int cvcl_gemm256(int epi, const cvcl_gemm_args* args, void* stream);
+int cvcl_gemm256_supported(int M, int N, int K, int lda, int ldw, int ldc);
+int cvcl_gemm256_stats_rows(int M);
 
 /* out[c][r] = in[r][c], f32 (operand re-layout for the weight-gradient GEMMs). */
 int cvcl_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);

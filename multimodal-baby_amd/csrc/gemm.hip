@@ -766,6 +766,35 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
 }
 
 
+}  // namespace
+extern "C" int cvcl_gemm256(int epi, const cvcl_gemm_args* a, void* stream);
+extern "C" int cvcl_gemm256_supported(int M, int N, int K, int lda, int ldw, int ldc);
+extern "C" int cvcl_gemm256_stats_rows(int M);
+namespace {
+
+// Policy for the 256 x 256 phase-interleaved kernel (gemm256.hip).  OPT-IN ($CVCL_GEMM256=1): measured on MI355X it wins
+// only when K is long (4096^3: 1046 vs 949 TFLOP/s, 8192^3: 961 vs 888); on this workload's shapes (K = 512 .. 3072, one
+// workgroup per CU so nothing overlaps a tile's epilogue) it is equal or slower (ResNeXt layers 3-4: 590-690 vs 640-710
+// TFLOP/s; ViT-B linears with bias/GELU/residual: 365-640 vs 500-740) -- tools/gemm_bench.py.  When selected: K >= 512,
+// enough tiles to fill the chip, plain operands, and -- when BN statistics are requested -- a statistics buffer sized by
+// cvcl_gemm_stats_rows.  Returns -1 (not selected) or the epilogue id.
+inline int pick_gemm256(int dtype, const cvcl_gemm_args* a) {
+    static const bool on = [] { const char* e = getenv("CVCL_GEMM256"); return e && e[0] == '1'; }();
+    if (!on || dtype != CVCL_BF16) return -1;
+    if (!cvcl_gemm256_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) || a->K < 512) return -1;
+    if (a->a_scale || a->gather_stride > 1 || a->exp_scale || a->c_scale) return -1;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!al16(a->A) || !al16(a->W) || !al16(a->C) || !al16(a->R) || !al16(a->bias) || (a->R && a->ldr % 8)) return -1;
+    if ((long)cvcl_div_up(a->M, 256) * (a->N / 256) < 128) return -1;
+    const bool plain = !a->bias && !a->R && a->act == CVCL_ACT_NONE;
+    if (a->stats) {
+        if (!plain || a->stats_rows < cvcl_gemm256_stats_rows(a->M)) return -1;
+        return 0;
+    }
+    if (!a->C) return -1;
+    return plain ? 0 : 1;
+}
+
 inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
     return d.vec_in && d.vec_out && !a->bias && !a->exp_scale && !a->R && a->act == CVCL_ACT_NONE && (a->N % BN) == 0;
 }
@@ -808,6 +837,8 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.num_m_tiles = cvcl_div_up(a->M, BM);
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
+        const int e256 = pick_gemm256(CVCL_BF16, a);
+        if (e256 >= 0) return cvcl_gemm256(e256, a, stream);
         static const bool use_glds = [] { const char* e = getenv("CVCL_GEMM_GLDS"); return !(e && e[0] == '0'); }();
         if (use_glds && a->c_scale) {                // Bottleneck tail epilogue: only the direct-to-LDS kernel implements it
             CVCL_CHECK_ARG(d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && a->R && a->c_shift &&
@@ -854,6 +885,18 @@ int grid_m_query(int M, int N) {
 extern "C" int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue) {
     (void)has_prologue;
     return dtype == CVCL_BF16 ? grid_m_query<bf16_t>(M, N) : grid_m_query<float>(M, N);
+}
+
+// exact number of BN-statistics rows cvcl_gemm will write for these arguments (a->stats / a->stats_rows need not be set:
+// the answer assumes a buffer of that many rows will be passed)
+extern "C" int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* a) {
+    if (!a) return 0;
+    cvcl_gemm_args t = *a;
+    static float dummy;
+    t.stats = &dummy;
+    t.stats_rows = 1 << 30;
+    if (pick_gemm256(dtype, &t) == 0) return cvcl_gemm256_stats_rows(a->M);
+    return cvcl_gemm_grid_m(dtype, a->M, a->N, 0);
 }
 
 extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {

@@ -117,6 +117,10 @@ SIGNATURES = {
     "cvcl_stem_im2col": (_I, [_P, _P, _I, _I, _I, _P]),
     "cvcl_conv1x1_bn_stats_gram_workspace_bytes": (C.c_size_t, [C.c_long, _I]),
     "cvcl_conv1x1_bn_stats_gram": (_I, [_P, _I, _P, _I, C.c_long, _I, _I, _P, _P, C.c_size_t, _P]),
+    "cvcl_gemm_stats_rows": (_I, [_I, _P]),
+    "cvcl_gemm256": (_I, [_I, _P, _P]),
+    "cvcl_gemm256_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cvcl_gemm256_stats_rows": (_I, [_I]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }

@@ -134,3 +134,78 @@ def test_bn_stats_from_gram_matrix(dev, M, K, N):
     assert float((got[0] - ref_sum).abs().max() / ref_sum.abs().max()) < 1e-5
     assert float(((got[1] - ref_sq).abs() / ref_sq).max()) < 2e-5
     assert float(((var_got - var_ref).abs() / var_ref).max()) < 2e-4       # what BatchNorm consumes
+
+
+def _gemm256(H, epi, A, W, C=None, stats=None, bias=None, act=0, R=None):
+    import ctypes as Cc
+    a = H.GemmArgs()
+    M, K = A.shape
+    N = W.shape[0]
+    a.A, a.W, a.C = H.ptr(A), H.ptr(W), H.ptr(C)
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
+    if stats is not None:
+        a.stats, a.stats_rows = H.ptr(stats), stats.shape[0]
+    if bias is not None:
+        a.bias = H.ptr(bias)
+    a.act = act
+    if R is not None:
+        a.R, a.ldr = H.ptr(R), N
+    H.check(H.lib().cvcl_gemm256(epi, Cc.byref(a), H.stream_ptr()), "cvcl_gemm256")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 512, 512), (12544, 2048, 1024), (50176, 512, 1024), (777, 768, 3072),
+                                   (4099, 256, 2048)])
+def test_gemm256_exact_on_small_integers_and_race_free(dev, M, N, K):
+    """256 x 256 phase-interleaved kernel, conv epilogue: with small-integer operands every partial sum is exact, so C must
+    equal the float64 product bit for bit -- any half-tile read before its global_load_lds landed, a wrong swizzle or a
+    quadrant mix-up shows up as a wrong integer.  Repeated launches (different timing) must agree; BN statistics rows
+    (2 per 256-row tile) must sum to the column sums of what was stored."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    ref = (a.double() @ w.double().t())
+    ad, wd = a.bfloat16().to(dev), w.bfloat16().to(dev)
+    rows = H.lib().cvcl_gemm256_stats_rows(M)
+    outs = []
+    for _ in range(4):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        st = torch.full((rows, 2, N), float("nan"), device=dev)
+        _gemm256(H, 0, ad, wd, C, st)
+        outs.append((C, st))
+    torch.cuda.synchronize()
+    C0, st0 = outs[0]
+    assert all(torch.equal(C0, c) and torch.equal(st0, s) for c, s in outs[1:])
+    want = ref.float().bfloat16()                                            # the kernel rounds the exact sum to bf16
+    assert torch.equal(C0.cpu(), want)
+    col = want.double().sum(0)
+    assert torch.equal(st0[:, 0].double().sum(0).cpu(), col)
+    assert torch.allclose(st0[:, 1].double().sum(0).cpu(), (want.double() ** 2).sum(0), rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(1024, 768, 768, 0, True), (3000, 3072, 768, 2, False), (5000, 768, 3072, 0, True),
+                                           (600, 2304, 768, 0, False)])
+def test_gemm256_linear_epilogue_matches_128_tile_kernel(dev, M, N, K, act, res):
+    """EPI 1 (bias + activation + residual, the ViT linears): bit-identical to the 128-tile kernel on random data
+    (same products, same fp32 accumulation order per output is NOT guaranteed across tilings -> compare with tolerance to
+    float64 and require both kernels to be equally close)."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(N + K)
+    a = torch.randn(M, K, generator=g).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).bfloat16() if res else None
+    y = a.double() @ w.double().t() + bias.double()
+    if act == 2:
+        y = 0.5 * y * (1 + torch.erf(y / 2 ** 0.5))
+    y = y.float().bfloat16().double()
+    if res:
+        y = y + r.double()
+    ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
+    rd = r.to(dev) if res else None
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    _gemm256(H, 1, ad, wd, C, None, bd, act, rd)
+    C2 = torch.empty_like(C)
+    _gemm256(H, 1, ad, wd, C2, None, bd, act, rd)
+    assert torch.equal(C, C2)
+    assert maxrel(C.float(), y.float()) < 8e-3

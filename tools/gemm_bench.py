@@ -1,0 +1,25 @@
+"""Micro-benchmark of cvcl_gemm (bf16) on the MFMA-bound shapes; run with CVCL_GEMM256=0 / 1 to compare the two kernels."""
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "multimodal-baby_amd"))
+from multimodal import _hip as H
+dev = torch.device("cuda:0")
+shapes = [("l3.conv1", 50176, 512, 1024, 0), ("l3.conv3", 50176, 1024, 512, 0), ("l4.conv1", 12544, 1024, 2048, 0),
+          ("l4.conv3", 12544, 2048, 1024, 0), ("l3.0.conv1", 200704, 512, 512, 0), ("l4.0.conv1", 50176, 1024, 1024, 0),
+          ("vit.qkv", 50432, 2304, 768, 1), ("vit.proj", 50432, 768, 768, 1), ("vit.fc1", 50432, 3072, 768, 2), ("vit.fc2", 50432, 768, 3072, 1),
+          ("4096^3", 4096, 4096, 4096, 0), ("8192^3", 8192, 8192, 8192, 0)]
+for name, M, N, K, kind in shapes:
+    a = (torch.randn(M, K, device=dev)).bfloat16(); w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    bias = torch.randn(N, device=dev) if kind else None
+    res = torch.randn(M, N, device=dev).bfloat16() if kind == 1 else None
+    act = H.ACT_GELU if kind == 2 else H.ACT_NONE
+    f = lambda: H.gemm(a, w, out=out, bias=bias, act=act, residual=res)
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    print(f"{name:12s} M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2*M*N*K/us/1e6:7.0f} TFLOP/s")
