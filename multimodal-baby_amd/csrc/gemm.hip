@@ -68,6 +68,27 @@ __device__ inline float apply_act(float v, int act) {
     return v;
 }
 
+// bf16 epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result) on
+// v_rcp_f32 / v_exp_f32: the library erff costs ~3x the instructions (fc1 + GELU of ViT-B: 424 us vs 330 us without the
+// activation).  The fp32 parity kernels keep erff.
+__device__ inline float gelu_erf_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+    const float erf_abs = fmaf(-poly, e, 1.f);
+    return 0.5f * v * (1.f + copysignf(erf_abs, v));
+}
+__device__ inline float apply_act_bf16(float v, int act) {
+    if (act == CVCL_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == CVCL_ACT_GELU) return gelu_erf_fast(v);
+    return v;
+}
+
 constexpr int BM = 128, BN = 128;
 constexpr int ROWB = 144;   // LDS row pitch in bytes (128 B of K + 16 B pad)
 
@@ -384,12 +405,17 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
 }
 
 // EPI = 0: convolution epilogue (round, BN partial sums; C may be NULL = statistics only).
-// EPI = 1: + bias, activation, residual (the ViT / nn.Linear epilogue: out = round(round(act(acc + bias)) + R)).
+// EPI = 1 / 3 / 4: + bias, activation (none / ReLU / GELU), residual (the ViT / nn.Linear epilogue:
+//          out = round(round(act(acc + bias)) + R)).
 // EPI = 2: Bottleneck tail: out = relu(round(acc) * c_scale[n] + c_shift[n] + (R | R * r_scale[n] + r_shift[n])) --
 //          BatchNorm of this conv's (rounded) output + identity / normalised downsample branch + ReLU, no statistics.
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // EPI 1 / 3 / 4 = linear epilogue with activation none / ReLU / GELU compiled in (a run-time switch per element cost
+    // two scalar branches per value and inlined erff 64 times behind them)
+    constexpr bool LIN = EPI == 1 || EPI == 3 || EPI == 4;
+    constexpr int ACT = EPI == 3 ? CVCL_ACT_RELU : (EPI == 4 ? CVCL_ACT_GELU : CVCL_ACT_NONE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l31 = lane & 31, h = lane >> 5;
@@ -449,6 +475,21 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
         }
     }
 
+    // EPI 1: the column tile is fixed per workgroup, so the bias values this lane adds (n = n0 + wn*64 + nt*32 + 8g + 4h + e)
+    // are loaded once.  Loading them per tile put global loads behind the next tile's in-flight global_load_lds in the
+    // in-order vmcnt queue: every tile's epilogue then waited for a full operand fetch (qkv GEMM of ViT-B: 357 vs 292 us;
+    // same reason the residual rows are fetched before the K loop).
+    f32x4 bias_r[2][4];
+    if constexpr (LIN) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bias_r[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bias_r[nt][g] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + nt * 32 + 8 * g + 4 * h);
+            }
+    }
+
     // fragment read offsets inside a buffer (rows fixed per lane, swizzle per row)
     int fw_off[2], fa_off[2], fw_sw[2], fa_sw[2];
 #pragma unroll
@@ -475,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
         // EPI 2: the residual rows this lane will need in the read-back phase are fetched now, so that their latency
         // hides behind the K loop instead of sitting between the last MFMA and the stores
         bf16x8 rpre[8];
-        if constexpr (EPI == 2) {
+        if (EPI == 2 || (LIN && R)) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 int m = m0 + wm * 64 + j * 8 + (lane >> 3);
@@ -527,12 +568,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                     const int row = mt * 32 + l31;
                     const int chunk = nt * 4 + g;                // 8 channels per 16-B chunk; this lane owns half h
                     bf16x4 q;
-                    if constexpr (EPI == 1) {
-                        const int n_glob = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h;
-                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n_glob);
+                    if constexpr (LIN) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) q[e] = (bf16_t)apply_act(acc[nt][mt][4 * g + e] + bv[e], p.act);
+                        for (int e = 0; e < 4; ++e) q[e] = (bf16_t)apply_act_bf16(acc[nt][mt][4 * g + e] + bias_r[nt][g][e], ACT);
                     } else {
                         q = bf16x4{(bf16_t)acc[nt][mt][4 * g + 0], (bf16_t)acc[nt][mt][4 * g + 1],
                                    (bf16_t)acc[nt][mt][4 * g + 2], (bf16_t)acc[nt][mt][4 * g + 3]};
@@ -545,9 +583,9 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
             const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4));
             if (m < p.M) {
-                if constexpr (EPI == 1) {
+                if constexpr (LIN) {
                     if (R) {
-                        const bf16x8 r = *reinterpret_cast<const bf16x8*>(R + (long)m * p.ldr + n);
+                        const bf16x8 r = rpre[j];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                     }
@@ -851,7 +889,8 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
         const bool al = ((uintptr_t)a->bias & 15) == 0;
         if (use_glds && d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && !a->exp_scale &&
             !a->stats && al && !(a->gather_stride > 1))
-            return launch_gemm_glds<1>(a, d, stream);
+            return a->act == CVCL_ACT_GELU ? launch_gemm_glds<4>(a, d, stream)
+                 : a->act == CVCL_ACT_RELU ? launch_gemm_glds<3>(a, d, stream) : launch_gemm_glds<1>(a, d, stream);
     }
     CVCL_CHECK_ARG(a->C && !a->c_scale, "cvcl_gemm: statistics-only / BN-tail epilogues need the direct-to-LDS bf16 path");
     if constexpr (sizeof(T) == 4) {

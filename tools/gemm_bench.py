@@ -6,6 +6,7 @@ dev = torch.device("cuda:0")
 shapes = [("l3.conv1", 50176, 512, 1024, 0), ("l3.conv3", 50176, 1024, 512, 0), ("l4.conv1", 12544, 1024, 2048, 0),
           ("l4.conv3", 12544, 2048, 1024, 0), ("l3.0.conv1", 200704, 512, 512, 0), ("l4.0.conv1", 50176, 1024, 1024, 0),
           ("vit.qkv", 50432, 2304, 768, 1), ("vit.proj", 50432, 768, 768, 1), ("vit.fc1", 50432, 3072, 768, 2), ("vit.fc2", 50432, 768, 3072, 1),
+          ("qkv.plain", 50432, 2304, 768, 0), ("fc1.plain", 50432, 3072, 768, 0), ("fc1.bias", 50432, 3072, 768, 3), ("proj.plain", 50432, 768, 768, 0),
           ("4096^3", 4096, 4096, 4096, 0), ("8192^3", 8192, 8192, 8192, 0)]
 for name, M, N, K, kind in shapes:
     a = (torch.randn(M, K, device=dev)).bfloat16(); w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
@@ -13,6 +14,7 @@ for name, M, N, K, kind in shapes:
     bias = torch.randn(N, device=dev) if kind else None
     res = torch.randn(M, N, device=dev).bfloat16() if kind == 1 else None
     act = H.ACT_GELU if kind == 2 else H.ACT_NONE
+    if kind == 3: res = None
     f = lambda: H.gemm(a, w, out=out, bias=bias, act=act, residual=res)
     for _ in range(3): f()
     torch.cuda.synchronize()
