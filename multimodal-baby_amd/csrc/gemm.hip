@@ -503,6 +503,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
     bool l_live = l_mt < p.num_m_tiles;
     if (l_live) { set_rows(l_mt); issue(0, 0); }
 
+    // true when the previous output tile of this workgroup issued exactly 8 stores per wave (all 128 rows inside M, C given)
+    bool counted_wait = false;
     for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
         const int m0 = cm * BM;
         f32x16 acc[2][2];
@@ -526,7 +528,16 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
         }
 
         for (int kt = 0; kt < ktiles; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the current tile has landed
+            // this wave's part of the current K tile has landed.  vmcnt retires in issue order (loads and stores alike
+            // on gfx9-family parts), so at the first K tile of an output tile only the operand loads -- issued BEFORE
+            // the previous tile's 8 epilogue stores (and this tile's 8 residual-row loads) -- have to be complete:
+            // a plain vmcnt(0) also waited for the store acknowledgements of the previous tile, once per output tile.
+            if (kt == 0 && counted_wait) {
+                if (EPI == 2 || (LIN && R)) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();                        // ... and everybody's; buffer buf^1 is free again
             if (++l_kt == ktiles) {
                 l_kt = 0;
@@ -608,7 +619,8 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                 if (EPI != 0 || C) *reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n) = v;
             }
         }
-        // the next loop iteration's vmcnt(0) + barrier orders these staging reads before the buffer is refilled
+        // the next loop iteration's vmcnt wait + barrier orders these staging reads before the buffer is refilled
+        counted_wait = (EPI != 0 || C != nullptr) && (m0 + BM <= p.M);
     }
 
     if (EPI == 0 && p.stats) {
