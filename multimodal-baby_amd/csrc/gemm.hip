@@ -666,16 +666,22 @@ __global__ void transpose_f32_kernel(const float* __restrict__ in, float* __rest
     }
 }
 
-// d_bias[n] = sum_m dY[m][n]; one workgroup per 64 columns, 4 row-slices reduced through LDS in a fixed order
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ dY, float* __restrict__ out, int M, int N) {
-    __shared__ float part[4][64];
-    const int c = threadIdx.x & 63, s = threadIdx.x >> 6, n = blockIdx.x * 64 + c;
+// d_bias[n] = sum_m dY[m][n]; one workgroup per 16 columns, 64 row slices reduced through LDS in a fixed order
+// (the first version used 64 columns x 4 slices: N / 64 workgroups walking M / 4 dependent loads each -- 60 us for a
+// 1280 x 2048 gradient)
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restrict__ dY, float* __restrict__ out, int M, int N) {
+    __shared__ float part[64][16];
+    const int c = threadIdx.x & 15, s = threadIdx.x >> 4, n = blockIdx.x * 16 + c;
     float acc = 0.f;
     if (n < N)
-        for (int m = s; m < M; m += 4) acc += dY[(long)m * N + n];
+        for (int m = s; m < M; m += 64) acc += dY[(long)m * N + n];
     part[s][c] = acc;
     __syncthreads();
-    if (s == 0 && n < N) out[n] = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+    if (s == 0 && n < N) {
+        float t = 0.f;
+        for (int i = 0; i < 64; ++i) t += part[i][c];
+        out[n] = t;
+    }
 }
 
 // Resident workgroups per CU of each kernel variant (queried once); the persistent grid never exceeds what is
@@ -909,7 +915,10 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
         auto al16p = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
         if (pro_kind(a) == 0 && !(a->gather_stride > 1) && !a->stats && !a->R && a->act == CVCL_ACT_NONE && a->K % 4 == 0 &&
             a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) &&
-            (long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN) <= 64) {
+            // measured cost models (us, MI355X): the split-K VALU kernel runs ~13.4 GMAC/s-per-us of work on any shape; the
+            // 128-tile fp32 MFMA kernel needs ~4.6 us per 64-deep K step per round of <= 256 tiles, whatever M and N are
+            (double)a->M * a->N * a->K / 13.4e6 + 5.0 <
+                12.0 + (a->K / 64.0) * 4.6 * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256)) {
             CvclProfScope prof(stream, CVCL_K_GEMM_F32);
             hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cvcl_div_up(a->N, 16), cvcl_div_up(a->M, 16)), dim3(256), 0, stream,
                                (const float*)a->A, (const float*)a->W, (float*)a->C, a->M, a->N, a->K, a->lda, a->ldw, a->ldc,
@@ -973,7 +982,7 @@ extern "C" int cvcl_transpose_f32(const float* in, float* out, int rows, int col
 extern "C" int cvcl_colsum_f32(const float* dY, float* d_bias, int M, int N, void* stream) {
     CVCL_CHECK_ARG(dY && d_bias && M > 0 && N > 0, "cvcl_colsum_f32: bad args");
     CvclProfScope prof(stream, CVCL_K_OTHER);
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3(cvcl_div_up(N, 64)), dim3(256), 0, (hipStream_t)stream, dY, d_bias, M, N);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(cvcl_div_up(N, 16)), dim3(1024), 0, (hipStream_t)stream, dY, d_bias, M, N);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
