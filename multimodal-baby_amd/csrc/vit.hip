@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int ATT_TPAD_MAX = 288;      // keys padded to a multiple of 32 (T <= 288 covers ViT-B/14 at 224: 257)
 constexpr int ATT_KP = 144;            // LDS bytes per K row (128 + 16)
-constexpr int ATT_VP = 160;            // LDS bytes per V row (128 + 32)
+constexpr int ATT_VP = 192;            // LDS bytes per V row (128 + 64): the 4 rows x 64 B that 32 lanes touch in one
+                                       // ds_read_b64_tr_b16 land on banks 0-15 / 48-63 / 32-47 / 16-31
 
 typedef __bf16 att_tr4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
 __device__ inline bf16x4 att_tr_read(const char* p) {
@@ -193,21 +194,32 @@ __device__ inline bf16x4 att_tr_read(const char* p) {
     return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16(lp));
 }
 
-__global__ __launch_bounds__(512) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B,
-                                                             int Tn, int heads, float scale, int Tpad, int nwaves) {
+// One workgroup (4 waves) per (image, head); K and V of the head are staged into LDS once (row-major, coalesced); every
+// wave walks 32-query tiles, streaming over 32-key tiles with an online softmax (running max / sum per query):
+//   S^T = K Q^T     v_mfma_f32_32x32x16_bf16, A = K rows from LDS (ds_read_b128), B = Q^T fragments from global; a lane
+//                   ends up with 16 of the 32 keys of the tile for ONE query (its column l31): keys 8b + 4h + c
+//   softmax         in registers: the lane's query statistics are shared only with lane ^ 32
+//   O^T += V^T P^T  P never leaves the registers: the 8 probabilities a lane holds for a 16-key step (keys 16u + 4h + c
+//                   and 16u + 8 + 4h + c) ARE a valid B-operand k block for its query, provided the A operand uses the
+//                   same key assignment -- V^T fragments (8 keys of one d per lane = the transpose of the row-major
+//                   image) come from two ds_read_b64_tr_b16 at key offsets 4h and 8 + 4h.  O^T keeps the query in the
+//                   lane's column, so the running rescale is one multiplier per lane.
+//   LDS = Tpad * 336 B (75 KB at T = 197): two workgroups per CU, so one stages while the other multiplies.
+// (v1: one workgroup per 64 queries, V^T rebuilt with 2-byte scatters: 440 us per ViT-B/16 layer at B = 256;
+//  v2: per-head workgroup, 16-query tiles, all of S in registers, P through LDS, 1 workgroup/CU: 190 us.)
+__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B,
+                                                                int Tn, int heads, float scale, int NT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int PP = (Tpad + 8) * 2;                                  // bytes per P row
+    const int Tpad = 32 * NT;
     char* sK = smem;                                                // [Tpad][ATT_KP]
     char* sV = sK + Tpad * ATT_KP;                                  // [Tpad][ATT_VP]
-    char* sP = sV + Tpad * ATT_VP;                                  // [nwaves][16 q][PP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, g = lane >> 4;
+    const int l31 = lane & 31, h = lane >> 5;
     const int hh = blockIdx.x % heads, b = blockIdx.x / heads;
     const int D = heads * 64;
     const bf16_t* base = qkv + (long)b * Tn * 3 * D;
 
-    // stage K and V rows of this head (zeros beyond Tn): 8 chunks of 16 B per row
-    for (int i = tid; i < Tpad * 8; i += blockDim.x) {
+    for (int i = tid; i < Tpad * 8; i += 256) {                     // 8 chunks of 16 B per row, zeros beyond Tn
         const int j = i >> 3, c = i & 7;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
         if (j < Tn) {
@@ -218,90 +230,82 @@ __global__ __launch_bounds__(512) void attention_mfma_kernel(const bf16_t* __res
         *reinterpret_cast<u32x4*>(sV + j * ATT_VP + c * 16) = vv;
     }
     __syncthreads();
-    if (wave >= nwaves) return;
 
-    const int ntile = Tpad / 16, nqt = (Tn + 15) / 16;
-    const float scale2 = scale * 1.4426950408889634f;
-    char* myP = sP + wave * 16 * PP;
-    // tr-read lane addressing inside a [4 keys][16 d] block: row (lane & 15) >> 2, d columns 4 * (lane & 3)
-    const int v_lane_off = (4 * g + (l15 >> 2)) * ATT_VP + (l15 & 3) * 8;
+    const float scale2 = scale * 1.4426950408889634f;               // logits in units of log2(e): exp(x) = 2^(x log2 e)
+    const int nqt = (Tn + 31) / 32;
+    // tr-read addressing inside a [4 keys][16 d] block: 16-lane group (lane >> 4) & 1 takes d columns +16
+    const int l15 = lane & 15;
+    const int v_lane_off = (4 * h + (l15 >> 2)) * ATT_VP + (((lane >> 4) & 1) * 16 + (l15 & 3) * 4) * 2;
 
-    for (int qt = wave; qt < nqt; qt += nwaves) {
-        const int q0 = qt * 16;
-        const int qrow = min(q0 + l15, Tn - 1);
-        bf16x8 qf[2];
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q0 = qt * 32;
+        const int qrow = min(q0 + l31, Tn - 1);
+        bf16x8 qf[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * 3 * D + hh * 64 + ks * 32 + g * 8);
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(base + (long)qrow * 3 * D + hh * 64 + ks * 16 + h * 8);
 
-        // S^T tiles: rows = keys (16 per tile), cols = queries; lane holds keys 4g..4g+3 of each tile for query l15
-        f32x4 s[ATT_TPAD_MAX / 16];
-        float mx = -INFINITY;
+        f32x16 o[2];                                                // O^T: rows d = 32 dt + 8b + 4h + c, column = this lane's query
 #pragma unroll
-        for (int t = 0; t < ATT_TPAD_MAX / 16; ++t) {
-            if (t < ntile) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 16 + l15) * ATT_KP + ks * 64 + g * 16);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+            for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;                       // l_run: this lane's share of the row sum
+
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * ATT_KP + ks * 32 + h * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                acc[r] = key < Tn ? acc[r] * scale2 : -INFINITY;
+                mx = fmaxf(mx, acc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);                   // finite: key 0 of tile 0 is always valid
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = __builtin_amdgcn_exp2f(acc[r] - m_new); psum += acc[r]; }   // v_exp_f32
+            l_run = fmaf(l_run, alpha, psum);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)acc[8 * u + e];
+                const char* vb = sV + (t * 32 + 16 * u) * ATT_VP + v_lane_off;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16x4 v0 = att_tr_read(vb + dt * 64);
+                    const bf16x4 v1 = att_tr_read(vb + 8 * ATT_VP + dt * 64);
+                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = t * 16 + g * 4 + e;
-                    acc[e] = key < Tn ? acc[e] * scale2 : -INFINITY;       // logits in units of log2(e): exp(x) = 2^(x log2 e)
-                    mx = fmaxf(mx, acc[e]);
-                }
-                s[t] = acc;
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
+        const float inv = 1.f / (l_run + __shfl_xor(l_run, 32, 64));
+        // this lane's query row: 8 runs of 4 consecutive d (d = 32 dt + 8b + 4h + c)
+        if (q0 + l31 < Tn) {
+            bf16_t* orow = out + ((long)b * Tn + q0 + l31) * D + hh * 64;
 #pragma unroll
-        for (int t = 0; t < ATT_TPAD_MAX / 16; ++t)
-            if (t < ntile) {
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { s[t][e] = __builtin_amdgcn_exp2f(s[t][e] - mx); sum += s[t][e]; }   // v_exp_f32
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
-        // P (bf16) -> wave-private LDS strip [q][key]
-#pragma unroll
-        for (int t = 0; t < ATT_TPAD_MAX / 16; ++t)
-            if (t < ntile) {
-                bf16x4 pv = {(bf16_t)(s[t][0] * inv), (bf16_t)(s[t][1] * inv), (bf16_t)(s[t][2] * inv), (bf16_t)(s[t][3] * inv)};
-                *reinterpret_cast<bf16x4*>(myP + l15 * PP + (t * 16 + g * 4) * 2) = pv;
-            }
-        // O[16 q][64 d] = P V over 32-key steps; lane's k block = keys {32ks + 4g + e} U {32ks + 16 + 4g + e}
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < Tpad / 32; ++ks) {
-            const bf16x4 p0 = *reinterpret_cast<const bf16x4*>(myP + l15 * PP + (ks * 32 + g * 4) * 2);
-            const bf16x4 p1 = *reinterpret_cast<const bf16x4*>(myP + l15 * PP + (ks * 32 + 16 + g * 4) * 2);
-            const bf16x8 pf = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const char* vb = sV + (ks * 32) * ATT_VP + v_lane_off;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const bf16x4 v0 = att_tr_read(vb + dt * 32);
-                const bf16x4 v1 = att_tr_read(vb + 16 * ATT_VP + dt * 32);
-                const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[dt], 0, 0, 0);
-            }
-        }
-        // D[row = query 4g+e][col = d 16dt + l15] -> strip as [q][64 d] (pitch 144 B) -> 16-byte row pieces
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                *reinterpret_cast<bf16_t*>(myP + (g * 4 + e) * ATT_KP + (dt * 16 + l15) * 2) = (bf16_t)o[dt][e];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = lane + 64 * i, q = idx >> 3, c = idx & 7;
-            if (q0 + q < Tn)
-                *reinterpret_cast<u32x4*>(out + ((long)b * Tn + q0 + q) * D + hh * 64 + c * 8) =
-                    *reinterpret_cast<const u32x4*>(myP + q * ATT_KP + c * 16);
+                for (int bb = 0; bb < 4; ++bb) {
+                    const bf16x4 v = {(bf16_t)(o[dt][4 * bb + 0] * inv), (bf16_t)(o[dt][4 * bb + 1] * inv),
+                                      (bf16_t)(o[dt][4 * bb + 2] * inv), (bf16_t)(o[dt][4 * bb + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(orow + dt * 32 + 8 * bb + 4 * h) = v;
+                }
         }
     }
 }
@@ -439,14 +443,8 @@ extern "C" int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok
     CvclProfScope prof(stream, CVCL_K_ATTENTION);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16 && head_dim == 64 && !key_tok && T > 32 && T <= ATT_TPAD_MAX) {   // T <= 32: generic kernel below
-        const int Tpad = (T + 31) / 32 * 32;
-        const size_t fixed = (size_t)Tpad * (ATT_KP + ATT_VP), strip = (size_t)16 * (Tpad + 8) * 2;
-        int nwaves = (int)((160 * 1024 - fixed) / strip);
-        if (nwaves > 8) nwaves = 8;
-        const int nqt = (T + 15) / 16;
-        if (nwaves > nqt) nwaves = nqt;
-        CVCL_CHECK_ARG(nwaves >= 1 && strip >= (size_t)16 * ATT_KP, "cvcl_attention: sequence too long for the MFMA kernel (%d)", T);
-        const size_t lds = fixed + nwaves * strip;
+        const int nt = (T + 31) / 32;
+        const size_t lds = (size_t)nt * 32 * (ATT_KP + ATT_VP);
         static bool attr_set = false;
         if (!attr_set) {
             if (hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -455,9 +453,8 @@ extern "C" int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok
             }
             attr_set = true;
         }
-        const int threads = nwaves <= 4 ? 256 : 512;
-        hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * heads), dim3(threads), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, T, heads,
-                           scale, Tpad, nwaves);
+        hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * heads), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, T, heads,
+                           scale, nt);
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }
