@@ -178,7 +178,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss = float(out["loss"])
+    loss = float(out["loss"].detach())
     pairs = world * PER_GPU_BATCH * a.steps
     value = pairs / elapsed
 

@@ -343,12 +343,12 @@ __global__ __launch_bounds__(256) void gram_bn_stats_kernel(const float* __restr
 
 struct TnPlan { int S; long chunk; int tiles_n, tiles_k, ntile; };
 
-TnPlan tn_plan(long M, int N, int K, int taps, bool diag, int tile, int target_wgs = 1024) {
+TnPlan tn_plan(long M, int N, int K, int taps, bool diag, int tile, int target_wgs = 512) {
     TnPlan pl;
     pl.tiles_n = cvcl_div_up(N, tile);
     pl.tiles_k = cvcl_div_up(K, tile);
     pl.ntile = diag ? pl.tiles_n : pl.tiles_n * pl.tiles_k;
-    long want = cvcl_div_up(target_wgs, (long)pl.ntile * taps);      // default ~4 workgroups per CU in total
+    long want = cvcl_div_up(target_wgs, (long)pl.ntile * taps);      // default ~2 workgroups per CU in total (1024: partial-tile traffic dominates, 256: too few)
     const long max_s = cvcl_div_up(M, 1024);                         // >= 1024 rows per split
     if (want > max_s) want = max_s;
     if (want < 1) want = 1;
