@@ -272,6 +272,10 @@ int cvcl_add(int dtype, const void* a, const void* b, void* y, long n, int relu,
 int cvcl_relu_mask(int dtype, const void* y, const void* dy, void* dx, long n, void* stream);    /* dx = dy where y > 0 */
 /* max pool 3x3/2 pad 1, NHWC: dy == NULL -> forward (out = pooled); else backward (out = dx, first arg-max wins) */
 int cvcl_maxpool3x3s2(int dtype, const void* x, const void* dy, void* out, int B, int H, int W, int C, void* stream);
+/* same pooling with the arg-max recorded (idx [B,Ho,Wo,C] u8, window position 0..8, first maximum): dy == NULL ->
+ * forward (reads x, writes out = pooled and idx); else backward from idx (x unused, out = dx)               */
+int cvcl_maxpool3x3s2_idx(int dtype, const void* x, const void* dy, void* out, uint8_t* idx, int B, int H, int W, int C,
+                          void* stream);
 int cvcl_avgpool_bwd(int dtype, const float* d_pooled, void* dx, int B, int HW, int C, void* stream);
 /* z[b,2oy,2ox,:] = dy[b,oy,ox,:], zeros elsewhere ([B,2Ho,2Wo,C]): data gradient of a stride-2 conv = stride-1 conv of z */
 int cvcl_zero_stuff2(int dtype, const void* dy, void* z, int B, int Ho, int Wo, int C, void* stream);

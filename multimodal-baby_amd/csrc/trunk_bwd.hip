@@ -289,6 +289,75 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// max pool with recorded arg-max (first maximum in row-major window order, like torch): the backward then needs, per input
+// pixel, the <= 4 covering windows' index bytes and gradients instead of re-scanning 4 x 9 inputs
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_idx_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                              int B, int H, int W, int C) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, CC = C / EPC;
+    const long total = (long)B * Ho * Wo * CC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CC) * EPC;
+        const long p = i / CC;
+        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
+        float m[EPC];
+        uint8_t k[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { m[e] = -INFINITY; k[e] = 0; }
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yin = 2 * oy - 1 + ky;
+            if (yin < 0 || yin >= H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xin = 2 * ox - 1 + kx;
+                if (xin < 0 || xin >= W) continue;
+                Chunk<T> v;
+                v.load(x + (((long)b * H + yin) * W + xin) * C + c);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (v.get(e) > m[e]) { m[e] = v.get(e); k[e] = (uint8_t)(ky * 3 + kx); }
+            }
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { o.set(e, m[e]); idx[p * C + c + e] = k[e]; }
+        o.store(y + p * C + c);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __restrict__ idx, const T* __restrict__ dy,
+                                                              T* __restrict__ dx, int B, int H, int W, int C) {
+    constexpr int EPC = ElemTraits<T>::kPerChunk;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, CC = C / EPC;
+    const long total = (long)B * H * W * CC;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CC) * EPC;
+        const long p = i / CC;
+        const int xi = (int)(p % W), yi = (int)((p / W) % H), b = (int)(p / ((long)W * H));
+        float acc[EPC];
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+        for (int oy = (yi + 1) / 2 - 1; oy <= (yi + 1) / 2; ++oy) {
+            if (oy < 0 || oy >= Ho || 2 * oy - 1 > yi || 2 * oy + 1 < yi) continue;
+            for (int ox = (xi + 1) / 2 - 1; ox <= (xi + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= Wo || 2 * ox - 1 > xi || 2 * ox + 1 < xi) continue;
+                const int code = (yi - (2 * oy - 1)) * 3 + (xi - (2 * ox - 1));
+                const long q = (((long)b * Ho + oy) * Wo + ox) * C + c;
+                Chunk<T> g;
+                g.load(dy + q);
+#pragma unroll
+                for (int e = 0; e < EPC; ++e)
+                    if (idx[q + e] == code) acc[e] += g.get(e);
+            }
+        }
+        Chunk<T> o;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) o.set(e, acc[e]);
+        o.store(dx + p * C + c);
+    }
+}
+
 // ---- avg pool backward: dx[b,p,c] = d_pooled[b,c] / HW -------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dp, T* __restrict__ dx, int B, int HW, int C) {
@@ -526,6 +595,26 @@ extern "C" int cvcl_maxpool3x3s2(int dtype, const void* x, const void* dy, void*
     } else {         // backward: out = dx [B,H,W,C]
         if (dtype == CVCL_F32) hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for((long)B * H * W * C / 4)), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)out, B, H, W, C);
         else hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid_for((long)B * H * W * C / 8)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)out, B, H, W, C);
+    }
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_maxpool3x3s2_idx(int dtype, const void* x, const void* dy, void* out, uint8_t* idx, int B, int H, int W, int C,
+                                     void* stream) {
+    CVCL_CHECK_ARG(out && idx && (x || dy) && B > 0 && H > 0 && W > 0 && C > 0 && C % epc_of(dtype) == 0, "cvcl_maxpool3x3s2_idx: bad args");
+    CvclProfScope prof(stream, CVCL_K_MAXPOOL);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipStream_t s = (hipStream_t)stream;
+    const int epc = epc_of(dtype);
+    if (!dy) {       // forward: out = pooled [B,Ho,Wo,C], idx = arg-max code 0..8 per output element
+        const int g = grid_for((long)B * Ho * Wo * C / epc);
+        if (dtype == CVCL_F32) hipLaunchKernelGGL(maxpool_fwd_idx_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)x, (float*)out, idx, B, H, W, C);
+        else hipLaunchKernelGGL(maxpool_fwd_idx_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, idx, B, H, W, C);
+    } else {         // backward: out = dx [B,H,W,C]
+        const int g = grid_for((long)B * H * W * C / epc);
+        if (dtype == CVCL_F32) hipLaunchKernelGGL(maxpool_bwd_idx_kernel<float>, dim3(g), dim3(256), 0, s, idx, (const float*)dy, (float*)out, B, H, W, C);
+        else hipLaunchKernelGGL(maxpool_bwd_idx_kernel<bf16_t>, dim3(g), dim3(256), 0, s, idx, (const bf16_t*)dy, (bf16_t*)out, B, H, W, C);
     }
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;

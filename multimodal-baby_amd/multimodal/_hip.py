@@ -107,6 +107,7 @@ SIGNATURES = {
     "cvcl_add": (_I, [_I, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_relu_mask": (_I, [_I, _P, _P, _P, C.c_long, _P]),
     "cvcl_maxpool3x3s2": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_maxpool3x3s2_idx": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_avgpool_bwd": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "cvcl_zero_stuff2": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_conv_wgrad_direct": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -273,21 +273,27 @@ class BnAddRelu(torch.autograd.Function):
 
 
 class MaxPool3x3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) on NHWC; the forward records the arg-max (one byte per output) for the backward."""
+
     @staticmethod
     def forward(ctx, x):
         B, Hh, Ww, Cn = x.shape
-        out = torch.empty(B, (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1, Cn, dtype=x.dtype, device=x.device)
-        H.check(H.lib().cvcl_maxpool3x3s2(_cd(x), H.ptr(x), None, H.ptr(out), B, Hh, Ww, Cn, H.stream_ptr()), "cvcl_maxpool3x3s2")
-        ctx.save_for_backward(x)
+        Ho, Wo = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+        out = torch.empty(B, Ho, Wo, Cn, dtype=x.dtype, device=x.device)
+        idx = torch.empty(B, Ho, Wo, Cn, dtype=torch.uint8, device=x.device)
+        H.check(H.lib().cvcl_maxpool3x3s2_idx(_cd(x), H.ptr(x), None, H.ptr(out), H.ptr(idx), B, Hh, Ww, Cn, H.stream_ptr()),
+                "cvcl_maxpool3x3s2_idx")
+        ctx.save_for_backward(idx)
+        ctx.in_shape, ctx.dt = (B, Hh, Ww, Cn), x.dtype
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
-        B, Hh, Ww, Cn = x.shape
-        dx = torch.empty_like(x)
-        H.check(H.lib().cvcl_maxpool3x3s2(_cd(x), H.ptr(x), H.ptr(dy.contiguous()), H.ptr(dx), B, Hh, Ww, Cn, H.stream_ptr()),
-                "cvcl_maxpool3x3s2")
+        (idx,) = ctx.saved_tensors
+        B, Hh, Ww, Cn = ctx.in_shape
+        dx = torch.empty(ctx.in_shape, dtype=ctx.dt, device=dy.device)
+        H.check(H.lib().cvcl_maxpool3x3s2_idx(H.cvcl_dtype(ctx.dt), None, H.ptr(dy.contiguous()), H.ptr(dx), H.ptr(idx), B, Hh, Ww, Cn,
+                                              H.stream_ptr()), "cvcl_maxpool3x3s2_idx")
         return dx
 
 
