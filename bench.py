@@ -153,12 +153,22 @@ def main():
     engine = parallel.DataParallelEngine(device, global_negatives=True).attach(lit)
     batch = synthetic_batch_on_device(PER_GPU_BATCH, seed=rank, device=device) + (None,)
 
+    # multi-GPU: the all-reduce + optimizer step of step k are enqueued behind the frozen trunk of step k+1
+    # (parallel.OverlappedUpdate; same parameter sequence as the sequential schedule); flushed before the clock stops
+    upd = parallel.OverlappedUpdate(engine, opt, ve) if world > 1 else None
+
     def step():
-        opt.zero_grad(set_to_none=True)
-        out = lit.training_step(batch, 0)
+        if upd is None:
+            opt.zero_grad(set_to_none=True)
+            out = lit.training_step(batch, 0)
+            out["loss"].backward()
+            engine.reduce_gradients()
+            opt.step()
+            return out
+        out = lit.training_step(batch, 0)          # trunk, then (hook) the previous step's update, then fc / text / loss
+        upd.zero_grad()
         out["loss"].backward()
-        engine.reduce_gradients()
-        opt.step()
+        upd.step_done()
         return out
 
     def barrier():
@@ -172,6 +182,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
+    if upd is not None:
+        upd.flush()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -190,6 +202,8 @@ def main():
         H.prof_enable(True)
         for _ in range(nprof):
             step()
+        if upd is not None:
+            upd.flush()
         torch.cuda.synchronize()
         prof = H.prof_collect()
         H.prof_enable(False)

@@ -221,6 +221,9 @@ class Trainer:
                 opt.load_state_dict(ckpt["optimizer_states"][0])
             start_epoch, self.global_step = int(ckpt.get("epoch", -1)) + 1, int(ckpt.get("global_step", 0))
         engine.attach(model)
+        upd = None
+        if parallel.is_distributed() and hasattr(model, "vision_encoder"):
+            upd = parallel.OverlappedUpdate(engine, opt, model.vision_encoder)
         for epoch in range(start_epoch, self.max_epochs):
             self.current_epoch = epoch
             model.train()
@@ -229,13 +232,21 @@ class Trainer:
                 if self.limit_train_batches is not None and bi >= self.limit_train_batches:
                     break
                 batch = _move(batch, device)
-                opt.zero_grad(set_to_none=True)
-                out = model.training_step(batch, bi)
-                out["loss"].backward()
-                engine.reduce_gradients()
-                opt.step()
+                if upd is None:
+                    opt.zero_grad(set_to_none=True)
+                    out = model.training_step(batch, bi)
+                    out["loss"].backward()
+                    engine.reduce_gradients()
+                    opt.step()
+                else:              # multi-GPU, frozen trunk: step k's all-reduce + update overlap step k+1's trunk forward
+                    out = model.training_step(batch, bi)
+                    upd.zero_grad()
+                    out["loss"].backward()
+                    upd.step_done()
                 self.global_step += 1
                 outs.append({k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()})
+            if upd is not None:
+                upd.flush()                    # every update applied before epoch-end hooks / validation / checkpoints
             if hasattr(model, "training_epoch_end") and outs:
                 model.training_epoch_end(outs)
             self.logged_metrics.update(model._logged)

@@ -157,3 +157,43 @@ class DataParallelEngine:
                 off += n
             b["pending"], b["handle"] = len(b["params"]), None
             b["seen"].clear()
+
+
+class OverlappedUpdate:
+    """Hide the gradient all-reduce and the optimizer step of step k behind the frozen image trunk of step k+1.
+
+    With a frozen CNN / ViT every trainable parameter (fc / head, text encoder, temperature) is used AFTER the trunk in
+    the forward pass, and nothing the optimizer changes is read by the trunk.  So after ``loss.backward()`` (whose hooks
+    have already launched the bucketed RCCL all-reduce) the next step's trunk can be enqueued immediately; the wait for
+    the collective, the write-back and ``optimizer.step()`` run from a hook placed just before the trunk's output is
+    consumed.  The sequence of parameter values is exactly the one of the sequential schedule; only the order in which
+    independent work is enqueued changes.  ``flush()`` completes the last pending update.  No-op schedule change when a
+    trunk parameter is trainable (``--finetune_cnn``): then the update is applied immediately.
+    """
+
+    def __init__(self, engine: DataParallelEngine, optimizer, vision_encoder):
+        self.engine, self.opt = engine, optimizer
+        self.pending = False
+        trunk = getattr(vision_encoder, "model", None)
+        head_names = ("fc.", "head.")
+        self.can_defer = trunk is not None and hasattr(trunk, "_pre_head_callback") and not any(
+            p.requires_grad for n, p in trunk.named_parameters() if not n.startswith(head_names))
+        if self.can_defer:
+            trunk._pre_head_callback = self.flush
+
+    def flush(self):
+        if self.pending:
+            self.pending = False
+            self.engine.reduce_gradients()
+            self.opt.step()
+
+    def step_done(self):
+        """call right after loss.backward()"""
+        self.pending = True
+        if not self.can_defer:
+            self.flush()
+
+    def zero_grad(self):
+        """call after the forward pass (which ran flush() through the hook) and before backward"""
+        self.flush()
+        self.opt.zero_grad(set_to_none=True)

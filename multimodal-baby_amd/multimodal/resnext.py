@@ -81,6 +81,7 @@ class ResNet(nn.Module):
         self.compute_dtype = torch.float32             # torch.bfloat16 = perf mode
         self._pack_cache = {}
         self._ws_cache = {}
+        self._pre_head_callback = None                  # parallel.OverlappedUpdate: runs between the trunk and fc
 
     # ---- (conv, bn) pairs in torchvision state_dict order -----------------------------------
     def conv_bn_pairs(self):
@@ -151,6 +152,7 @@ class ResNet(nn.Module):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_pack_cache"], d["_ws_cache"] = {}, {}
+        d["_pre_head_callback"] = None
         return d
 
     def __setstate__(self, d):
@@ -158,9 +160,13 @@ class ResNet(nn.Module):
         self.__dict__.setdefault("compute_dtype", torch.float32)      # objects pickled by torchvision lack these
         self.__dict__.setdefault("_pack_cache", {})
         self.__dict__.setdefault("_ws_cache", {})
+        self.__dict__.setdefault("_pre_head_callback", None)
 
     def forward(self, x):
         pooled, fmap = self.trunk(x)
+        cb = self.__dict__.get("_pre_head_callback")
+        if cb is not None:
+            cb()                                         # deferred all-reduce wait + optimizer step of the previous step
         # fire the forward hooks registered on layer4 (the reference's Hook(model.layer4)); done by hand so that it
         # also works when layer4 is a plain nn.Sequential unpickled from a torchvision-built checkpoint
         for hook in list(self.layer4._forward_hooks.values()):

@@ -81,3 +81,58 @@ def test_validation_and_four_way_trials(dev, tmp_path, monkeypatch):
     with contextlib.redirect_stdout(io.StringIO()):
         res = trainer.test(lit, dm)[0]
     assert "test_loss" in res and "test_accuracy" in res
+
+
+def test_overlapped_update_matches_sequential_schedule(dev):
+    """parallel.OverlappedUpdate defers the (all-reduce +) optimizer step of step k to a hook between the frozen trunk and
+    fc of step k+1: losses and final parameters must be bit-identical to the sequential schedule."""
+    import contextlib, io, copy
+    sys.path.insert(0, ROOT)
+    from bench import c2_args, synthetic_batch_on_device
+    from multimodal import parallel
+    from multimodal.multimodal import TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import read_vocab
+    from multimodal.multimodal_lit import MultiModalLitModel
+
+    def build():
+        torch.manual_seed(0)
+        args = c2_args()
+        with contextlib.redirect_stdout(io.StringIO()):
+            ve = VisionEncoder(args)
+            te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args)
+            lit = MultiModalLitModel(ve, te, args)
+        lit.to(dev); lit.set_precision("bf16"); lit.train()
+        return ve, lit
+
+    batches = [synthetic_batch_on_device(16, seed, dev) + (None,) for seed in range(4)]
+    ve, lit = build()
+    opt = lit.configure_optimizers()
+    seq_losses = []
+    for bt in batches:
+        opt.zero_grad(set_to_none=True)
+        out = lit.training_step(bt, 0)
+        out["loss"].backward()
+        opt.step()
+        seq_losses.append(float(out["loss"].detach()))
+    seq_params = {k: v.detach().clone() for k, v in lit.state_dict().items()}
+
+    ve2, lit2 = build()
+    opt2 = lit2.configure_optimizers()
+    eng = parallel.DataParallelEngine(dev).attach(lit2)
+    upd = parallel.OverlappedUpdate(eng, opt2, ve2)
+    assert upd.can_defer
+    ov_losses = []
+    for bt in batches:
+        out = lit2.training_step(bt, 0)
+        upd.zero_grad()
+        out["loss"].backward()
+        upd.step_done()
+        ov_losses.append(float(out["loss"].detach()))
+    assert upd.pending
+    upd.flush()
+    assert ov_losses == seq_losses
+    sd2 = lit2.state_dict()
+    assert all(torch.equal(seq_params[k], sd2[k]) for k in seq_params)
+    # a trainable trunk disables the deferral
+    ve2.model.layer4[0].conv1.weight.requires_grad_(True)
+    assert not parallel.OverlappedUpdate(eng, opt2, ve2).can_defer
