@@ -152,7 +152,9 @@ class Trainer:
         if self.gpus and self.gpus > 0:
             if not torch.cuda.is_available():
                 raise RuntimeError("--gpus > 0 but no GPU is visible")
-            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+            # one process per GPU; the modulo only matters when more ranks than GPUs are started on purpose
+            # (CVCL_DIST_BACKEND=gloo smoke runs of the N > 1 path on a single-GPU box)
+            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
         return torch.device("cpu")
 
     def _eval_loop(self, model, loaders, step_name, epoch_end_name, device):
