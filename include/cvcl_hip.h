@@ -305,6 +305,19 @@ size_t cvcl_conv1x1_bn_stats_gram_workspace_bytes(long M, int K);
 int cvcl_conv1x1_bn_stats_gram(const void* A, int lda, const void* W, int ldw, long M, int N, int K, float* stats,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* embedding_type == "spatial", sim == "max" (multimodal/multimodal.py:770-787).  mm [Bi*HW, Bt*L] f32 is the match map
+ * <image location, word> (one cvcl_gemm of the per-location image rows [Bi*HW, E] against the per-word text rows
+ * [Bt*L, E]);  logits[i][t] = exp(*neg_log_temp) * sum_l max_p mm[(i,p)][(t,l)] / len[t]  (all L positions, as the
+ * reference), arg [Bi, Bt*L] u8 = the winning location (first maximum).  HW <= 256.  The backward writes the dense
+ * d_mm (zero except at the winners), from which d image rows = d_mm . text rows and d text rows = d_mm^T . image rows.
+ * sim == "mean" needs no kernel of its own: mean over locations / words (cvcl_seq_sum_div) then cvcl_sim_logits.     */
+int cvcl_bf16_to_f32(const void* x, float* y, long n, void* stream);      /* n % 8 == 0, 16-byte aligned */
+int cvcl_spatial_max_fwd(const float* mm, const int64_t* len, const float* neg_log_temp, float* logits, uint8_t* arg,
+                         int Bi, int HW, int Bt, int L, void* stream);
+int cvcl_spatial_max_bwd(const float* d_logits, const uint8_t* arg, const int64_t* len, const float* neg_log_temp,
+                         const float* logits, float* d_mm, float* d_neg_log_temp /* nullable */, int Bi, int HW, int Bt, int L,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

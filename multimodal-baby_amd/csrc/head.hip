@@ -306,6 +306,54 @@ extern "C" int cvcl_embed_meanpool_fwd(const float* table, const int64_t* tok, c
     return CVCL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// embedding_type == "spatial", sim == "max" (reference multimodal/multimodal.py:770-780): the match map
+// mm[(i,p)][(t,l)] = <image location p of image i, word l of utterance t> comes from one fp32 GEMM; this kernel takes the
+// best location per word, sums over ALL L positions and divides by the utterance length:
+//   logits[i][t] = exp(neg_log_temp) * sum_l max_p mm[(i,p)][(t,l)] / len[t];   arg[i][(t,l)] = that location (first max)
+// one workgroup per image i; thread per (t,l) column (coalesced over columns), then thread per t.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spatial_max_fwd_kernel(const float* __restrict__ mm, const int64_t* __restrict__ len,
+                                                              const float* __restrict__ neg_log_temp, float* __restrict__ logits,
+                                                              uint8_t* __restrict__ arg, int HW, int Bt, int L) {
+    extern __shared__ float colmax[];                           // [Bt * L]
+    const int i = blockIdx.x, ncol = Bt * L;
+    const float* base = mm + (long)i * HW * ncol;
+    for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
+        float best = base[c];
+        int bp = 0;
+        for (int p = 1; p < HW; ++p) {
+            const float v = base[(long)p * ncol + c];
+            if (v > best) { best = v; bp = p; }
+        }
+        colmax[c] = best;
+        arg[(long)i * ncol + c] = (uint8_t)bp;
+    }
+    __syncthreads();
+    const float scale = expf(*neg_log_temp);
+    for (int t = threadIdx.x; t < Bt; t += blockDim.x) {
+        float s = 0.f;
+        for (int l = 0; l < L; ++l) s += colmax[t * L + l];
+        logits[(long)i * Bt + t] = s / (float)len[t] * scale;
+    }
+}
+
+// d_mm[(i,p)][(t,l)] = (p == arg[i][(t,l)]) * d_logits[i][t] * exp(neg_log_temp) / len[t]   (dense, fully overwritten)
+__global__ __launch_bounds__(256) void spatial_max_bwd_kernel(const float* __restrict__ d_logits, const uint8_t* __restrict__ arg,
+                                                              const int64_t* __restrict__ len, const float* __restrict__ neg_log_temp,
+                                                              float* __restrict__ d_mm, int Bi, int HW, int Bt, int L) {
+    const int ncol = Bt * L;
+    const long total = (long)Bi * HW * ncol;
+    const float scale = expf(*neg_log_temp);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % ncol);
+        const long r = e / ncol;
+        const int p = (int)(r % HW), i = (int)(r / HW);
+        const int t = c / L;
+        d_mm[e] = arg[(long)i * ncol + c] == p ? d_logits[(long)i * Bt + t] * scale / (float)len[t] : 0.f;
+    }
+}
+
 extern "C" int cvcl_embed_meanpool_bwd(const float* d_ret, const int64_t* tok, const int64_t* len, float* d_table,
                                        int B, int L, int E, int V, void* stream) {
     CVCL_CHECK_ARG(d_ret && tok && len && d_table, "cvcl_embed_meanpool_bwd: null pointer");
@@ -428,6 +476,45 @@ extern "C" int cvcl_row_entropy(const float* x, float* out, int R, int N, void* 
     CVCL_CHECK_ARG(x && out && R > 0 && N > 0, "cvcl_row_entropy: bad args");
     CvclProfScope prof(stream, CVCL_K_HEAD);
     hipLaunchKernelGGL(row_entropy_kernel, dim3(cvcl_div_up(R, 4)), dim3(256), 0, (hipStream_t)stream, x, out, R, N);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_spatial_max_fwd(const float* mm, const int64_t* len, const float* neg_log_temp, float* logits, uint8_t* arg,
+                                    int Bi, int HW, int Bt, int L, void* stream) {
+    CVCL_CHECK_ARG(mm && len && neg_log_temp && logits && arg && Bi > 0 && HW > 0 && HW <= 256 && Bt > 0 && L > 0,
+                   "cvcl_spatial_max_fwd: bad args");
+    const size_t lds = (size_t)Bt * L * sizeof(float);
+    CVCL_CHECK_ARG(lds <= 64 * 1024, "cvcl_spatial_max_fwd: %d text positions exceed the LDS row buffer", Bt * L);
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(spatial_max_fwd_kernel, dim3(Bi), dim3(256), lds, (hipStream_t)stream, mm, len, neg_log_temp, logits, arg, HW, Bt, L);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+// d_neg_log_temp = sum d_logits * logits (logits = match * exp(nlt)); one workgroup, fixed order
+__global__ __launch_bounds__(1024) void dot_all_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
+                                                       float* __restrict__ out) {
+    __shared__ float scratch[16];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) acc = fmaf(a[i], b[i], acc);
+    acc = block_sum(acc, scratch);
+    if (threadIdx.x == 0) *out = acc;
+}
+
+extern "C" int cvcl_spatial_max_bwd(const float* d_logits, const uint8_t* arg, const int64_t* len, const float* neg_log_temp,
+                                    const float* logits, float* d_mm, float* d_neg_log_temp, int Bi, int HW, int Bt, int L,
+                                    void* stream) {
+    CVCL_CHECK_ARG(d_logits && arg && len && neg_log_temp && d_mm && Bi > 0 && HW > 0 && Bt > 0 && L > 0 &&
+                       (!d_neg_log_temp || logits), "cvcl_spatial_max_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    if (d_neg_log_temp)
+        hipLaunchKernelGGL(dot_all_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_logits, logits, (long)Bi * Bt, d_neg_log_temp);
+    const long total = (long)Bi * HW * Bt * L;
+    long g = (total + 255) / 256;
+    if (g > 16384) g = 16384;
+    hipLaunchKernelGGL(spatial_max_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, d_logits, arg, len, neg_log_temp, d_mm, Bi,
+                       HW, Bt, L);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

@@ -358,6 +358,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const uint8_t* __r
     }
 }
 
+// ---- bf16 -> f32 copy (spatial head: the per-location features leave the bf16 trunk for the fp32 projection) -----------
+__global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 8; i += (long)gridDim.x * blockDim.x) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + i * 8);
+        *reinterpret_cast<f32x4*>(y + i * 8) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        *reinterpret_cast<f32x4*>(y + i * 8 + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    }
+}
+
 // ---- avg pool backward: dx[b,p,c] = d_pooled[b,c] / HW -------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dp, T* __restrict__ dx, int B, int HW, int C) {
@@ -652,6 +661,14 @@ extern "C" int cvcl_conv_wgrad_direct(int dtype, const void* x, const void* dy, 
     else
         hipLaunchKernelGGL(conv_wgrad_direct_kernel<bf16_t>, dim3(nw), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)dy, dw, B, H, W,
                            Cin, Cout, cin_per_group, k, stride, pad, Ho, Wo, x_is_nchw_f32);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_bf16_to_f32(const void* x, float* y, long n, void* stream) {
+    CVCL_CHECK_ARG(x && y && n > 0 && n % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cvcl_bf16_to_f32: bad args");
+    CvclProfScope prof(stream, CVCL_K_OTHER);
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

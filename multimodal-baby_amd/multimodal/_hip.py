@@ -122,6 +122,9 @@ SIGNATURES = {
     "cvcl_gemm256": (_I, [_I, _P, _P]),
     "cvcl_gemm256_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cvcl_gemm256_stats_rows": (_I, [_I]),
+    "cvcl_bf16_to_f32": (_I, [_P, _P, C.c_long, _P]),
+    "cvcl_spatial_max_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_spatial_max_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }

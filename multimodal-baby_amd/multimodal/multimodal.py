@@ -74,9 +74,8 @@ class VisionEncoder(nn.Module):
         if getattr(self, "vit_dino", False):
             cls = self.model(x)                               # pre-head cls token (reference :91)
             return ops.linear_f32(cls, self.model.head.weight, self.model.head.bias), None   # reference :92
-        if self.embedding_type == "spatial":
-            raise NotImplementedError("spatial embeddings are outside the contrastive hot path (SURVEY.md 8f4)")
-        with Hook(self.model.layer4, requires_grad=False) as hook:    # reference :100-102
+        layer = self.model[-2] if self.embedding_type == "spatial" else self.model.layer4     # reference :96-99
+        with Hook(layer, requires_grad=False) as hook:                # reference :100-102
             features = self.model(x)
             feature_map = hook.activation
         return features, feature_map
@@ -113,9 +112,12 @@ class VisionEncoder(nn.Module):
             set_parameter_requires_grad(model)
         else:
             print("Fine-tuning CNN layers!")
-        if self.embedding_type == "spatial":
-            raise NotImplementedError("spatial embeddings are outside the contrastive hot path (SURVEY.md 8f4)")
-        if self.embedding_type == "flat":
+        if self.embedding_type == "spatial":                          # reference :181-185
+            if self.vit_dino:
+                raise NotImplementedError("spatial embeddings are defined for the CNN encoders only")
+            from .resnext import SpatialResNet
+            model = SpatialResNet(model, self.embedding_dim)
+        elif self.embedding_type == "flat":
             print("Adding linear layer to vision encoder!")
             if self.vit_dino:
                 model.head = nn.Linear(self.last_cnn_out_dim, self.embedding_dim)
@@ -200,11 +202,15 @@ class TextEncoder(nn.Module):
 
     def forward(self, x, x_len, image_features=None, image_feature_map=None):
         attns = None
-        if self.embedding_type != "flat":
-            raise NotImplementedError("spatial embeddings are outside the contrastive hot path (SURVEY.md 8f4)")
         if self.dropout_o and self.training:
             raise NotImplementedError("output dropout > 0 is not used by any contrastive configuration")
-        if self.text_encoder == "embedding":
+        spatial = self.embedding_type == "spatial"
+        if self.text_encoder == "embedding" and spatial:
+            # per-word embeddings are the features (reference :499, :579-580); differentiable gather
+            B, L = x.shape
+            raw_output = text_train.EmbedGatherPos.apply(self.embedding.weight, None, x).view(B, L, self.embedding_dim)
+            ret = raw_output
+        elif self.text_encoder == "embedding":
             ret, raw_output = ops.embed_meanpool(self.embedding.weight, x, x_len, True)       # reference :496-503
         elif self.text_encoder == "lstm":                                                    # reference :513-552
             if self.training or torch.is_grad_enabled():
@@ -222,6 +228,8 @@ class TextEncoder(nn.Module):
                 ret, raw_output = ops.transformer_text(self.embedding.weight, layer, pos, x, x_len)
         else:
             raise NotImplementedError(f"text encoder {self.text_encoder!r} is outside the contrastive hot path")
+        if spatial and self.text_encoder != "embedding":
+            ret = raw_output                                                                  # reference :579-580
         return ret, raw_output, attns
 
     @property
@@ -289,20 +297,51 @@ class MultiModalModel(nn.Module):
     def encode_image(self, image):
         image_features, image_feature_map = self.image_embed(image)
         if self.normalize_features:
-            image_features = ops.l2_normalize(image_features)               # reference :736
+            if image_features.dim() == 4:            # spatial: F.normalize(dim=1) = per location over E (NHWC rows underneath)
+                B, E, Hh, Ww = image_features.shape
+                rows = ops.l2_normalize(image_features.permute(0, 2, 3, 1).reshape(B * Hh * Ww, E))
+                image_features = rows.view(B, Hh, Ww, E).permute(0, 3, 1, 2)
+            else:
+                image_features = ops.l2_normalize(image_features)           # reference :736
         return image_features, image_feature_map
 
     def encode_text(self, text, text_length):
         text_features, text_outputs, attns = self.text_embed(text, text_length)
         if self.normalize_features:
-            text_features = ops.l2_normalize(text_features)                  # reference :743
+            if text_features.dim() == 3:             # spatial: per word over E
+                B, L, E = text_features.shape
+                text_features = ops.l2_normalize(text_features.reshape(B * L, E)).view(B, L, E)
+            else:
+                text_features = ops.l2_normalize(text_features)              # reference :743
         return text_features, text_outputs
 
     def forward(self, image, text, text_length, return_image_features=False, return_text_outputs=False):
         image_features, image_feature_map = self.encode_image(image)
         text_features, text_outputs = self.encode_text(text, text_length)
-        if self.embedding_type != "flat":
-            raise NotImplementedError("spatial similarity is outside the contrastive hot path (SURVEY.md 8f4)")
+        if self.embedding_type == "spatial":                                 # reference :757-780
+            if self.training and self.global_negatives and parallel.is_distributed():
+                raise NotImplementedError("spatial embeddings under data parallelism need --local_negatives")
+            Bi, E, Hh, Ww = image_features.shape
+            Bt, L, _ = text_features.shape
+            rows_i = image_features.permute(0, 2, 3, 1).reshape(Bi * Hh * Ww, E)
+            rows_t = text_features.reshape(Bt * L, E)
+            nlt = self._temperature_on(rows_i.device)
+            if self.sim == "max":        # best location per word, summed over all L positions, / len
+                logits_per_image = ops.spatial_max_logits(rows_i, rows_t, text_length, nlt, Bi, Hh * Ww, Bt, L)
+            elif self.sim == "mean":     # sum of all location x word products / (H W len) = <mean location, sum words / len>
+                hw = torch.full((Bi,), Hh * Ww, dtype=torch.int64, device=rows_i.device)
+                pi = text_train.SeqSumDiv.apply(rows_i, hw, Bi, Hh * Ww)
+                pt = text_train.SeqSumDiv.apply(rows_t, text_length, Bt, L)
+                logits_per_image = ops.sim_logits(pi, pt, nlt)
+            else:
+                raise ValueError(self.sim)
+            logits_per_text = logits_per_image.t()
+            ret = logits_per_image, logits_per_text
+            if return_image_features:
+                ret = ret + (image_features, image_feature_map)
+            if return_text_outputs:
+                ret = ret + (text_outputs,)
+            return ret
         fi, ft = image_features, text_features
         if self.training and self.global_negatives and parallel.is_distributed():
             fi, ft = parallel.gather_features(fi, ft)                        # RCCL all-gather over xGMI

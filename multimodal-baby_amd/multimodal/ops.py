@@ -102,6 +102,49 @@ class SimLogits(torch.autograd.Function):
         return d_img, d_txt, (d_s.reshape(ctx.temp_shape) if need_s else None)
 
 
+class SpatialMaxLogits(torch.autograd.Function):
+    """embedding_type='spatial', sim='max' (reference multimodal/multimodal.py:770-787):
+    logits[i][t] = exp(nlt) * sum_l max_p <img[i,p,:], txt[t,l,:]> / len[t].
+    img_rows [Bi*HW, E] (per-location features, NHWC order), txt_rows [Bt*L, E] (per-word outputs)."""
+
+    @staticmethod
+    def forward(ctx, img_rows, txt_rows, length, neg_log_temp, Bi, HW, Bt, L):
+        img_rows, txt_rows = img_rows.contiguous(), txt_rows.contiguous()
+        dev = img_rows.device
+        nlt = neg_log_temp.reshape(1).contiguous()
+        mm = H.gemm(img_rows, txt_rows)                                  # [Bi*HW, Bt*L] match map, fp32
+        logits = torch.empty(Bi, Bt, dtype=_F, device=dev)
+        arg = torch.empty(Bi, Bt * L, dtype=torch.uint8, device=dev)
+        H.check(H.lib().cvcl_spatial_max_fwd(H.ptr(mm), H.ptr(length, torch.int64), H.ptr(nlt, _F), H.ptr(logits), H.ptr(arg),
+                                             Bi, HW, Bt, L, H.stream_ptr()), "cvcl_spatial_max_fwd")
+        ctx.save_for_backward(img_rows, txt_rows, length, nlt, logits, arg)
+        ctx.dims = (Bi, HW, Bt, L)
+        ctx.temp_shape = neg_log_temp.shape
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        img_rows, txt_rows, length, nlt, logits, arg = ctx.saved_tensors
+        Bi, HW, Bt, L = ctx.dims
+        dev = img_rows.device
+        E = img_rows.shape[1]
+        need_i, need_t, _nl, need_s = ctx.needs_input_grad[:4]
+        d_mm = torch.empty(Bi * HW, Bt * L, dtype=_F, device=dev)
+        d_s = torch.empty(1, dtype=_F, device=dev) if need_s else None
+        s = H.stream_ptr()
+        H.check(H.lib().cvcl_spatial_max_bwd(H.ptr(d_logits.contiguous(), _F), H.ptr(arg), H.ptr(length), H.ptr(nlt), H.ptr(logits),
+                                             H.ptr(d_mm), H.ptr(d_s), Bi, HW, Bt, L, s), "cvcl_spatial_max_bwd")
+
+        def transposed(t2d):
+            r, c = t2d.shape
+            out = torch.empty(c, r, dtype=_F, device=dev)
+            H.check(H.lib().cvcl_transpose_f32(H.ptr(t2d), H.ptr(out), r, c, s), "cvcl_transpose_f32")
+            return out
+        d_img = H.gemm(d_mm, transposed(txt_rows)) if need_i else None               # [Bi*HW, E] = d_mm . txt_rows
+        d_txt = H.gemm(transposed(d_mm), transposed(img_rows)) if need_t else None   # [Bt*L, E] = d_mm^T . img_rows
+        return d_img, d_txt, None, (d_s.reshape(ctx.temp_shape) if need_s else None), None, None, None, None
+
+
 class InfoNCE(torch.autograd.Function):
     """Symmetric InfoNCE + accuracies + entropies (reference multimodal/multimodal.py:801-818)."""
 
@@ -169,6 +212,10 @@ class LinearF32(torch.autograd.Function):
             db = torch.empty(N, dtype=_F, device=x.device)
             H.check(H.lib().cvcl_colsum_f32(H.ptr(dy), H.ptr(db), M, N, s), "cvcl_colsum_f32")
         return dx, dw, db
+
+
+def spatial_max_logits(img_rows, txt_rows, length, neg_log_temp, Bi, HW, Bt, L):
+    return SpatialMaxLogits.apply(img_rows, txt_rows, length, neg_log_temp, Bi, HW, Bt, L)
 
 
 def embed_meanpool(table, tok, length, want_output=True):

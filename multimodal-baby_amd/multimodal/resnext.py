@@ -176,6 +176,49 @@ class ResNet(nn.Module):
         return self.fc(pooled)                           # e.g. nn.Identity (utils.build_dino_mugs)
 
 
+class SpatialResNet(nn.Sequential):
+    """embedding_type='spatial' vision model of the reference (multimodal.py:181-185):
+    ``nn.Sequential(*list(resnet.children())[:-2], nn.Conv2d(2048, E, 1))`` -- same child indices, hence the same
+    state_dict keys (``0.weight`` = conv1 ... ``7.*`` = layer4, ``8.*`` = the 1x1 projection).  The children ARE the
+    ResNet's modules (shared parameters); the trunk runs through ``cvcl_resnext50_fwd`` and the projection as an fp32
+    GEMM over the per-location rows.  Output: ([B, E, H/32, W/32] view of NHWC rows, layer4 map)."""
+
+    def __init__(self, resnet: ResNet, embedding_dim: int):
+        super().__init__(resnet.conv1, resnet.bn1, resnet.relu, resnet.maxpool, resnet.layer1, resnet.layer2, resnet.layer3,
+                         resnet.layer4, nn.Conv2d(2048, embedding_dim, 1))
+        object.__setattr__(self, "_resnet", resnet)          # not a registered child: its modules are already children 0..7
+
+    @property
+    def compute_dtype(self):
+        return self._resnet.compute_dtype
+
+    @compute_dtype.setter
+    def compute_dtype(self, dt):
+        self._resnet.compute_dtype = dt
+
+    def train(self, mode: bool = True):
+        super().train(mode)
+        self._resnet.training = mode
+        return self
+
+    def forward(self, x):
+        r = self._resnet
+        if torch.is_grad_enabled() and any(p.requires_grad for c, b, _ in r.conv_bn_pairs() for p in (c.weight, b.weight, b.bias)):
+            raise NotImplementedError("fine-tuning the trunk together with spatial embeddings is not implemented")
+        _pooled, fmap = r.trunk(x)                           # fmap: NCHW view of the NHWC layer-4 map
+        for hook in list(self[7]._forward_hooks.values()):   # the reference hooks model[-2] = layer4
+            hook(self[7], (fmap,), fmap)
+        B, Cc, Hh, Ww = fmap.shape
+        rows = fmap.permute(0, 2, 3, 1).reshape(B * Hh * Ww, Cc)
+        if rows.dtype != torch.float32:
+            r32 = torch.empty(rows.shape, dtype=torch.float32, device=rows.device)
+            H.check(H.lib().cvcl_bf16_to_f32(H.ptr(rows), H.ptr(r32), rows.numel(), H.stream_ptr()), "cvcl_bf16_to_f32")
+            rows = r32
+        proj = self[8]
+        feat = ops.linear_f32(rows, proj.weight.view(proj.out_channels, Cc), proj.bias)       # [B*H*W, E]
+        return feat.view(B, Hh, Ww, proj.out_channels).permute(0, 3, 1, 2)
+
+
 def register_torchvision_alias():
     """Make ``torchvision.models.resnet.{ResNet,Bottleneck}`` resolvable when torchvision is absent, so that the
     reference's Lightning checkpoints (whose ``hyper_parameters`` pickle the whole VisionEncoder, i.e. a torchvision

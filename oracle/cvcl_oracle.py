@@ -183,6 +183,25 @@ def similarity_logits(image_features: Tensor, text_features: Tensor,
     return match * logit_scale, match.t() * logit_scale      # :786-787
 
 
+# f4  spatial similarity (embedding_type == "spatial")         multimodal.py:757-787
+def spatial_similarity_logits(image_features: Tensor, text_features: Tensor, text_length: Tensor,
+                              logit_neg_log_temperature: Tensor, sim: str = "max") -> Tuple[Tensor, Tensor]:
+    """image_features [Bi,E,H,W], text_features [Bt,L,E] (per-word outputs), text_length [Bt].
+    mean: sum of all location x word dot products / (H W len[t])                       (:761-769)
+    max:  for every word the best location, summed over ALL L positions / len[t]       (:770-780)"""
+    Bi, E, Hh, Ww = image_features.shape
+    img = image_features.reshape(Bi, E, Hh * Ww)
+    if sim == "mean":
+        match = torch.einsum("iep,tle->it", img, text_features) / (Hh * Ww * text_length)
+    elif sim == "max":
+        mm = torch.einsum("iep,tle->itlp", img, text_features)
+        match = mm.amax(dim=3).sum(dim=2) / text_length
+    else:
+        raise ValueError(sim)
+    logit_scale = logit_neg_log_temperature.exp()
+    return match * logit_scale, match.t() * logit_scale
+
+
 # --------------------------------------------------------------------------------------
 # a9  symmetric InfoNCE + accuracies + entropies               multimodal.py:801-818, utils.py:106-108
 # --------------------------------------------------------------------------------------

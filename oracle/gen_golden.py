@@ -411,6 +411,52 @@ def case_tokenizer(lit_mod):
     save("tokenizer", texts=np.array(texts), tokens=tok, lengths=ln, vocab_size=np.array([len(vocab)]))
 
 
+def case_spatial(mm):
+    """embedding_type='spatial' (reference multimodal.py:757-780): per-location image features x per-word text features,
+    'max' and 'mean' similarity, through the reference's own MultiModalModel.forward / calculate_contrastive_loss."""
+    class ImgEnc(nn.Module):
+        def __init__(self, f):
+            super().__init__()
+            self.f = nn.Parameter(f.clone())
+
+        def forward(self, x):
+            return self.f, None
+
+    class TxtEnc(nn.Module):
+        def __init__(self, f):
+            super().__init__()
+            self.f = nn.Parameter(f.clone())
+
+        def forward(self, x, x_len=None):
+            return self.f, self.f, None
+
+    for sim in ("max", "mean"):
+        g = torch.Generator().manual_seed(7 if sim == "max" else 8)
+        B, E, Hh, Ww, L = 6, 24, 3, 3, 5
+        lens = torch.tensor([5, 3, 4, 2, 5, 1])
+        fi = torch.randn(B, E, Hh, Ww, generator=g)
+        ft = torch.randn(B, L, E, generator=g)
+        ft = ft + 0.5 * fi.mean(dim=(2, 3))[:, None, :]
+        ft = ft * (torch.arange(L)[None, :, None] < lens[:, None, None])            # pad positions embed to zero rows
+        args = argparse.Namespace(sim=sim, embedding_type="spatial", normalize_features=True, temperature=0.07,
+                                  fix_temperature=False)
+        model = mm.MultiModalModel(ImgEnc(fi), TxtEnc(ft), args)
+        dummy = torch.zeros(B, 1)
+        out = model.calculate_contrastive_loss(dummy, dummy, lens)
+        out[0].backward()
+        names = "infonce image_accuracy text_accuracy image_entropy text_entropy".split()
+        arrs = dict(image_raw=fi, text_raw=ft, lens=lens, neg_log_temp=model.logit_neg_log_temperature.detach().reshape(1),
+                    logits_per_image=out[5], d_image_raw=model.image_embed.f.grad, d_text_raw=model.text_embed.f.grad,
+                    d_neg_log_temp=model.logit_neg_log_temperature.grad.reshape(1))
+        arrs.update({k: out[i].detach().reshape(1) for i, k in enumerate(names)})
+        a = torch.nn.functional.normalize(fi, p=2, dim=1)
+        b = torch.nn.functional.normalize(ft, p=2, dim=-1)
+        lpi, lpt = O.spatial_similarity_logits(a, b, lens, model.logit_neg_log_temperature.detach(), sim)
+        print(f"spatial/{sim}: oracle logits rel {maxrel(lpi, out[5]):.2e}")
+        assert maxrel(lpi, out[5]) < 5e-6 and torch.equal(out[6], out[5].t())
+        save(f"spatial_{sim}", **arrs)
+
+
 def main():
     install_stubs()
     from multimodal import multimodal as mm
@@ -419,6 +465,7 @@ def main():
     torch.set_num_threads(8)
     case_text_encoders(mm)
     case_head(mm)
+    case_spatial(mm)
     case_vit(vits)
     case_tokenizer(lit_mod)
     case_cvcl_step(mm, lit_mod)

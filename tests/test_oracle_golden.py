@@ -62,6 +62,24 @@ def test_head_square(name, norm):
     assert maxrel(O.infonce_dlogits(lpi.detach()), lp.grad) < 1e-5
 
 
+@pytest.mark.parametrize("sim", ["max", "mean"])
+def test_spatial_similarity(sim):
+    """embedding_type='spatial' (reference multimodal.py:757-780): logits, loss scalars and feature / temperature gradients."""
+    import torch.nn.functional as F
+    g = load_golden("spatial_" + sim)
+    fi = g["image_raw"].clone().requires_grad_(True)
+    ft = g["text_raw"].clone().requires_grad_(True)
+    nlt = g["neg_log_temp"].reshape(()).clone().requires_grad_(True)
+    lpi, lpt = O.spatial_similarity_logits(F.normalize(fi, p=2, dim=1), F.normalize(ft, p=2, dim=-1), g["lens"], nlt, sim)
+    out = O.contrastive_loss(lpi, lpt)
+    assert maxrel(lpi, g["logits_per_image"]) < TOL
+    for i, k in enumerate("infonce image_accuracy text_accuracy image_entropy text_entropy".split()):
+        assert abs(float(out[i]) - float(g[k])) < 2e-5, k
+    out[0].backward()
+    assert maxrel(fi.grad, g["d_image_raw"]) < 2e-5 and maxrel(ft.grad, g["d_text_raw"]) < 2e-5
+    assert abs(float(nlt.grad) - float(g["d_neg_log_temp"])) < 1e-5 * max(1.0, abs(float(g["d_neg_log_temp"])))
+
+
 @pytest.mark.parametrize("name", ["eval_4x1", "eval_1x4"])
 def test_head_nonsquare(name):
     g = load_golden("head_" + name)

@@ -1,0 +1,132 @@
+"""GPU parity of the embedding_type='spatial' branch (reference multimodal/multimodal.py:96-99, 181-185, 579-580, 757-787):
+per-location image features x per-word text features with 'max' / 'mean' similarity, vs golden vectors produced by the
+reference's own MultiModalModel and vs the oracle end to end."""
+import argparse
+import contextlib
+import io
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import cvcl_oracle as O
+from conftest import ROOT, load_golden, maxrel
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, ROOT)
+
+
+class _ImgEnc(nn.Module):
+    def __init__(self, f):
+        super().__init__()
+        self.f = nn.Parameter(f.clone())
+
+    def forward(self, x):
+        return self.f, None
+
+
+class _TxtEnc(nn.Module):
+    def __init__(self, f):
+        super().__init__()
+        self.f = nn.Parameter(f.clone())
+
+    def forward(self, x, x_len=None):
+        return self.f, self.f, None
+
+
+@pytest.mark.parametrize("sim", ["max", "mean"])
+def test_spatial_head_golden(dev, sim):
+    """normalise + spatial similarity + InfoNCE through multimodal.MultiModalModel on given features == reference."""
+    from multimodal.multimodal import MultiModalModel
+    g = load_golden("spatial_" + sim)
+    args = argparse.Namespace(sim=sim, embedding_type="spatial", normalize_features=True, temperature=0.07, fix_temperature=False)
+    # the HIP path keeps per-location features as NHWC rows: hand the model an NCHW *view* of NHWC storage, like the encoder does
+    fi = g["image_raw"].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    model = MultiModalModel(_ImgEnc(fi), _TxtEnc(g["text_raw"]), args).to(dev)
+    lens = g["lens"].to(dev)
+    out = model.calculate_contrastive_loss(torch.zeros(6, 1, device=dev), torch.zeros(6, 1, device=dev), lens)
+    assert maxrel(out[5], g["logits_per_image"]) < 2e-5 and torch.equal(out[6], out[5].t())
+    for i, k in enumerate("infonce image_accuracy text_accuracy image_entropy text_entropy".split()):
+        assert abs(float(out[i].detach()) - float(g[k])) < 2e-5, k
+    out[0].backward()
+    assert maxrel(model.image_embed.f.grad, g["d_image_raw"]) < 5e-5
+    # pad positions hold zero vectors: F.normalize's backward divides by eps there and torch.amax splits the gradient
+    # among the tied (all-zero) locations, the kernel gives it to the first one -- those rows feed padding_idx, which
+    # receives no gradient in the model, so only real words are compared
+    real = (torch.arange(g["text_raw"].shape[1])[None, :] < g["lens"][:, None])
+    assert maxrel(model.text_embed.f.grad.cpu()[real], g["d_text_raw"][real]) < 5e-5
+    assert abs(float(model.logit_neg_log_temperature.grad) - float(g["d_neg_log_temp"])) < 1e-4 * max(1.0, abs(float(g["d_neg_log_temp"])))
+
+
+@pytest.mark.parametrize("sim", ["max", "mean"])
+@pytest.mark.parametrize("Bi,HW,Bt,L,E", [(256, 49, 256, 5, 512), (9, 4, 7, 25, 40)])
+def test_spatial_logits_oracle_sizes(dev, sim, Bi, HW, Bt, L, E):
+    """C2-sized batch (256 images x 49 locations x 256 utterances) and a ragged small case vs the oracle, incl. gradients."""
+    from multimodal.multimodal import MultiModalModel
+    g = torch.Generator().manual_seed(Bi + L)
+    side = int(HW ** 0.5)
+    fi = torch.randn(Bi, E, side, side, generator=g)
+    ft = torch.randn(Bt, L, E, generator=g)
+    lens = torch.randint(1, L + 1, (Bt,), generator=g)
+    ft = ft * (torch.arange(L)[None, :, None] < lens[:, None, None])
+    nlt = torch.tensor(2.0)
+    fo, to, no = fi.clone().requires_grad_(), ft.clone().requires_grad_(), nlt.clone().requires_grad_()
+    lpi, _ = O.spatial_similarity_logits(F.normalize(fo, p=2, dim=1), F.normalize(to, p=2, dim=-1), lens, no, sim)
+    d = torch.randn(Bi, Bt, generator=g)
+    (lpi * d).sum().backward()
+    args = argparse.Namespace(sim=sim, embedding_type="spatial", normalize_features=True, temperature=float(torch.exp(-nlt)),
+                              fix_temperature=False)
+    model = MultiModalModel(_ImgEnc(fi.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)), _TxtEnc(ft), args).to(dev)
+    out = model(torch.zeros(1, device=dev), torch.zeros(1, device=dev), lens.to(dev))
+    assert maxrel(out[0], lpi.detach()) < 5e-5
+    (out[0] * d.to(dev)).sum().backward()
+    real = (torch.arange(L)[None, :] < lens[:, None])
+    assert maxrel(model.image_embed.f.grad, fo.grad) < 2e-4 and maxrel(model.text_embed.f.grad.cpu()[real], to.grad[real]) < 2e-4
+    assert abs(float(model.logit_neg_log_temperature.grad) - float(no.grad)) < 2e-4 * max(1.0, abs(float(no.grad)))
+
+
+@pytest.mark.parametrize("sim", ["max", "mean"])
+def test_spatial_end_to_end_vs_oracle(dev, sim):
+    """train.py objects with --embedding_type spatial (fp32 parity mode): state_dict layout of the reference's
+    nn.Sequential vision model, loss vs the oracle (ResNeXt trunk -> 1x1 projection -> normalise -> spatial similarity)."""
+    import train
+    argv = (f"--dataset synthetic --batch_size 4 --gpus 1 --text_encoder embedding --embedding_dim 32 --embedding_type spatial "
+            f"--sim {sim} --normalize_features --lambda_lm 0 --optimize_unused --fast_dev_run --checkpoint_callback False "
+            f"--logger False").split()
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer, lit = train.main(argv)
+    sd = lit.state_dict()
+    for k in ("vision_encoder.model.0.weight", "vision_encoder.model.1.running_mean", "vision_encoder.model.4.0.conv2.weight",
+              "vision_encoder.model.7.2.bn3.bias", "vision_encoder.model.8.weight", "vision_encoder.model.8.bias"):
+        assert k in sd, k
+    assert sd["vision_encoder.model.8.weight"].shape == (32, 2048, 1, 1)
+    trainable = sorted(n for n, p in lit.named_parameters() if p.requires_grad and n.startswith("vision_encoder"))
+    assert trainable == ["vision_encoder.model.8.bias", "vision_encoder.model.8.weight"]
+    # one more step by hand against the oracle
+    from multimodal.multimodal_data_module import SyntheticDataModule
+    dm = SyntheticDataModule(train._setup_parser().parse_args(argv))
+    dm.setup()
+    x, y, y_len, _ = next(iter(dm.train_dataloader()))
+    lit.train()
+    p = {k[len("vision_encoder.model."):]: v.detach().cpu() for k, v in sd.items() if k.startswith("vision_encoder.model.")}
+    names = ["conv1", "bn1", None, None, "layer1", "layer2", "layer3", "layer4"]
+    po = {}
+    for k, v in p.items():
+        idx, rest = k.split(".", 1)
+        if int(idx) < 8:
+            po[f"{names[int(idx)]}.{rest}"] = v.clone()
+    _pooled, fmap = O.resnext50_forward(po, x, True, None, stats_out={})
+    feat = F.conv2d(fmap, p["8.weight"], p["8.bias"])
+    table = sd["text_encoder.embedding.weight"].detach().cpu()
+    txt = F.embedding(y, table, padding_idx=0)
+    nlt = lit.model.logit_neg_log_temperature.detach().cpu()
+    lpi, lpt = O.spatial_similarity_logits(F.normalize(feat, p=2, dim=1), F.normalize(txt, p=2, dim=-1), y_len, nlt, sim)
+    ref = O.contrastive_loss(lpi, lpt)[0]
+    out = lit.training_step((x.to(dev), y.to(dev), y_len.to(dev), None), 0)
+    out["loss"].backward()
+    assert abs(float(out["loss"].detach()) - float(ref)) < 2e-3 * max(1.0, abs(float(ref)))
+    gw = lit.vision_encoder.model[8].weight.grad
+    assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().sum()) > 0
+    assert lit.text_encoder.embedding.weight.grad is not None
