@@ -318,6 +318,20 @@ int cvcl_spatial_max_bwd(const float* d_logits, const uint8_t* arg, const int64_
                          const float* logits, float* d_mm, float* d_neg_log_temp /* nullable */, int Bi, int HW, int Bt, int L,
                          void* stream);
 
+/* Language-model loss (lambda_lm > 0 configs; multimodal/multimodal.py:861-890, multimodal_lit.py:266-300).
+ * token-wise F.cross_entropy(logits [R,V], labels [R], ignore_index, reduction "none"): loss[r] (0 for ignored rows), lse[r]
+ * saved for the backward d_logits = (softmax - onehot) * d_loss.                                               */
+/* BPTT with gradients on the per-step outputs: dh[b] += d_out[b][t] where len[b] > t (before cvcl_lstm_cell_bwd of step t) */
+int cvcl_lstm_add_dout(float* dh, const float* d_out, const int64_t* len, int t, int B, int L, int Hd, void* stream);
+int cvcl_token_ce_fwd(const float* logits, const int64_t* labels, float* loss, float* lse, long R, int V, int ignore_index,
+                      void* stream);
+int cvcl_token_ce_bwd(const float* logits, const int64_t* labels, const float* lse, const float* d_loss, float* d_logits,
+                      long R, int V, int ignore_index, void* stream);
+/* the three masked means of multimodal_lit.py:284-300 and their token counts.  d_loss == NULL: forward (means[3],
+ * counts[3] written); else backward: d_loss[r] = sum_k d_means[k] * mask_k[r] / counts[k].                      */
+int cvcl_lm_loss_summaries(const float* loss, const int64_t* labels, const float* d_means, float* means, float* counts,
+                           float* d_loss, int R, int pad, int sos, int eos, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

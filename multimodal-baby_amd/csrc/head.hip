@@ -492,6 +492,76 @@ extern "C" int cvcl_spatial_max_fwd(const float* mm, const int64_t* len, const f
     return CVCL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// language-model cross entropy (reference multimodal/multimodal.py:884-889: F.cross_entropy(..., ignore_index = PAD,
+// reduction "none")): one workgroup per token row of logits [R, V]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void token_ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, int V,
+                                                           int ignore, float* __restrict__ loss, float* __restrict__ lse) {
+    __shared__ float scratch[8];
+    const long r = blockIdx.x;
+    const float* row = logits + r * V;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, row[v]);
+    mx = block_max(mx, scratch);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) s += expf(row[v] - mx);
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) {
+        const float l = mx + logf(s);
+        lse[r] = l;
+        const int64_t lab = labels[r];
+        loss[r] = (lab == ignore || lab < 0 || lab >= V) ? 0.f : l - row[lab];
+    }
+}
+
+__global__ __launch_bounds__(256) void token_ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                           const float* __restrict__ lse, const float* __restrict__ d_loss,
+                                                           float* __restrict__ d_logits, int V, int ignore) {
+    const long r = blockIdx.x;
+    const int64_t lab = labels[r];
+    const bool live = !(lab == ignore || lab < 0 || lab >= V);
+    const float g = live ? d_loss[r] : 0.f, l = lse[r];
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const float p = expf(logits[r * V + v] - l);
+        d_logits[r * V + v] = (p - (v == lab ? 1.f : 0.f)) * g;
+    }
+}
+
+// the three masked means of multimodal_lit.py:284-300 (all non-pad tokens / without <sos> / without <sos>, <eos>) and their
+// token counts; single workgroup, fixed order.  bwd: d_loss[r] = sum_k d_means[k] * mask_k[r] / count_k
+__global__ __launch_bounds__(256) void lm_summaries_kernel(const float* __restrict__ loss, const int64_t* __restrict__ labels, int R,
+                                                           int pad, int sos, int eos, float* __restrict__ means,
+                                                           float* __restrict__ counts) {
+    __shared__ float scratch[8];
+    float s[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 0.f};
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const int64_t lab = labels[r];
+        const bool m0 = lab != pad, m1 = m0 && lab != sos, m2 = m1 && lab != eos;
+        const float v = loss[r];
+        s[0] += v; n[0] += m0;                       // reference :287 sums the unmasked loss (pads are already 0)
+        if (m1) { s[1] += v; n[1] += 1.f; }
+        if (m2) { s[2] += v; n[2] += 1.f; }
+    }
+    for (int k = 0; k < 3; ++k) {
+        const float ts = block_sum(s[k], scratch), tn = block_sum(n[k], scratch);
+        if (threadIdx.x == 0) { means[k] = ts / tn; counts[k] = tn; }
+    }
+}
+
+__global__ __launch_bounds__(256) void lm_summaries_bwd_kernel(const float* __restrict__ d_means, const int64_t* __restrict__ labels,
+                                                               const float* __restrict__ counts, int R, int pad, int sos, int eos,
+                                                               float* __restrict__ d_loss) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+        const int64_t lab = labels[r];
+        const bool m0 = lab != pad, m1 = m0 && lab != sos, m2 = m1 && lab != eos;
+        float g = d_means[0] / counts[0];
+        if (m1) g += d_means[1] / counts[1];
+        if (m2) g += d_means[2] / counts[2];
+        d_loss[r] = g;
+    }
+}
+
 // d_neg_log_temp = sum d_logits * logits (logits = match * exp(nlt)); one workgroup, fixed order
 __global__ __launch_bounds__(1024) void dot_all_kernel(const float* __restrict__ a, const float* __restrict__ b, long n,
                                                        float* __restrict__ out) {
@@ -515,6 +585,38 @@ extern "C" int cvcl_spatial_max_bwd(const float* d_logits, const uint8_t* arg, c
     if (g > 16384) g = 16384;
     hipLaunchKernelGGL(spatial_max_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, d_logits, arg, len, neg_log_temp, d_mm, Bi,
                        HW, Bt, L);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_token_ce_fwd(const float* logits, const int64_t* labels, float* loss, float* lse, long R, int V, int ignore_index,
+                                 void* stream) {
+    CVCL_CHECK_ARG(logits && labels && loss && lse && R > 0 && V > 0, "cvcl_token_ce_fwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(token_ce_fwd_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, labels, V, ignore_index, loss, lse);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_token_ce_bwd(const float* logits, const int64_t* labels, const float* lse, const float* d_loss, float* d_logits,
+                                 long R, int V, int ignore_index, void* stream) {
+    CVCL_CHECK_ARG(logits && labels && lse && d_loss && d_logits && R > 0 && V > 0, "cvcl_token_ce_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(token_ce_bwd_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, labels, lse, d_loss, d_logits, V,
+                       ignore_index);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_lm_loss_summaries(const float* loss, const int64_t* labels, const float* d_means, float* means, float* counts,
+                                      float* d_loss, int R, int pad, int sos, int eos, void* stream) {
+    CVCL_CHECK_ARG(labels && counts && R > 0 && ((loss && means) || (d_means && d_loss)), "cvcl_lm_loss_summaries: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    if (!d_loss)
+        hipLaunchKernelGGL(lm_summaries_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss, labels, R, pad, sos, eos, means, counts);
+    else
+        hipLaunchKernelGGL(lm_summaries_bwd_kernel, dim3(cvcl_div_up(R, 256)), dim3(256), 0, (hipStream_t)stream, d_means, labels, counts,
+                           R, pad, sos, eos, d_loss);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

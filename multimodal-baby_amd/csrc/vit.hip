@@ -863,3 +863,25 @@ extern "C" int cvcl_lstm_cell_bwd(const float* gates_act, const float* c_save, c
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
+
+// dh[b][:] += d_out[b][t][:] for the sequences still running at step t (out[b][t] = h_t there, 0 beyond the length): lets
+// the per-step outputs of the LSTM (the language-model branch, multimodal.py:859) take part in the BPTT
+namespace {
+__global__ __launch_bounds__(256) void lstm_add_dout_kernel(float* __restrict__ dh, const float* __restrict__ d_out,
+                                                            const int64_t* __restrict__ len, int t, int B, int L, int Hd) {
+    const long total = (long)B * Hd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / Hd;
+        const int j = (int)(i % Hd);
+        if (len[b] > t) dh[i] += d_out[(b * L + t) * Hd + j];
+    }
+}
+}  // namespace
+
+extern "C" int cvcl_lstm_add_dout(float* dh, const float* d_out, const int64_t* len, int t, int B, int L, int Hd, void* stream) {
+    CVCL_CHECK_ARG(dh && d_out && len && B > 0 && L > 0 && Hd > 0 && t >= 0 && t < L, "cvcl_lstm_add_dout: bad args");
+    CvclProfScope prof(stream, CVCL_K_LSTM);
+    hipLaunchKernelGGL(lstm_add_dout_kernel, dim3(grid_for((long)B * Hd)), dim3(256), 0, (hipStream_t)stream, dh, d_out, len, t, B, L, Hd);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}

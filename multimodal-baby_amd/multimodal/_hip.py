@@ -125,6 +125,10 @@ SIGNATURES = {
     "cvcl_bf16_to_f32": (_I, [_P, _P, C.c_long, _P]),
     "cvcl_spatial_max_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_spatial_max_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_lstm_add_dout": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_token_ce_fwd": (_I, [_P, _P, _P, _P, C.c_long, _I, _I, _P]),
+    "cvcl_token_ce_bwd": (_I, [_P, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
+    "cvcl_lm_loss_summaries": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
 }

@@ -363,8 +363,9 @@ class MultiModalModel(nn.Module):
 
 
 class LanguageModel(nn.Module):
-    """Parameter container for the tied output layer the reference always constructs
-    (multimodal_lit.py:65; multimodal.py:825-843).  Its loss branch is outside the contrastive path."""
+    """Tied output layer + token-wise cross entropy (reference multimodal.py:825-890): the ``lambda_lm > 0`` branch of the
+    joint loss.  The projection is an fp32 GEMM (LinearF32: its weight gradient adds into the tied embedding table), the
+    loss ``cvcl_token_ce_fwd/bwd``.  Captioning / attention decoders and beam search stay out of scope."""
 
     def __init__(self, text_encoder, args):
         super().__init__()
@@ -379,11 +380,45 @@ class LanguageModel(nn.Module):
         parser.add_argument("--tie", type=lambda s: bool(eval(s)), default=True)
         parser.add_argument("--bias", type=lambda s: bool(eval(s)), default=True)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("the language-model loss (lambda_lm > 0) is outside the contrastive hot path")
+    def forward(self, y, y_len, outputs=None, image_features=None, image_feature_map=None):
+        if image_features is not None or image_feature_map is not None:
+            raise NotImplementedError("captioning / attention language models are outside the implemented path")
+        te = self.text_encoder
+        if te.text_encoder == "embedding":
+            # per-word embeddings, gathered differentiably (the mean-pool op marks its per-word output non-differentiable)
+            B, L = y.shape
+            outputs = text_train.EmbedGatherPos.apply(te.embedding.weight, None, y).view(B, L, te.embedding_dim)
+        elif outputs is None:
+            _feat, outputs, _attns = te(y, y_len)
+        B, L, E = outputs.shape
+        logits = ops.linear_f32(outputs.reshape(B * L, E), self.output_layer.weight, self.output_layer.bias)   # :859
+        return outputs, logits.view(B, L, -1), None
 
-    calculate_ce_loss = forward
-    beam_search_decode = forward
+    def calculate_ce_loss(self, y, y_len, outputs=None, image_features=None, image_feature_map=None, tokenwise=False,
+                          weight=None):
+        if weight is not None:
+            raise NotImplementedError("class weights are not used by any reference configuration")
+        te = self.text_encoder
+        if te.regressional:                                  # predict token l+1 from position l (:879-883)
+            if te.text_encoder != "embedding" and outputs is None:
+                _feat, outputs, _attns = te(y, y_len)
+            outputs_in = outputs[:, :-1].contiguous() if outputs is not None else None
+            outs, logits, attns = self(y[:, :-1], y_len, outputs=outputs_in)
+            labels = y[:, 1:1 + logits.size(1)].contiguous()
+            outputs = outputs if outputs is not None else outs
+        else:
+            outputs, logits, attns = self(y, y_len, outputs=outputs)
+            labels = y.contiguous()
+        B, Lp, V = logits.shape
+        loss = ops.token_cross_entropy(logits.reshape(B * Lp, V), labels.reshape(-1), PAD_TOKEN_ID)
+        if tokenwise:
+            loss = loss.view(B, Lp)
+        else:                                                # reduction "mean" over the non-ignored tokens
+            loss = ops.lm_loss_summaries(loss, labels.reshape(-1))[0][0]
+        return loss, outputs, logits, attns, labels
+
+    def beam_search_decode(self, *a, **k):
+        raise NotImplementedError("beam search decoding (text generation evaluation) is outside the implemented path")
 
 
 def calculate_attn_reg_loss(attns):

@@ -9,11 +9,14 @@ import functools
 import json
 import os
 
+import numpy as np
 import torch
 
+from . import ops
 from .lightning import LightningModule
 from .multimodal import LanguageModel, MultiModalModel
-from .multimodal_data_module import MAX_LEN_UTTERANCE, N_VAL_DATALOADERS_PER_SPLIT
+from .multimodal_data_module import (EOS_TOKEN_ID, MAX_LEN_UTTERANCE, N_VAL_DATALOADERS_PER_SPLIT, PAD_TOKEN_ID,
+                                     SOS_TOKEN_ID)
 from .utils import get_entropy
 
 OPTIMIZER = torch.optim.AdamW
@@ -129,6 +132,17 @@ class MultiModalLitModel(LightningModule):
             all_tokens.append(ids + [self.vocab["<pad>"]] * (max_seq_len - len(ids)))
         return torch.tensor(all_tokens, dtype=torch.long), torch.tensor(lengths, dtype=torch.long)
 
+    def calculate_ce_loss(self, y, y_len, x=None, outputs=None, image_features=None, image_feature_map=None,
+                          return_image_features=False, **kwargs):
+        """Wraps language_model.calculate_ce_loss (reference :192-225; captioning / attention variants out of scope)."""
+        te = self.language_model.text_encoder
+        if te.captioning or te.has_attention:
+            raise NotImplementedError("captioning / attention language models are outside the implemented path")
+        ret = self.language_model.calculate_ce_loss(y, y_len, outputs=outputs, **kwargs)
+        if return_image_features:
+            ret = ret + (None, None)
+        return ret
+
     def calculate_joint_loss(self, batch, stage, log, eval_textgen=False, ce_weight=None):
         x, y, y_len, raw_y = batch
         ret = {"batch_size": x.size(0)}
@@ -145,12 +159,24 @@ class MultiModalLitModel(LightningModule):
             ret.update({"infonce_loss": infonce_loss.detach(), "image_accuracy": image_accuracy,
                         "text_accuracy": text_accuracy, "image_entropy": image_entropy.detach(),
                         "text_entropy": text_entropy.detach()})
+            text_outputs = _rest[-1]
         else:
             infonce_loss = 0.
-        if self.lambda_lm or not self.optimize_unused:
-            raise NotImplementedError("the language-model loss is outside the contrastive hot path: run with "
-                                      "--lambda_lm 0 --optimize_unused (as every contrastive config does)")
-        loss = self.lambda_mm * infonce_loss
+            text_outputs = None
+        if self.lambda_lm or not self.optimize_unused:                       # reference :266-309
+            if eval_textgen:
+                raise NotImplementedError("text generation evaluation (beam search) is outside the implemented path")
+            ce_loss, _o, _l, _attns, labels = self.calculate_ce_loss(y, y_len, x=x, outputs=text_outputs, tokenwise=True,
+                                                                      weight=ce_weight)
+            means, counts = ops.lm_loss_summaries(ce_loss.reshape(-1), labels.reshape(-1), PAD_TOKEN_ID, SOS_TOKEN_ID, EOS_TOKEN_ID)
+            lm_ce_loss = means[0]
+            for i, suffix in enumerate(("", "_wo_sos", "_wo_sos_eos")):
+                log(f"{stage}_ce_loss{suffix}", means[i].detach())
+                ret[f"ce_loss{suffix}"] = means[i].detach()
+                ret[f"n_tokens{suffix}"] = counts[i]
+        else:
+            lm_ce_loss = 0.
+        loss = self.lambda_mm * infonce_loss + self.lambda_lm * lm_ce_loss
         log(f"{stage}_loss", loss)
         ret.update({"loss": loss})
         return ret
@@ -162,9 +188,20 @@ class MultiModalLitModel(LightningModule):
                 n += o["batch_size"]
                 total += float(o[name]) * o["batch_size"]
             return total / n
+        def mean_over_tokens(name, n_name):
+            n, total = 0., 0.
+            for o in outputs:
+                n += float(o[n_name])
+                total += float(o[name]) * float(o[n_name])
+            return total / n
         if self.lambda_mm or not self.optimize_unused:
             for name in ("infonce_loss", "image_accuracy", "text_accuracy", "image_entropy", "text_entropy"):
                 log(f"{stage}_{name}", mean_over_examples(name))
+        if self.lambda_lm or not self.optimize_unused:                       # reference :420-428
+            for suffix in ("", "_wo_sos", "_wo_sos_eos"):
+                value_mean = mean_over_tokens(f"ce_loss{suffix}", f"n_tokens{suffix}")
+                log(f"{stage}_ce_loss{suffix}", value_mean)
+                log(f"{stage}_perplexity{suffix}", float(np.exp(value_mean)))
         log(f"{stage}_loss", mean_over_examples("loss"))
 
     def training_step(self, batch, batch_idx):

@@ -145,6 +145,58 @@ class SpatialMaxLogits(torch.autograd.Function):
         return d_img, d_txt, None, (d_s.reshape(ctx.temp_shape) if need_s else None), None, None, None, None
 
 
+class TokenCrossEntropy(torch.autograd.Function):
+    """F.cross_entropy(logits [R,V], labels [R], ignore_index, reduction='none') (reference multimodal.py:884-889)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        logits = logits.contiguous()
+        R, V = logits.shape
+        loss = torch.empty(R, dtype=_F, device=logits.device)
+        lse = torch.empty(R, dtype=_F, device=logits.device)
+        H.check(H.lib().cvcl_token_ce_fwd(H.ptr(logits, _F), H.ptr(labels, torch.int64), H.ptr(loss), H.ptr(lse), R, V, ignore_index,
+                                          H.stream_ptr()), "cvcl_token_ce_fwd")
+        ctx.save_for_backward(logits, labels, lse)
+        ctx.ignore = ignore_index
+        return loss
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        logits, labels, lse = ctx.saved_tensors
+        R, V = logits.shape
+        d_logits = torch.empty_like(logits)
+        H.check(H.lib().cvcl_token_ce_bwd(H.ptr(logits), H.ptr(labels), H.ptr(lse), H.ptr(d_loss.contiguous(), _F), H.ptr(d_logits),
+                                          R, V, ctx.ignore, H.stream_ptr()), "cvcl_token_ce_bwd")
+        return d_logits, None, None
+
+
+class LmLossSummaries(torch.autograd.Function):
+    """(means [3], counts [3]) of the token-wise LM loss: all non-pad tokens / without <sos> / without <sos>, <eos>
+    (reference multimodal_lit.py:284-300)."""
+
+    @staticmethod
+    def forward(ctx, loss, labels, pad, sos, eos):
+        loss = loss.contiguous()
+        R = loss.numel()
+        means = torch.empty(3, dtype=_F, device=loss.device)
+        counts = torch.empty(3, dtype=_F, device=loss.device)
+        H.check(H.lib().cvcl_lm_loss_summaries(H.ptr(loss, _F), H.ptr(labels, torch.int64), None, H.ptr(means), H.ptr(counts), None,
+                                               R, pad, sos, eos, H.stream_ptr()), "cvcl_lm_loss_summaries")
+        ctx.save_for_backward(labels, counts)
+        ctx.meta = (R, pad, sos, eos)
+        ctx.mark_non_differentiable(counts)
+        return means, counts
+
+    @staticmethod
+    def backward(ctx, d_means, _d_counts):
+        labels, counts = ctx.saved_tensors
+        R, pad, sos, eos = ctx.meta
+        d_loss = torch.empty(R, dtype=_F, device=d_means.device)
+        H.check(H.lib().cvcl_lm_loss_summaries(None, H.ptr(labels), H.ptr(d_means.contiguous(), _F), None, H.ptr(counts), H.ptr(d_loss),
+                                               R, pad, sos, eos, H.stream_ptr()), "cvcl_lm_loss_summaries")
+        return d_loss, None, None, None, None
+
+
 class InfoNCE(torch.autograd.Function):
     """Symmetric InfoNCE + accuracies + entropies (reference multimodal/multimodal.py:801-818)."""
 
@@ -212,6 +264,14 @@ class LinearF32(torch.autograd.Function):
             db = torch.empty(N, dtype=_F, device=x.device)
             H.check(H.lib().cvcl_colsum_f32(H.ptr(dy), H.ptr(db), M, N, s), "cvcl_colsum_f32")
         return dx, dw, db
+
+
+def token_cross_entropy(logits, labels, ignore_index=0):
+    return TokenCrossEntropy.apply(logits, labels, ignore_index)
+
+
+def lm_loss_summaries(loss, labels, pad=0, sos=2, eos=3):
+    return LmLossSummaries.apply(loss, labels, pad, sos, eos)
 
 
 def spatial_max_logits(img_rows, txt_rows, length, neg_log_temp, Bi, HW, Bt, L):

@@ -247,23 +247,27 @@ class LstmCore(torch.autograd.Function):
                                              H.ptr(csave), H.ptr(hprev), B, L, Hd, s), "cvcl_lstm_cell_train")
         ctx.save_for_backward(x, w_ih, w_hh_c, length, gact, csave, hprev)
         ctx.dims = (B, L, Hd)
-        ctx.mark_non_differentiable(out)      # the per-step outputs only feed the LM branch (outside the contrastive path)
+        ctx.set_materialize_grads(False)       # the unused one of (h, out) arrives as None instead of a zero tensor
         return h, out
 
     @staticmethod
-    def backward(ctx, dh_final, _d_out):
+    def backward(ctx, dh_final, d_out):
         x, w_ih, w_hh, length, gact, csave, hprev = ctx.saved_tensors
         B, L, Hd = ctx.dims
         dev = x.device
         lib, s = H.lib(), H.stream_ptr()
-        dh = dh_final.contiguous().clone()
+        dh = dh_final.contiguous().clone() if dh_final is not None else torch.zeros(B, Hd, dtype=_F, device=dev)
         dc = torch.zeros(B, Hd, dtype=_F, device=dev)
         dG = torch.empty(B * L, 4 * Hd, dtype=_F, device=dev)
         carry = torch.empty(B, Hd, dtype=_F, device=dev)
         w_hhT = torch.empty(Hd, 4 * Hd, dtype=_F, device=dev)
         H.check(lib.cvcl_transpose_f32(H.ptr(w_hh), H.ptr(w_hhT), 4 * Hd, Hd, s), "cvcl_transpose_f32")
         dh_next = torch.empty_like(dh)
+        if d_out is not None:
+            d_out = d_out.contiguous()
         for t in range(L - 1, -1, -1):
+            if d_out is not None:             # per-step outputs feed the language-model branch: out[b,t] = h_t while running
+                H.check(lib.cvcl_lstm_add_dout(H.ptr(dh), H.ptr(d_out, _F), H.ptr(length), t, B, L, Hd, s), "cvcl_lstm_add_dout")
             H.check(lib.cvcl_lstm_cell_bwd(H.ptr(gact), H.ptr(csave), H.ptr(length), t, H.ptr(dh), H.ptr(dc), H.ptr(dG), H.ptr(carry),
                                            B, L, Hd, s), "cvcl_lstm_cell_bwd")
             a = H.GemmArgs()                                                       # dh_{t-1} = dG_t . W_hh + carry

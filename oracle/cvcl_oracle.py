@@ -183,6 +183,36 @@ def similarity_logits(image_features: Tensor, text_features: Tensor,
     return match * logit_scale, match.t() * logit_scale      # :786-787
 
 
+# f4  language-model cross entropy                              multimodal.py:861-890, multimodal_lit.py:266-300
+def lm_ce_loss(outputs: Tensor, out_weight: Tensor, out_bias, y: Tensor, regressional: bool):
+    """logits = output_layer(outputs) (:859); regressional (LSTM): predict token l+1 from position l (:879-883), else
+    labels = y; token-wise F.cross_entropy with ignore_index = PAD (:884-889) -> (loss [B,L'], labels [B,L'])."""
+    logits = outputs @ out_weight.t()
+    if out_bias is not None:
+        logits = logits + out_bias
+    if regressional:
+        logits = logits[:, :-1]
+        labels = y[:, 1:1 + logits.size(1)]
+    else:
+        labels = y
+    loss = F.cross_entropy(logits.transpose(-2, -1), labels, ignore_index=PAD_TOKEN_ID, reduction="none")
+    return loss, labels
+
+
+def lm_loss_summaries(ce_loss: Tensor, labels: Tensor):
+    """the three masked means of multimodal_lit.py:284-300: all non-pad tokens, without <sos>, without <sos>/<eos>."""
+    mask = labels != PAD_TOKEN_ID
+    n0 = mask.sum()
+    l0 = ce_loss.sum() / n0
+    mask = mask & (labels != SOS_TOKEN_ID)
+    n1 = mask.sum()
+    l1 = (ce_loss * mask).sum() / n1
+    mask = mask & (labels != EOS_TOKEN_ID)
+    n2 = mask.sum()
+    l2 = (ce_loss * mask).sum() / n2
+    return (l0, l1, l2), (n0, n1, n2)
+
+
 # f4  spatial similarity (embedding_type == "spatial")         multimodal.py:757-787
 def spatial_similarity_logits(image_features: Tensor, text_features: Tensor, text_length: Tensor,
                               logit_neg_log_temperature: Tensor, sim: str = "max") -> Tuple[Tensor, Tensor]:

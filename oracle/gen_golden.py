@@ -411,6 +411,42 @@ def case_tokenizer(lit_mod):
     save("tokenizer", texts=np.array(texts), tokens=tok, lengths=ln, vocab_size=np.array([len(vocab)]))
 
 
+def case_lm(mm):
+    """language-model cross entropy (lambda_lm > 0 configs): reference LanguageModel.calculate_ce_loss (tokenwise) on the
+    LSTM (regressional) and embedding (non-regressional) text encoders, eval mode, + the masked means of
+    multimodal_lit.py:284-300 and the gradients of the mean loss."""
+    vocab = small_vocab(50)
+    E = 32
+    x, xl = ragged_tokens(6, 7, 50, seed=3)
+    x[:, 0] = 2                                            # <sos> ... <eos> like real utterances
+    for b in range(x.shape[0]):
+        x[b, int(xl[b]) - 1] = 3
+    for kind in ("lstm", "embedding"):
+        torch.manual_seed(11)
+        te = mm.TextEncoder(vocab, 2048, text_args(kind, E, "no_pos_embed")).eval()
+        lm = mm.LanguageModel(te, argparse.Namespace(tie=True, bias=True)).eval()
+        with torch.no_grad():
+            lm.output_layer.bias.normal_(0, 0.3)
+        loss, outputs, logits, attns, labels = lm.calculate_ce_loss(x, xl, tokenwise=True)
+        mask = labels != 0
+        mean = loss.sum() / mask.sum()
+        lm.zero_grad()
+        mean.backward()
+        sd = sd_np(te)
+        if kind == "lstm":
+            _r, o_out = O.lstm_text(sd, x, xl)
+        else:
+            _r, o_out = O.embedding_meanpool(sd["embedding.weight"], x, xl)
+        o_loss, o_labels = O.lm_ce_loss(o_out, sd["embedding.weight"], lm.output_layer.bias.detach(), x, kind == "lstm")
+        (s0, s1, s2), (n0, n1, n2) = O.lm_loss_summaries(o_loss, o_labels)
+        print(f"lm/{kind}: oracle tokenwise loss rel {maxrel(o_loss, loss.detach()):.2e}, mean {abs(float(s0) - float(mean)):.2e}")
+        assert maxrel(o_loss, loss.detach()) < 5e-6 and torch.equal(o_labels, labels)
+        w = {"w." + k: v for k, v in sd.items()}
+        grads = {"g." + k: v.grad for k, v in te.named_parameters() if v.grad is not None}
+        save(f"lm_{kind}", x=x, x_len=xl, out_bias=lm.output_layer.bias.detach(), loss=loss.detach(), labels=labels,
+             means=torch.stack([s0, s1, s2]), counts=torch.stack([n0, n1, n2]), d_out_bias=lm.output_layer.bias.grad, **w, **grads)
+
+
 def case_spatial(mm):
     """embedding_type='spatial' (reference multimodal.py:757-780): per-location image features x per-word text features,
     'max' and 'mean' similarity, through the reference's own MultiModalModel.forward / calculate_contrastive_loss."""
@@ -466,6 +502,7 @@ def main():
     case_text_encoders(mm)
     case_head(mm)
     case_spatial(mm)
+    case_lm(mm)
     case_vit(vits)
     case_tokenizer(lit_mod)
     case_cvcl_step(mm, lit_mod)

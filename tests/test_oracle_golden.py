@@ -62,6 +62,21 @@ def test_head_square(name, norm):
     assert maxrel(O.infonce_dlogits(lpi.detach()), lp.grad) < 1e-5
 
 
+@pytest.mark.parametrize("kind", ["lstm", "embedding"])
+def test_lm_ce_loss(kind):
+    """language-model branch: token-wise loss, labels and the three masked means vs the reference (golden)."""
+    g = load_golden("lm_" + kind)
+    w = _weights(g)
+    if kind == "lstm":
+        _r, out = O.lstm_text(w, g["x"], g["x_len"])
+    else:
+        _r, out = O.embedding_meanpool(w["embedding.weight"], g["x"], g["x_len"])
+    loss, labels = O.lm_ce_loss(out, w["embedding.weight"], g["out_bias"], g["x"], kind == "lstm")
+    assert torch.equal(labels, g["labels"]) and float((loss - g["loss"]).abs().max()) < 1e-4
+    means, counts = O.lm_loss_summaries(loss, labels)
+    assert float((torch.stack(means) - g["means"]).abs().max()) < 1e-4 and torch.equal(torch.stack(counts), g["counts"])
+
+
 @pytest.mark.parametrize("sim", ["max", "mean"])
 def test_spatial_similarity(sim):
     """embedding_type='spatial' (reference multimodal.py:757-780): logits, loss scalars and feature / temperature gradients."""
