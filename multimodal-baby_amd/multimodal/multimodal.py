@@ -80,6 +80,16 @@ class VisionEncoder(nn.Module):
             feature_map = hook.activation
         return features, feature_map
 
+    def _forward_unbatched(self, x):
+        """reference :106-114: one image at a time through self.model (what tests/test_batching.py compares with)."""
+        outs = []
+        for i in x:
+            out = self.model(i.unsqueeze(0))
+            if getattr(self, "vit_dino", False):
+                out = ops.linear_f32(out, self.model.head.weight, self.model.head.bias)
+            outs.append(out.squeeze(0))
+        return torch.stack(outs)
+
     @property
     def last_cnn_out_dim(self):
         return 768 if self.vit_dino else 2048
@@ -231,6 +241,20 @@ class TextEncoder(nn.Module):
         if spatial and self.text_encoder != "embedding":
             ret = raw_output                                                                  # reference :579-580
         return ret, raw_output, attns
+
+    def _forward_unbatched(self, x, x_len, image_features=None):
+        """reference :586-668: every utterance on its own (batch of one, trimmed to its length), stacked back; flat
+        embeddings -> [B, E], spatial -> [B, L, E] zero-padded.  Used by the reference's batched == unbatched tests."""
+        outs = []
+        L = x.shape[1]
+        for i in range(x.shape[0]):
+            n = int(x_len[i])
+            ret, _out, _a = self.forward(x[i:i + 1, :n].contiguous(), x_len[i:i + 1])
+            ret = ret.squeeze(0)
+            if self.embedding_type == "spatial" and ret.shape[0] < L:
+                ret = torch.cat([ret, ret.new_zeros(L - ret.shape[0], ret.shape[1])], 0)
+            outs.append(ret)
+        return torch.stack(outs)
 
     @property
     def vocab_size(self):
