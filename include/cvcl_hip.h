@@ -323,6 +323,13 @@ int cvcl_spatial_max_bwd(const float* d_logits, const uint8_t* arg, const int64_
  * saved for the backward d_logits = (softmax - onehot) * d_loss.                                               */
 /* BPTT with gradients on the per-step outputs: dh[b] += d_out[b][t] where len[b] > t (before cvcl_lstm_cell_bwd of step t) */
 int cvcl_lstm_add_dout(float* dh, const float* d_out, const int64_t* len, int t, int B, int L, int Hd, void* stream);
+/* remaining --text_encoder choices (multimodal.py:505-552).  cvcl_seq_reverse: y[b][t] = x[b][len-1-t] (t < len, else 0):
+ * input / output permutation of the backward LSTM direction, self-adjoint.  cvcl_scale_add_f32: y = alpha * (a + b), b
+ * nullable (mean of the two directions and its backward).  cvcl_cbow: window sum without the centre / (2 crange),
+ * self-adjoint. */
+int cvcl_seq_reverse(const float* x, const int64_t* len, float* y, int B, int L, int E, void* stream);
+int cvcl_scale_add_f32(const float* a, const float* b, float alpha, float* y, long n, void* stream);
+int cvcl_cbow(const float* x, float* y, int B, int L, int E, int crange, void* stream);
 int cvcl_token_ce_fwd(const float* logits, const int64_t* labels, float* loss, float* lse, long R, int V, int ignore_index,
                       void* stream);
 int cvcl_token_ce_bwd(const float* logits, const int64_t* labels, const float* lse, const float* d_loss, float* d_logits,

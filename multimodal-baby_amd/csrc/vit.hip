@@ -885,3 +885,66 @@ extern "C" int cvcl_lstm_add_dout(float* dh, const float* d_out, const int64_t* 
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
+
+// ---- remaining text encoders (reference multimodal/multimodal.py:505-552) -------------------------------------------
+namespace {
+// y[b][t] = x[b][len[b]-1-t] for t < len[b], 0 beyond: the backward direction of a packed bidirectional LSTM runs over each
+// sequence from its last valid token; the same permutation un-reverses its outputs (and is its own adjoint)
+__global__ __launch_bounds__(256) void seq_reverse_kernel(const float* __restrict__ x, const int64_t* __restrict__ len,
+                                                          float* __restrict__ y, int B, int L, int E) {
+    const long total = (long)B * L * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const long r = i / E;
+        const int t = (int)(r % L);
+        const long b = r / L;
+        const int n = (int)len[b];
+        y[i] = t < n ? x[(b * L + (n - 1 - t)) * E + e] : 0.f;
+    }
+}
+// y = alpha * (a + b)   (b may be NULL): mean of the two LSTM directions and its backward
+__global__ __launch_bounds__(256) void scale_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float alpha,
+                                                        float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = alpha * (a[i] + (b ? b[i] : 0.f));
+}
+// continuous bag of words: y[b][j] = (sum_{|k-j| <= c, k != j, 0 <= k < L} x[b][k]) / (2c); symmetric -> its own backward
+__global__ __launch_bounds__(256) void cbow_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int L, int E, int c) {
+    const long total = (long)B * L * E;
+    const float inv = 1.f / (float)(2 * c);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const long r = i / E;
+        const int j = (int)(r % L);
+        const long b = r / L;
+        float acc = 0.f;
+        for (int k = max(j - c, 0); k <= min(j + c, L - 1); ++k)
+            if (k != j) acc += x[(b * L + k) * E + e];
+        y[i] = acc * inv;
+    }
+}
+}  // namespace
+
+extern "C" int cvcl_seq_reverse(const float* x, const int64_t* len, float* y, int B, int L, int E, void* stream) {
+    CVCL_CHECK_ARG(x && len && y && x != y && B > 0 && L > 0 && E > 0, "cvcl_seq_reverse: bad args");
+    CvclProfScope prof(stream, CVCL_K_LSTM);
+    hipLaunchKernelGGL(seq_reverse_kernel, dim3(grid_for((long)B * L * E)), dim3(256), 0, (hipStream_t)stream, x, len, y, B, L, E);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_scale_add_f32(const float* a, const float* b, float alpha, float* y, long n, void* stream) {
+    CVCL_CHECK_ARG(a && y && n > 0, "cvcl_scale_add_f32: bad args");
+    CvclProfScope prof(stream, CVCL_K_OTHER);
+    hipLaunchKernelGGL(scale_add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, alpha, y, n);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_cbow(const float* x, float* y, int B, int L, int E, int crange, void* stream) {
+    CVCL_CHECK_ARG(x && y && x != y && B > 0 && L > 0 && E > 0 && crange > 0, "cvcl_cbow: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(cbow_kernel, dim3(grid_for((long)B * L * E)), dim3(256), 0, (hipStream_t)stream, x, y, B, L, E, crange);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}

@@ -126,6 +126,9 @@ SIGNATURES = {
     "cvcl_spatial_max_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_spatial_max_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_lstm_add_dout": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_seq_reverse": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_scale_add_f32": (_I, [_P, _P, C.c_float, _P, C.c_long, _P]),
+    "cvcl_cbow": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "cvcl_token_ce_fwd": (_I, [_P, _P, _P, _P, C.c_long, _I, _I, _P]),
     "cvcl_token_ce_bwd": (_I, [_P, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
     "cvcl_lm_loss_summaries": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

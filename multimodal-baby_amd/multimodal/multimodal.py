@@ -222,6 +222,13 @@ class TextEncoder(nn.Module):
             ret = raw_output
         elif self.text_encoder == "embedding":
             ret, raw_output = ops.embed_meanpool(self.embedding.weight, x, x_len, True)       # reference :496-503
+        elif self.text_encoder == "cbow":                                                    # reference :505-511
+            assert spatial, "cbow with flat embedding is nonsense"
+            raw_output = text_train.cbow_text_train(self.embedding.weight, x, self.crange)
+            ret = raw_output
+        elif self.text_encoder == "bilstm":                                                  # reference :513-552
+            ret, raw_output = text_train.bilstm_text_train(self.embedding.weight, self.lstm, x, x_len, self.dropout_i,
+                                                           self.training)
         elif self.text_encoder == "lstm":                                                    # reference :513-552
             if self.training or torch.is_grad_enabled():
                 # differentiable path: embedding -> LockedDropout(dropout_i) -> LSTM (BPTT in the backward)

@@ -298,6 +298,91 @@ class LstmCore(torch.autograd.Function):
         return dx, dwi, dwh, db, (db.clone() if db is not None else None), None, None, None
 
 
+class SeqReverse(torch.autograd.Function):
+    """y[b,t] = x[b, len-1-t] inside each sequence, zeros beyond (x: [B*L, E] rows); self-adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, length, B, L):
+        y = torch.empty_like(x)
+        H.check(H.lib().cvcl_seq_reverse(H.ptr(x.contiguous(), _F), H.ptr(length, torch.int64), H.ptr(y), B, L, x.shape[-1],
+                                         H.stream_ptr()), "cvcl_seq_reverse")
+        ctx.save_for_backward(length)
+        ctx.dims = (B, L)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (length,) = ctx.saved_tensors
+        B, L = ctx.dims
+        dx = torch.empty_like(dy)
+        H.check(H.lib().cvcl_seq_reverse(H.ptr(dy.contiguous(), _F), H.ptr(length), H.ptr(dx), B, L, dy.shape[-1], H.stream_ptr()),
+                "cvcl_seq_reverse")
+        return dx, None, None, None
+
+
+class Mean2(torch.autograd.Function):
+    """0.5 * (a + b): mean of the forward and backward LSTM directions (reference :540-547, :552)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        y = torch.empty_like(a)
+        H.check(H.lib().cvcl_scale_add_f32(H.ptr(a.contiguous(), _F), H.ptr(b.contiguous(), _F), 0.5, H.ptr(y), a.numel(), H.stream_ptr()),
+                "cvcl_scale_add_f32")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = torch.empty_like(dy)
+        H.check(H.lib().cvcl_scale_add_f32(H.ptr(dy.contiguous(), _F), None, 0.5, H.ptr(g), dy.numel(), H.stream_ptr()),
+                "cvcl_scale_add_f32")
+        return g, g
+
+
+class Cbow(torch.autograd.Function):
+    """continuous bag of words over [B, L, E] (reference :505-511); the window operator is symmetric."""
+
+    @staticmethod
+    def forward(ctx, x, B, L, crange):
+        y = torch.empty_like(x)
+        H.check(H.lib().cvcl_cbow(H.ptr(x.contiguous(), _F), H.ptr(y), B, L, x.shape[-1], crange, H.stream_ptr()), "cvcl_cbow")
+        ctx.dims = (B, L, crange)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, crange = ctx.dims
+        dx = torch.empty_like(dy)
+        H.check(H.lib().cvcl_cbow(H.ptr(dy.contiguous(), _F), H.ptr(dx), B, L, dy.shape[-1], crange, H.stream_ptr()), "cvcl_cbow")
+        return dx, None, None, None
+
+
+def cbow_text_train(table, tok, crange: int):
+    B, L = tok.shape
+    x = EmbedGatherPos.apply(table, None, tok)
+    return Cbow.apply(x, B, L, int(crange)).view(B, L, table.shape[1])
+
+
+def bilstm_text_train(table, lstm, tok, length, dropout_i: float, training: bool):
+    """Differentiable embedding -> LockedDropout -> bidirectional LSTM (multimodal.py:513-552 with 'bilstm'):
+    (mean of the two final hidden states [B,E], mean of the two directions' outputs [B,Lmax,E])."""
+    if not lstm.bidirectional or lstm.num_layers != 1:
+        raise NotImplementedError("bilstm_text_train expects a one-layer bidirectional nn.LSTM")
+    B, L = tok.shape
+    E = table.shape[1]
+    x = EmbedGatherPos.apply(table, None, tok)
+    if training and dropout_i:
+        x = DropoutAdd.apply(x, None, float(dropout_i), _seed(), L, E)
+    h_f, out_f = LstmCore.apply(x, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, length, B, L)
+    xr = SeqReverse.apply(x, length, B, L)
+    h_b, out_r = LstmCore.apply(xr, lstm.weight_ih_l0_reverse, lstm.weight_hh_l0_reverse, lstm.bias_ih_l0_reverse,
+                                lstm.bias_hh_l0_reverse, length, B, L)
+    Hd = out_r.shape[-1]
+    out_b = SeqReverse.apply(out_r.reshape(B * L, Hd), length, B, L).view(B, L, Hd)
+    ret = Mean2.apply(h_f, h_b)
+    out = Mean2.apply(out_f.contiguous(), out_b)
+    return ret, out[:, :int(length.max())]
+
+
 def lstm_text_train(table, lstm, tok, length, dropout_i: float, training: bool):
     """Differentiable embedding -> LockedDropout(dropout_i) -> LSTM -> last hidden state (multimodal.py:513-552)."""
     if lstm.bidirectional or lstm.num_layers != 1:

@@ -119,6 +119,51 @@ def lstm_text(p: Dict[str, Tensor], x: Tensor, x_len: Tensor, prefix: str = "") 
     return h, out
 
 
+def bilstm_text(p: Dict[str, Tensor], x: Tensor, x_len: Tensor, prefix: str = "") -> Tuple[Tensor, Tensor]:
+    """Bidirectional one-layer LSTM (multimodal.py:513-552 with text_encoder == 'bilstm'): the backward direction runs over
+    each sequence from its last valid token to its first; per-step outputs are the mean of both directions (:540-547) and
+    the flat feature the mean of the two final hidden states (:552).  Returns (ret [B,E], raw_output [B,Lmax,E])."""
+    table = p[prefix + "embedding.weight"]
+    B, L = x.shape
+    emb = F.embedding(x, table, padding_idx=PAD_TOKEN_ID)
+    Lmax = int(x_len.max())
+
+    def run(sfx, reverse):
+        w_ih, w_hh = p[prefix + "lstm.weight_ih_l0" + sfx], p[prefix + "lstm.weight_hh_l0" + sfx]
+        b = p[prefix + "lstm.bias_ih_l0" + sfx] + p[prefix + "lstm.bias_hh_l0" + sfx]
+        Hd = w_hh.shape[1]
+        h = torch.zeros(B, Hd, dtype=table.dtype)
+        c = torch.zeros(B, Hd, dtype=table.dtype)
+        outs = [None] * Lmax
+        steps = range(Lmax - 1, -1, -1) if reverse else range(Lmax)
+        for t in steps:
+            gates = emb[:, t] @ w_ih.t() + h @ w_hh.t() + b
+            i, f, g, o = gates.split(Hd, dim=1)
+            c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h_new = torch.sigmoid(o) * torch.tanh(c_new)
+            live = (x_len > t).unsqueeze(1)
+            c = torch.where(live, c_new, c)
+            h = torch.where(live, h_new, h)
+            outs[t] = torch.where(live, h_new, torch.zeros_like(h_new))
+        return h, torch.stack(outs, dim=1)
+
+    h_f, out_f = run("", False)
+    h_b, out_b = run("_reverse", True)
+    return (h_f + h_b) / 2, (out_f + out_b) / 2
+
+
+def cbow_text(p: Dict[str, Tensor], x: Tensor, crange: int, prefix: str = "") -> Tensor:
+    """Continuous bag of words (multimodal.py:505-511, spatial embeddings only): every position gets the sum of its
+    neighbours within +-crange (zeros outside the sequence tensor, the position itself excluded) / (2 crange)."""
+    emb = F.embedding(x, p[prefix + "embedding.weight"], padding_idx=PAD_TOKEN_ID)
+    B, L, E = emb.shape
+    out = torch.zeros_like(emb)
+    for j in range(L):
+        lo, hi = max(j - crange, 0), min(j + crange, L - 1)
+        out[:, j] = (emb[:, lo:hi + 1].sum(dim=1) - emb[:, j]) / (2 * crange)
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # a6  transformer text encoder                                 multimodal.py:553-573
 # --------------------------------------------------------------------------------------

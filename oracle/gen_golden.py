@@ -165,6 +165,35 @@ def case_text_encoders(mm):
         save(f"text_{tag}", x=x, x_len=xl, ret=ret, output=out, **w, **extra)
 
 
+def case_text_extra(mm):
+    """the remaining --text_encoder choices: bilstm (flat + spatial outputs) and cbow (spatial only)."""
+    vocab = small_vocab(50)
+    E = 32
+    x, xl = ragged_tokens(6, 7, 50, seed=2)
+    torch.manual_seed(12)
+    a = text_args("bilstm", E)
+    te = mm.TextEncoder(vocab, 2048, a).eval()
+    with torch.no_grad():
+        ret, out, _ = te(x, xl)
+    sd = sd_np(te)
+    o_ret, o_out = O.bilstm_text(sd, x, xl)
+    print(f"text/bilstm: oracle-vs-reference rel err ret {maxrel(o_ret, ret):.2e} out {maxrel(o_out, out):.2e}")
+    assert maxrel(o_ret, ret) < 2e-6 and maxrel(o_out, out) < 2e-6
+    save("text_bilstm", x=x, x_len=xl, ret=ret, output=out, **{"w." + k: v for k, v in sd.items()})
+    for crange in (1, 2):
+        torch.manual_seed(13)
+        a = text_args("cbow", E)
+        a.embedding_type, a.crange = "spatial", crange
+        te = mm.TextEncoder(vocab, 2048, a).eval()
+        with torch.no_grad():
+            ret, out, _ = te(x, xl)
+        sd = sd_np(te)
+        o_out = O.cbow_text(sd, x, crange)
+        print(f"text/cbow{crange}: oracle-vs-reference rel err {maxrel(o_out, out):.2e}")
+        assert maxrel(o_out, out) < 2e-6 and torch.equal(ret, out)
+        save(f"text_cbow{crange}", x=x, x_len=xl, output=out, **{"w." + k: v for k, v in sd.items()})
+
+
 def case_head(mm):
     """normalise + similarity + InfoNCE 10-tuple on given features, through the reference's own
     MultiModalModel.forward / calculate_contrastive_loss with trivial encoders."""
@@ -500,6 +529,7 @@ def main():
     from multimodal import vision_transformer_dino_mugs as vits
     torch.set_num_threads(8)
     case_text_encoders(mm)
+    case_text_extra(mm)
     case_head(mm)
     case_spatial(mm)
     case_lm(mm)

@@ -62,6 +62,15 @@ def test_head_square(name, norm):
     assert maxrel(O.infonce_dlogits(lpi.detach()), lp.grad) < 1e-5
 
 
+def test_text_bilstm_and_cbow():
+    g = load_golden("text_bilstm")
+    ret, out = O.bilstm_text(_weights(g), g["x"], g["x_len"])
+    assert maxrel(ret, g["ret"]) < TOL and maxrel(out, g["output"]) < TOL
+    for c in (1, 2):
+        g = load_golden(f"text_cbow{c}")
+        assert maxrel(O.cbow_text(_weights(g), g["x"], c), g["output"]) < TOL
+
+
 @pytest.mark.parametrize("kind", ["lstm", "embedding"])
 def test_lm_ce_loss(kind):
     """language-model branch: token-wise loss, labels and the three masked means vs the reference (golden)."""

@@ -55,9 +55,9 @@ def test_embedding(dev, embedding_type):                 # reference test_spatia
     assert torch.allclose(y_batched, y_unbatched, atol=1e-5)
 
 
-@pytest.mark.parametrize("embedding_type", ["flat", "spatial"])
-def test_lstm(dev, embedding_type):                      # reference test_lstm, uni-directional configurations
-    model = _text_encoder(dev, "lstm", embedding_type)
+@pytest.mark.parametrize("embedding_type,bidirectional", list(itertools.product(["flat", "spatial"], [True, False])))
+def test_lstm(dev, embedding_type, bidirectional):       # reference test_lstm: the cartesian product of its configs
+    model = _text_encoder(dev, "bilstm" if bidirectional else "lstm", embedding_type)
     x, x_len = random_padded_tensor(dev, 2)
     with torch.no_grad():
         y_batched = model(x, x_len)[0]

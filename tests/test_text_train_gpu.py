@@ -142,3 +142,56 @@ def test_c4_train_step_runs_with_dropout(dev):
         assert torch.isfinite(p.grad).all(), n
         if n != "embedding.weight":
             assert not torch.equal(p.detach(), before[n]), n
+
+
+def _extra_te(kind, embedding_type, E, V, crange=1):
+    import argparse, contextlib, io
+    from multimodal.multimodal import TextEncoder
+    vocab = {f"w{i}": i for i in range(V)}
+    args = argparse.Namespace(text_encoder=kind, embedding_type=embedding_type, embedding_dim=E, crange=crange, dropout_i=0.0,
+                              dropout_o=0.0, pos_embed_type="no_pos_embed", captioning=False, attention=False, attention_gate=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        return TextEncoder(vocab, 2048, args)
+
+
+def test_bilstm_golden_and_backward(dev):
+    """text_encoder='bilstm' (reference :513-552): golden forward from the reference, gradients vs oracle autograd."""
+    from conftest import load_golden
+    g = load_golden("text_bilstm")
+    te = _extra_te("bilstm", "flat", 32, 50)
+    sd = te.state_dict()
+    for k, v in g.items():
+        if k.startswith("w."):
+            sd[k[2:]].copy_(v)
+    te = te.to(dev).eval()
+    ret, out, _ = te(g["x"].to(dev), g["x_len"].to(dev))
+    assert maxrel(ret, g["ret"]) < 2e-5 and maxrel(out, g["output"]) < 2e-5
+    tok, lens = _tokens(9, 11, 50, 4)
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in te.state_dict().items()}
+    r_o, o_o = O.bilstm_text(p, tok, lens)
+    gr = torch.randn(r_o.shape, generator=torch.Generator().manual_seed(1))
+    go = torch.randn(o_o.shape, generator=torch.Generator().manual_seed(2))
+    ((r_o * gr).sum() + (o_o * go).sum()).backward()
+    for prm in te.parameters():
+        prm.grad = None
+    ret, out, _ = te(tok.to(dev), lens.to(dev))
+    assert maxrel(ret, r_o) < 2e-5 and maxrel(out, o_o) < 2e-5
+    ((ret * gr.to(dev)).sum() + (out * go.to(dev)).sum()).backward()
+    for name, prm in te.named_parameters():
+        assert maxrel(prm.grad, p[name].grad) < 2e-4, name
+
+
+@pytest.mark.parametrize("crange", [1, 2])
+def test_cbow_golden_and_backward(dev, crange):
+    from conftest import load_golden
+    g = load_golden(f"text_cbow{crange}")
+    te = _extra_te("cbow", "spatial", 32, 50, crange)
+    te.state_dict()["embedding.weight"].copy_(g["w.embedding.weight"])
+    te = te.to(dev).eval()
+    ret, out, _ = te(g["x"].to(dev), g["x_len"].to(dev))
+    assert maxrel(out, g["output"]) < 2e-5 and ret is out
+    p = {"embedding.weight": g["w.embedding.weight"].clone().requires_grad_(True)}
+    go = torch.randn(g["output"].shape, generator=torch.Generator().manual_seed(5))
+    (O.cbow_text(p, g["x"], crange) * go).sum().backward()
+    (out * go.to(dev)).sum().backward()
+    assert maxrel(te.embedding.weight.grad, p["embedding.weight"].grad) < 2e-5
