@@ -339,6 +339,18 @@ int cvcl_token_ce_bwd(const float* logits, const int64_t* labels, const float* l
 int cvcl_lm_loss_summaries(const float* loss, const int64_t* labels, const float* d_means, float* means, float* counts,
                            float* d_loss, int R, int pad, int sos, int eos, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * FP8 (OCP e4m3) linears for the ViT encoder -- BASELINE configs[4] "fp8 MFMA weights/activations".
+ * cvcl_quant_rows_fp8: q[r][:] = e4m3(y[r][:] / s[r]), s[r] = amax_k |y[r][k]| / 448 (1 for a zero row), where y = x or,
+ *   with ln_gamma/ln_beta, nn.LayerNorm(x) (the vit blocks' norm1 / norm2 fused with the quantisation).  src_dtype: CVCL_BF16
+ *   activations or CVCL_F32 (weights: one scale per output channel).  K % 8 == 0, K <= 4096.
+ * cvcl_gemm_fp8: C[M,N] bf16 = act((A8 . W8^T) * a_scale[m] * w_scale[n] + bias[n]) (+ R), products on
+ *   v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, fp32 accumulation.  K % 128 == 0, N % 128 == 0.     */
+int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stride, const float* ln_gamma, const float* ln_beta,
+                        float ln_eps, void* q, float* scale, long rows, int K, void* stream);
+int cvcl_gemm_fp8(const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
+                  const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,354 @@
+// FP8 (OCP e4m3) linear layers for the ViT encoder: BASELINE configs[4] ("fp8 MFMA weights/activations").
+//
+//   C[M,N] (bf16) = act( (A8[M,K] . W8[N,K]^T) * sa[m] * sw[n] + bias[n] ) (+ R[M,N])
+//
+// A8 / W8 are e4m3 bytes with one fp32 scale per activation row (per token, dynamic: cvcl_quant_rows_fp8 /
+// cvcl_layernorm_fp8) and per weight row (per output channel, static: cvcl_quant_rows_fp8 on the weight).  The products
+// run on v_mfma_scale_f32_32x32x64_f8f6f4 with all block scales = 2^0: gfx950's non-scaled fp8 MFMA runs at the bf16 rate,
+// only the block-scaled K = 64 form doubles it (MI355X_MICROARCH.md), and with unit block scales it is a plain e4m3 x e4m3
+// -> fp32 MFMA; the row scales are applied to the fp32 accumulators in the epilogue.
+//
+// Same skeleton as gemm_glds_kernel (gemm.hip): 128 x 128 tile, 4 waves x (64 x 64), persistent over m tiles, operand tiles
+// of 128 rows x 128 BYTES (= 128 k values: twice the K depth of the bf16 tile in the same LDS image) fetched with
+// global_load_lds_dwordx4 under the source-side XOR chunk swizzle, two buffers, one barrier per K tile.  A lane's fragment
+// for one MFMA is 32 consecutive k bytes of its row (two swizzled 16-byte chunks); A and B use the same (lane, byte) -> k
+// assignment, which is all a contraction needs.
+#include "cvcl_common.h"
+
+namespace {
+
+constexpr int F8_BM = 128, F8_BN = 128;
+constexpr int F8_OPER = 128 * 128;
+constexpr int F8_BUF = 2 * F8_OPER;
+constexpr int F8_LDS = 2 * F8_BUF;
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+
+struct F8Dev {
+    const unsigned char* A; const unsigned char* W; bf16_t* C; const bf16_t* R;
+    const float* sa; const float* sw; const float* bias;
+    int M, N, K, lda, ldw, ldc, ldr, act, num_m_tiles;
+};
+
+__device__ __forceinline__ void f8_glds16(const unsigned char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ inline float f8_gelu(float v) {            // Abramowitz-Stegun 7.1.26 erf, as the bf16 linear epilogue
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+    return 0.5f * v * (1.f + copysignf(fmaf(-poly, e, 1.f), v));
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.y * F8_BN;
+    const int ktiles = p.K / 128;
+
+    // staging: wave w, instruction j covers tile rows (4w + j) * 8 .. + 7; lane -> row + lane / 8, chunk position lane % 8
+    int s_row[4];
+    long w_off[4], a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave * 4 + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        s_row[j] = r;
+        w_off[j] = (long)(n0 + r) * p.ldw + c * 16;
+    }
+    auto set_rows = [&](int mt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = mt * F8_BM + s_row[j];
+            if (m >= p.M) m = p.M - 1;
+            const int c = (lane & 7) ^ ((s_row[j] >> 1) & 7);
+            a_off[j] = (long)m * p.lda + c * 16;
+        }
+    };
+    auto issue = [&](int buf, int kt) {
+        char* base = smem + buf * F8_BUF + wave * 4 * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f8_glds16(p.A + a_off[j] + kt * 128, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f8_glds16(p.W + w_off[j] + kt * 128, base + F8_OPER + j * 1024);
+    };
+
+    // per-lane epilogue constants: output n = n0 + wn*64 + nt*32 + 8g + 4h + e  (weight-row scale and bias), fixed per workgroup
+    f32x4 sw_r[2][4], bias_r[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h;
+            sw_r[nt][g] = *reinterpret_cast<const f32x4*>(p.sw + n);
+            bias_r[nt][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    int fw_off[2], fa_off[2], fw_sw[2], fa_sw[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int rw = wn * 64 + q * 32 + l31, ra = wm * 64 + q * 32 + l31;
+        fw_off[q] = F8_OPER + rw * 128; fw_sw[q] = (rw >> 1) & 7;
+        fa_off[q] = ra * 128;           fa_sw[q] = (ra >> 1) & 7;
+    }
+
+    int l_mt = blockIdx.x, l_kt = 0, buf = 0;
+    bool l_live = l_mt < p.num_m_tiles;
+    if (l_live) { set_rows(l_mt); issue(0, 0); }
+
+    for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
+        const int m0 = cm * F8_BM;
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        // activation-row scales of this tile's rows (column of the MFMA output = this lane's row l31) and the residual rows
+        float sa_r[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            int m = m0 + wm * 64 + mt * 32 + l31;
+            if (m >= p.M) m = p.M - 1;
+            sa_r[mt] = p.sa[m];
+        }
+        bf16x8 rpre[8];
+        if (p.R) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int m = m0 + wm * 64 + j * 8 + (lane >> 3);
+                if (m >= p.M) m = p.M - 1;
+                rpre[j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + (lane & 7) * 8);
+            }
+        }
+
+        for (int kt = 0; kt < ktiles; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (++l_kt == ktiles) {
+                l_kt = 0;
+                l_mt += gridDim.x;
+                l_live = l_mt < p.num_m_tiles;
+                if (l_live) set_rows(l_mt);
+            }
+            if (l_live) issue(buf ^ 1, l_kt);
+            const char* cur = smem + buf * F8_BUF;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                         // two K = 64 steps per 128-byte row
+                v8i fw[2], fa[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int c0 = 4 * s + 2 * h;                   // this lane's 32 bytes = chunks c0, c0 + 1
+                    const u32x4 w0 = *reinterpret_cast<const u32x4*>(cur + fw_off[q] + ((c0 ^ fw_sw[q]) << 4));
+                    const u32x4 w1 = *reinterpret_cast<const u32x4*>(cur + fw_off[q] + (((c0 + 1) ^ fw_sw[q]) << 4));
+                    const u32x4 a0 = *reinterpret_cast<const u32x4*>(cur + fa_off[q] + ((c0 ^ fa_sw[q]) << 4));
+                    const u32x4 a1 = *reinterpret_cast<const u32x4*>(cur + fa_off[q] + (((c0 + 1) ^ fa_sw[q]) << 4));
+                    fw[q] = v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                    fa[q] = v8i{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                                     0x7f7f7f7f);
+            }
+            buf ^= 1;
+        }
+
+        // ---- epilogue: scales, bias, activation -> bf16 through the consumed buffer -> full 128-byte rows (+ residual)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        char* stg = smem + (buf ^ 1) * F8_BUF + wave * 8192;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = mt * 32 + l31;
+                    const int chunk = nt * 4 + g;
+                    bf16x4 q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = fmaf(acc[nt][mt][4 * g + e] * sa_r[mt], sw_r[nt][g][e], bias_r[nt][g][e]);
+                        if (ACT == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (ACT == CVCL_ACT_GELU) v = f8_gelu(v);
+                        q[e] = (bf16_t)v;
+                    }
+                    *reinterpret_cast<bf16x4*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4) + h * 8) = q;
+                }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = j * 8 + (lane >> 3), chunk = lane & 7;
+            const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4));
+            if (m < p.M) {
+                if (p.R) {
+                    const bf16x8 r = rpre[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
+                }
+                *reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n) = v;
+            }
+        }
+    }
+}
+
+// ---- quantisation: one wave per row; q = e4m3(x / s), s = amax / 448 (s = 1 for an all-zero row) ------------------------
+__device__ inline unsigned pack4_fp8(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
+// src: bf16 rows (SRC_F32 = false) or fp32 rows (weights); optional LayerNorm (gamma/beta != NULL) before quantising.
+// K % 8 == 0, K <= 4096 (8 chunks of 8 per lane)
+template <bool SRC_F32>
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ xin, long x_row_stride, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, unsigned char* __restrict__ q,
+                                                             float* __restrict__ scale, long rows, int K) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nch = K >> 3;
+    float v[8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            if (SRC_F32) {
+                const float* xr = (const float*)xin + row * x_row_stride + c * 8;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(xr), b = *reinterpret_cast<const f32x4*>(xr + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[i][e] = a[e]; v[i][4 + e] = b[e]; }
+            } else {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>((const bf16_t*)xin + row * x_row_stride + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = (float)a[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[i][e];
+        }
+    }
+    if (gamma) {                                         // nn.LayerNorm first (vit blocks: norm1 / norm2 feed the fp8 GEMMs)
+        const float mean = wave_sum(s) / (float)K;
+        float qq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (lane + 64 * i < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; qq = fmaf(c, c, qq); }
+            }
+        const float rstd = 1.f / sqrtf(wave_sum(qq) / (float)K + eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mean) * rstd * gamma[c * 8 + e] + beta[c * 8 + e];
+            }
+        }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (lane + 64 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+        }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax / 448.f : 1.f;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf(v[i][e] / sc, -448.f), 448.f);   // true division: same rounding as the oracle's y / s
+            u32x2 w = {pack4_fp8(t[0], t[1], t[2], t[3]), pack4_fp8(t[4], t[5], t[6], t[7])};
+            *reinterpret_cast<u32x2*>(q + row * K + c * 8) = w;
+        }
+    }
+}
+
+int f8_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+}  // namespace
+
+extern "C" int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stride, const float* ln_gamma, const float* ln_beta,
+                                   float ln_eps, void* q, float* scale, long rows, int K, void* stream) {
+    CVCL_CHECK_ARG(x && q && scale && rows > 0 && K > 0 && K % 8 == 0 && K <= 4096 && x_row_stride % 8 == 0 &&
+                       ((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 7) == 0 && (!ln_gamma == !ln_beta),
+                   "cvcl_quant_rows_fp8: bad args (K %d)", K);
+    CvclProfScope prof(stream, CVCL_K_LAYERNORM);
+    dim3 grid(cvcl_div_up(rows, 4));
+    if (src_dtype == CVCL_F32)
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, ln_gamma, ln_beta, ln_eps,
+                           (unsigned char*)q, scale, rows, K);
+    else
+        hipLaunchKernelGGL(quant_rows_fp8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, ln_gamma, ln_beta, ln_eps,
+                           (unsigned char*)q, scale, rows, K);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_gemm_fp8(const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
+                             const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream) {
+    CVCL_CHECK_ARG(A8 && W8 && a_scale && w_scale && C && M > 0 && N > 0 && K > 0, "cvcl_gemm_fp8: null operand");
+    CVCL_CHECK_ARG(K % 128 == 0 && N % 128 == 0 && lda % 16 == 0 && ldw % 16 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0),
+                   "cvcl_gemm_fp8: needs K %% 128 == 0, N %% 128 == 0 and 16-byte aligned rows (M %d N %d K %d)", M, N, K);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    CVCL_CHECK_ARG(al16(A8) && al16(W8) && al16(C) && al16(R) && al16(bias) && al16(w_scale), "cvcl_gemm_fp8: operands must be 16-byte aligned");
+    CVCL_CHECK_ARG(act == CVCL_ACT_NONE || act == CVCL_ACT_RELU || act == CVCL_ACT_GELU, "cvcl_gemm_fp8: activation %d", act);
+    F8Dev d;
+    d.A = (const unsigned char*)A8; d.W = (const unsigned char*)W8; d.C = (bf16_t*)C; d.R = (const bf16_t*)R;
+    d.sa = a_scale; d.sw = w_scale; d.bias = bias;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc; d.ldr = ldr; d.act = act;
+    d.num_m_tiles = cvcl_div_up(M, F8_BM);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_fp8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_fp8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)gemm_fp8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess) {
+            cvcl_set_error("cvcl_gemm_fp8: cannot raise the dynamic LDS limit");
+            return CVCL_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    const int ntn = N / F8_BN;
+    int gm = 2 * f8_num_cus() / ntn;                       // persistent: two workgroups per CU in total
+    gm = gm >= 8 ? (gm & ~7) : (gm < 1 ? 1 : gm);           // multiples of 8: column tiles of a row group share an XCD
+    if (gm > d.num_m_tiles) gm = d.num_m_tiles;
+    dim3 grid(gm, ntn);
+    CvclProfScope prof(stream, CVCL_K_GEMM);
+    if (act == CVCL_ACT_GELU) hipLaunchKernelGGL(gemm_fp8_kernel<CVCL_ACT_GELU>, grid, dim3(256), F8_LDS, (hipStream_t)stream, d);
+    else if (act == CVCL_ACT_RELU) hipLaunchKernelGGL(gemm_fp8_kernel<CVCL_ACT_RELU>, grid, dim3(256), F8_LDS, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(gemm_fp8_kernel<CVCL_ACT_NONE>, grid, dim3(256), F8_LDS, (hipStream_t)stream, d);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}

@@ -209,3 +209,72 @@ def test_gemm256_linear_epilogue_matches_128_tile_kernel(dev, M, N, K, act, res)
     _gemm256(H, 1, ad, wd, C2, None, bd, act, rd)
     assert torch.equal(C, C2)
     assert maxrel(C.float(), y.float()) < 8e-3
+
+
+def _quant_rows_ref(y):
+    """oracle of cvcl_quant_rows_fp8: per-row scale amax/448, OCP e4m3 round-to-nearest-even (torch.float8_e4m3fn)."""
+    amax = y.abs().amax(dim=1)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    q = (y / s[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q, s
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 256, 768), (777, 768, 3072), (4096, 2304, 768)])
+def test_gemm_fp8_exact_on_small_integers(dev, M, N, K):
+    """e4m3 x e4m3 -> fp32 on the block-scaled MFMA with unit block scales: small integers are exact in e4m3 and their sums
+    in fp32, so C must equal the (bf16-rounded) float64 product exactly -- pins the fragment / swizzle / scale plumbing."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    sa = 2.0 ** torch.randint(-3, 2, (M,), generator=g).float()
+    sw = 2.0 ** torch.randint(-3, 2, (N,), generator=g).float()
+    ref = ((a.double() @ w.double().t()) * sa.double()[:, None] * sw.double()[None, :]).float().bfloat16()
+    a8, w8 = a.to(torch.float8_e4m3fn).to(dev), w.to(torch.float8_e4m3fn).to(dev)
+    sad, swd = sa.to(dev), sw.to(dev)
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    for _ in range(2):
+        H.check(H.lib().cvcl_gemm_fp8(a8.data_ptr(), H.ptr(sad), K, w8.data_ptr(), H.ptr(swd), K, H.ptr(C), N, None, 0, None, 0,
+                                      M, N, K, H.stream_ptr()), "cvcl_gemm_fp8")
+    assert torch.equal(C.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [(1000, 768, 768, 0, True), (600, 3072, 768, 2, False), (900, 768, 3072, 0, True)])
+def test_fp8_linear_pipeline_vs_emulation(dev, M, N, K, act, res):
+    """quantise activations (per row) and weights (per output channel) with cvcl_quant_rows_fp8 -- bit-identical to the
+    torch.float8_e4m3fn emulation -- then cvcl_gemm_fp8 with bias / GELU / residual vs float64 maths on the dequantised
+    operands, and the end-to-end quantisation error vs the unquantised linear stays at the fp8 level."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(N + K)
+    x = (torch.randn(M, K, generator=g) * 1.7).bfloat16()
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    r = torch.randn(M, N, generator=g).bfloat16() if res else None
+    xq_ref, xs_ref = _quant_rows_ref(x.float())
+    wq_ref, ws_ref = _quant_rows_ref(w)
+    xd, wd = x.to(dev), w.to(dev)
+    xq, xs = torch.empty(M, K, dtype=torch.uint8, device=dev), torch.empty(M, device=dev)
+    wq, ws = torch.empty(N, K, dtype=torch.uint8, device=dev), torch.empty(N, device=dev)
+    H.check(H.lib().cvcl_quant_rows_fp8(H.BF16, H.ptr(xd), K, None, None, 0.0, H.ptr(xq), H.ptr(xs), M, K, H.stream_ptr()), "quant")
+    H.check(H.lib().cvcl_quant_rows_fp8(H.F32, H.ptr(wd), K, None, None, 0.0, H.ptr(wq), H.ptr(ws), N, K, H.stream_ptr()), "quant")
+    assert torch.equal(xs.cpu(), xs_ref) and torch.equal(xq.cpu(), xq_ref.view(torch.uint8))
+    assert torch.equal(ws.cpu(), ws_ref) and torch.equal(wq.cpu(), wq_ref.view(torch.uint8))
+    y = (xq_ref.double() @ wq_ref.double().t()) * xs_ref.double()[:, None] * ws_ref.double()[None, :] + bias.double()
+    if act == 2:
+        y = 0.5 * y * (1 + torch.erf(y / 2 ** 0.5))
+    y = y.float().bfloat16().double()
+    if res:
+        y = y + r.double()
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    bd = bias.to(dev)
+    rd = r.to(dev) if res else None
+    H.check(H.lib().cvcl_gemm_fp8(H.ptr(xq), H.ptr(xs), K, H.ptr(wq), H.ptr(ws), K, H.ptr(C), N, H.ptr(bd), act, H.ptr(rd), N, M, N, K,
+                                  H.stream_ptr()), "cvcl_gemm_fp8")
+    assert maxrel(C.float(), y.float()) < 8e-3
+    full = x.double() @ w.double().t() + bias.double()
+    if act == 2:
+        full = 0.5 * full * (1 + torch.erf(full / 2 ** 0.5))
+    if res:
+        full = full + r.double()
+    rel = float((C.double().cpu() - full).norm() / full.norm())
+    assert rel < 0.05, rel
