@@ -217,19 +217,32 @@ __device__ inline unsigned pack4_fp8(float a, float b, float c, float d) {
 
 // src: bf16 rows (SRC_F32 = false) or fp32 rows (weights); optional LayerNorm (gamma/beta != NULL) before quantising.
 // K % 8 == 0, K <= 4096 (8 chunks of 8 per lane)
-template <bool SRC_F32>
+// LPR lanes per row (32 for K <= 1024: a 768-wide row is 96 chunks = 3 per lane with no idle lanes; 64 otherwise)
+template <int LPR> __device__ inline float lanes_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int LPR> __device__ inline float lanes_max(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <bool SRC_F32, int LPR>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ xin, long x_row_stride, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, unsigned char* __restrict__ q,
                                                              float* __restrict__ scale, long rows, int K) {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+    const int lane = threadIdx.x % LPR;
     if (row >= rows) return;
     const int nch = K >> 3;
-    float v[8][8];
+    constexpr int NCH = LPR == 32 ? 4 : 8;           // chunks per lane held in registers
+    float v[NCH][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + LPR * i;
         if (c < nch) {
             if (SRC_F32) {
                 const float* xr = (const float*)xin + row * x_row_stride + c * 8;
@@ -246,18 +259,18 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
         }
     }
     if (gamma) {                                         // nn.LayerNorm first (vit blocks: norm1 / norm2 feed the fp8 GEMMs)
-        const float mean = wave_sum(s) / (float)K;
+        const float mean = lanes_sum<LPR>(s) / (float)K;
         float qq = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (lane + 64 * i < nch) {
+        for (int i = 0; i < NCH; ++i)
+            if (lane + LPR * i < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; qq = fmaf(c, c, qq); }
             }
-        const float rstd = 1.f / sqrtf(wave_sum(qq) / (float)K + eps);
+        const float rstd = 1.f / sqrtf(lanes_sum<LPR>(qq) / (float)K + eps);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = lane + 64 * i;
+        for (int i = 0; i < NCH; ++i) {
+            const int c = lane + LPR * i;
             if (c < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mean) * rstd * gamma[c * 8 + e] + beta[c * 8 + e];
@@ -266,17 +279,17 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
     }
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        if (lane + 64 * i < nch) {
+    for (int i = 0; i < NCH; ++i)
+        if (lane + LPR * i < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
         }
-    amax = wave_max(amax);
+    amax = lanes_max<LPR>(amax);
     const float sc = amax > 0.f ? amax / 448.f : 1.f;
     if (lane == 0) scale[row] = sc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + LPR * i;
         if (c < nch) {
             float t[8];
 #pragma unroll
@@ -306,13 +319,17 @@ extern "C" int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stri
                        ((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 7) == 0 && (!ln_gamma == !ln_beta),
                    "cvcl_quant_rows_fp8: bad args (K %d)", K);
     CvclProfScope prof(stream, CVCL_K_LAYERNORM);
-    dim3 grid(cvcl_div_up(rows, 4));
-    if (src_dtype == CVCL_F32)
-        hipLaunchKernelGGL(quant_rows_fp8_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, ln_gamma, ln_beta, ln_eps,
-                           (unsigned char*)q, scale, rows, K);
-    else
-        hipLaunchKernelGGL(quant_rows_fp8_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, x_row_stride, ln_gamma, ln_beta, ln_eps,
-                           (unsigned char*)q, scale, rows, K);
+    const bool narrow = K <= 1024;                      // 32 lanes per row
+    dim3 grid(cvcl_div_up(rows, narrow ? 8 : 4));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* qq = (unsigned char*)q;
+    if (src_dtype == CVCL_F32) {
+        if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 32>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 64>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+    } else {
+        if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 64>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+    }
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

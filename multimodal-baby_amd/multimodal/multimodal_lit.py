@@ -82,9 +82,14 @@ class MultiModalLitModel(LightningModule):
         parser.add_argument("--length_penalty_alpha", type=float, default=LENGTH_PENALTY_ALPHA)
 
     def set_precision(self, precision):
-        """Trainer ``--precision``: 'bf16' / '16' -> bf16 storage + bf16 MFMA trunk; '32' -> exact-fp32 parity mode."""
-        dt = torch.bfloat16 if str(precision) in ("bf16", "16", "bf16-mixed", "16-mixed") else torch.float32
+        """Trainer ``--precision``: 'bf16' / '16' -> bf16 storage + bf16 MFMA trunk; '32' -> exact-fp32 parity mode;
+        'fp8' -> bf16 storage with e4m3 weights / activations in the ViT linears (BASELINE configs[4]; the ResNeXt trunk
+        has no fp8 path and runs in bf16)."""
+        p = str(precision)
+        dt = torch.bfloat16 if p in ("bf16", "16", "bf16-mixed", "16-mixed", "fp8", "8") else torch.float32
         self.vision_encoder.set_compute_dtype(dt)
+        if getattr(self.vision_encoder, "vit_dino", False):
+            self.vision_encoder.model.fp8_linears = p in ("fp8", "8")
 
     def configure_optimizers(self):
         kw = {}

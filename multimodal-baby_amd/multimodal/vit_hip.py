@@ -12,7 +12,7 @@ from . import _hip as H
 
 
 def _packed(model, dt, device):
-    key = (str(dt), str(device)) + tuple((p.data_ptr(), p._version) for p in model.parameters())
+    key = (str(dt), str(device), bool(getattr(model, "fp8_linears", False))) + tuple((p.data_ptr(), p._version) for p in model.parameters())
     hit = model._cache.get("w")
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -39,8 +39,34 @@ def _packed(model, dt, device):
             "fc2_w": blk.mlp.fc2.weight.detach().to(dt).contiguous(), "fc2_b": blk.mlp.fc2.bias.detach().float().contiguous(),
             "eps": blk.norm1.eps, "scale": float(blk.attn.scale), "heads": blk.attn.num_heads})
     w["nw"], w["nb"], w["neps"] = model.norm.weight.detach().float().contiguous(), model.norm.bias.detach().float().contiguous(), model.norm.eps
+    if getattr(model, "fp8_linears", False):
+        # BASELINE configs[4]: e4m3 weights with one scale per output channel (static), quantised once per weight version
+        lib = H.lib()
+        for blk, bw in zip(model.blocks, w["blocks"]):
+            for name, lin in (("qkv", blk.attn.qkv), ("proj", blk.attn.proj), ("fc1", blk.mlp.fc1), ("fc2", blk.mlp.fc2)):
+                wf = lin.weight.detach().float().contiguous()
+                N, K = wf.shape
+                q = torch.empty(N, K, dtype=torch.uint8, device=device)
+                sc = torch.empty(N, dtype=torch.float32, device=device)
+                H.check(lib.cvcl_quant_rows_fp8(H.F32, H.ptr(wf), K, None, None, 0.0, H.ptr(q), H.ptr(sc), N, K, H.stream_ptr()),
+                        "cvcl_quant_rows_fp8")
+                bw[name + "_q"], bw[name + "_s"] = q, sc
     model._cache["w"] = (key, w)
     return w
+
+
+def _quant(x, rows, K, q, sc, ln=None):
+    """bf16 rows -> e4m3 rows + per-row scales, optionally through nn.LayerNorm first (ln = (gamma, beta, eps))."""
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    H.check(H.lib().cvcl_quant_rows_fp8(H.BF16, H.ptr(x), K, H.ptr(g), H.ptr(b), eps, H.ptr(q), H.ptr(sc), rows, K, H.stream_ptr()),
+            "cvcl_quant_rows_fp8")
+
+
+def _gemm8(q, sc, wq, ws, out, bias, act=H.ACT_NONE, residual=None):
+    M, K = q.shape
+    N = wq.shape[0]
+    H.check(H.lib().cvcl_gemm_fp8(H.ptr(q), H.ptr(sc), K, H.ptr(wq), H.ptr(ws), K, H.ptr(out), N, H.ptr(bias), act, H.ptr(residual), N,
+                                  M, N, K, H.stream_ptr()), "cvcl_gemm_fp8")
 
 
 def _ln(cd, x, stride, g, b, eps, out, out_f32, rows, D):
@@ -77,7 +103,27 @@ def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
         att = torch.empty_like(h)
         qkv = torch.empty(B * T, 3 * D, dtype=dt, device=dev)
         mid = torch.empty(B * T, w["blocks"][0]["fc1_w"].shape[0], dtype=dt, device=dev) if w["blocks"] else None
-        for bw in w["blocks"]:
+        fp8 = bool(getattr(model, "fp8_linears", False)) and dt == torch.bfloat16 and D % 128 == 0
+        if fp8:
+            # fp8 linears (BASELINE configs[4]): every GEMM operand is e4m3 with a per-token scale -- norm1 / norm2 are fused
+            # with the quantisation, the attention output and the GELU output get their own quantisation pass; the residual
+            # stream, attention and the statistics stay bf16 / fp32
+            Dm = mid.shape[1]
+            q_d = torch.empty(B * T, D, dtype=torch.uint8, device=dev)
+            q_m = torch.empty(B * T, Dm, dtype=torch.uint8, device=dev)
+            sc = torch.empty(B * T, dtype=torch.float32, device=dev)
+            for bw in w["blocks"]:
+                _quant(h, B * T, D, q_d, sc, (bw["n1w"], bw["n1b"], bw["eps"]))
+                _gemm8(q_d, sc, bw["qkv_q"], bw["qkv_s"], qkv, bw["qkv_b"])
+                H.check(lib.cvcl_attention(cd, H.ptr(qkv), None, H.ptr(att), B, T, bw["heads"], D // bw["heads"], bw["scale"], s),
+                        "cvcl_attention")
+                _quant(att, B * T, D, q_d, sc)
+                _gemm8(q_d, sc, bw["proj_q"], bw["proj_s"], h, bw["proj_b"], residual=h)
+                _quant(h, B * T, D, q_d, sc, (bw["n2w"], bw["n2b"], bw["eps"]))
+                _gemm8(q_d, sc, bw["fc1_q"], bw["fc1_s"], mid, bw["fc1_b"], act=H.ACT_GELU)
+                _quant(mid, B * T, Dm, q_m, sc)
+                _gemm8(q_m, sc, bw["fc2_q"], bw["fc2_s"], h, bw["fc2_b"], residual=h)
+        for bw in (w["blocks"] if not fp8 else ()):
             _ln(cd, h, D, bw["n1w"], bw["n1b"], bw["eps"], y, False, B * T, D)
             H.gemm(y, bw["qkv_w"], out=qkv, bias=bw["qkv_b"])
             H.check(lib.cvcl_attention(cd, H.ptr(qkv), None, H.ptr(att), B, T, bw["heads"], D // bw["heads"], bw["scale"], s),

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from bench import synthetic_batch_on_device
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--patch", type=int, default=16)
-ap.add_argument("--steps", type=int, default=10); a = ap.parse_args()
+ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", default="bf16"); a = ap.parse_args()
 dev = torch.device("cuda:0")
 args = argparse.Namespace(embedding_type="flat", embedding_dim=512, pretrained_cnn=False, cnn_dino=False, vit_dino=True,
                           finetune_cnn=False, text_encoder="transformer", crange=1, dropout_i=0.0, dropout_o=0.0,
@@ -26,7 +26,7 @@ mm.load_model = lambda name, pretrained: vits.vit_base(patch_size=a.patch, num_c
 with contextlib.redirect_stdout(io.StringIO()):
     ve = VisionEncoder(args); te = TextEncoder(read_vocab(), 768, args); lit = MultiModalLitModel(ve, te, args)
 mm.load_model = orig
-lit.to(dev); lit.set_precision("bf16"); lit.train()
+lit.to(dev); lit.set_precision(a.precision); lit.train()
 opt = lit.configure_optimizers()
 batch = synthetic_batch_on_device(a.batch, 0, dev) + (None,)
 def step():
@@ -39,6 +39,6 @@ H.prof_enable(True)
 for _ in range(3): step()
 torch.cuda.synchronize(); prof = H.prof_collect(); H.prof_enable(False)
 flops = {16: 35.1e9, 14: 46.3e9}[a.patch] * a.batch
-print(f"C4 ViT-B/{a.patch} + transformer text, B={a.batch}, bf16: {dt*1e3:.2f} ms/step, {a.batch/dt:.0f} pairs/s, "
+print(f"{'C5' if a.precision == 'fp8' else 'C4'} ViT-B/{a.patch} + transformer text, B={a.batch}, {a.precision}: {dt*1e3:.2f} ms/step, {a.batch/dt:.0f} pairs/s, "
       f"{flops/dt/1e12:.0f} TFLOP/s fwd-equivalent, loss {float(out['loss']):.4f}")
 print({k: round(v[0] / 3, 3) for k, v in prof.items() if v[1] > 0})

@@ -25,3 +25,20 @@ for name, M, N, K, kind in shapes:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     print(f"{name:12s} M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2*M*N*K/us/1e6:7.0f} TFLOP/s")
+
+print("fp8 (cvcl_gemm_fp8, bias only):")
+for name, M, N, K in [("vit.qkv", 50432, 2304, 768), ("vit.proj", 50432, 768, 768), ("vit.fc1", 50432, 3072, 768), ("vit.fc2", 50432, 768, 3072),
+                      ("4096^3", 4096, 4096, 4096), ("8192^3", 8192, 8192, 8192)]:
+    a8 = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev); w8 = torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev)
+    sa = torch.ones(M, device=dev); sw = torch.ones(N, device=dev); bias = torch.zeros(N, device=dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    f = lambda: H.check(H.lib().cvcl_gemm_fp8(H.ptr(a8), H.ptr(sa), K, H.ptr(w8), H.ptr(sw), K, H.ptr(out), N, H.ptr(bias), 0, None, 0, M, N, K,
+                                              H.stream_ptr()), "fp8")
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): f()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    print(f"{name:12s} M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2*M*N*K/us/1e6:7.0f} TFLOP/s")
