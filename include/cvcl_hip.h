@@ -213,6 +213,10 @@ int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const float* gam
  * (vit:119-127; nn.MultiheadAttention inside nn.TransformerEncoderLayer).  bf16, hd = 64, no mask -> MFMA kernel. */
 int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok, void* out, int B, int T, int heads, int head_dim,
                    float scale, void* stream);
+/* same attention (bf16 qkv, head_dim 64, 32 < T), output written as e4m3 [B*T][heads*64] + e8m0 block scales tiled
+ * [heads*64/128][B*T][4] -- cvcl_gemm_fp8_mx's MX input, so the fp8 projection needs no quantisation pass in between. */
+int cvcl_attention_mx(const void* qkv, void* out8, void* out_block_scales, int B, int T, int heads, int head_dim, float scale,
+                      void* stream);
 /* x[b,l,:] = table[tok[b,l]] (+ pos[l]) (multimodal.py:496, 561-563) */
 int cvcl_embed_gather_pos(const float* table, const int64_t* tok, const float* pos, float* x, int B, int L, int E, int V,
                           void* stream);
@@ -348,6 +352,13 @@ int cvcl_lm_loss_summaries(const float* loss, const int64_t* labels, const float
  *   v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales, fp32 accumulation.  K % 128 == 0, N % 128 == 0.     */
 int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stride, const float* ln_gamma, const float* ln_beta,
                         float ln_eps, void* q, float* scale, long rows, int K, void* stream);
+/* MX variants: a_block_scales = one e8m0 byte (2^(b-127)) per 32-element block of A instead of the per-row fp32 scale (the
+ * scaled MFMA applies it in hardware), tiled [K/128][M][4] (block k/32 of row m at ((k/128)*M + m)*4 + (k/32)%4, so 32 rows'
+ * words are contiguous); c8 / c_block_scales = e4m3 output [M][ldc8] + e8m0 scales in the same tiling [N/128][M][4]
+ * (2^ceil(log2(amax/448)) per block) instead of bf16 C, ready to be the next GEMM's MX input -- no separate quantisation pass. */
+int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void* a_block_scales, int lda, const void* W8,
+                     const float* w_scale, int ldw, void* C, int ldc, void* c8, void* c_block_scales, int ldc8,
+                     const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream);
 int cvcl_gemm_fp8(const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
                   const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream);
 

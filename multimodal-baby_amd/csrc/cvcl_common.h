@@ -116,4 +116,20 @@ __device__ inline float block_max(float v, float* scratch) {
     for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
     return r;
 }
+
+// ---- fp8 e4m3 / MX (e8m0 block scale) helpers shared by the fp8 GEMM epilogue and the attention epilogue
+// e8m0 block scale (power of two) that maps a block's amax into the e4m3 range: 2^ceil(log2(amax / 448)), byte = exponent + 127
+__device__ inline unsigned mx_scale_byte(float amax) {
+    const unsigned bits = __float_as_uint(amax * (1.f / 448.f));
+    unsigned e = (bits >> 23) & 0xffu;
+    if (bits & 0x7fffffu) e += 1;
+    return e < 1u ? 1u : (e > 254u ? 254u : e);
+}
+__device__ inline float mx_inv_scale(unsigned byte) { return __uint_as_float((254u - byte) << 23); }   // 2^(127 - byte)
+__device__ inline unsigned pack4_fp8(float a, float b, float c, float d) {
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
 #endif  // __HIPCC__

@@ -27,7 +27,9 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 struct F8Dev {
     const unsigned char* A; const unsigned char* W; bf16_t* C; const bf16_t* R;
     const float* sa; const float* sw; const float* bias;
-    int M, N, K, lda, ldw, ldc, ldr, act, num_m_tiles;
+    const unsigned char* a_bs;        // MXA: e8m0 scale per 32-element block of A, tiled [K/128][M][4] (sa unused)
+    unsigned char* C8; unsigned char* c_bs;   // MXOUT: e4m3 output [M][ldc8] + e8m0 block scales [M][N/32] instead of bf16 C
+    int M, N, K, lda, ldw, ldc, ldr, act, num_m_tiles, ldc8;
 };
 
 __device__ __forceinline__ void f8_glds16(const unsigned char* src, char* lds_wave_base) {
@@ -47,7 +49,10 @@ __device__ inline float f8_gelu(float v) {            // Abramowitz-Stegun 7.1.2
     return 0.5f * v * (1.f + copysignf(fmaf(-poly, e, 1.f), v));
 }
 
-template <int ACT>
+// ---- quantisation: one wave per row; q = e4m3(x / s), s = amax / 448 (s = 1 for an all-zero row) ------------------------
+// src: bf16 rows (SRC_F32 = false) or fp32 rows (weights); optional LayerNorm (gamma/beta != NULL) before quantising.
+// K % 8 == 0, K <= 4096 (8 chunks of 8 per lane)
+template <int ACT, bool MXA, bool MXOUT>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -102,9 +107,23 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
         fa_off[q] = ra * 128;           fa_sw[q] = (ra >> 1) & 7;
     }
 
+    // MXA: the 4 block-scale bytes of a K tile (128 k = 4 blocks of 32) for this lane's rows of the two m tiles, fetched one
+    // K tile ahead together with the operand tiles (same vmcnt wait)
+    unsigned aw_next[2] = {0x7f7f7f7fu, 0x7f7f7f7fu}, aw[2] = {0x7f7f7f7fu, 0x7f7f7f7fu};
+    auto load_scales = [&](int mt_tile, int kt) {
+        if constexpr (MXA) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                int m = mt_tile * F8_BM + wm * 64 + mt * 32 + l31;
+                if (m >= p.M) m = p.M - 1;
+                aw_next[mt] = *reinterpret_cast<const unsigned*>(p.a_bs + ((long)kt * p.M + m) * 4);      // coalesced over rows
+            }
+        }
+    };
+
     int l_mt = blockIdx.x, l_kt = 0, buf = 0;
     bool l_live = l_mt < p.num_m_tiles;
-    if (l_live) { set_rows(l_mt); issue(0, 0); }
+    if (l_live) { set_rows(l_mt); issue(0, 0); load_scales(l_mt, 0); }
 
     for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
         const int m0 = cm * F8_BM;
@@ -117,12 +136,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
         // activation-row scales of this tile's rows (column of the MFMA output = this lane's row l31) and the residual rows
-        float sa_r[2];
+        float sa_r[2] = {1.f, 1.f};
+        if constexpr (!MXA) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            int m = m0 + wm * 64 + mt * 32 + l31;
-            if (m >= p.M) m = p.M - 1;
-            sa_r[mt] = p.sa[m];
+            for (int mt = 0; mt < 2; ++mt) {
+                int m = m0 + wm * 64 + mt * 32 + l31;
+                if (m >= p.M) m = p.M - 1;
+                sa_r[mt] = p.sa[m];
+            }
         }
         bf16x8 rpre[8];
         if (p.R) {
@@ -143,18 +164,21 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
                 l_live = l_mt < p.num_m_tiles;
                 if (l_live) set_rows(l_mt);
             }
-            if (l_live) issue(buf ^ 1, l_kt);
+            if constexpr (MXA) { aw[0] = aw_next[0]; aw[1] = aw_next[1]; }
+            if (l_live) { issue(buf ^ 1, l_kt); load_scales(l_mt, l_kt); }
             const char* cur = smem + buf * F8_BUF;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {                         // two K = 64 steps per 128-byte row
                 v8i fw[2], fa[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    const int c0 = 4 * s + 2 * h;                   // this lane's 32 bytes = chunks c0, c0 + 1
+                    // the MFMA's k order per lane is interleaved: lane half h holds k 16h..16h+15 and 32+16h..32+16h+15 of the 64,
+                    // and scale lane half h covers k 32h..32h+31 (tools/probes/mx_scale_probe_b.hip) -> chunks c0 and c0 + 2
+                    const int c0 = 4 * s + h;
                     const u32x4 w0 = *reinterpret_cast<const u32x4*>(cur + fw_off[q] + ((c0 ^ fw_sw[q]) << 4));
-                    const u32x4 w1 = *reinterpret_cast<const u32x4*>(cur + fw_off[q] + (((c0 + 1) ^ fw_sw[q]) << 4));
+                    const u32x4 w1 = *reinterpret_cast<const u32x4*>(cur + fw_off[q] + (((c0 + 2) ^ fw_sw[q]) << 4));
                     const u32x4 a0 = *reinterpret_cast<const u32x4*>(cur + fa_off[q] + ((c0 ^ fa_sw[q]) << 4));
-                    const u32x4 a1 = *reinterpret_cast<const u32x4*>(cur + fa_off[q] + (((c0 + 1) ^ fa_sw[q]) << 4));
+                    const u32x4 a1 = *reinterpret_cast<const u32x4*>(cur + fa_off[q] + (((c0 + 2) ^ fa_sw[q]) << 4));
                     fw[q] = v8i{(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
                     fa[q] = v8i{(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
                 }
@@ -162,8 +186,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0,
-                                                                                     0x7f7f7f7f);
+                        acc[nt][mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                            fw[nt], fa[mt], acc[nt][mt], 0, 0, 0, 0x7f7f7f7f, 0,
+                            MXA ? (int)(aw[mt] >> (8 * (2 * s + h))) : 0x7f7f7f7f);      // byte 0 = scale of k block 2s + h of this lane's row
             }
             buf ^= 1;
         }
@@ -201,22 +226,28 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                 }
-                *reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n) = v;
+                if constexpr (!MXOUT) *reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n) = v;
+            }
+            if constexpr (MXOUT) {
+                // e4m3 + one e8m0 scale per 32 columns of the row: the block = 4 adjacent lanes (chunks 4b .. 4b+3)
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[e]));
+                amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0xB1, 0xf, 0xf, true)));
+                amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0x4E, 0xf, 0xf, true)));
+                const unsigned sb = mx_scale_byte(amax);
+                const float inv = mx_inv_scale(sb);
+                if (m < p.M) {
+                    u32x2 w = {pack4_fp8((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv),
+                               pack4_fp8((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv)};
+                    *reinterpret_cast<u32x2*>(p.C8 + (long)m * p.ldc8 + n) = w;
+                    if ((chunk & 3) == 0) p.c_bs[((long)(n >> 7) * p.M + m) * 4 + ((n >> 5) & 3)] = (unsigned char)sb;
+                }
             }
         }
     }
 }
 
-// ---- quantisation: one wave per row; q = e4m3(x / s), s = amax / 448 (s = 1 for an all-zero row) ------------------------
-__device__ inline unsigned pack4_fp8(float a, float b, float c, float d) {
-    int w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return (unsigned)w;
-}
-
-// src: bf16 rows (SRC_F32 = false) or fp32 rows (weights); optional LayerNorm (gamma/beta != NULL) before quantising.
-// K % 8 == 0, K <= 4096 (8 chunks of 8 per lane)
 // LPR lanes per row (32 for K <= 1024: a 768-wide row is 96 chunks = 3 per lane with no idle lanes; 64 otherwise)
 template <int LPR> __device__ inline float lanes_sum(float v) {
 #pragma unroll
@@ -334,38 +365,70 @@ extern "C" int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stri
     return CVCL_OK;
 }
 
-extern "C" int cvcl_gemm_fp8(const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
-                             const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream) {
-    CVCL_CHECK_ARG(A8 && W8 && a_scale && w_scale && C && M > 0 && N > 0 && K > 0, "cvcl_gemm_fp8: null operand");
-    CVCL_CHECK_ARG(K % 128 == 0 && N % 128 == 0 && lda % 16 == 0 && ldw % 16 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0),
-                   "cvcl_gemm_fp8: needs K %% 128 == 0, N %% 128 == 0 and 16-byte aligned rows (M %d N %d K %d)", M, N, K);
-    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    CVCL_CHECK_ARG(al16(A8) && al16(W8) && al16(C) && al16(R) && al16(bias) && al16(w_scale), "cvcl_gemm_fp8: operands must be 16-byte aligned");
-    CVCL_CHECK_ARG(act == CVCL_ACT_NONE || act == CVCL_ACT_RELU || act == CVCL_ACT_GELU, "cvcl_gemm_fp8: activation %d", act);
-    F8Dev d;
-    d.A = (const unsigned char*)A8; d.W = (const unsigned char*)W8; d.C = (bf16_t*)C; d.R = (const bf16_t*)R;
-    d.sa = a_scale; d.sw = w_scale; d.bias = bias;
-    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc; d.ldr = ldr; d.act = act;
-    d.num_m_tiles = cvcl_div_up(M, F8_BM);
+namespace {
+template <int ACT, bool MXA, bool MXOUT>
+int launch_fp8(const F8Dev& d, dim3 grid, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_fp8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_fp8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm_fp8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_fp8_kernel<ACT, MXA, MXOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess) {
             cvcl_set_error("cvcl_gemm_fp8: cannot raise the dynamic LDS limit");
             return CVCL_ELAUNCH;
         }
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemm_fp8_kernel<ACT, MXA, MXOUT>), grid, dim3(256), F8_LDS, st, d);
+    return CVCL_OK;
+}
+}  // namespace
+
+// a_scale: per-row fp32 scales [M], or NULL with a_block_scales (e8m0, MX) tiled [K/128][M][4]: the four block scales of one
+// row's 128-wide K tile are one word, rows adjacent, so a wave's 32 rows read them coalesced.  C: bf16 [M][ldc], or NULL with
+// c8 [M][ldc8] e4m3 + c_block_scales [N/128][M][4] (MX output for the next fp8 GEMM; no residual in that mode).
+extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void* a_block_scales, int lda, const void* W8,
+                                const float* w_scale, int ldw, void* C, int ldc, void* c8, void* c_block_scales, int ldc8,
+                                const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream) {
+    CVCL_CHECK_ARG(A8 && W8 && w_scale && M > 0 && N > 0 && K > 0 && (!a_scale != !a_block_scales) && (!C != !c8) &&
+                       (!c8 == !c_block_scales), "cvcl_gemm_fp8: null / inconsistent operands");
+    CVCL_CHECK_ARG(K % 128 == 0 && N % 128 == 0 && lda % 16 == 0 && ldw % 16 == 0 && (!C || ldc % 8 == 0) && (!c8 || ldc8 % 8 == 0) &&
+                       (!R || ldr % 8 == 0),
+                   "cvcl_gemm_fp8: needs K %% 128 == 0, N %% 128 == 0 and 16-byte aligned rows (M %d N %d K %d)", M, N, K);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    CVCL_CHECK_ARG(al16(A8) && al16(W8) && al16(C) && al16(R) && al16(bias) && al16(w_scale) && (((uintptr_t)c8 & 7) == 0) &&
+                       (((uintptr_t)a_block_scales & 3) == 0), "cvcl_gemm_fp8: operands must be 16-byte aligned");
+    CVCL_CHECK_ARG(act == CVCL_ACT_NONE || act == CVCL_ACT_RELU || act == CVCL_ACT_GELU, "cvcl_gemm_fp8: activation %d", act);
+    CVCL_CHECK_ARG(!c8 || !R, "cvcl_gemm_fp8: the MX output mode takes no residual");
+    F8Dev d;
+    d.A = (const unsigned char*)A8; d.W = (const unsigned char*)W8; d.C = (bf16_t*)C; d.R = (const bf16_t*)R;
+    d.sa = a_scale; d.sw = w_scale; d.bias = bias;
+    d.a_bs = (const unsigned char*)a_block_scales; d.C8 = (unsigned char*)c8; d.c_bs = (unsigned char*)c_block_scales;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc; d.ldr = ldr; d.act = act; d.ldc8 = ldc8;
+    d.num_m_tiles = cvcl_div_up(M, F8_BM);
     const int ntn = N / F8_BN;
     int gm = 2 * f8_num_cus() / ntn;                       // persistent: two workgroups per CU in total
     gm = gm >= 8 ? (gm & ~7) : (gm < 1 ? 1 : gm);           // multiples of 8: column tiles of a row group share an XCD
     if (gm > d.num_m_tiles) gm = d.num_m_tiles;
     dim3 grid(gm, ntn);
+    hipStream_t st = (hipStream_t)stream;
     CvclProfScope prof(stream, CVCL_K_GEMM);
-    if (act == CVCL_ACT_GELU) hipLaunchKernelGGL(gemm_fp8_kernel<CVCL_ACT_GELU>, grid, dim3(256), F8_LDS, (hipStream_t)stream, d);
-    else if (act == CVCL_ACT_RELU) hipLaunchKernelGGL(gemm_fp8_kernel<CVCL_ACT_RELU>, grid, dim3(256), F8_LDS, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL(gemm_fp8_kernel<CVCL_ACT_NONE>, grid, dim3(256), F8_LDS, (hipStream_t)stream, d);
+    const bool mxa = a_block_scales != nullptr, mxo = c8 != nullptr;
+    int rc;
+    if (mxo) {
+        CVCL_CHECK_ARG(!mxa, "cvcl_gemm_fp8: MX input together with MX output is not instantiated");
+        rc = act == CVCL_ACT_GELU ? launch_fp8<CVCL_ACT_GELU, false, true>(d, grid, st)
+           : act == CVCL_ACT_RELU ? launch_fp8<CVCL_ACT_RELU, false, true>(d, grid, st) : launch_fp8<CVCL_ACT_NONE, false, true>(d, grid, st);
+    } else if (mxa) {
+        CVCL_CHECK_ARG(act == CVCL_ACT_NONE, "cvcl_gemm_fp8: MX input is instantiated without activation only");
+        rc = launch_fp8<CVCL_ACT_NONE, true, false>(d, grid, st);
+    } else {
+        rc = act == CVCL_ACT_GELU ? launch_fp8<CVCL_ACT_GELU, false, false>(d, grid, st)
+           : act == CVCL_ACT_RELU ? launch_fp8<CVCL_ACT_RELU, false, false>(d, grid, st) : launch_fp8<CVCL_ACT_NONE, false, false>(d, grid, st);
+    }
+    if (rc) return rc;
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
+}
+
+extern "C" int cvcl_gemm_fp8(const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
+                             const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream) {
+    return cvcl_gemm_fp8_mx(A8, a_scale, nullptr, lda, W8, w_scale, ldw, C, ldc, nullptr, nullptr, 0, bias, act, R, ldr, M, N, K, stream);
 }

@@ -207,7 +207,11 @@ __device__ inline bf16x4 att_tr_read(const char* p) {
 //   LDS = Tpad * 336 B (75 KB at T = 197): two workgroups per CU, so one stages while the other multiplies.
 // (v1: one workgroup per 64 queries, V^T rebuilt with 2-byte scatters: 440 us per ViT-B/16 layer at B = 256;
 //  v2: per-head workgroup, 16-query tiles, all of S in registers, P through LDS, 1 workgroup/CU: 190 us.)
-__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int B,
+// MX = true: the output is written as e4m3 with one e8m0 scale per (row, 32 d) instead of bf16 (cvcl_gemm_fp8_mx's input format:
+// bytes [B*T][D], scales tiled [D/128][B*T][4]) -- a lane and its partner lane ^ 32 hold the 32 d of one block of one query.
+template <bool MX>
+__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                unsigned char* __restrict__ out8, unsigned char* __restrict__ out_bs, int B,
                                                                 int Tn, int heads, float scale, int NT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Tpad = 32 * NT;
@@ -296,7 +300,28 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
         }
         const float inv = 1.f / (l_run + __shfl_xor(l_run, 32, 64));
         // this lane's query row: 8 runs of 4 consecutive d (d = 32 dt + 8b + 4h + c)
-        if (q0 + l31 < Tn) {
+        if constexpr (MX) {
+            const long mrow = (long)b * Tn + q0 + l31, Mtot = (long)B * Tn;
+            unsigned sbs[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                float vq[16], amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { vq[e] = (float)(bf16_t)(o[dt][e] * inv); amax = fmaxf(amax, fabsf(vq[e])); }   // as the bf16 output
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                sbs[dt] = mx_scale_byte(amax);
+                const float qi = mx_inv_scale(sbs[dt]);
+                if (q0 + l31 < Tn) {
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb)
+                        *reinterpret_cast<unsigned*>(out8 + mrow * D + hh * 64 + dt * 32 + 8 * bb + 4 * h) =
+                            pack4_fp8(vq[4 * bb] * qi, vq[4 * bb + 1] * qi, vq[4 * bb + 2] * qi, vq[4 * bb + 3] * qi);
+                }
+            }
+            if (q0 + l31 < Tn && h == 0)                           // d blocks 2 hh, 2 hh + 1 of tile hh / 2
+                *reinterpret_cast<unsigned short*>(out_bs + ((long)(hh >> 1) * Mtot + mrow) * 4 + 2 * (hh & 1)) =
+                    (unsigned short)(sbs[0] | (sbs[1] << 8));
+        } else if (q0 + l31 < Tn) {
             bf16_t* orow = out + ((long)b * Tn + q0 + l31) * D + hh * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -437,24 +462,47 @@ extern "C" int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const
     return CVCL_OK;
 }
 
+namespace {
+template <bool MX>
+int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, int B, int T, int heads, float scale, hipStream_t s) {
+    const int nt = (T + 31) / 32;
+    const size_t lds = (size_t)nt * 32 * (ATT_KP + ATT_VP);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attention_mfma_kernel<MX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            cvcl_set_error("cvcl_attention: cannot raise the dynamic LDS limit");
+            return CVCL_ELAUNCH;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_mfma_kernel<MX>, dim3(B * heads), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, (unsigned char*)out8,
+                       (unsigned char*)out_bs, B, T, heads, scale, nt);
+    return CVCL_OK;
+}
+}  // namespace
+
+// bf16 qkv -> attention output as e4m3 [B*T][D] + e8m0 block scales [D/128][B*T][4] (the MX input of cvcl_gemm_fp8_mx)
+extern "C" int cvcl_attention_mx(const void* qkv, void* out8, void* out_block_scales, int B, int T, int heads, int head_dim, float scale,
+                                 void* stream) {
+    CVCL_CHECK_ARG(qkv && out8 && out_block_scales && B > 0 && T > 0 && heads > 0, "cvcl_attention_mx: bad args");
+    CVCL_CHECK_ARG(head_dim == 64 && heads % 2 == 0 && T > 32 && T <= ATT_TPAD_MAX,
+                   "cvcl_attention_mx: needs head_dim 64, an even head count and 32 < T <= %d (got hd %d heads %d T %d)", ATT_TPAD_MAX, head_dim,
+                   heads, T);
+    CvclProfScope prof(stream, CVCL_K_ATTENTION);
+    const int rc = launch_attention_mfma<true>(qkv, nullptr, out8, out_block_scales, B, T, heads, scale, (hipStream_t)stream);
+    if (rc) return rc;
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
 extern "C" int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok, void* out, int B, int T, int heads,
                               int head_dim, float scale, void* stream) {
     CVCL_CHECK_ARG(qkv && out && B > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim <= 128, "cvcl_attention: bad args");
     CvclProfScope prof(stream, CVCL_K_ATTENTION);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16 && head_dim == 64 && !key_tok && T > 32 && T <= ATT_TPAD_MAX) {   // T <= 32: generic kernel below
-        const int nt = (T + 31) / 32;
-        const size_t lds = (size_t)nt * 32 * (ATT_KP + ATT_VP);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)attention_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                cvcl_set_error("cvcl_attention: cannot raise the dynamic LDS limit");
-                return CVCL_ELAUNCH;
-            }
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(attention_mfma_kernel, dim3(B * heads), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, B, T, heads,
-                           scale, nt);
+        const int rc = launch_attention_mfma<false>(qkv, out, nullptr, nullptr, B, T, heads, scale, s);
+        if (rc) return rc;
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }

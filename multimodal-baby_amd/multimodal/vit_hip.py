@@ -69,6 +69,14 @@ def _gemm8(q, sc, wq, ws, out, bias, act=H.ACT_NONE, residual=None):
                                   M, N, K, H.stream_ptr()), "cvcl_gemm_fp8")
 
 
+def _gemm8_mx(q, sc, bs, wq, ws, out, out8, out_bs, bias, act=H.ACT_NONE, residual=None):
+    """fp8 GEMM with MX (e8m0 per 32 elements) block scales on the input (bs) and/or the output (out8, out_bs)."""
+    M, K = q.shape
+    N = wq.shape[0]
+    H.check(H.lib().cvcl_gemm_fp8_mx(H.ptr(q), H.ptr(sc), H.ptr(bs), K, H.ptr(wq), H.ptr(ws), K, H.ptr(out), N, H.ptr(out8), H.ptr(out_bs), N,
+                                     H.ptr(bias), act, H.ptr(residual), N, M, N, K, H.stream_ptr()), "cvcl_gemm_fp8_mx")
+
+
 def _ln(cd, x, stride, g, b, eps, out, out_f32, rows, D):
     H.check(H.lib().cvcl_layernorm(cd, H.ptr(x), stride, H.ptr(g), H.ptr(b), eps, H.ptr(out), int(out_f32), rows, D,
                                    H.stream_ptr()), "cvcl_layernorm")
@@ -106,23 +114,31 @@ def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
         fp8 = bool(getattr(model, "fp8_linears", False)) and dt == torch.bfloat16 and D % 128 == 0
         if fp8:
             # fp8 linears (BASELINE configs[4]): every GEMM operand is e4m3 with a per-token scale -- norm1 / norm2 are fused
-            # with the quantisation, the attention output and the GELU output get their own quantisation pass; the residual
-            # stream, attention and the statistics stay bf16 / fp32
+            # with the quantisation; the attention kernel and fc1's (GELU) epilogue emit e4m3 with MX block scales (one e8m0
+            # per 32 elements) that the scaled MFMAs of proj / fc2 consume directly -- no quantisation pass in between;
+            # the residual stream, the attention maths and the statistics stay bf16 / fp32
             Dm = mid.shape[1]
+            bw0 = w["blocks"][0]
             q_d = torch.empty(B * T, D, dtype=torch.uint8, device=dev)
             q_m = torch.empty(B * T, Dm, dtype=torch.uint8, device=dev)
             sc = torch.empty(B * T, dtype=torch.float32, device=dev)
+            bs_m = torch.empty(Dm // 128, B * T, 4, dtype=torch.uint8, device=dev)
+            bs_d = torch.empty(D // 128, B * T, 4, dtype=torch.uint8, device=dev)
+            mx_att = D // bw0["heads"] == 64 and bw0["heads"] % 2 == 0 and T > 32
             for bw in w["blocks"]:
                 _quant(h, B * T, D, q_d, sc, (bw["n1w"], bw["n1b"], bw["eps"]))
                 _gemm8(q_d, sc, bw["qkv_q"], bw["qkv_s"], qkv, bw["qkv_b"])
-                H.check(lib.cvcl_attention(cd, H.ptr(qkv), None, H.ptr(att), B, T, bw["heads"], D // bw["heads"], bw["scale"], s),
-                        "cvcl_attention")
-                _quant(att, B * T, D, q_d, sc)
-                _gemm8(q_d, sc, bw["proj_q"], bw["proj_s"], h, bw["proj_b"], residual=h)
+                if mx_att:
+                    H.check(lib.cvcl_attention_mx(H.ptr(qkv), H.ptr(q_d), H.ptr(bs_d), B, T, bw["heads"], 64, bw["scale"], s), "cvcl_attention_mx")
+                    _gemm8_mx(q_d, None, bs_d, bw["proj_q"], bw["proj_s"], h, None, None, bw["proj_b"], residual=h)
+                else:
+                    H.check(lib.cvcl_attention(cd, H.ptr(qkv), None, H.ptr(att), B, T, bw["heads"], D // bw["heads"], bw["scale"], s),
+                            "cvcl_attention")
+                    _quant(att, B * T, D, q_d, sc)
+                    _gemm8(q_d, sc, bw["proj_q"], bw["proj_s"], h, bw["proj_b"], residual=h)
                 _quant(h, B * T, D, q_d, sc, (bw["n2w"], bw["n2b"], bw["eps"]))
-                _gemm8(q_d, sc, bw["fc1_q"], bw["fc1_s"], mid, bw["fc1_b"], act=H.ACT_GELU)
-                _quant(mid, B * T, Dm, q_m, sc)
-                _gemm8(q_m, sc, bw["fc2_q"], bw["fc2_s"], h, bw["fc2_b"], residual=h)
+                _gemm8_mx(q_d, sc, None, bw["fc1_q"], bw["fc1_s"], None, q_m, bs_m, bw["fc1_b"], act=H.ACT_GELU)
+                _gemm8_mx(q_m, None, bs_m, bw["fc2_q"], bw["fc2_s"], h, None, None, bw["fc2_b"], residual=h)
         for bw in (w["blocks"] if not fp8 else ()):
             _ln(cd, h, D, bw["n1w"], bw["n1b"], bw["eps"], y, False, B * T, D)
             H.gemm(y, bw["qkv_w"], out=qkv, bias=bw["qkv_b"])

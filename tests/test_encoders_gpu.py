@@ -188,9 +188,41 @@ def test_attention_bf16_mfma_vs_float64(dev, B, T, heads):
     assert err < 2e-2, err
 
 
+def _mx_quant_ref(y):
+    """MX block quantiser oracle: per 32 elements of a row, scale 2^ceil(log2(amax / 448)) (e8m0 byte = exponent + 127), e4m3 RNE.
+    Returns (e4m3 values, scale bytes [rows][K/32], dequantised fp32)."""
+    shp = y.shape
+    blk = y.reshape(-1, shp[-1] // 32, 32)
+    x = (blk.abs().amax(dim=2) / 448.0).float()
+    bits = x.view(torch.int32)
+    e = ((bits >> 23) & 0xff) + ((bits & 0x7fffff) != 0).int()
+    e = e.clamp(1, 254)
+    scale = torch.pow(2.0, (e - 127).double()).float()
+    q = (blk / scale[:, :, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q.reshape(shp), e.to(torch.uint8), (q.float() * scale[:, :, None]).reshape(shp)
+
+
+@pytest.mark.parametrize("B,T,heads", [(3, 197, 12), (2, 50, 4)])
+def test_attention_mx_output_matches_block_quantiser(dev, B, T, heads):
+    """cvcl_attention_mx = cvcl_attention's bf16 output pushed through the MX block quantiser, bit for bit (bytes and scales)."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(T + heads)
+    D = heads * 64
+    qd = (torch.randn(B, T, 3, heads, 64, generator=g) * 1.5).bfloat16().to(dev).contiguous()
+    out = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().cvcl_attention(H.BF16, H.ptr(qd), None, H.ptr(out), B, T, heads, 64, 0.125, H.stream_ptr()), "attention")
+    o8 = torch.full((B * T, D), 0xAA, dtype=torch.uint8, device=dev)
+    obs = torch.full((D // 128, B * T, 4), 0xAA, dtype=torch.uint8, device=dev)
+    H.check(H.lib().cvcl_attention_mx(H.ptr(qd), H.ptr(o8), H.ptr(obs), B, T, heads, 64, 0.125, H.stream_ptr()), "attention_mx")
+    q_ref, e_ref, _ = _mx_quant_ref(out.float().cpu().reshape(B * T, D))
+    e_tiled = e_ref.reshape(B * T, D // 128, 4).permute(1, 0, 2).contiguous()
+    assert torch.equal(obs.cpu(), e_tiled)
+    assert torch.equal(o8.cpu(), q_ref.view(torch.uint8))
+
+
 def test_vit_fp8_linears_vs_emulation_and_bf16(dev):
     """BASELINE configs[4]: ViT-B/16 with e4m3 weights / activations in the four linears of every block.  Compared with (a) an
-    oracle emulation of the same quantisation points (per-token activation scales, per-channel weight scales,
+    oracle emulation of the same quantisation points (per-token or MX block activation scales, per-channel weight scales,
     torch.float8_e4m3fn rounding, fp32 maths elsewhere) and (b) the bf16 path of the same weights."""
     import torch.nn.functional as F
     from multimodal import vision_transformer_dino_mugs as vits
@@ -216,6 +248,7 @@ def test_vit_fp8_linears_vs_emulation_and_bf16(dev):
         amax = y.abs().amax(dim=-1, keepdim=True)
         s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
         return (y / s).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s
+    qmx = lambda y: _mx_quant_ref(y)[2]                    # attention output and GELU output: MX block scales (no extra pass)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     p = 16
     xc = x.cpu()
@@ -226,8 +259,8 @@ def test_vit_fp8_linears_vs_emulation_and_bf16(dev):
     h = h.bfloat16().float()
     for i in range(12):
         pre = f"blocks.{i}."
-        def lin(a, name, act=False):
-            y = q(a) @ q(sd[pre + name + ".weight"]).t() + sd[pre + name + ".bias"]
+        def lin(a, name, act=False, mx=False):
+            y = (qmx(a) if mx else q(a)) @ q(sd[pre + name + ".weight"]).t() + sd[pre + name + ".bias"]
             if act:
                 y = F.gelu(y)
             return y.bfloat16().float()
@@ -235,9 +268,9 @@ def test_vit_fp8_linears_vs_emulation_and_bf16(dev):
         qkv = lin(y, "attn.qkv").reshape(B, -1, 3, 12, 64).permute(2, 0, 3, 1, 4)
         att = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) * 0.125, -1).bfloat16().float() @ qkv[2]
         att = att.transpose(1, 2).reshape(B, -1, 768).bfloat16().float()
-        h = (h + lin(att, "attn.proj")).bfloat16().float()
+        h = (h + lin(att, "attn.proj", mx=True)).bfloat16().float()
         y = F.layer_norm(h, (768,), sd[pre + "norm2.weight"], sd[pre + "norm2.bias"], 1e-6)
-        h = (h + lin(lin(y, "mlp.fc1", True), "mlp.fc2")).bfloat16().float()
+        h = (h + lin(lin(y, "mlp.fc1", True), "mlp.fc2", mx=True)).bfloat16().float()
     emu = F.layer_norm(h[:, 0], (768,), sd["norm.weight"], sd["norm.bias"], 1e-6)
     cos_e = F.cosine_similarity(out, emu, dim=1)
     rel_e = float((out - emu).norm() / emu.norm())

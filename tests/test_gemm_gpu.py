@@ -278,3 +278,68 @@ def test_fp8_linear_pipeline_vs_emulation(dev, M, N, K, act, res):
         full = full + r.double()
     rel = float((C.double().cpu() - full).norm() / full.norm())
     assert rel < 0.05, rel
+
+
+def _mx_quant_ref(y):
+    """oracle of the MX block quantisation: per 32 elements, scale 2^ceil(log2(amax/448)) (e8m0 byte = exponent + 127), e4m3 RNE."""
+    M, K = y.shape
+    blk = y.reshape(M, K // 32, 32)
+    amax = blk.abs().amax(dim=2)
+    x = (amax / 448.0).float()
+    bits = x.view(torch.int32)
+    e = (bits >> 23) & 0xff
+    e = e + ((bits & 0x7fffff) != 0).int()
+    e = e.clamp(1, 254)
+    scale = torch.pow(2.0, (e - 127).double()).float()
+    q = (blk / scale[:, :, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    return q.reshape(M, K), e.to(torch.uint8), scale
+
+
+def _mx_tile_scales(e):
+    """[M][K/32] block-scale bytes -> the C-ABI's [K/128][M][4] tiling."""
+    M, nb = e.shape
+    return e.reshape(M, nb // 4, 4).permute(1, 0, 2).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (1000, 768, 768), (700, 768, 3072)])
+def test_gemm_fp8_mx_input_exact(dev, M, N, K):
+    """A operand with per-32-element e8m0 block scales applied by the scaled MFMA: integers x powers of two stay exact."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    eb = torch.randint(124, 130, (M, K // 32), generator=g).to(torch.uint8)                 # block scales 2^-3 .. 2^2
+    sw = 2.0 ** torch.randint(-2, 2, (N,), generator=g).float()
+    a_eff = a.reshape(M, K // 32, 32) * torch.pow(2.0, (eb.double() - 127))[:, :, None]
+    ref = ((a_eff.reshape(M, K).double() @ w.double().t()) * sw.double()[None, :]).float().bfloat16()
+    a8, w8, ebd, swd = a.to(torch.float8_e4m3fn).to(dev), w.to(torch.float8_e4m3fn).to(dev), _mx_tile_scales(eb).to(dev), sw.to(dev)
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().cvcl_gemm_fp8_mx(a8.data_ptr(), None, H.ptr(ebd), K, w8.data_ptr(), H.ptr(swd), K, H.ptr(C), N, None, None, 0, None, 0,
+                                     None, 0, M, N, K, H.stream_ptr()), "cvcl_gemm_fp8_mx")
+    assert torch.equal(C.cpu(), ref)
+
+
+@pytest.mark.parametrize("act", [0, 2])
+def test_gemm_fp8_mx_output_matches_block_quantiser(dev, act):
+    """fc1-style epilogue: bias (+GELU) -> bf16 rounding -> per-32-column e8m0 scale + e4m3 bytes, vs the oracle quantiser
+    applied to the bf16 output of the plain fp8 GEMM on the same operands (bit-identical bytes and scales)."""
+    from multimodal import _hip as H
+    M, N, K = 900, 3072, 768
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=g) * 1.3).bfloat16()
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g) * 0.1
+    xd, wd, bd = x.to(dev), w.to(dev), bias.to(dev)
+    xq, xs = torch.empty(M, K, dtype=torch.uint8, device=dev), torch.empty(M, device=dev)
+    wq, ws = torch.empty(N, K, dtype=torch.uint8, device=dev), torch.empty(N, device=dev)
+    H.check(H.lib().cvcl_quant_rows_fp8(H.BF16, H.ptr(xd), K, None, None, 0.0, H.ptr(xq), H.ptr(xs), M, K, H.stream_ptr()), "quant")
+    H.check(H.lib().cvcl_quant_rows_fp8(H.F32, H.ptr(wd), K, None, None, 0.0, H.ptr(wq), H.ptr(ws), N, K, H.stream_ptr()), "quant")
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().cvcl_gemm_fp8(H.ptr(xq), H.ptr(xs), K, H.ptr(wq), H.ptr(ws), K, H.ptr(C), N, H.ptr(bd), act, None, 0, M, N, K,
+                                  H.stream_ptr()), "cvcl_gemm_fp8")
+    c8 = torch.empty(M, N, dtype=torch.uint8, device=dev)
+    cb = torch.empty(N // 128, M, 4, dtype=torch.uint8, device=dev)
+    H.check(H.lib().cvcl_gemm_fp8_mx(H.ptr(xq), H.ptr(xs), None, K, H.ptr(wq), H.ptr(ws), K, None, 0, H.ptr(c8), H.ptr(cb), N, H.ptr(bd), act,
+                                     None, 0, M, N, K, H.stream_ptr()), "cvcl_gemm_fp8_mx")
+    q_ref, e_ref, _ = _mx_quant_ref(C.float().cpu())
+    assert torch.equal(cb.cpu(), _mx_tile_scales(e_ref)) and torch.equal(c8.cpu(), q_ref.view(torch.uint8))

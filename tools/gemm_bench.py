@@ -42,3 +42,25 @@ for name, M, N, K in [("vit.qkv", 50432, 2304, 768), ("vit.proj", 50432, 768, 76
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 10 * 1e3
     print(f"{name:12s} M={M:6d} N={N:5d} K={K:5d}: {us:8.1f} us  {2*M*N*K/us/1e6:7.0f} TFLOP/s")
+
+print("fp8 MX variants (vit.fc1 GELU -> e4m3 + e8m0 blocks; vit.fc2 / vit.proj with block-scaled A + residual):")
+def _t(f):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / 10 * 1e3
+for name, M, N, K, act, res in [("vit.fc1", 50432, 3072, 768, 2, False), ("vit.fc2", 50432, 768, 3072, 0, True), ("vit.proj", 50432, 768, 768, 0, True)]:
+    a8 = torch.randint(0, 120, (M, K), dtype=torch.uint8, device=dev); w8 = torch.randint(0, 120, (N, K), dtype=torch.uint8, device=dev)
+    sa = torch.ones(M, device=dev); sw = torch.full((N,), 1e-3, device=dev); bias = torch.zeros(N, device=dev)
+    ab = torch.full((M, K // 32), 127, dtype=torch.uint8, device=dev)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev); c8 = torch.empty(M, N, dtype=torch.uint8, device=dev)
+    cb = torch.empty(M, N // 32, dtype=torch.uint8, device=dev)
+    R = H.ptr(out) if res else None
+    L = H.lib()
+    base = _t(lambda: H.check(L.cvcl_gemm_fp8(H.ptr(a8), H.ptr(sa), K, H.ptr(w8), H.ptr(sw), K, H.ptr(out), N, H.ptr(bias), act, R, N, M, N, K, H.stream_ptr()), "fp8"))
+    mxa = _t(lambda: H.check(L.cvcl_gemm_fp8_mx(H.ptr(a8), None, H.ptr(ab), K, H.ptr(w8), H.ptr(sw), K, H.ptr(out), N, None, None, 0, H.ptr(bias), 0, R, N, M, N, K, H.stream_ptr()), "mxa")) if act == 0 else float("nan")
+    mxo = _t(lambda: H.check(L.cvcl_gemm_fp8_mx(H.ptr(a8), H.ptr(sa), None, K, H.ptr(w8), H.ptr(sw), K, None, 0, H.ptr(c8), H.ptr(cb), N, H.ptr(bias), act, None, 0, M, N, K, H.stream_ptr()), "mxo")) if not res else float("nan")
+    print(f"{name:12s} per-row in / bf16 out {base:7.1f} us | MX in {mxa:7.1f} us | MX out {mxo:7.1f} us")
