@@ -30,6 +30,7 @@ struct F8Dev {
     const unsigned char* a_bs;        // MXA: e8m0 scale per 32-element block of A, tiled [K/128][M][4] (sa unused)
     unsigned char* C8; unsigned char* c_bs;   // MXOUT: e4m3 output [M][ldc8] + e8m0 block scales [M][N/32] instead of bf16 C
     int M, N, K, lda, ldw, ldc, ldr, act, num_m_tiles, ldc8;
+    int xcd_split;                    // 1: XCD x = blockIdx.x % 8 owns row tiles x, x + 8, ...; 0: one list over all tiles
 };
 
 __device__ __forceinline__ void f8_glds16(const unsigned char* src, char* lds_wave_base) {
@@ -58,8 +59,20 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
     const int l31 = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.y * F8_BN;
-    const int ktiles = p.K / 128;
+    const int ktiles = p.K / 128, ntn = p.N / F8_BN;
+    // tile walk: the workgroups of one XCD (blockIdx.x % 8: its own L2) share a list of output tiles ordered column-fastest
+    // over that XCD's row tiles (x, x + 8, ...), so the tiles in flight on an XCD at any time cover ~S / ntn row tiles x all
+    // columns -- every A tile is fetched from HBM once per XCD and W stays L2-resident -- while every workgroup slot stays
+    // busy to the end whatever ntn is (a (row groups) x (columns) grid left 25% of the slots empty at ntn = 24)
+    const int xcd = p.xcd_split ? (blockIdx.x & 7) : 0;
+    const int slot = p.xcd_split ? (blockIdx.x >> 3) : blockIdx.x, nslots = p.xcd_split ? (gridDim.x >> 3) : gridDim.x;
+    const int my_m_tiles = p.xcd_split ? ((p.num_m_tiles - xcd + 7) >> 3) : p.num_m_tiles;
+    const int ntiles = my_m_tiles * ntn;
+    auto tile_of = [&](int t, int& mt, int& n0) {
+        const int ml = t / ntn;
+        n0 = (t - ml * ntn) * F8_BN;
+        mt = p.xcd_split ? ml * 8 + xcd : ml;
+    };
 
     // staging: wave w, instruction j covers tile rows (4w + j) * 8 .. + 7; lane -> row + lane / 8, chunk position lane % 8
     int s_row[4];
@@ -69,15 +82,18 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
         const int r = (wave * 4 + j) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         s_row[j] = r;
-        w_off[j] = (long)(n0 + r) * p.ldw + c * 16;
+        (void)c;
     }
-    auto set_rows = [&](int mt) {
+    auto set_rows = [&](int t) {
+        int mt, n0;
+        tile_of(t, mt, n0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int m = mt * F8_BM + s_row[j];
             if (m >= p.M) m = p.M - 1;
             const int c = (lane & 7) ^ ((s_row[j] >> 1) & 7);
             a_off[j] = (long)m * p.lda + c * 16;
+            w_off[j] = (long)(n0 + s_row[j]) * p.ldw + c * 16;
         }
     };
     auto issue = [&](int buf, int kt) {
@@ -87,17 +103,6 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) f8_glds16(p.W + w_off[j] + kt * 128, base + F8_OPER + j * 1024);
     };
-
-    // per-lane epilogue constants: output n = n0 + wn*64 + nt*32 + 8g + 4h + e  (weight-row scale and bias), fixed per workgroup
-    f32x4 sw_r[2][4], bias_r[2][4];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h;
-            sw_r[nt][g] = *reinterpret_cast<const f32x4*>(p.sw + n);
-            bias_r[nt][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
 
     int fw_off[2], fa_off[2], fw_sw[2], fa_sw[2];
 #pragma unroll
@@ -110,8 +115,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
     // MXA: the 4 block-scale bytes of a K tile (128 k = 4 blocks of 32) for this lane's rows of the two m tiles, fetched one
     // K tile ahead together with the operand tiles (same vmcnt wait)
     unsigned aw_next[2] = {0x7f7f7f7fu, 0x7f7f7f7fu}, aw[2] = {0x7f7f7f7fu, 0x7f7f7f7fu};
-    auto load_scales = [&](int mt_tile, int kt) {
+    auto load_scales = [&](int t, int kt) {
         if constexpr (MXA) {
+            int mt_tile, n_unused;
+            tile_of(t, mt_tile, n_unused);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 int m = mt_tile * F8_BM + wm * 64 + mt * 32 + l31;
@@ -121,11 +128,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
         }
     };
 
-    int l_mt = blockIdx.x, l_kt = 0, buf = 0;
-    bool l_live = l_mt < p.num_m_tiles;
+    int l_mt = slot, l_kt = 0, buf = 0;                 // l_mt: the tile (list index) being staged
+    bool l_live = l_mt < ntiles;
     if (l_live) { set_rows(l_mt); issue(0, 0); load_scales(l_mt, 0); }
 
-    for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
+    for (int ct = slot; ct < ntiles; ct += nslots) {
+        int cm, n0;
+        tile_of(ct, cm, n0);
         const int m0 = cm * F8_BM;
         f32x16 acc[2][2];
 #pragma unroll
@@ -135,37 +144,53 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        // activation-row scales of this tile's rows (column of the MFMA output = this lane's row l31) and the residual rows
+        // per-lane epilogue operands of this tile: weight-row scales and bias of output n = n0 + wn*64 + nt*32 + 8g + 4h + e,
+        // activation-row scales (column of the MFMA output = this lane's row l31) and the residual rows.  They are fetched in
+        // the first K iteration right behind the staging of the next K tile: the K loop hides them, whereas loads issued
+        // ahead of the loop hold up its first wait (the operands of K tile 0 were staged one epilogue ago and have long
+        // landed) and loads issued in the epilogue queue behind in-flight staging.
+        f32x4 sw_r[2][4], bias_r[2][4];
         float sa_r[2] = {1.f, 1.f};
-        if constexpr (!MXA) {
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                int m = m0 + wm * 64 + mt * 32 + l31;
-                if (m >= p.M) m = p.M - 1;
-                sa_r[mt] = p.sa[m];
-            }
-        }
         bf16x8 rpre[8];
-        if (p.R) {
+        auto fetch_epilogue_operands = [&]() {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int m = m0 + wm * 64 + j * 8 + (lane >> 3);
-                if (m >= p.M) m = p.M - 1;
-                rpre[j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + (lane & 7) * 8);
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * h;
+                    sw_r[nt][g] = *reinterpret_cast<const f32x4*>(p.sw + n);
+                    bias_r[nt][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            if constexpr (!MXA) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    int m = m0 + wm * 64 + mt * 32 + l31;
+                    if (m >= p.M) m = p.M - 1;
+                    sa_r[mt] = p.sa[m];
+                }
             }
-        }
+            if (p.R) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int m = m0 + wm * 64 + j * 8 + (lane >> 3);
+                    if (m >= p.M) m = p.M - 1;
+                    rpre[j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + (lane & 7) * 8);
+                }
+            }
+        };
 
         for (int kt = 0; kt < ktiles; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (++l_kt == ktiles) {
                 l_kt = 0;
-                l_mt += gridDim.x;
-                l_live = l_mt < p.num_m_tiles;
+                l_mt += nslots;
+                l_live = l_mt < ntiles;
                 if (l_live) set_rows(l_mt);
             }
             if constexpr (MXA) { aw[0] = aw_next[0]; aw[1] = aw_next[1]; }
             if (l_live) { issue(buf ^ 1, l_kt); load_scales(l_mt, l_kt); }
+            if (kt == 0) fetch_epilogue_operands();
             const char* cur = smem + buf * F8_BUF;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {                         // two K = 64 steps per 128-byte row
@@ -404,10 +429,17 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc; d.ldr = ldr; d.act = act; d.ldc8 = ldc8;
     d.num_m_tiles = cvcl_div_up(M, F8_BM);
     const int ntn = N / F8_BN;
-    int gm = 2 * f8_num_cus() / ntn;                       // persistent: two workgroups per CU in total
-    gm = gm >= 8 ? (gm & ~7) : (gm < 1 ? 1 : gm);           // multiples of 8: column tiles of a row group share an XCD
-    if (gm > d.num_m_tiles) gm = d.num_m_tiles;
-    dim3 grid(gm, ntn);
+    const long total_tiles = (long)d.num_m_tiles * ntn;
+    int g = 2 * f8_num_cus();                              // persistent: two workgroups per CU
+    d.xcd_split = d.num_m_tiles >= 16 ? 1 : 0;
+    if (d.xcd_split) {
+        const long per_xcd = (long)cvcl_div_up(d.num_m_tiles, 8) * ntn;      // the longest per-XCD list
+        if (g / 8 > per_xcd) g = (int)per_xcd * 8;
+        g &= ~7;
+    } else if (g > total_tiles) {
+        g = (int)total_tiles;
+    }
+    dim3 grid(g);
     hipStream_t st = (hipStream_t)stream;
     CvclProfScope prof(stream, CVCL_K_GEMM);
     const bool mxa = a_block_scales != nullptr, mxo = c8 != nullptr;
