@@ -334,6 +334,23 @@ int cvcl_lstm_add_dout(float* dh, const float* d_out, const int64_t* len, int t,
 int cvcl_seq_reverse(const float* x, const int64_t* len, float* y, int B, int L, int E, void* stream);
 int cvcl_scale_add_f32(const float* a, const float* b, float alpha, float* y, long n, void* stream);
 int cvcl_cbow(const float* x, float* y, int B, int L, int E, int crange, void* stream);
+
+/* ---- f3: the training-time frame transform on the device ----------------------------------------------------------------
+ * Replaces the per-frame PIL pipeline of multimodal_data_module.py:244-256 (RandomResizedCrop((224,224), scale (0.2,1)) ->
+ * RandomApply([GaussianBlur([.1,2.])], p .5) (utils.py:94-103) -> RandomHorizontalFlip -> ToTensor -> Normalize (:57)) for a
+ * whole batch in one launch, bit-identically to Pillow's integer pixel arithmetic (Resample.c bilinear with the down-scale
+ * widened triangle filter, BoxBlur.c three-pass fractional box blur) and torch's fp32 (u8 / 255 - mean) / std.
+ *   frames      uint8 [B][H][W][3]   decoded RGB frames (HWC), device memory
+ *   crop        int32 [B][4]         top, left, h, w per frame (RandomResizedCrop.get_params order), device memory
+ *   blur_sigma  fp32  [B]            <= 0 where RandomApply skipped the blur, device memory
+ *   flip        int32 [B]            device memory
+ *   mean, std3  3 HOST floats each
+ *   out         fp32  [B][3][out_h][out_w]; out_u8 (nullable): uint8 [B][out_h][out_w][3], the image before ToTensor
+ *   max_crop_h  upper bound of crop[:, 2] (H always works): sizes the LDS plan; boxes taller than ~500 rows at 224 x 224
+ *               output do not fit the single-pass plan and are refused (CVCL_EARG)                                            */
+int cvcl_augment_frames(const void* frames, int B, int H, int W, const int32_t* crop, const float* blur_sigma, const int32_t* flip,
+                        const float* mean, const float* std3, void* out, int out_h, int out_w, void* out_u8, int max_crop_h,
+                        void* stream);
 int cvcl_token_ce_fwd(const float* logits, const int64_t* labels, float* loss, float* lse, long R, int V, int ignore_index,
                       void* stream);
 int cvcl_token_ce_bwd(const float* logits, const int64_t* labels, const float* lse, const float* d_loss, float* d_logits,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "cvcl_lstm_add_dout": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_seq_reverse": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "cvcl_scale_add_f32": (_I, [_P, _P, C.c_float, _P, C.c_long, _P]),
+    "cvcl_augment_frames": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P]),
     "cvcl_cbow": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "cvcl_token_ce_fwd": (_I, [_P, _P, _P, _P, C.c_long, _I, _I, _P]),
     "cvcl_token_ce_bwd": (_I, [_P, _P, _P, _P, _P, C.c_long, _I, _I, _P]),

@@ -157,7 +157,7 @@ class Trainer:
             return torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
         return torch.device("cpu")
 
-    def _eval_loop(self, model, loaders, step_name, epoch_end_name, device):
+    def _eval_loop(self, model, loaders, step_name, epoch_end_name, device, datamodule=None):
         """Lightning's evaluation loop: eval mode (BatchNorm on running statistics, no dropout), no autograd, one pass
         over every dataloader with its ``dataloader_idx``, then the ``*_epoch_end`` hook on the per-loader output lists."""
         if loaders is None:
@@ -174,7 +174,10 @@ class Trainer:
                 for bi, batch in enumerate(dl):
                     if self.limit_val_batches is not None and bi >= self.limit_val_batches:
                         break
-                    out = getattr(model, step_name)(_move(batch, device), bi, dataloader_idx=di)
+                    batch = _move(batch, device)
+                    if datamodule is not None and hasattr(datamodule, "on_after_batch_transfer"):
+                        batch = datamodule.on_after_batch_transfer(batch, di, training=False)
+                    out = getattr(model, step_name)(batch, bi, dataloader_idx=di)
                     outs.append({k: (v.detach() if torch.is_tensor(v) else v) for k, v in (out or {}).items()})
                 outputs.append(outs)
             if hasattr(model, epoch_end_name) and outputs and outputs[0]:
@@ -195,11 +198,11 @@ class Trainer:
 
     def validate(self, model, datamodule=None):
         device = self._prepare(model, datamodule)
-        return [self._eval_loop(model, datamodule.val_dataloader(), "validation_step", "validation_epoch_end", device)]
+        return [self._eval_loop(model, datamodule.val_dataloader(), "validation_step", "validation_epoch_end", device, datamodule)]
 
     def test(self, model, datamodule=None):
         device = self._prepare(model, datamodule)
-        return [self._eval_loop(model, datamodule.test_dataloader(), "test_step", "test_epoch_end", device)]
+        return [self._eval_loop(model, datamodule.test_dataloader(), "test_step", "test_epoch_end", device, datamodule)]
 
     def fit(self, model, datamodule=None, ckpt_path=None):
         from . import parallel
@@ -234,6 +237,8 @@ class Trainer:
                 if self.limit_train_batches is not None and bi >= self.limit_train_batches:
                     break
                 batch = _move(batch, device)
+                if hasattr(datamodule, "on_after_batch_transfer"):
+                    batch = datamodule.on_after_batch_transfer(batch, 0, training=True)
                 if upd is None:
                     opt.zero_grad(set_to_none=True)
                     out = model.training_step(batch, bi)
@@ -254,7 +259,7 @@ class Trainer:
             self.logged_metrics.update(model._logged)
             if (epoch + 1) % self.check_val_every_n_epoch == 0 and hasattr(datamodule, "val_dataloader") \
                     and hasattr(model, "validation_step"):
-                self._eval_loop(model, datamodule.val_dataloader(), "validation_step", "validation_epoch_end", device)
+                self._eval_loop(model, datamodule.val_dataloader(), "validation_step", "validation_epoch_end", device, datamodule)
             if sched is not None and "val_loss" in self.logged_metrics:
                 sched["scheduler"].step(float(self.logged_metrics["val_loss"]))
             if self.enable_checkpointing and parallel.rank() == 0:

@@ -56,6 +56,27 @@ class MultiModalDataModule(LightningDataModule):
         self.drop_last = self.args.get("drop_last", False)
         self.val_batch_size = self.args.get("val_batch_size", VAL_BATCH_SIZE)
         self.num_workers = self.args.get("num_workers", NUM_WORKERS)
+        self.augment_frames = self.args.get("augment_frames", False)
+        # --device_frames: the datasets hand over decoded uint8 frames [H, W, 3] and the transform of :244-256 (or the base
+        # transform) runs on the device after the batch transfer (multimodal/augment.py) instead of per frame in the workers
+        self.device_frames = bool(self.args.get("device_frames", False))
+        self._frame_transforms = None
+
+    def on_after_batch_transfer(self, batch, dataloader_idx=0, training=True):
+        """Lightning's hook of the same name: uint8 frame batches [B, H, W, 3] (or evaluation trials [B, n, H, W, 3]) become
+        normalised fp32 [.., 3, 224, 224] tensors on the device; the training transform only while training (the reference
+        keeps ``base_transform`` for val / test, :271-275).  Batches that already hold float images pass through."""
+        img = batch[0] if isinstance(batch, (list, tuple)) and len(batch) > 0 else None
+        if not torch.is_tensor(img) or img.dtype != torch.uint8:
+            return batch
+        from .augment import DeviceFrameAugment
+        if self._frame_transforms is None:
+            self._frame_transforms = {True: DeviceFrameAugment(augment_frames=self.augment_frames),
+                                      False: DeviceFrameAugment(augment_frames=False)}
+        tf = self._frame_transforms[bool(training)]
+        lead = img.shape[:-3]
+        out = tf(img.reshape(-1, *img.shape[-3:]))
+        return type(batch)((out.reshape(*lead, *out.shape[1:]),) + tuple(batch[1:]))
 
     @staticmethod
     def add_to_argparse(parser):
@@ -64,6 +85,8 @@ class MultiModalDataModule(LightningDataModule):
         parser.add_argument("--val_batch_size", type=int, default=VAL_BATCH_SIZE)
         parser.add_argument("--num_workers", type=int, default=NUM_WORKERS)
         parser.add_argument("--augment_frames", action="store_true")
+        parser.add_argument("--device_frames", action="store_true",
+                            help="datasets yield uint8 frames; the (augmentation or base) transform runs on the GPU per batch")
         parser.add_argument("--eval_include_sos_eos", action="store_true")
         parser.add_argument("--test_while_val", action="store_true")
         parser.add_argument("--eval_type", type=str, default=EVAL_TYPE, choices=["image", "text"])
@@ -86,8 +109,9 @@ class SyntheticPairs(torch.utils.data.Dataset):
     """``rand -> ImageNet normalise`` frames and ``<sos> w1..wn <eos>`` utterances (reference item shape:
     multimodal_saycam_data_module.py:93-124; image statistics: multimodal_data_module.py:57)."""
 
-    def __init__(self, n_items: int, vocab_size: int, n_words: int = 3, seed: int = 0):
+    def __init__(self, n_items: int, vocab_size: int, n_words: int = 3, seed: int = 0, raw_frames: bool = False):
         self.n, self.vocab_size, self.n_words, self.seed = n_items, vocab_size, n_words, seed
+        self.raw_frames = raw_frames                       # uint8 [H, W, 3] frames for the device transform
         self.mean = torch.tensor(IMAGENET_MEAN).view(3, 1, 1)
         self.std = torch.tensor(IMAGENET_STD).view(3, 1, 1)
 
@@ -96,7 +120,10 @@ class SyntheticPairs(torch.utils.data.Dataset):
 
     def __getitem__(self, idx):
         g = torch.Generator().manual_seed(self.seed * 1000003 + idx)
-        img = (torch.rand(3, IMAGE_H, IMAGE_W, generator=g) - self.mean) / self.std
+        if self.raw_frames:
+            img = torch.randint(0, 256, (IMAGE_H, IMAGE_W, 3), dtype=torch.uint8, generator=g)
+        else:
+            img = (torch.rand(3, IMAGE_H, IMAGE_W, generator=g) - self.mean) / self.std
         words = torch.randint(4, self.vocab_size, (self.n_words,), generator=g)
         idxs = torch.cat([torch.tensor([SOS_TOKEN_ID]), words, torch.tensor([EOS_TOKEN_ID])]).long()
         return img, idxs, int(idxs.numel()), [" ".join(f"w{int(w)}" for w in words)]
@@ -106,8 +133,9 @@ class SyntheticEvalTrials(torch.utils.data.Dataset):
     """4-way evaluation trials with the item layout of the reference's LabeledSEvalDataset
     (multimodal_data_module.py:112-160): (imgs [4,3,H,W] target first, label ids, label length, [raw category])."""
 
-    def __init__(self, n_trials, vocab_size, seed=0, eval_include_sos_eos=False, n_images=4):
+    def __init__(self, n_trials, vocab_size, seed=0, eval_include_sos_eos=False, n_images=4, raw_frames=False):
         self.n, self.v, self.seed, self.sos_eos, self.n_images = n_trials, vocab_size, seed, eval_include_sos_eos, n_images
+        self.raw_frames = raw_frames
 
     def __len__(self):
         return self.n
@@ -116,7 +144,10 @@ class SyntheticEvalTrials(torch.utils.data.Dataset):
         g = torch.Generator().manual_seed(self.seed * 7919 + idx)
         mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
         std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
-        imgs = (torch.rand(self.n_images, 3, IMAGE_H, IMAGE_W, generator=g) - mean) / std
+        if self.raw_frames:
+            imgs = torch.randint(0, 256, (self.n_images, IMAGE_H, IMAGE_W, 3), dtype=torch.uint8, generator=g)
+        else:
+            imgs = (torch.rand(self.n_images, 3, IMAGE_H, IMAGE_W, generator=g) - mean) / std
         word = int(torch.randint(4, self.v, (1,), generator=g))
         label = [word]
         if self.sos_eos:
@@ -137,12 +168,13 @@ class SyntheticDataModule(MultiModalDataModule):
 
     def setup(self, *a, **k):
         v = len(self.read_vocab())
-        self.train_set = SyntheticPairs(self.n_items, v, seed=self.seed)
-        self.val_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 1)
-        self.test_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 2)
+        raw = self.device_frames
+        self.train_set = SyntheticPairs(self.n_items, v, seed=self.seed, raw_frames=raw)
+        self.val_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 1, raw_frames=raw)
+        self.test_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 2, raw_frames=raw)
         sos_eos = bool(self.args.get("eval_include_sos_eos", False))
-        self.eval_sets = {"val": SyntheticEvalTrials(4, v, seed=self.seed + 3, eval_include_sos_eos=sos_eos),
-                          "test": SyntheticEvalTrials(4, v, seed=self.seed + 4, eval_include_sos_eos=sos_eos)}
+        self.eval_sets = {"val": SyntheticEvalTrials(4, v, seed=self.seed + 3, eval_include_sos_eos=sos_eos, raw_frames=raw),
+                          "test": SyntheticEvalTrials(4, v, seed=self.seed + 4, eval_include_sos_eos=sos_eos, raw_frames=raw)}
 
     def train_dataloader(self):
         return torch.utils.data.DataLoader(self.train_set, batch_size=self.batch_size, shuffle=False,

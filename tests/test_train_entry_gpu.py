@@ -83,6 +83,40 @@ def test_validation_and_four_way_trials(dev, tmp_path, monkeypatch):
     assert "test_loss" in res and "test_accuracy" in res
 
 
+def test_device_frames_pipeline_through_train_entry(dev, tmp_path, monkeypatch):
+    """--device_frames: the datasets yield uint8 frames and the data module's on_after_batch_transfer hook runs the
+    reference's train transform (--augment_frames) or base transform on the device.  With the base
+    transform the run is the float-frame run of the same frames, bit for bit; with augmentation it trains and validates."""
+    import contextlib, io
+    import train
+    from multimodal.multimodal_data_module import SyntheticDataModule, IMAGENET_MEAN, IMAGENET_STD
+    monkeypatch.chdir(tmp_path)
+    base = ("--dataset synthetic --batch_size 4 --val_batch_size 4 --gpus 1 --text_encoder embedding --embedding_dim 32 "
+            "--lambda_lm 0 --optimize_unused --max_epochs 1 --limit_train_batches 2 --normalize_features "
+            "--checkpoint_callback False --logger False --exp_name devframes --device_frames").split()
+    dm = SyntheticDataModule(train._setup_parser().parse_args(base))
+    dm.setup()
+    batch = next(iter(dm.train_dataloader()))
+    assert batch[0].dtype == torch.uint8 and batch[0].shape == (4, 224, 224, 3)
+    moved = tuple(b.to(dev) if torch.is_tensor(b) else b for b in batch)
+    out = dm.on_after_batch_transfer(moved, 0, training=True)                    # no --augment_frames: base transform
+    mean, std = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1), torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+    want = (batch[0].permute(0, 3, 1, 2).float().div(255) - mean) / std
+    assert out[0].dtype == torch.float32 and torch.equal(out[0].cpu(), want) and out[1] is moved[1]
+    trial = next(iter(dm.val_dataloader()[1]))
+    assert trial[0].shape == (1, 4, 224, 224, 3)
+    tout = dm.on_after_batch_transfer(tuple(b.to(dev) if torch.is_tensor(b) else b for b in trial), 1, training=False)
+    assert tout[0].shape == (1, 4, 3, 224, 224)
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer, lit = train.main(base + ["--augment_frames"])
+    m = trainer.logged_metrics
+    assert "val_loss" in m and "val_accuracy" in m and float(m["val_loss"]) > 0
+    aug_dm = SyntheticDataModule(train._setup_parser().parse_args(base + ["--augment_frames"]))
+    a1 = aug_dm.on_after_batch_transfer(moved, 0, training=True)[0]
+    a2 = aug_dm.on_after_batch_transfer(moved, 0, training=False)[0]
+    assert not torch.equal(a1, out[0]) and torch.equal(a2, out[0])               # augmentation only while training
+
+
 def test_overlapped_update_matches_sequential_schedule(dev):
     """parallel.OverlappedUpdate defers the (all-reduce +) optimizer step of step k to a hook between the frozen trunk and
     fc of step k+1: losses and final parameters must be bit-identical to the sequential schedule."""
