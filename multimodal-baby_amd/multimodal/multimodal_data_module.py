@@ -130,29 +130,48 @@ class SyntheticPairs(torch.utils.data.Dataset):
 
 
 class SyntheticEvalTrials(torch.utils.data.Dataset):
-    """4-way evaluation trials with the item layout of the reference's LabeledSEvalDataset
-    (multimodal_data_module.py:112-160): (imgs [4,3,H,W] target first, label ids, label length, [raw category])."""
+    """4-way evaluation trials with the item layout of the reference's LabeledSEvalDataset (``eval_type='image'``:
+    (imgs [4,3,H,W] target first, label ids [L], label length, [raw category]); multimodal_data_module.py:112-160) or
+    LabeledSTextEvalDataset (``eval_type='text'``: (img [1,3,H,W], label ids [4,L] target first, [4 lengths], [raw target]);
+    :163-213).  ``metadata()`` is the list the reference reads from eval_*.json (target_category / foil_categories)."""
 
-    def __init__(self, n_trials, vocab_size, seed=0, eval_include_sos_eos=False, n_images=4, raw_frames=False):
+    def __init__(self, n_trials, vocab_size, seed=0, eval_include_sos_eos=False, n_images=4, raw_frames=False, eval_type="image"):
         self.n, self.v, self.seed, self.sos_eos, self.n_images = n_trials, vocab_size, seed, eval_include_sos_eos, n_images
         self.raw_frames = raw_frames
+        self.eval_type = eval_type
 
     def __len__(self):
         return self.n
 
-    def __getitem__(self, idx):
+    def _words(self, idx):
         g = torch.Generator().manual_seed(self.seed * 7919 + idx)
-        mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
-        std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        words = torch.randperm(self.v - 4, generator=g)[: self.n_images] + 4          # target + distinct foil categories
+        return g, [int(w) for w in words]
+
+    def metadata(self):
+        out = []
+        for idx in range(self.n):
+            _, words = self._words(idx)
+            out.append({"target_category": f"w{words[0]}", "foil_categories": [f"w{w}" for w in words[1:]]})
+        return out
+
+    def _wrap(self, word):
+        return [SOS_TOKEN_ID, word, EOS_TOKEN_ID] if self.sos_eos else [word]
+
+    def __getitem__(self, idx):
+        g, words = self._words(idx)
+        n_img = self.n_images if self.eval_type == "image" else 1
         if self.raw_frames:
-            imgs = torch.randint(0, 256, (self.n_images, IMAGE_H, IMAGE_W, 3), dtype=torch.uint8, generator=g)
+            imgs = torch.randint(0, 256, (n_img, IMAGE_H, IMAGE_W, 3), dtype=torch.uint8, generator=g)
         else:
-            imgs = (torch.rand(self.n_images, 3, IMAGE_H, IMAGE_W, generator=g) - mean) / std
-        word = int(torch.randint(4, self.v, (1,), generator=g))
-        label = [word]
-        if self.sos_eos:
-            label = [SOS_TOKEN_ID] + label + [EOS_TOKEN_ID]
-        return imgs, torch.tensor(label, dtype=torch.long), len(label), [f"w{word}"]
+            mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+            std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+            imgs = (torch.rand(n_img, 3, IMAGE_H, IMAGE_W, generator=g) - mean) / std
+        if self.eval_type == "image":
+            label = self._wrap(words[0])
+            return imgs, torch.tensor(label, dtype=torch.long), len(label), [f"w{words[0]}"]
+        labels = [self._wrap(w) for w in words]
+        return imgs, torch.tensor(labels, dtype=torch.long), [len(l) for l in labels], [f"w{words[0]}"]
 
 
 class SyntheticDataModule(MultiModalDataModule):
@@ -173,8 +192,12 @@ class SyntheticDataModule(MultiModalDataModule):
         self.val_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 1, raw_frames=raw)
         self.test_set = SyntheticPairs(self.val_batch_size, v, seed=self.seed + 2, raw_frames=raw)
         sos_eos = bool(self.args.get("eval_include_sos_eos", False))
-        self.eval_sets = {"val": SyntheticEvalTrials(4, v, seed=self.seed + 3, eval_include_sos_eos=sos_eos, raw_frames=raw),
-                          "test": SyntheticEvalTrials(4, v, seed=self.seed + 4, eval_include_sos_eos=sos_eos, raw_frames=raw)}
+        et = self.args.get("eval_type", EVAL_TYPE) or EVAL_TYPE
+        n_trials = int(self.args.get("n_eval_trials", 4) or 4)
+        self.eval_sets = {"val": SyntheticEvalTrials(n_trials, v, seed=self.seed + 3, eval_include_sos_eos=sos_eos, raw_frames=raw,
+                                                     eval_type=et),
+                          "test": SyntheticEvalTrials(n_trials, v, seed=self.seed + 4, eval_include_sos_eos=sos_eos, raw_frames=raw,
+                                                      eval_type=et)}
 
     def train_dataloader(self):
         return torch.utils.data.DataLoader(self.train_set, batch_size=self.batch_size, shuffle=False,

@@ -170,3 +170,53 @@ def test_overlapped_update_matches_sequential_schedule(dev):
     # a trainable trunk disables the deferral
     ve2.model.layer4[0].conv1.weight.requires_grad_(True)
     assert not parallel.OverlappedUpdate(eng, opt2, ve2).can_defer
+
+
+def test_eval_entry_batched_trials_match_reference_loop(dev, tmp_path, monkeypatch):
+    """eval.py (reference eval.py:27-331): train.py writes a Lightning-layout checkpoint, eval.py reloads it (pickled encoder
+    hyper-parameters), runs the 4-way trials and writes the reference's prediction records.  Encoding 64 trials per device
+    pass gives the numbers of the reference's batch-1 loop (--trial_batch 1), for both evaluation types; a trial by hand
+    through encode_image / encode_text agrees."""
+    import contextlib, io, json
+    import eval as ev
+    import train
+    monkeypatch.chdir(tmp_path)
+    exp = "multimodal_text_encoder_embedding_pretrained_cnn_False_finetune_cnn_False_seed_0"
+    argv = ("--dataset synthetic --batch_size 4 --val_batch_size 4 --gpus 1 --text_encoder embedding --embedding_dim 32 "
+            "--lambda_lm 0 --optimize_unused --max_epochs 1 --limit_train_batches 2 --normalize_features "
+            f"--checkpoint_callback True --logger False --exp_name {exp}").split()
+    with contextlib.redirect_stdout(io.StringIO()):
+        train.main(argv)
+    for eval_type in ("image", "text"):
+        runs = {}
+        for tb in (1, 64):
+            a = ev._parser().parse_args(["--checkpoint", exp, "--eval_dataset", "synthetic", "--eval_type", eval_type, "--n_trials", "10",
+                                         "--trial_batch", str(tb), "--save_predictions"])
+            out = io.StringIO()
+            with contextlib.redirect_stdout(out):
+                runs[tb] = ev.main(a)
+            assert "Total accuracy:" in out.getvalue()
+        assert len(runs[1]) == len(runs[64]) == 10
+        for r1, r64 in zip(runs[1], runs[64]):
+            assert r1["pred"] == r64["pred"] and r1["correct"] == r64["correct"] and r1["categories"] == r64["categories"]
+            assert torch.allclose(torch.tensor(r1["logits"]), torch.tensor(r64["logits"]), rtol=1e-4, atol=1e-6)
+        fn = tmp_path / "results" / "synthetic" / f"embedding_frozen_random_init_seed_0_{eval_type}_synthetic_test_eval_predictions.json"
+        rec = json.loads(fn.read_text())["data"]
+        assert len(rec) == 10
+        assert list(rec[0]) == ["checkpoint", "model", "seed", "shuffle_utterances", "augment_frames", "multiple_frames", "cnn", "eval_type",
+                                "eval_dataset", "stage", "trial_idx", "categories", "logits", "pred", "correct"]
+        assert rec[3]["trial_idx"] == 3 and rec[3]["checkpoint"] == exp and rec[3]["cnn"] == "frozen_random_init" and rec[3]["seed"] == 0
+        assert len(rec[3]["logits"]) == 4 and abs(sum(rec[3]["logits"]) - 1.0) < 1e-5 and rec[3]["correct"] == (rec[3]["pred"] == 0)
+    # one image-type trial by hand
+    from multimodal.multimodal_lit import MultiModalLitModel
+    from multimodal.multimodal_data_module import SyntheticEvalTrials
+    lit = MultiModalLitModel.load_from_checkpoint(ev.resolve_checkpoint(exp), map_location=dev).to(dev).eval()
+    a = ev._parser().parse_args(["--checkpoint", exp, "--eval_dataset", "synthetic", "--n_trials", "10"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = ev.main(a)
+    imgs, label, n, raw = SyntheticEvalTrials(10, 2350, seed=0 + 4)[2]
+    with torch.no_grad():
+        fi = lit.encode_image(imgs.to(dev))
+        ft = lit.encode_text(label.view(1, -1).to(dev), torch.tensor([n], device=dev))
+        want = torch.softmax((ft @ fi.t())[0] * float(lit.model.logit_neg_log_temperature.exp().detach()), -1).cpu()
+    assert torch.allclose(torch.tensor(res[2]["logits"]), want, rtol=1e-4, atol=1e-6)
