@@ -152,6 +152,13 @@ def main():
     opt = lit.configure_optimizers()
     engine = parallel.DataParallelEngine(device, global_negatives=True).attach(lit)
     batch = synthetic_batch_on_device(PER_GPU_BATCH, seed=rank, device=device) + (None,)
+    # opt-in (CVCL_TRUNK_STREAM=1): the frozen trunk on its own stream, so that step k+1's trunk overlaps step k's trainable
+    # tail (fc, text, loss, backward, AdamW, collectives), which stays on the main stream; every step's work is unchanged and
+    # all of it is complete when the clock stops.  Measured on one MI355X: 7.36-7.40 vs 7.42 ms/step -- the tail is only
+    # 0.26 ms and the cross-stream events cost 0.1 ms -- so it is not the default.
+    if os.environ.get("CVCL_TRUNK_STREAM", "0") == "1":
+        torch.cuda.synchronize()
+        ve.model.enable_trunk_stream(device, inputs="ready")          # the benchmark batch is resident and never rewritten
 
     # multi-GPU: the all-reduce + optimizer step of step k are enqueued behind the frozen trunk of step k+1
     # (parallel.OverlappedUpdate; same parameter sequence as the sequential schedule); flushed before the clock stops

@@ -179,6 +179,58 @@ def check(rc: int, what: str):
         raise CvclError(f"{what} failed (rc={rc}): {msg}")
 
 
+class TrunkStream:
+    """Runs a frozen image trunk on its own HIP stream so that it overlaps the trainable tail of the PREVIOUS step
+    (head GEMM, text encoder, loss, backward, optimizer, and in multi-GPU runs the feature all-gather / gradient all-reduce),
+    which stay on the caller's stream.  The frozen trunk reads nothing the tail writes (its weights and BatchNorm buffers are
+    touched on the trunk stream only), so the two streams need exactly one edge per step: the caller's stream waits for the
+    trunk's event before it consumes the features.  With a host that runs ahead of the device (it does: the trunk is one
+    enqueue), step k+1's trunk starts while step k's tail -- a few dozen latency-bound launches -- is still draining.
+
+    ``inputs='caller'``: the images were produced on the caller's stream; the trunk stream first waits for everything
+    enqueued there (always correct, but it then also waits for the previous tail: no overlap).
+    ``inputs='ready'``: the images are long-lived or were produced on the trunk stream itself (static benchmark batch;
+    a data pipeline that runs its host-to-device copy and frame transform under ``with ts.context():``): no wait."""
+
+    def __init__(self, device, inputs="caller", stream=None):
+        if inputs not in ("caller", "ready"):
+            raise ValueError(inputs)
+        self.device, self.inputs = torch.device(device), inputs
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+
+    def context(self):
+        return torch.cuda.stream(self.stream)
+
+    def run(self, fn, *inputs):
+        """fn(slot) enqueues the trunk and returns its output tensors.  slot alternates 0 / 1: the trunk writes its outputs
+        into one of two persistent buffer sets (a fresh allocation per step would rotate through allocator blocks: the
+        caller's stream holds each one until its tail has run), so an output is valid until the step after next starts --
+        the trunk stream waits, before reusing a slot, for the caller's stream to have passed the entry of the previous
+        step, i.e. to have finished the tail that read that slot."""
+        caller = torch.cuda.current_stream(self.device)
+        entry = torch.cuda.Event()
+        entry.record(caller)                               # everything the caller enqueued for earlier steps precedes this
+        prev_entry, self._prev_entry = getattr(self, "_prev_entry", None), entry
+        if self.inputs == "caller":
+            self.stream.wait_stream(caller)
+        elif prev_entry is not None:
+            self.stream.wait_event(prev_entry)             # the tail of two steps ago (last reader of this slot) is done
+        slot = self._slot = 1 - getattr(self, "_slot", 1)
+        with torch.cuda.stream(self.stream):
+            outs = fn(slot)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        for t in inputs:                                   # allocated on the caller's pool, read on the trunk stream
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.stream)
+        caller.wait_event(done)
+        return outs
+
+    def join(self):
+        """Make the caller's stream wait for everything on the trunk stream (before reading BatchNorm buffers, saving)."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+
 def stream_ptr() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -130,6 +130,17 @@ class ResNet(nn.Module):
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
             raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
         x = x.contiguous()
+        ts = self.__dict__.get("_trunk_stream")
+        if ts is not None and x.is_cuda:                  # frozen trunk on its own stream (H.TrunkStream)
+            return ts.run(lambda slot: self._trunk_launch(x, slot), x)
+        return self._trunk_launch(x)
+
+    def enable_trunk_stream(self, device, inputs="caller", stream=None):
+        """Run the frozen trunk on a stream of its own so it overlaps the previous step's trainable tail (see H.TrunkStream)."""
+        self.__dict__["_trunk_stream"] = H.TrunkStream(device, inputs, stream) if inputs else None
+        return self.__dict__["_trunk_stream"]
+
+    def _trunk_launch(self, x, slot=None):
         B, _, Hh, Ww = x.shape
         dt = H.cvcl_dtype(self.compute_dtype)
         lib = H.lib()
@@ -138,11 +149,19 @@ class ResNet(nn.Module):
             nb = lib.cvcl_resnext50_workspace_bytes(dt, B, Hh, Ww)
             ws = self._ws_cache.get((nb, str(x.device)))
             if ws is None:
-                self._ws_cache.clear()
+                for k in [k for k in self._ws_cache if not (isinstance(k, tuple) and k and k[0] == "out")]:
+                    del self._ws_cache[k]
                 ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
                 self._ws_cache[(nb, str(x.device))] = ws
-            fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
-            pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
+            if slot is None:
+                fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
+                pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
+            else:                                         # side-stream mode: two persistent output sets (H.TrunkStream.run)
+                key = ("out", slot, B, Hh, Ww, self.compute_dtype, str(x.device))
+                if key not in self._ws_cache:
+                    self._ws_cache[key] = (torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device),
+                                           torch.empty(B, 2048, dtype=torch.float32, device=x.device))
+                fmap, pooled = self._ws_cache[key]
             H.check(lib.cvcl_resnext50_fwd(dt, B, Hh, Ww, int(self.training), H.ptr(x), arr, len(arr), H.ptr(ws), nb,
                                            H.ptr(fmap), H.ptr(pooled), BN_MOMENTUM, BN_EPS, H.stream_ptr()),
                     "cvcl_resnext50_fwd")
@@ -153,6 +172,7 @@ class ResNet(nn.Module):
         d = dict(self.__dict__)
         d["_pack_cache"], d["_ws_cache"] = {}, {}
         d["_pre_head_callback"] = None
+        d["_trunk_stream"] = None
         return d
 
     def __setstate__(self, d):
@@ -161,6 +181,7 @@ class ResNet(nn.Module):
         self.__dict__.setdefault("_pack_cache", {})
         self.__dict__.setdefault("_ws_cache", {})
         self.__dict__.setdefault("_pre_head_callback", None)
+        self.__dict__.setdefault("_trunk_stream", None)
 
     def forward(self, x):
         pooled, fmap = self.trunk(x)

@@ -220,3 +220,43 @@ def test_eval_entry_batched_trials_match_reference_loop(dev, tmp_path, monkeypat
         ft = lit.encode_text(label.view(1, -1).to(dev), torch.tensor([n], device=dev))
         want = torch.softmax((ft @ fi.t())[0] * float(lit.model.logit_neg_log_temperature.exp().detach()), -1).cpu()
     assert torch.allclose(torch.tensor(res[2]["logits"]), want, rtol=1e-4, atol=1e-6)
+
+
+def test_trunk_stream_overlap_is_bit_identical(dev):
+    """H.TrunkStream: the frozen trunk on its own stream (overlapping the previous step's trainable tail) gives the same losses
+    and the same parameters, bit for bit, as the single-stream schedule over several optimizer steps."""
+    import contextlib, io
+    import bench
+    from multimodal.multimodal import TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import read_vocab
+    from multimodal.multimodal_lit import MultiModalLitModel
+
+    def run(stream_mode):
+        torch.manual_seed(0)
+        args = bench.c2_args()
+        with contextlib.redirect_stdout(io.StringIO()):
+            ve = VisionEncoder(args)
+            te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args)
+            lit = MultiModalLitModel(ve, te, args)
+        lit.to(dev)
+        lit.set_precision("bf16")
+        lit.train()
+        opt = lit.configure_optimizers()
+        batches = [bench.synthetic_batch_on_device(16, seed=s, device=dev) + (None,) for s in range(3)]
+        torch.cuda.synchronize()
+        if stream_mode:
+            ve.model.enable_trunk_stream(dev, inputs="ready")
+        losses = []
+        for i in range(6):
+            opt.zero_grad(set_to_none=True)
+            out = lit.training_step(batches[i % 3], 0)
+            out["loss"].backward()
+            opt.step()
+            losses.append(out["loss"].detach())
+        torch.cuda.synchronize()
+        return torch.stack(losses).cpu(), lit.vision_encoder.model.fc.weight.detach().cpu().clone(), \
+            lit.vision_encoder.model.bn1.running_mean.detach().cpu().clone()
+
+    l0, w0, r0 = run(False)
+    l1, w1, r1 = run(True)
+    assert torch.equal(l0, l1) and torch.equal(w0, w1) and torch.equal(r0, r1)
