@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                 }
-                if constexpr (!MXOUT) *reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n) = v;
+                if constexpr (!MXOUT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
             }
             if constexpr (MXOUT) {
                 // e4m3 + one e8m0 scale per 32 columns of the row: the block = 4 adjacent lanes (chunks 4b .. 4b+3)
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
                 if (m < p.M) {
                     u32x2 w = {pack4_fp8((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv),
                                pack4_fp8((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv)};
-                    *reinterpret_cast<u32x2*>(p.C8 + (long)m * p.ldc8 + n) = w;
+                    __builtin_nontemporal_store(w, reinterpret_cast<u32x2*>(p.C8 + (long)m * p.ldc8 + n));
                     if ((chunk & 3) == 0) p.c_bs[((long)(n >> 7) * p.M + m) * 4 + ((n >> 5) & 3)] = (unsigned char)sb;
                 }
             }
