@@ -8,6 +8,7 @@ collection, ``save_hyperparameters`` and a one-process-per-GPU data-parallel mod
 from __future__ import annotations
 
 import argparse
+import contextlib
 import os
 import random
 
@@ -112,7 +113,7 @@ class Trainer:
     FLAGS = (("gpus", int, 0), ("max_epochs", int, 1), ("check_val_every_n_epoch", int, 1),
              ("checkpoint_callback", _str2bool, True), ("logger", _str2bool, True), ("fast_dev_run", None, False),
              ("strategy", str, None), ("devices", int, None), ("precision", str, "32"), ("limit_train_batches", int, None),
-             ("limit_val_batches", int, None))
+             ("limit_val_batches", int, None), ("trunk_stream", _str2bool, False))
 
     @classmethod
     def add_argparse_args(cls, parser):
@@ -131,9 +132,12 @@ class Trainer:
 
     def __init__(self, gpus=0, max_epochs=1, check_val_every_n_epoch=1, checkpoint_callback=True, logger=True,
                  fast_dev_run=False, strategy=None, devices=None, precision="32", limit_train_batches=None,
-                 limit_val_batches=None, callbacks=None, enable_checkpointing=None, **_ignored):
+                 limit_val_batches=None, callbacks=None, enable_checkpointing=None, trunk_stream=False, **_ignored):
         self.gpus, self.max_epochs = gpus or 0, max_epochs
         self.fast_dev_run = fast_dev_run
+        # --trunk_stream True: a frozen image trunk, the host-to-device copy of the batch and the device frame transform run on
+        # their own HIP stream and overlap the previous step's trainable tail (H.TrunkStream); same numbers, bit for bit
+        self.trunk_stream = bool(trunk_stream)
         self.precision = str(precision)
         self.limit_train_batches = 1 if fast_dev_run else limit_train_batches
         self.limit_val_batches = 1 if fast_dev_run else limit_val_batches
@@ -229,16 +233,33 @@ class Trainer:
         upd = None
         if parallel.is_distributed() and hasattr(model, "vision_encoder"):
             upd = parallel.OverlappedUpdate(engine, opt, model.vision_encoder)
+        ts = None
+        trunk = getattr(getattr(model, "vision_encoder", None), "model", None)
+        if self.trunk_stream and device.type == "cuda" and hasattr(trunk, "enable_trunk_stream") \
+                and not any(p.requires_grad for n, p in trunk.named_parameters() if not n.startswith(("fc.", "head."))):
+            torch.cuda.synchronize(device)
+            ts = trunk.enable_trunk_stream(device, inputs="caller")    # "ready" only inside the training loop (below)
         for epoch in range(start_epoch, self.max_epochs):
             self.current_epoch = epoch
             model.train()
             outs = []
+            if ts is not None:
+                ts.inputs = "ready"            # the batch is produced on the trunk stream itself (below)
             for bi, batch in enumerate(datamodule.train_dataloader()):
                 if self.limit_train_batches is not None and bi >= self.limit_train_batches:
                     break
-                batch = _move(batch, device)
-                if hasattr(datamodule, "on_after_batch_transfer"):
-                    batch = datamodule.on_after_batch_transfer(batch, 0, training=True)
+                with (ts.context() if ts is not None else contextlib.nullcontext()):
+                    batch = _move(batch, device)
+                    if hasattr(datamodule, "on_after_batch_transfer"):
+                        batch = datamodule.on_after_batch_transfer(batch, 0, training=True)
+                if ts is not None:            # tokens / lengths were copied on the trunk stream and are read on this one
+                    main = torch.cuda.current_stream(device)
+                    copied = torch.cuda.Event()
+                    copied.record(ts.stream)
+                    main.wait_event(copied)    # (the copy sits right behind the previous trunk: this stream is past it anyway)
+                    for t in batch:
+                        if torch.is_tensor(t) and t.is_cuda:
+                            t.record_stream(main)
                 if upd is None:
                     opt.zero_grad(set_to_none=True)
                     out = model.training_step(batch, bi)
@@ -254,6 +275,9 @@ class Trainer:
                 outs.append({k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()})
             if upd is not None:
                 upd.flush()                    # every update applied before epoch-end hooks / validation / checkpoints
+            if ts is not None:
+                ts.join()                      # BatchNorm buffers written on the trunk stream are read (saved) on this one
+                ts.inputs = "caller"           # evaluation batches are produced on this stream
             if hasattr(model, "training_epoch_end") and outs:
                 model.training_epoch_end(outs)
             self.logged_metrics.update(model._logged)

@@ -93,12 +93,19 @@ class VisionTransformer(nn.Module):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_cache"] = {}
+        d.pop("_trunk_stream", None)          # streams / ring buffers of H.TrunkStream are never pickled
+        d.pop("_trunk_out", None)
         return d
 
     def __setstate__(self, d):
         self.__dict__.update(d)
         self.__dict__.setdefault("compute_dtype", torch.float32)
         self.__dict__.setdefault("_cache", {})
+
+    def enable_trunk_stream(self, device, inputs="caller", stream=None):
+        """Run the frozen ViT on a stream of its own so it overlaps the previous step's trainable tail (see H.TrunkStream)."""
+        from . import vit_hip
+        return vit_hip.enable_trunk_stream(self, device, inputs, stream)
 
     def forward(self, x):
         """-> cls token after the final LayerNorm, [B, D] fp32 (reference :245-250)."""

@@ -83,6 +83,19 @@ def _ln(cd, x, stride, g, b, eps, out, out_f32, rows, D):
 
 
 def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
+    ts = model.__dict__.get("_trunk_stream")
+    if ts is not None and x.is_cuda:          # frozen ViT on its own stream: overlaps the previous step's text encoder / loss /
+        x = x.contiguous()                    # backward / optimizer, which stay on the caller's stream (H.TrunkStream)
+        return ts.run(lambda slot: _vit_forward(model, x, slot), x)
+    return _vit_forward(model, x, None)
+
+
+def enable_trunk_stream(model, device, inputs="caller", stream=None):
+    model.__dict__["_trunk_stream"] = H.TrunkStream(device, inputs, stream) if inputs else None
+    return model.__dict__["_trunk_stream"]
+
+
+def _vit_forward(model, x: torch.Tensor, slot) -> torch.Tensor:
     if torch.is_grad_enabled() and any(p.requires_grad for n, p in model.named_parameters() if not n.startswith("head.")):
         raise NotImplementedError("fine-tuning the ViT trunk needs its backward kernels, which this build does not ship "
                                   "(frozen-ViT configurations only)")
@@ -148,6 +161,13 @@ def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
             _ln(cd, h, D, bw["n2w"], bw["n2b"], bw["eps"], y, False, B * T, D)
             H.gemm(y, bw["fc1_w"], out=mid, bias=bw["fc1_b"], act=H.ACT_GELU)
             H.gemm(mid, bw["fc2_w"], out=h, bias=bw["fc2_b"], residual=h)            # h = h + mlp(...)     (vit:147)
-        cls = torch.empty(B, D, dtype=torch.float32, device=dev)
+        if slot is None:
+            cls = torch.empty(B, D, dtype=torch.float32, device=dev)
+        else:                                 # side-stream mode: two persistent outputs (see H.TrunkStream.run)
+            ring = model.__dict__.setdefault("_trunk_out", {})
+            key = (slot, B, D, str(dev))
+            if key not in ring:
+                ring[key] = torch.empty(B, D, dtype=torch.float32, device=dev)
+            cls = ring[key]
         _ln(cd, h, T * D, w["nw"], w["nb"], w["neps"], cls, True, B, D)              # norm(x)[:, 0]        (vit:249-250)
     return cls

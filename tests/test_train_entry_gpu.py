@@ -260,3 +260,35 @@ def test_trunk_stream_overlap_is_bit_identical(dev):
     l0, w0, r0 = run(False)
     l1, w1, r1 = run(True)
     assert torch.equal(l0, l1) and torch.equal(w0, w1) and torch.equal(r0, r1)
+
+
+def test_trainer_trunk_stream_flag_bit_identical(dev, tmp_path, monkeypatch):
+    """train.py --trunk_stream True (batch copy + device frame transform + frozen trunk on their own stream, overlapping the
+    previous step's tail; validation back on the main stream) trains to the same parameters and validation metrics, bit for
+    bit, as the single-stream run -- ResNeXt and ViT trunks."""
+    import contextlib, io
+    import train
+    import multimodal.multimodal as mm
+    from multimodal import vision_transformer_dino_mugs as vits
+    monkeypatch.chdir(tmp_path)
+    base = ("--dataset synthetic --batch_size 4 --val_batch_size 4 --gpus 1 --text_encoder embedding --embedding_dim 32 "
+            "--lambda_lm 0 --optimize_unused --max_epochs 2 --limit_train_batches 3 --normalize_features --device_frames "
+            "--checkpoint_callback False --logger False --exp_name ts").split()
+    for vit in (False, True):
+        extra = ["--vit_dino"] if vit else []
+        orig = mm.load_model
+        if vit:
+            mm.load_model = lambda name, pretrained: vits.vit_base(patch_size=16, num_classes=0)
+        try:
+            res = []
+            for flag in ("False", "True"):
+                torch.manual_seed(0)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    trainer, lit = train.main(base + extra + ["--trunk_stream", flag])
+                torch.cuda.synchronize()
+                head = lit.vision_encoder.model.head if vit else lit.vision_encoder.model.fc
+                res.append((head.weight.detach().cpu().clone(), lit.text_encoder.embedding.weight.detach().cpu().clone(),
+                            float(trainer.logged_metrics["val_loss"])))
+        finally:
+            mm.load_model = orig
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], vit

@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 from bench import synthetic_batch_on_device
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--patch", type=int, default=16)
-ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", default="bf16"); a = ap.parse_args()
+ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", default="bf16")
+ap.add_argument("--trunk-stream", action="store_true"); a = ap.parse_args()
 dev = torch.device("cuda:0")
 args = argparse.Namespace(embedding_type="flat", embedding_dim=512, pretrained_cnn=False, cnn_dino=False, vit_dino=True,
                           finetune_cnn=False, text_encoder="transformer", crange=1, dropout_i=0.0, dropout_o=0.0,
@@ -28,6 +29,9 @@ with contextlib.redirect_stdout(io.StringIO()):
 mm.load_model = orig
 lit.to(dev); lit.set_precision(a.precision); lit.train()
 opt = lit.configure_optimizers()
+if a.trunk_stream:
+    from multimodal import vit_hip
+    vit_hip.enable_trunk_stream(ve.model, dev, inputs="ready")
 batch = synthetic_batch_on_device(a.batch, 0, dev) + (None,)
 def step():
     opt.zero_grad(set_to_none=True); out = lit.training_step(batch, 0); out["loss"].backward(); opt.step(); return out
