@@ -274,18 +274,32 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
 }
 
 // LPR lanes per row (32 for K <= 1024: a 768-wide row is 96 chunks = 3 per lane with no idle lanes; 64 otherwise)
+// reductions over LPR (32 | 64) consecutive lanes, result in every lane: the four steps inside a 16-lane row are DPP moves
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: VALU-rate, no LDS round trip); only the row-crossing steps are
+// ds_bpermute shuffles -- 1 (2) instead of 5 (6) per reduction, three reductions per row on the LayerNorm + quantise path
+__device__ inline float dpp_f(float v, int ctrl_sel) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    if (ctrl_sel == 0) r = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);          // quad_perm [1,0,3,2]
+    else if (ctrl_sel == 1) r = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    else if (ctrl_sel == 2) r = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    else r = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);                       // row_mirror
+    return __builtin_bit_cast(float, r);
+}
 template <int LPR> __device__ inline float lanes_sum(float v) {
+    v += dpp_f(v, 0); v += dpp_f(v, 1); v += dpp_f(v, 2); v += dpp_f(v, 3);
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 16; o < LPR; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 template <int LPR> __device__ inline float lanes_max(float v) {
+    v = fmaxf(v, dpp_f(v, 0)); v = fmaxf(v, dpp_f(v, 1)); v = fmaxf(v, dpp_f(v, 2)); v = fmaxf(v, dpp_f(v, 3));
 #pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    for (int o = 16; o < LPR; o <<= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 
-template <bool SRC_F32, int LPR>
+template <bool SRC_F32, int LPR, int NCH>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ xin, long x_row_stride, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, unsigned char* __restrict__ q,
                                                              float* __restrict__ scale, long rows, int K) {
@@ -293,7 +307,8 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
     const int lane = threadIdx.x % LPR;
     if (row >= rows) return;
     const int nch = K >> 3;
-    constexpr int NCH = LPR == 32 ? 4 : 8;           // chunks per lane held in registers
+    // NCH chunks (of 8 elements) per lane held in registers: 3 x 32 lanes = a 768-wide row (ViT-B) with no idle slot and few
+    // enough registers for 8 waves per SIMD -- the kernel is latency-bound, occupancy is what hides the row load
     float v[NCH][8];
     float s = 0.f;
 #pragma unroll
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
         for (int i = 0; i < NCH; ++i)
             if (lane + LPR * i < nch) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; qq = fmaf(c, c, qq); }
+                for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; v[i][e] = c; qq = fmaf(c, c, qq); }   // keep the centred value
             }
         const float rstd = 1.f / sqrtf(lanes_sum<LPR>(qq) / (float)K + eps);
 #pragma unroll
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
             const int c = lane + LPR * i;
             if (c < nch) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[i][e] = (v[i][e] - mean) * rstd * gamma[c * 8 + e] + beta[c * 8 + e];
+                for (int e = 0; e < 8; ++e) v[i][e] = fmaf(v[i][e], rstd * gamma[c * 8 + e], beta[c * 8 + e]);
             }
         }
     }
@@ -343,13 +358,21 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
     amax = lanes_max<LPR>(amax);
     const float sc = amax > 0.f ? amax / 448.f : 1.f;
     if (lane == 0) scale[row] = sc;
+    // y / sc for every element of the row, correctly rounded (the oracle's y / s), without a division per element: with
+    // r = RN(1 / sc) computed once, q0 = RN(y r), rem = y - sc q0 (exact in an fma), q = RN(q0 + rem r) is RN(y / sc)
+    // (Markstein's quotient refinement; no overflow / underflow here: |y / sc| <= 448, sc is a normal number)
+    const float rinv = 1.0f / sc;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + LPR * i;
         if (c < nch) {
             float t[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = fminf(fmaxf(v[i][e] / sc, -448.f), 448.f);   // true division: same rounding as the oracle's y / s
+            for (int e = 0; e < 8; ++e) {
+                const float q0 = v[i][e] * rinv;
+                const float qd = fmaf(fmaf(-sc, q0, v[i][e]), rinv, q0);
+                t[e] = fminf(fmaxf(qd, -448.f), 448.f);
+            }
             u32x2 w = {pack4_fp8(t[0], t[1], t[2], t[3]), pack4_fp8(t[4], t[5], t[6], t[7])};
             *reinterpret_cast<u32x2*>(q + row * K + c * 8) = w;
         }
@@ -380,11 +403,12 @@ extern "C" int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stri
     hipStream_t st = (hipStream_t)stream;
     unsigned char* qq = (unsigned char*)q;
     if (src_dtype == CVCL_F32) {
-        if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 32>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
-        else hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 64>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 32, 4>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 64, 8>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
     } else {
-        if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
-        else hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 64>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        if (K <= 768) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 3>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 4>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 64, 8>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
     }
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
