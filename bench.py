@@ -152,11 +152,13 @@ def main():
     opt = lit.configure_optimizers()
     engine = parallel.DataParallelEngine(device, global_negatives=True).attach(lit)
     batch = synthetic_batch_on_device(PER_GPU_BATCH, seed=rank, device=device) + (None,)
-    # opt-in (CVCL_TRUNK_STREAM=1): the frozen trunk on its own stream, so that step k+1's trunk overlaps step k's trainable
-    # tail (fc, text, loss, backward, AdamW, collectives), which stays on the main stream; every step's work is unchanged and
-    # all of it is complete when the clock stops.  Measured on one MI355X: 7.36-7.40 vs 7.42 ms/step -- the tail is only
-    # 0.26 ms and the cross-stream events cost 0.1 ms -- so it is not the default.
-    if os.environ.get("CVCL_TRUNK_STREAM", "0") == "1":
+    # the frozen trunk runs on its own HIP stream (H.TrunkStream; CVCL_TRUNK_STREAM=0 restores the single-stream schedule):
+    # step k+1's trunk overlaps step k's trainable tail -- fc, text, loss, backward, AdamW, and with world > 1 the feature
+    # all-gathers, the larger global-negatives loss and the deferred all-reduce wait + optimizer step -- which stays on the
+    # main stream.  Every step does the same work with the same numbers (bit-identical, tests/test_train_entry_gpu.py), and
+    # all of it is complete when the clock stops (torch.cuda.synchronize() waits for both streams).  One GPU: 7.42 -> 7.38
+    # ms/step (the tail is only 0.26 ms there and the cross-stream events cost 0.1 ms).
+    if os.environ.get("CVCL_TRUNK_STREAM", "1") != "0":
         torch.cuda.synchronize()
         ve.model.enable_trunk_stream(device, inputs="ready")          # the benchmark batch is resident and never rewritten
 

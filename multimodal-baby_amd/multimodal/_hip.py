@@ -201,12 +201,14 @@ class TrunkStream:
     def context(self):
         return torch.cuda.stream(self.stream)
 
-    def run(self, fn, *inputs):
-        """fn(slot) enqueues the trunk and returns its output tensors.  slot alternates 0 / 1: the trunk writes its outputs
-        into one of two persistent buffer sets (a fresh allocation per step would rotate through allocator blocks: the
-        caller's stream holds each one until its tail has run), so an output is valid until the step after next starts --
-        the trunk stream waits, before reusing a slot, for the caller's stream to have passed the entry of the previous
-        step, i.e. to have finished the tail that read that slot."""
+    def launch(self, fn, *inputs):
+        """fn(slot) enqueues the trunk on the trunk stream and returns its output tensors; the caller's stream does NOT wait
+        yet (``wait`` does), so work enqueued on it in between -- e.g. the deferred optimizer step of the previous batch --
+        overlaps the trunk too.  slot alternates 0 / 1: the trunk writes its outputs into one of two persistent buffer sets
+        (a fresh allocation per step would rotate through allocator blocks: the caller's stream holds each one until its
+        tail has run), so an output is valid until the step after next starts -- the trunk stream waits, before reusing a
+        slot, for the caller's stream to have passed the entry of the previous step, i.e. to have finished the tail that
+        read that slot."""
         caller = torch.cuda.current_stream(self.device)
         entry = torch.cuda.Event()
         entry.record(caller)                               # everything the caller enqueued for earlier steps precedes this
@@ -223,8 +225,15 @@ class TrunkStream:
         for t in inputs:                                   # allocated on the caller's pool, read on the trunk stream
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(self.stream)
-        caller.wait_event(done)
+        return outs, done
+
+    def wait(self, handle):
+        outs, done = handle
+        torch.cuda.current_stream(self.device).wait_event(done)
         return outs
+
+    def run(self, fn, *inputs):
+        return self.wait(self.launch(fn, *inputs))
 
     def join(self):
         """Make the caller's stream wait for everything on the trunk stream (before reading BatchNorm buffers, saving)."""

@@ -122,8 +122,9 @@ class ResNet(nn.Module):
         self._pack_cache["k"] = (key, (arr, keep))
         return arr, keep
 
-    def trunk(self, x: torch.Tensor):
-        """conv1 .. layer4 + avgpool.  -> (pooled [B,2048] f32, layer4 map as a logical NCHW view)."""
+    def trunk(self, x: torch.Tensor, defer_wait: bool = False):
+        """conv1 .. layer4 + avgpool.  -> (pooled [B,2048] f32, layer4 map as a logical NCHW view).  With a trunk stream and
+        ``defer_wait`` the result is a handle for ``self._trunk_stream.wait`` (the caller's stream has not waited yet)."""
         if torch.is_grad_enabled() and any(p.requires_grad for c, b, _ in self.conv_bn_pairs() for p in (c.weight, b.weight, b.bias)):
             from .trunk_train import trunk_train       # --finetune_cnn: differentiable twin (saves activations)
             return trunk_train(self, x)
@@ -132,7 +133,10 @@ class ResNet(nn.Module):
         x = x.contiguous()
         ts = self.__dict__.get("_trunk_stream")
         if ts is not None and x.is_cuda:                  # frozen trunk on its own stream (H.TrunkStream)
-            return ts.run(lambda slot: self._trunk_launch(x, slot), x)
+            handle = ts.launch(lambda slot: self._trunk_launch(x, slot), x)
+            if defer_wait:
+                return handle
+            return ts.wait(handle)
         return self._trunk_launch(x)
 
     def enable_trunk_stream(self, device, inputs="caller", stream=None):
@@ -184,10 +188,14 @@ class ResNet(nn.Module):
         self.__dict__.setdefault("_trunk_stream", None)
 
     def forward(self, x):
-        pooled, fmap = self.trunk(x)
+        ts = self.__dict__.get("_trunk_stream")
+        out = self.trunk(x, defer_wait=True)
         cb = self.__dict__.get("_pre_head_callback")
         if cb is not None:
             cb()                                         # deferred all-reduce wait + optimizer step of the previous step
+        if ts is not None and isinstance(out, tuple) and len(out) == 2 and isinstance(out[1], torch.cuda.Event):
+            out = ts.wait(out)                           # (with a trunk stream the update above overlapped the trunk)
+        pooled, fmap = out
         # fire the forward hooks registered on layer4 (the reference's Hook(model.layer4)); done by hand so that it
         # also works when layer4 is a plain nn.Sequential unpickled from a torchvision-built checkpoint
         for hook in list(self.layer4._forward_hooks.values()):
