@@ -217,6 +217,13 @@ int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok, void* out
  * [heads*64/128][B*T][4] -- cvcl_gemm_fp8_mx's MX input, so the fp8 projection needs no quantisation pass in between. */
 int cvcl_attention_mx(const void* qkv, void* out8, void* out_block_scales, int B, int T, int heads, int head_dim, float scale,
                       void* stream);
+/* Attention for a fine-tuned ViT (autograd of vision_transformer_dino_mugs.py:106-130): the forward above that also saves the
+ * log-sum-exp of every row (lse [B][heads][T] fp32, log2 units), and the backward: d_qkv [B][T][3][heads][64] bf16 from
+ * qkv, the forward output o and d_o ([B][T][heads*64] bf16).  Two kernels (queries own dQ; keys own dK, dV), probabilities
+ * rebuilt from lse, no atomics: deterministic.  head_dim 64; 32 < T <= 288 (forward) / 224 (backward). */
+int cvcl_attention_train(const void* qkv, void* out, float* lse, int B, int T, int heads, int head_dim, float scale, void* stream);
+int cvcl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* d_qkv, int B, int T, int heads,
+                       int head_dim, float scale, void* stream);
 /* x[b,l,:] = table[tok[b,l]] (+ pos[l]) (multimodal.py:496, 561-563) */
 int cvcl_embed_gather_pos(const float* table, const int64_t* tok, const float* pos, float* x, int B, int L, int E, int V,
                           void* stream);

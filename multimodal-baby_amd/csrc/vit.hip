@@ -211,8 +211,8 @@ __device__ inline bf16x4 att_tr_read(const char* p) {
 // bytes [B*T][D], scales tiled [D/128][B*T][4]) -- a lane and its partner lane ^ 32 hold the 32 d of one block of one query.
 template <bool MX>
 __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                unsigned char* __restrict__ out8, unsigned char* __restrict__ out_bs, int B,
-                                                                int Tn, int heads, float scale, int NT) {
+                                                                unsigned char* __restrict__ out8, unsigned char* __restrict__ out_bs,
+                                                                float* __restrict__ lse, int B, int Tn, int heads, float scale, int NT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Tpad = 32 * NT;
     char* sK = smem;                                                // [Tpad][ATT_KP]
@@ -298,7 +298,10 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
                 }
             }
         }
-        const float inv = 1.f / (l_run + __shfl_xor(l_run, 32, 64));
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        const float inv = 1.f / l_tot;
+        // log-sum-exp of the row's logits in log2 units (what the backward kernels rebuild the probabilities from)
+        if (lse && h == 0 && q0 + l31 < Tn) lse[((long)b * heads + hh) * Tn + q0 + l31] = m_run + log2f(l_tot);
         // this lane's query row: 8 runs of 4 consecutive d (d = 32 dt + 8b + 4h + c)
         if constexpr (MX) {
             const long mrow = (long)b * Tn + q0 + l31, Mtot = (long)B * Tn;
@@ -464,7 +467,8 @@ extern "C" int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const
 
 namespace {
 template <bool MX>
-int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, int B, int T, int heads, float scale, hipStream_t s) {
+int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, float* lse, int B, int T, int heads, float scale,
+                          hipStream_t s) {
     const int nt = (T + 31) / 32;
     const size_t lds = (size_t)nt * 32 * (ATT_KP + ATT_VP);
     static bool attr_set = false;
@@ -476,7 +480,7 @@ int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, 
         attr_set = true;
     }
     hipLaunchKernelGGL(attention_mfma_kernel<MX>, dim3(B * heads), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, (unsigned char*)out8,
-                       (unsigned char*)out_bs, B, T, heads, scale, nt);
+                       (unsigned char*)out_bs, lse, B, T, heads, scale, nt);
     return CVCL_OK;
 }
 }  // namespace
@@ -489,7 +493,20 @@ extern "C" int cvcl_attention_mx(const void* qkv, void* out8, void* out_block_sc
                    "cvcl_attention_mx: needs head_dim 64, an even head count and 32 < T <= %d (got hd %d heads %d T %d)", ATT_TPAD_MAX, head_dim,
                    heads, T);
     CvclProfScope prof(stream, CVCL_K_ATTENTION);
-    const int rc = launch_attention_mfma<true>(qkv, nullptr, out8, out_block_scales, B, T, heads, scale, (hipStream_t)stream);
+    const int rc = launch_attention_mfma<true>(qkv, nullptr, out8, out_block_scales, nullptr, B, T, heads, scale, (hipStream_t)stream);
+    if (rc) return rc;
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+// forward for training: the bf16 MFMA kernel, additionally saving each row's log-sum-exp (log2 units) for cvcl_attention_bwd
+extern "C" int cvcl_attention_train(const void* qkv, void* out, float* lse, int B, int T, int heads, int head_dim, float scale,
+                                    void* stream) {
+    CVCL_CHECK_ARG(qkv && out && lse && B > 0 && heads > 0, "cvcl_attention_train: bad args");
+    CVCL_CHECK_ARG(head_dim == 64 && T > 32 && T <= ATT_TPAD_MAX, "cvcl_attention_train: needs head_dim 64 and 32 < T <= %d (got hd %d, T %d)",
+                   ATT_TPAD_MAX, head_dim, T);
+    CvclProfScope prof(stream, CVCL_K_ATTENTION);
+    const int rc = launch_attention_mfma<false>(qkv, out, nullptr, nullptr, lse, B, T, heads, scale, (hipStream_t)stream);
     if (rc) return rc;
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
@@ -501,7 +518,7 @@ extern "C" int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok
     CvclProfScope prof(stream, CVCL_K_ATTENTION);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16 && head_dim == 64 && !key_tok && T > 32 && T <= ATT_TPAD_MAX) {   // T <= 32: generic kernel below
-        const int rc = launch_attention_mfma<false>(qkv, out, nullptr, nullptr, B, T, heads, scale, s);
+        const int rc = launch_attention_mfma<false>(qkv, out, nullptr, nullptr, nullptr, B, T, heads, scale, s);
         if (rc) return rc;
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;

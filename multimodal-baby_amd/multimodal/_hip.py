@@ -134,6 +134,8 @@ SIGNATURES = {
     "cvcl_token_ce_bwd": (_I, [_P, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
     "cvcl_lm_loss_summaries": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_quant_rows_fp8": (_I, [_I, _P, C.c_long, _P, _P, C.c_float, _P, _P, C.c_long, _I, _P]),
+    "cvcl_attention_train": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "cvcl_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "cvcl_attention_mx": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "cvcl_gemm_fp8_mx": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "cvcl_gemm_fp8": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),

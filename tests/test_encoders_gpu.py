@@ -188,6 +188,41 @@ def test_attention_bf16_mfma_vs_float64(dev, B, T, heads):
     assert err < 2e-2, err
 
 
+@pytest.mark.parametrize("B,T,heads", [(2, 197, 3), (1, 50, 2), (3, 224, 12)])
+def test_attention_backward_vs_float64(dev, B, T, heads):
+    """cvcl_attention_train + cvcl_attention_bwd (bf16 MFMA, probabilities rebuilt from the saved log-sum-exp) vs autograd of
+    softmax(q k^T / 8) v in float64 on the same bf16-rounded operands; deterministic run to run."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(T + heads)
+    D = heads * 64
+    qkv = (torch.randn(B, T, 3, heads, 64, generator=g) * 1.2).bfloat16()
+    d_o = torch.randn(B, T, D, generator=g).bfloat16()
+    q64 = qkv.double().requires_grad_(True)
+    q, k, v = (q64[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, T, D)
+    ref.backward(d_o.double())
+    qd, dod = qkv.to(dev).contiguous(), d_o.to(dev)
+    out = torch.empty(B, T, D, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, heads, T, dtype=torch.float32, device=dev)
+    H.check(H.lib().cvcl_attention_train(H.ptr(qd), H.ptr(out), H.ptr(lse), B, T, heads, 64, 0.125, H.stream_ptr()), "attention_train")
+    assert float((out.double().cpu() - ref.detach()).abs().max() / ref.abs().max()) < 2e-2
+    lse_ref = torch.logsumexp(q.detach() @ k.detach().transpose(-1, -2) * 0.125, dim=-1) / 0.6931471805599453
+    assert float((lse.double().cpu() - lse_ref).abs().max()) < 2e-2
+    grads = []
+    for _ in range(2):
+        dq = torch.full((B, T, 3, heads, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+        H.check(H.lib().cvcl_attention_bwd(H.ptr(qd), H.ptr(out), H.ptr(dod), H.ptr(lse), H.ptr(dq), B, T, heads, 64, 0.125, H.stream_ptr()),
+                "attention_bwd")
+        grads.append(dq.cpu())
+    assert torch.equal(grads[0], grads[1]) and torch.isfinite(grads[0].float()).all()
+    got, want = grads[0].double(), q64.grad
+    for i, name in enumerate("qkv"):
+        err = float((got[:, :, i] - want[:, :, i]).abs().max() / want[:, :, i].abs().max())
+        cos = float(torch.nn.functional.cosine_similarity(got[:, :, i].flatten(), want[:, :, i].flatten(), dim=0))
+        assert err < 3e-2 and cos > 0.9995, (name, err, cos)
+
+
 def _mx_quant_ref(y):
     """MX block quantiser oracle: per 32 elements of a row, scale 2^ceil(log2(amax / 448)) (e8m0 byte = exponent + 127), e4m3 RNE.
     Returns (e4m3 values, scale bytes [rows][K/32], dequantised fp32)."""
