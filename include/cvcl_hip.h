@@ -224,6 +224,18 @@ int cvcl_attention_mx(const void* qkv, void* out8, void* out_block_scales, int B
 int cvcl_attention_train(const void* qkv, void* out, float* lse, int B, int T, int heads, int head_dim, float scale, void* stream);
 int cvcl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* d_qkv, int B, int T, int heads,
                        int head_dim, float scale, void* stream);
+/* LayerNorm backward on bf16 rows (32 lanes per row, D % 8 == 0, D <= 1024): dx = rstd (g - mean(g) - xhat mean(g xhat)) with
+ * g = dy gamma, plus `add` (nullable: the residual-stream gradient that bypasses the norm); dy bf16 or fp32; per-group partial
+ * sums of dgamma = sum dy xhat and dbeta = sum dy in partial [cvcl_layernorm_bwd_rows_partials(rows)][2][D] (reduce with
+ * cvcl_colsum_f32: fixed order, deterministic).                                                                          */
+int cvcl_layernorm_bwd_rows_partials(long rows);
+int cvcl_layernorm_bwd_rows(const void* x, long x_row_stride, const float* gamma, const void* dy, int dy_is_f32, long dy_row_stride,
+                            float eps, const void* add, void* dx, long dx_row_stride, float* partial, long rows, int D, void* stream);
+/* GELU (erf form) on bf16: d_y == NULL -> y = gelu(u); else y = d_y * gelu'(u) (u = the saved pre-activation).  n % 8 == 0 */
+int cvcl_gelu_bf16(const void* u, const void* d_y, void* y, long n, void* stream);
+/* backward of cvcl_vit_assemble_tokens: d_tok [B][T-1][D] bf16 = the patch rows of dh [B][T][D]; d_pos [T][D] fp32 = sum over
+ * the batch (its row 0 is also d_cls)                                                                                     */
+int cvcl_vit_tokens_bwd(const void* dh, void* d_tok, float* d_pos, int B, int T, int D, void* stream);
 /* x[b,l,:] = table[tok[b,l]] (+ pos[l]) (multimodal.py:496, 561-563) */
 int cvcl_embed_gather_pos(const float* table, const int64_t* tok, const float* pos, float* x, int B, int L, int E, int V,
                           void* stream);
@@ -301,6 +313,10 @@ int cvcl_conv_wgrad_direct(int dtype, const void* x, const void* dy, float* dw, 
 size_t cvcl_gemm_tn_workspace_bytes(int dtype, long M, int N, int K);
 int cvcl_gemm_tn(int dtype, const void* A, int lda, const void* B, int ldb, long M, int N, int K, float* C, int k_keep,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* nn.Linear backward in one pass over dY (bf16): C = A^T B as above and colsum[n] = sum_m A[m][n] (the bias gradient) */
+size_t cvcl_gemm_tn_colsum_workspace_bytes(long M, int N, int K);
+int cvcl_gemm_tn_colsum(const void* A, int lda, const void* B, int ldb, long M, int N, int K, float* C, int k_keep, float* colsum,
+                        void* workspace, size_t workspace_bytes, void* stream);
 /* grouped 3x3 (pad 1, stride 1|2) weight gradient, bf16 activations: dW [C][C/groups][3][3] f32 (reference OIHW) */
 size_t cvcl_gconv3x3_wgrad_workspace_bytes(int B, int H, int W, int C, int stride);
 int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int C, int groups, int stride,

@@ -408,6 +408,51 @@ extern "C" int cvcl_gemm_tn(int dtype, const void* A, int lda, const void* B, in
     return CVCL_OK;
 }
 
+// ---- linear layer: weight gradient C = A^T B and bias gradient colsum[n] = sum_m A[m][n] from one pass over A (= dY) ------------
+namespace {
+__global__ __launch_bounds__(256) void tn_colsum_reduce_kernel(const float* __restrict__ CS, int S, int tiles, int N, float* __restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double a = 0.0;
+    for (int s = 0; s < S; ++s) a += (double)CS[((long)s * tiles + n / TN_T) * TN_T + n % TN_T];      // fixed order: deterministic
+    out[n] = (float)a;
+}
+size_t tn_colsum_off(const TnPlan& pl, int N, int K) { return (tn_ws_bytes(pl, N, K, 1, false) + 255) & ~(size_t)255; }
+}  // namespace
+
+extern "C" size_t cvcl_gemm_tn_colsum_workspace_bytes(long M, int N, int K) {
+    const TnPlan pl = tn_plan(M, N, K, 1, false, TN_T);
+    return tn_colsum_off(pl, N, K) + (size_t)pl.S * pl.tiles_n * TN_T * 4;
+}
+
+// bf16 A [M, lda >= N], B [M, ldb >= K] -> C [N][k_keep] fp32 = A^T B and colsum [N] fp32 = column sums of A
+// (nn.Linear backward: A = dY, B = X -> dW and db; the staging pass of the TN kernel adds up the dY tile it holds anyway)
+extern "C" int cvcl_gemm_tn_colsum(const void* A, int lda, const void* B, int ldb, long M, int N, int K, float* C, int k_keep,
+                                   float* colsum, void* workspace, size_t workspace_bytes, void* stream) {
+    CVCL_CHECK_ARG(A && B && C && colsum && workspace && M > 0 && N > 0 && K > 0 && lda >= N && ldb >= K && k_keep > 0 && k_keep <= K,
+                   "cvcl_gemm_tn_colsum: bad args");
+    CVCL_CHECK_ARG(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0,
+                   "cvcl_gemm_tn_colsum: bf16 operands need 16-byte aligned rows (N, K, lda, ldb multiples of 8)");
+    const TnPlan pl = tn_plan(M, N, K, 1, false, TN_T);
+    if (workspace_bytes < cvcl_gemm_tn_colsum_workspace_bytes(M, N, K)) {
+        cvcl_set_error("cvcl_gemm_tn_colsum: workspace too small");
+        return CVCL_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    CvclProfScope prof(stream, CVCL_K_WGRAD);
+    TnDev d = {};
+    d.A = (const bf16_t*)A; d.B = (const bf16_t*)B; d.P = (float*)workspace;
+    d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.S = pl.S; d.chunk = pl.chunk;
+    d.tiles_n = pl.tiles_n; d.tiles_k = pl.tiles_k; d.diag = 0; d.taps = 1;
+    d.colsum = (float*)((char*)workspace + tn_colsum_off(pl, N, K));
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(pl.ntile * pl.S, 1), dim3(256), 0, st, d);
+    CVCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3(reduce_grid((long)N * k_keep)), dim3(256), 0, st, (const float*)workspace, C, pl.S, N, K, k_keep);
+    hipLaunchKernelGGL(tn_colsum_reduce_kernel, dim3(cvcl_div_up(N, 256)), dim3(256), 0, st, (const float*)d.colsum, pl.S, pl.tiles_n, N, colsum);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
 extern "C" size_t cvcl_gconv3x3_wgrad_workspace_bytes(int B, int H, int W, int C, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const TnPlan pl = tn_plan((long)B * Ho * Wo, C, C, 9, true, TN_T);

@@ -136,6 +136,12 @@ SIGNATURES = {
     "cvcl_quant_rows_fp8": (_I, [_I, _P, C.c_long, _P, _P, C.c_float, _P, _P, C.c_long, _I, _P]),
     "cvcl_attention_train": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "cvcl_attention_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "cvcl_layernorm_bwd_rows_partials": (_I, [C.c_long]),
+    "cvcl_layernorm_bwd_rows": (_I, [_P, C.c_long, _P, _P, _I, C.c_long, _F, _P, _P, C.c_long, _P, C.c_long, _I, _P]),
+    "cvcl_gelu_bf16": (_I, [_P, _P, _P, C.c_long, _P]),
+    "cvcl_vit_tokens_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "cvcl_gemm_tn_colsum_workspace_bytes": (C.c_size_t, [C.c_long, _I, _I]),
+    "cvcl_gemm_tn_colsum": (_I, [_P, _I, _P, _I, C.c_long, _I, _I, _P, _I, _P, _P, C.c_size_t, _P]),
     "cvcl_attention_mx": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "cvcl_gemm_fp8_mx": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "cvcl_gemm_fp8": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),

@@ -83,6 +83,9 @@ def _ln(cd, x, stride, g, b, eps, out, out_f32, rows, D):
 
 
 def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
+    if torch.is_grad_enabled() and any(p.requires_grad for n, p in model.named_parameters() if not n.startswith("head.")):
+        from .vit_train import vit_trunk_train         # --finetune_cnn: differentiable twin (saves activations)
+        return vit_trunk_train(model, x)
     ts = model.__dict__.get("_trunk_stream")
     if ts is not None and x.is_cuda:          # frozen ViT on its own stream: overlaps the previous step's text encoder / loss /
         x = x.contiguous()                    # backward / optimizer, which stay on the caller's stream (H.TrunkStream)
@@ -96,9 +99,6 @@ def enable_trunk_stream(model, device, inputs="caller", stream=None):
 
 
 def _vit_forward(model, x: torch.Tensor, slot) -> torch.Tensor:
-    if torch.is_grad_enabled() and any(p.requires_grad for n, p in model.named_parameters() if not n.startswith("head.")):
-        raise NotImplementedError("fine-tuning the ViT trunk needs its backward kernels, which this build does not ship "
-                                  "(frozen-ViT configurations only)")
     if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
         raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
     x = x.contiguous()

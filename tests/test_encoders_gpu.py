@@ -313,3 +313,57 @@ def test_vit_fp8_linears_vs_emulation_and_bf16(dev):
     # the emulation rounds at the same operand points but not bit-identically elsewhere (fp32 LayerNorm / softmax / GELU): e4m3
     # decisions near ties flip and 12 blocks amplify them; exactness is pinned at the operator level (tests/test_gemm_gpu.py)
     assert float(cos_e.min()) > 0.995 and rel_e < 0.1 and float(cos_e.min()) >= float(cos.min()) - 1e-3
+
+
+@pytest.mark.parametrize("D,heads,depth,B", [(128, 2, 2, 3), (768, 12, 1, 2)])
+def test_vit_finetune_gradients_vs_oracle_autograd(dev, D, heads, depth, B):
+    """--finetune_cnn with the ViT: vit_train.VitTrunk (forward that keeps activations + explicit backward kernels: attention
+    backward, LayerNorm backward, GELU backward, data / weight-gradient GEMMs, token assembly backward) vs torch.autograd
+    through the fp32 oracle on the same weights and images.  bf16 storage: every parameter gradient within cosine 0.99 /
+    rel-L2 0.1 of the fp32 one; the forward equals the frozen path's; gradients are bit-identical run to run."""
+    import torch.nn.functional as F
+    from multimodal import vision_transformer_dino_mugs as vits
+    torch.manual_seed(D + depth)
+    m = vits.VisionTransformer(img_size=[224], patch_size=16, embed_dim=D, depth=depth, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+                               num_classes=0).to(dev)
+    with torch.no_grad():                                   # non-trivial norms / biases so that every gradient is exercised
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            if "norm" in n and n.endswith("weight"):
+                p.uniform_(0.7, 1.3)
+    m.compute_dtype = torch.bfloat16
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    r = torch.randn(B, D, device=dev)
+    m.train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        cls = m(x)
+        (cls * r).sum().backward()
+        runs.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert all(torch.equal(runs[0][n], runs[1][n]) for n in runs[0])
+    with torch.no_grad():
+        for p in m.parameters():
+            p.requires_grad_(False)
+        frozen = m(x)
+    assert torch.allclose(cls.detach(), frozen, rtol=2e-2, atol=2e-2)        # fused GELU epilogue vs separate pass: bf16 rounding points
+    # oracle: fp32 autograd
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    yo = O.vit_forward(sd, x.cpu(), 16, heads)
+    (yo * r.cpu()).sum().backward()
+    assert maxrel(cls.detach(), yo.detach()) < 5e-2
+    got = runs[0]
+    names = [n for n, _ in m.named_parameters()]
+    assert set(got) == set(names), set(names) - set(got)
+    worst = (1.0, "", 0.0)
+    for n in names:
+        a, b = got[n].float().cpu().flatten(), sd[n].grad.flatten()
+        cos = float(F.cosine_similarity(a, b, dim=0))
+        rel = float((a - b).norm() / b.norm())
+        if cos < worst[0]:
+            worst = (cos, n, rel)
+        assert cos > 0.99 and rel < 0.1, (n, cos, rel)
+    print("worst parameter gradient:", worst)

@@ -15,10 +15,10 @@ from bench import synthetic_batch_on_device
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--patch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", default="bf16")
-ap.add_argument("--trunk-stream", action="store_true"); a = ap.parse_args()
+ap.add_argument("--trunk-stream", action="store_true"); ap.add_argument("--finetune", action="store_true"); a = ap.parse_args()
 dev = torch.device("cuda:0")
 args = argparse.Namespace(embedding_type="flat", embedding_dim=512, pretrained_cnn=False, cnn_dino=False, vit_dino=True,
-                          finetune_cnn=False, text_encoder="transformer", crange=1, dropout_i=0.0, dropout_o=0.0,
+                          finetune_cnn=a.finetune, text_encoder="transformer", crange=1, dropout_i=0.0, dropout_o=0.0,
                           pos_embed_type="learned", normalize_features=True, sim="max", temperature=0.07, fix_temperature=True,
                           tie=True, bias=True, optimizer=torch.optim.AdamW, lr=1e-4, weight_decay=0.1, lr_scheduler=False,
                           lambda_mm=1.0, lambda_lm=0.0, lambda_ar=0.0, optimize_unused=True)
