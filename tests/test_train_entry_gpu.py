@@ -292,3 +292,36 @@ def test_trainer_trunk_stream_flag_bit_identical(dev, tmp_path, monkeypatch):
         finally:
             mm.load_model = orig
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], vit
+
+
+def test_vit_finetune_through_train_entry(dev, tmp_path, monkeypatch):
+    """train.py --vit_dino --finetune_cnn: the ViT trunk trains through vit_train.VitTrunk (every trunk parameter receives a
+    gradient and moves), the loss is finite, and a checkpoint round-trips."""
+    import contextlib, io
+    import train
+    import multimodal.multimodal as mm
+    from multimodal import vision_transformer_dino_mugs as vits
+    monkeypatch.chdir(tmp_path)
+    argv = ("--dataset synthetic --batch_size 4 --val_batch_size 4 --gpus 1 --text_encoder embedding --embedding_dim 32 --precision bf16 "
+            "--lambda_lm 0 --optimize_unused --max_epochs 1 --limit_train_batches 2 --normalize_features --vit_dino --finetune_cnn "
+            "--checkpoint_callback True --logger False --exp_name vitft").split()
+    orig = mm.load_model
+    mm.load_model = lambda name, pretrained: vits.VisionTransformer(img_size=[224], patch_size=16, embed_dim=768, depth=2, num_heads=12,
+                                                                    mlp_ratio=4, qkv_bias=True, num_classes=0)
+    try:
+        torch.manual_seed(0)
+        ref = mm.load_model("x", False).state_dict()
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            trainer, lit = train.main(argv)
+    finally:
+        mm.load_model = orig
+    m = trainer.logged_metrics
+    assert float(m["val_loss"]) > 0 and torch.isfinite(torch.tensor(float(m["val_loss"])))
+    vit = lit.vision_encoder.model
+    moved = [n for n, p in vit.named_parameters() if p.requires_grad]
+    assert any(n.startswith("blocks.1.mlp.fc2") for n in moved) and "pos_embed" in moved and "patch_embed.proj.weight" in moved
+    for n in ("blocks.0.attn.qkv.weight", "blocks.1.norm2.bias", "pos_embed", "cls_token", "patch_embed.proj.weight", "norm.weight"):
+        p = dict(vit.named_parameters())[n]
+        assert torch.isfinite(p).all() and not torch.equal(p.detach().cpu(), ref[n]), n        # AdamW moved it
+    assert (tmp_path / "checkpoints" / "vitft" / "epoch=0.ckpt").exists()
