@@ -220,7 +220,7 @@ int cvcl_attention_mx(const void* qkv, void* out8, void* out_block_scales, int B
 /* Attention for a fine-tuned ViT (autograd of vision_transformer_dino_mugs.py:106-130): the forward above that also saves the
  * log-sum-exp of every row (lse [B][heads][T] fp32, log2 units), and the backward: d_qkv [B][T][3][heads][64] bf16 from
  * qkv, the forward output o and d_o ([B][T][heads*64] bf16).  Two kernels (queries own dQ; keys own dK, dV), probabilities
- * rebuilt from lse, no atomics: deterministic.  head_dim 64; 32 < T <= 288 (forward) / 224 (backward). */
+ * rebuilt from lse, no atomics: deterministic.  head_dim 64; 32 < T <= 288. */
 int cvcl_attention_train(const void* qkv, void* out, float* lse, int B, int T, int heads, int head_dim, float scale, void* stream);
 int cvcl_attention_bwd(const void* qkv, const void* o, const void* d_o, const float* lse, void* d_qkv, int B, int T, int heads,
                        int head_dim, float scale, void* stream);

@@ -11,16 +11,16 @@
 //   attention_bwd_dkv_kernel   a wave OWNS 32 keys (K, V fragments in registers) and streams over the query tiles in LDS:
 //                              S = Q K^T,  dP = dO V^T,  dV^T += dO^T P,  dK^T += Q^T dS   (LSE / D per query from LDS)
 // S and dP are computed in both (7 matrix products instead of 5): no atomics, no cross-wave reduction, deterministic.
-// Streamed operands sit in LDS twice: row-major at pitch 144 B (ds_read_b128 fragments, conflict-free) and at pitch 192 B
-// for the transposed fragments (ds_read_b64_tr_b16), as K and V do in the forward kernel.
+// Each streamed operand sits in LDS once, row-major at pitch 144 B: the ds_read_b128 fragments are conflict-free, the transposed
+// fragments (ds_read_b64_tr_b16 on the same rows) take 2-way bank conflicts -- a second copy at the conflict-free pitch of 192 B
+// (as the forward kernel keeps for V) doubled the LDS to one workgroup per CU and measured slower (580 vs 335 us per ViT-B/16 layer at B = 256).
 #include "cvcl_common.h"
 
 namespace {
 
 constexpr int AB_RP = 144;             // row-major pitch (128 + 16)
-constexpr int AB_TP = 192;             // transposed-read pitch (128 + 64)
-constexpr int AB_TPAD_MAX_DQ = 288;    // dQ kernel: 3 staged operands -> 288 * 480 B = 135 KB
-constexpr int AB_TPAD_MAX_DKV = 224;   // dK/dV kernel: 4 staged operands -> 224 * 672 B = 147 KB (+ LSE, D)
+constexpr int AB_TP = 144;             // transposed reads use the same copy (2-way bank conflicts on them, half the LDS: two workgroups per CU)
+constexpr int AB_TPAD_MAX_DKV = 288;   // two staged operands per kernel: 288 * 288 B = 81 KB (+ LSE, D)
 
 typedef __bf16 ab_tr4 __attribute__((__vector_size__(4 * sizeof(__bf16))));
 __device__ inline bf16x4 ab_tr_read(const char* p) {
@@ -30,7 +30,7 @@ __device__ inline bf16x4 ab_tr_read(const char* p) {
 
 // qkv: [B][T][3][heads][64] bf16;  o, d_o: [B][T][heads * 64] bf16;  lse: [B][heads][T] fp32 (log2 units);
 // d_qkv: [B][T][3][heads][64] bf16 -- this kernel writes the q third.
-__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                bf16_t* __restrict__ d_qkv, int B, int Tn, int heads, float scale,
                                                                int NT) {
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16_t* __r
     const int Tpad = 32 * NT;
     char* sK = smem;                       // [Tpad][AB_RP]  K rows (A operand of S^T)
     char* sV = sK + Tpad * AB_RP;          // [Tpad][AB_RP]  V rows (A operand of dP^T)
-    char* sKt = sV + Tpad * AB_RP;         // [Tpad][AB_TP]  K rows again, read transposed (A operand of dQ^T)
+    char* sKt = sK;                        // the same rows, read transposed (A operand of dQ^T)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int hh = blockIdx.x % heads, b = blockIdx.x / heads;
@@ -54,7 +54,6 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16_t* __r
         }
         *reinterpret_cast<u32x4*>(sK + j * AB_RP + c * 16) = kv;
         *reinterpret_cast<u32x4*>(sV + j * AB_RP + c * 16) = vv;
-        *reinterpret_cast<u32x4*>(sKt + j * AB_TP + c * 16) = kv;
     }
     __syncthreads();
 
@@ -134,7 +133,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(const bf16_t* __r
 }
 
 // writes the k and v thirds of d_qkv
-__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+__global__ __launch_bounds__(256, 2) void attention_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                                 const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ d_qkv, int B, int Tn, int heads, float scale,
                                                                 int NT) {
@@ -142,9 +141,9 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16_t* __
     const int Tpad = 32 * NT;
     char* sQ = smem;                       // [Tpad][AB_RP]  Q rows (A operand of S)
     char* sO = sQ + Tpad * AB_RP;          // [Tpad][AB_RP]  dO rows (A operand of dP)
-    char* sQt = sO + Tpad * AB_RP;         // [Tpad][AB_TP]  Q rows, read transposed (A operand of dK^T)
-    char* sOt = sQt + Tpad * AB_TP;        // [Tpad][AB_TP]  dO rows, read transposed (A operand of dV^T)
-    float* sL = (float*)(sOt + Tpad * AB_TP);   // [Tpad] log-sum-exp per query (+inf on padding rows: P = 0)
+    char* sQt = sQ;                        // the same rows, read transposed (A operands of dK^T / dV^T)
+    char* sOt = sO;
+    float* sL = (float*)(sO + Tpad * AB_RP);    // [Tpad] log-sum-exp per query (+inf on padding rows: P = 0)
     float* sD = sL + Tpad;                      // [Tpad] D per query
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -161,8 +160,6 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(const bf16_t* __
         }
         *reinterpret_cast<u32x4*>(sQ + j * AB_RP + c * 16) = qv;
         *reinterpret_cast<u32x4*>(sO + j * AB_RP + c * 16) = dv;
-        *reinterpret_cast<u32x4*>(sQt + j * AB_TP + c * 16) = qv;
-        *reinterpret_cast<u32x4*>(sOt + j * AB_TP + c * 16) = dv;
     }
     // D_i = sum_d dO_id O_id and the saved log-sum-exp, one query per 8 lanes (16 B of each row per lane)
     for (int i = tid; i < Tpad * 8; i += 256) {
@@ -284,9 +281,9 @@ extern "C" int cvcl_attention_bwd(const void* qkv, const void* o, const void* d_
     const int nt = (T + 31) / 32, Tpad = nt * 32;
     hipStream_t s = (hipStream_t)stream;
     CvclProfScope prof(stream, CVCL_K_ATTENTION);
-    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(B * heads), dim3(256), (size_t)Tpad * (2 * AB_RP + AB_TP), s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(B * heads), dim3(256), (size_t)Tpad * (2 * AB_RP), s, (const bf16_t*)qkv,
                        (const bf16_t*)o, (const bf16_t*)d_o, lse, (bf16_t*)d_qkv, B, T, heads, scale, nt);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(B * heads), dim3(256), (size_t)Tpad * (2 * AB_RP + 2 * AB_TP) + (size_t)Tpad * 8, s,
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(B * heads), dim3(256), (size_t)Tpad * (2 * AB_RP) + (size_t)Tpad * 8, s,
                        (const bf16_t*)qkv, (const bf16_t*)o, (const bf16_t*)d_o, lse, (bf16_t*)d_qkv, B, T, heads, scale, nt);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;

@@ -12,7 +12,7 @@ pre-activation and its GELU -- and the backward walks the blocks in reverse with
     tokens        cvcl_vit_tokens_bwd (patch rows -> patch-embedding weight gradient; batch sums -> pos_embed / cls_token)
 
 bf16 storage, fp32 accumulation and fp32 parameter gradients; every kernel is deterministic.  Needs head_dim 64 and
-32 < T <= 224 tokens (ViT-S/B/L at patch 16, 224 x 224).  There is no torch fallback: without the HIP library it fails."""
+32 < T <= 288 tokens (ViT-S/B/L at patch 16 or 14, 224 x 224).  There is no torch fallback: without the HIP library it fails."""
 import torch
 
 from . import _hip as H
@@ -89,8 +89,8 @@ class VitTrunk(torch.autograd.Function):
             raise NotImplementedError("positional-embedding interpolation (non-native resolution) is not on the hot path")
         w = vit_hip._packed(model, dt, dev)
         heads = w["blocks"][0]["heads"] if w["blocks"] else 1
-        if w["blocks"] and (D // heads != 64 or not 32 < T <= 224):
-            raise NotImplementedError(f"ViT fine-tuning needs head_dim 64 and 32 < tokens <= 224 (got head_dim {D // heads}, {T} tokens)")
+        if w["blocks"] and (D // heads != 64 or not 32 < T <= 288):
+            raise NotImplementedError(f"ViT fine-tuning needs head_dim 64 and 32 < tokens <= 288 (got head_dim {D // heads}, {T} tokens)")
         R = B * T
         cols = torch.empty(B * n_p, w["Kpad"], dtype=dt, device=dev)
         H.check(lib.cvcl_im2col_patches(cd, H.ptr(x), H.ptr(cols), B, Hh, Ww, p, w["Kpad"], s), "cvcl_im2col_patches")

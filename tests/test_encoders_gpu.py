@@ -188,7 +188,7 @@ def test_attention_bf16_mfma_vs_float64(dev, B, T, heads):
     assert err < 2e-2, err
 
 
-@pytest.mark.parametrize("B,T,heads", [(2, 197, 3), (1, 50, 2), (3, 224, 12)])
+@pytest.mark.parametrize("B,T,heads", [(2, 197, 3), (1, 50, 2), (3, 224, 12), (1, 257, 2)])
 def test_attention_backward_vs_float64(dev, B, T, heads):
     """cvcl_attention_train + cvcl_attention_bwd (bf16 MFMA, probabilities rebuilt from the saved log-sum-exp) vs autograd of
     softmax(q k^T / 8) v in float64 on the same bf16-rounded operands; deterministic run to run."""
