@@ -120,6 +120,10 @@ typedef struct {
     /* Bottleneck tail (bf16): C = relu(round(A'W^T) * c_scale[N] + c_shift[N] + (R | R * r_scale[N] + r_shift[N])).
      * With C == NULL and stats != NULL the product is not stored, only its column statistics (same rounding). */
     const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;
+    /* training epilogues of the ViT MLP (bf16): C_pre != NULL with act = GELU also stores the pre-activation u = round(acc + bias)
+     * (C = round(gelu(u))); G != NULL multiplies the rounded product by gelu'(G) (G [M][ldg] = the saved u): the data gradient
+     * through the GELU, C = round(round(A W^T) * gelu'(G)).  Both NULL for every other use. */
+    void* C_pre; const void* G; int ldg;
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);

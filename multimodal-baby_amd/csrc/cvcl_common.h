@@ -117,6 +117,34 @@ __device__ inline float block_max(float v, float* scratch) {
     return r;
 }
 
+// ---- GELU (erf form) with Abramowitz-Stegun 7.1.26 for erf (|error| < 1.5e-7, far below bf16 resolution) on v_rcp_f32 / v_exp_f32;
+// shared by the GEMM epilogues and the standalone passes so that fused and unfused paths round identically
+__device__ inline float gelu_erf_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
+    const float erf_abs = fmaf(-poly, e, 1.f);
+    return 0.5f * v * (1.f + copysignf(erf_abs, v));
+}
+// d gelu(v) / dv with the same erf approximation (backward of the fused GELU epilogue / cvcl_gelu_bf16)
+__device__ inline float gelu_grad_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);      // exp(-v^2 / 2)
+    const float cdf = 0.5f * (1.f + copysignf(fmaf(-poly, e, 1.f), v));
+    return fmaf(v, 0.3989422804014327f * e, cdf);
+}
+
 // ---- fp8 e4m3 / MX (e8m0 block scale) helpers shared by the fp8 GEMM epilogue and the attention epilogue
 // e8m0 block scale (power of two) that maps a block's amax into the e4m3 range: 2^ceil(log2(amax / 448)), byte = exponent + 127
 __device__ inline unsigned mx_scale_byte(float amax) {

@@ -43,6 +43,7 @@ struct GemmDev {
     int vec_in;    // A/W rows are 16-byte aligned and K is a whole number of chunks
     int vec_out;   // C/R rows are 16-byte aligned
     int num_m_tiles;
+    void* C2;      // EPI 5: second output (the GELU pre-activation)
 };
 
 template <typename T> struct FragOps;
@@ -71,18 +72,6 @@ __device__ inline float apply_act(float v, int act) {
 // bf16 epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result) on
 // v_rcp_f32 / v_exp_f32: the library erff costs ~3x the instructions (fc1 + GELU of ViT-B: 424 us vs 330 us without the
 // activation).  The fp32 parity kernels keep erff.
-__device__ inline float gelu_erf_fast(float v) {
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
-    const float erf_abs = fmaf(-poly, e, 1.f);
-    return 0.5f * v * (1.f + copysignf(erf_abs, v));
-}
 __device__ inline float apply_act_bf16(float v, int act) {
     if (act == CVCL_ACT_RELU) return fmaxf(v, 0.f);
     if (act == CVCL_ACT_GELU) return gelu_erf_fast(v);
@@ -409,12 +398,14 @@ __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
 //          out = round(round(act(acc + bias)) + R)).
 // EPI = 2: Bottleneck tail: out = relu(round(acc) * c_scale[n] + c_shift[n] + (R | R * r_scale[n] + r_shift[n])) --
 //          BatchNorm of this conv's (rounded) output + identity / normalised downsample branch + ReLU, no statistics.
+// EPI = 5: linear + GELU for training: C2 = u = round(acc + bias) (kept for the backward), C = round(gelu(u)).
+// EPI = 6: data-gradient GEMM through a GELU: C = round(round(acc) * gelu'(R)), R = the saved pre-activation tile.
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // EPI 1 / 3 / 4 = linear epilogue with activation none / ReLU / GELU compiled in (a run-time switch per element cost
     // two scalar branches per value and inlined erff 64 times behind them)
-    constexpr bool LIN = EPI == 1 || EPI == 3 || EPI == 4;
+    constexpr bool LIN = EPI == 1 || EPI == 3 || EPI == 4 || EPI == 5 || EPI == 6;
     constexpr int ACT = EPI == 3 ? CVCL_ACT_RELU : (EPI == 4 ? CVCL_ACT_GELU : CVCL_ACT_NONE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
@@ -594,7 +585,15 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
             const int m = m0 + wm * 64 + row, n = n0 + wn * 64 + chunk * 8;
             bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((chunk ^ (row & 7)) << 4));
             if (m < p.M) {
-                if constexpr (LIN) {
+                if constexpr (EPI == 5) {
+                    *reinterpret_cast<bf16x8*>((bf16_t*)p.C2 + (long)m * p.ldc + n) = v;          // the pre-activation, as stored
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)gelu_erf_fast((float)v[e]);
+                } else if constexpr (EPI == 6) {
+                    const bf16x8 r = rpre[j];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * gelu_grad_fast((float)r[e]));
+                } else if constexpr (LIN) {
                     if (R) {
                         const bf16x8 r = rpre[j];
 #pragma unroll
@@ -620,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
             }
         }
         // the next loop iteration's vmcnt wait + barrier orders these staging reads before the buffer is refilled
-        counted_wait = (EPI != 0 || C != nullptr) && (m0 + BM <= p.M);
+        counted_wait = EPI != 5 && (EPI != 0 || C != nullptr) && (m0 + BM <= p.M);   // (EPI 5 issues 16 stores per wave: plain wait)
     }
 
     if (EPI == 0 && p.stats) {
@@ -838,7 +837,7 @@ inline int pick_gemm256(int dtype, const cvcl_gemm_args* a) {
     static const bool on = [] { const char* e = getenv("CVCL_GEMM256"); return e && e[0] == '1'; }();
     if (!on || dtype != CVCL_BF16) return -1;
     if (!cvcl_gemm256_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) || a->K < 512) return -1;
-    if (a->a_scale || a->gather_stride > 1 || a->exp_scale || a->c_scale) return -1;
+    if (a->a_scale || a->gather_stride > 1 || a->exp_scale || a->c_scale || a->C_pre || a->G) return -1;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!al16(a->A) || !al16(a->W) || !al16(a->C) || !al16(a->R) || !al16(a->bias) || (a->R && a->ldr % 8)) return -1;
     if ((long)cvcl_div_up(a->M, 256) * (a->N / 256) < 128) return -1;
@@ -852,7 +851,7 @@ inline int pick_gemm256(int dtype, const cvcl_gemm_args* a) {
 }
 
 inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
-    return d.vec_in && d.vec_out && !a->bias && !a->exp_scale && !a->R && a->act == CVCL_ACT_NONE && (a->N % BN) == 0;
+    return d.vec_in && d.vec_out && !a->bias && !a->exp_scale && !a->R && !a->G && !a->C_pre && a->act == CVCL_ACT_NONE && (a->N % BN) == 0;
 }
 inline int pro_kind(const cvcl_gemm_args* a) { return !a->a_scale ? 0 : (a->a_relu ? 2 : 1); }
 
@@ -891,6 +890,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.vec_in = (a->K % EPC == 0) && (a->lda % EPC == 0) && (a->ldw % EPC == 0) && al16(a->A) && al16(a->W);
     d.vec_out = (a->ldc % EPC == 0) && al16(a->C) && (!a->R || ((a->ldr % EPC == 0) && al16(a->R)));
     d.num_m_tiles = cvcl_div_up(a->M, BM);
+    d.C2 = nullptr;
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
         const int e256 = pick_gemm256(CVCL_BF16, a);
@@ -905,8 +905,22 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
         if (use_glds && lean && pro_kind(a) == 0 && a->K % 64 == 0) return launch_gemm_glds<0>(a, d, stream);
         // ViT / nn.Linear shapes: bias, activation, residual, no statistics
         const bool al = ((uintptr_t)a->bias & 15) == 0;
-        if (use_glds && d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && !a->exp_scale &&
-            !a->stats && al && !(a->gather_stride > 1))
+        const bool lin_ok = use_glds && d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && !a->exp_scale &&
+                            !a->stats && al && !(a->gather_stride > 1);
+        if (a->C_pre || a->G) {                          // training epilogues: only this kernel implements them
+            CVCL_CHECK_ARG(lin_ok, "cvcl_gemm: the C_pre / G epilogues need bf16, K %% 64 == 0, N %% 128 == 0 and 16-byte aligned rows");
+            if (a->C_pre) {
+                CVCL_CHECK_ARG(a->act == CVCL_ACT_GELU && !a->R && !a->G && ((uintptr_t)a->C_pre & 15) == 0,
+                               "cvcl_gemm: C_pre goes with act = GELU and no residual");
+                d.C2 = a->C_pre;
+                return launch_gemm_glds<5>(a, d, stream);
+            }
+            CVCL_CHECK_ARG(a->act == CVCL_ACT_NONE && !a->R && !a->bias && a->ldg % 8 == 0 && ((uintptr_t)a->G & 15) == 0,
+                           "cvcl_gemm: G (GELU-backward epilogue) takes no bias / activation / residual");
+            d.R = a->G; d.ldr = a->ldg;
+            return launch_gemm_glds<6>(a, d, stream);
+        }
+        if (lin_ok)
             return a->act == CVCL_ACT_GELU ? launch_gemm_glds<4>(a, d, stream)
                  : a->act == CVCL_ACT_RELU ? launch_gemm_glds<3>(a, d, stream) : launch_gemm_glds<1>(a, d, stream);
     }

@@ -120,17 +120,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* _
     }
 }
 
-__device__ inline float erf_fast_abs(float x) {          // erf(|x| / sqrt 2)'s magnitude by Abramowitz-Stegun 7.1.26, as the forward epilogue
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
-    return fmaf(-poly, e, 1.f);
-}
-
 // d_u == NULL: y = gelu(u);  else: y = d_u * gelu'(u), gelu'(u) = 0.5 (1 + erf(u / sqrt 2)) + u exp(-u^2 / 2) / sqrt(2 pi)
 __global__ __launch_bounds__(256) void gelu_kernel(const bf16_t* __restrict__ u, const bf16_t* __restrict__ d_y, bf16_t* __restrict__ y, long n8) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
@@ -140,16 +129,12 @@ __global__ __launch_bounds__(256) void gelu_kernel(const bf16_t* __restrict__ u,
             const bf16x8 d = *reinterpret_cast<const bf16x8*>(d_y + i * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = (float)a[e];
-                const float cdf = 0.5f * (1.f + copysignf(erf_fast_abs(fabsf(v) * 0.70710678118654752440f), v));
-                const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.5f * v * v * 1.4426950408889634f);
-                o[e] = (bf16_t)((float)d[e] * fmaf(v, pdf, cdf));
+                o[e] = (bf16_t)((float)d[e] * gelu_grad_fast((float)a[e]));
             }
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = (float)a[e];
-                o[e] = (bf16_t)(0.5f * v * (1.f + copysignf(erf_fast_abs(fabsf(v) * 0.70710678118654752440f), v)));
+                o[e] = (bf16_t)gelu_erf_fast((float)a[e]);
             }
         }
         *reinterpret_cast<bf16x8*>(y + i * 8) = o;

@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("R", C.c_void_p), ("ldr", C.c_int),
         ("stats", C.c_void_p), ("stats_rows", C.c_int),
         ("c_scale", C.c_void_p), ("c_shift", C.c_void_p), ("r_scale", C.c_void_p), ("r_shift", C.c_void_p),
+        ("C_pre", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_int),
     ]
 
 
@@ -278,7 +279,7 @@ def cvcl_dtype(t: torch.dtype) -> int:
 
 
 def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None, a_shift=None, a_relu=False,
-         exp_scale=None, gather=None, stats=None, M=None, lda=None):
+         exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None):
     """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype."""
     dt = cvcl_dtype(A.dtype)
     if W.dtype != A.dtype:
@@ -303,6 +304,10 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
         a.R, a.ldr = ptr(residual), N
     if stats is not None:
         a.stats, a.stats_rows = ptr(stats, torch.float32), stats.shape[0]
+    if pre_out is not None:                               # act = GELU: also keep the pre-activation
+        a.C_pre = ptr(pre_out, A.dtype)
+    if gelu_grad_of is not None:                          # C = (A W^T) * gelu'(gelu_grad_of)
+        a.G, a.ldg = ptr(gelu_grad_of, A.dtype), N
     check(lib().cvcl_gemm(dt, C.byref(a), stream_ptr()), "cvcl_gemm")
     return out
 

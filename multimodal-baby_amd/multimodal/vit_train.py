@@ -8,7 +8,8 @@ pre-activation and its GELU -- and the backward walks the blocks in reverse with
     linear        dX = cvcl_gemm(dY, W^T copy)        dW, db = cvcl_gemm_tn_colsum(dY, X) (one pass over dY)
     attention     cvcl_attention_bwd (MFMA, probabilities rebuilt from the saved log-sum-exp)
     LayerNorm     cvcl_layernorm_bwd_rows (+ the residual gradient that bypasses the norm, in the same pass)
-    GELU          cvcl_gelu_bf16 on the saved pre-activation
+    GELU          in the GEMM epilogues: fc1 stores the pre-activation next to its GELU, the fc2 data-gradient GEMM multiplies
+                  by gelu'(pre-activation) (cvcl_gelu_bf16 is the standalone form, kept for tests)
     tokens        cvcl_vit_tokens_bwd (patch rows -> patch-embedding weight gradient; batch sums -> pos_embed / cls_token)
 
 bf16 storage, fp32 accumulation and fp32 parameter gradients; every kernel is deterministic.  Needs head_dim 64 and
@@ -109,8 +110,8 @@ class VitTrunk(torch.autograd.Function):
             h_mid = H.gemm(att, bw["proj_w"], bias=bw["proj_b"], residual=h_in)
             y2 = torch.empty(R, D, dtype=dt, device=dev)
             vit_hip._ln(cd, h_mid, D, bw["n2w"], bw["n2b"], bw["eps"], y2, False, R, D)
-            u = H.gemm(y2, bw["fc1_w"], bias=bw["fc1_b"])
-            g = _gelu(u)
+            u = torch.empty(R, bw["fc1_w"].shape[0], dtype=dt, device=dev)
+            g = H.gemm(y2, bw["fc1_w"], bias=bw["fc1_b"], act=H.ACT_GELU, pre_out=u)      # u kept for the backward, g = gelu(u)
             h = H.gemm(g, bw["fc2_w"], bias=bw["fc2_b"], residual=h_mid)
             saved.append((h_in, y1, qkv, att, lse, h_mid, y2, u, g))
         cls = torch.empty(B, D, dtype=_F, device=dev)
@@ -135,9 +136,8 @@ class VitTrunk(torch.autograd.Function):
         grads_blocks = []
         for bw, (h_in, y1, qkv, att, lse, h_mid, y2, u, g) in zip(reversed(w["blocks"]), reversed(saved)):
             # h_out = h_mid + fc2(gelu(fc1(norm2(h_mid))))
-            d_g = H.gemm(dh, _transpose_bf16(bw["fc2_w"]))                      # [R, Dm]
+            d_u = H.gemm(dh, _transpose_bf16(bw["fc2_w"]), gelu_grad_of=u)      # [R, Dm]: (dh W2) * gelu'(u) in the epilogue
             g_fc2w, g_fc2b = _linear_wgrad(dh, g)
-            d_u = _gelu(u, d_g)
             d_y2 = H.gemm(d_u, _transpose_bf16(bw["fc1_w"]))                    # [R, D]
             g_fc1w, g_fc1b = _linear_wgrad(d_u, y2)
             dh_mid = torch.empty(R, D, dtype=dt, device=dev)

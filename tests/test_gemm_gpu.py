@@ -343,3 +343,36 @@ def test_gemm_fp8_mx_output_matches_block_quantiser(dev, act):
                                      None, 0, M, N, K, H.stream_ptr()), "cvcl_gemm_fp8_mx")
     q_ref, e_ref, _ = _mx_quant_ref(C.float().cpu())
     assert torch.equal(cb.cpu(), _mx_tile_scales(e_ref)) and torch.equal(c8.cpu(), q_ref.view(torch.uint8))
+
+
+def test_gemm_training_gelu_epilogues_match_separate_passes(dev):
+    """The ViT-MLP training epilogues of cvcl_gemm: (a) act = GELU with C_pre also stores the pre-activation u and C = gelu(u);
+    (b) G multiplies the product by gelu'(G) (data gradient through the GELU).  Both equal, bit for bit, the plain GEMM followed
+    by the standalone cvcl_gelu_bf16 pass, and gelu / gelu' agree with torch's erf GELU in float64."""
+    from multimodal import _hip as H
+    M, N, K = 1000, 512, 256
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, K, generator=g).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(dev)
+    bias = (torch.randn(N, generator=g) * 0.2).to(dev)
+    u_ref = H.gemm(x, w, bias=bias)
+    g_ref = torch.empty_like(u_ref)
+    H.check(H.lib().cvcl_gelu_bf16(H.ptr(u_ref), None, H.ptr(g_ref), u_ref.numel(), H.stream_ptr()), "gelu")
+    u = torch.empty_like(u_ref)
+    gg = H.gemm(x, w, bias=bias, act=H.ACT_GELU, pre_out=u)
+    assert torch.equal(u, u_ref) and torch.equal(gg, g_ref)
+    exact = torch.nn.functional.gelu(u_ref.double().cpu())
+    assert float((g_ref.double().cpu() - exact).abs().max()) < 2e-2 * float(exact.abs().max())
+    # (b): dY [M, N2] @ W2 [N2 -> N] times gelu'(u)
+    N2 = 128
+    dy = torch.randn(M, N2, generator=g).bfloat16().to(dev)
+    w2t = (torch.randn(N, N2, generator=g) / N2 ** 0.5).bfloat16().to(dev)          # the "W^T copy": [N][N2]
+    dg = H.gemm(dy, w2t)
+    du_ref = torch.empty_like(dg)
+    H.check(H.lib().cvcl_gelu_bf16(H.ptr(u_ref), H.ptr(dg), H.ptr(du_ref), dg.numel(), H.stream_ptr()), "gelu bwd")
+    du = H.gemm(dy, w2t, gelu_grad_of=u_ref)
+    assert torch.equal(du, du_ref)
+    uu = u_ref.double().cpu().requires_grad_(True)
+    torch.nn.functional.gelu(uu).backward(dg.double().cpu())
+    err = float((du_ref.double().cpu() - uu.grad).abs().max() / uu.grad.abs().max())
+    assert err < 1e-2, err
