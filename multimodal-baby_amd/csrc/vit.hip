@@ -184,6 +184,8 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* __restrict
 //  bank conflicted, and K was re-read from L2 by every wave: 440 us per ViT-B/16 layer at B = 256.)
 // ------------------------------------------------------------------------------------------------
 constexpr int ATT_TPAD_MAX = 288;      // keys padded to a multiple of 32 (T <= 288 covers ViT-B/14 at 224: 257)
+constexpr int ATT_THREADS = 512;       // 8 waves: the 7 query tiles of a 197-token ViT-B/16 head run in ONE round (4 waves needed two, the
+                                       // second half empty), two workgroups per CU = 4 waves per SIMD
 constexpr int ATT_KP = 144;            // LDS bytes per K row (128 + 16)
 constexpr int ATT_VP = 192;            // LDS bytes per V row (128 + 64): the 4 rows x 64 B that 32 lanes touch in one
                                        // ds_read_b64_tr_b16 land on banks 0-15 / 48-63 / 32-47 / 16-31
@@ -210,7 +212,7 @@ __device__ inline bf16x4 att_tr_read(const char* p) {
 // MX = true: the output is written as e4m3 with one e8m0 scale per (row, 32 d) instead of bf16 (cvcl_gemm_fp8_mx's input format:
 // bytes [B*T][D], scales tiled [D/128][B*T][4]) -- a lane and its partner lane ^ 32 hold the 32 d of one block of one query.
 template <bool MX>
-__global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                 unsigned char* __restrict__ out8, unsigned char* __restrict__ out_bs,
                                                                 float* __restrict__ lse, int B, int Tn, int heads, float scale, int NT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     const int D = heads * 64;
     const bf16_t* base = qkv + (long)b * Tn * 3 * D;
 
-    for (int i = tid; i < Tpad * 8; i += 256) {                     // 8 chunks of 16 B per row, zeros beyond Tn
+    for (int i = tid; i < Tpad * 8; i += ATT_THREADS) {                     // 8 chunks of 16 B per row, zeros beyond Tn
         const int j = i >> 3, c = i & 7;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
         if (j < Tn) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void attention_mfma_kernel(const bf16_t* __
     const int l15 = lane & 15;
     const int v_lane_off = (4 * h + (l15 >> 2)) * ATT_VP + (((lane >> 4) & 1) * 16 + (l15 & 3) * 4) * 2;
 
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
         const int q0 = qt * 32;
         const int qrow = min(q0 + l31, Tn - 1);
         bf16x8 qf[4];
@@ -479,7 +481,7 @@ int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, 
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_mfma_kernel<MX>, dim3(B * heads), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, (unsigned char*)out8,
+    hipLaunchKernelGGL(attention_mfma_kernel<MX>, dim3(B * heads), dim3(ATT_THREADS), lds, s, (const bf16_t*)qkv, (bf16_t*)out, (unsigned char*)out8,
                        (unsigned char*)out_bs, lse, B, T, heads, scale, nt);
     return CVCL_OK;
 }
