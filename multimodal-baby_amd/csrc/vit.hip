@@ -123,6 +123,73 @@ __global__ __launch_bounds__(256) void layernorm_bf16_vec_kernel(const bf16_t* _
     }
 }
 
+// 32 lanes per row, NCH chunks of 16 B per lane (D <= 256 NCH: a 768-wide ViT-B row is exactly 3 chunks per lane, no idle lanes;
+// the wave-per-row kernel above leaves half the lanes with one chunk fewer), reductions by DPP inside a 16-lane row plus one
+// shuffle across (5 ds_bpermute round trips less per reduction)
+__device__ inline float ln_row32_sum(float v) {
+    auto dpp = [](float x, int sel) {
+        const int xi = __builtin_bit_cast(int, x);
+        int r;
+        if (sel == 0) r = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xf, 0xf, true);
+        else if (sel == 1) r = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xf, 0xf, true);
+        else if (sel == 2) r = __builtin_amdgcn_update_dpp(0, xi, 0x141, 0xf, 0xf, true);
+        else r = __builtin_amdgcn_update_dpp(0, xi, 0x140, 0xf, 0xf, true);
+        return __builtin_bit_cast(float, r);
+    };
+    v += dpp(v, 0); v += dpp(v, 1); v += dpp(v, 2); v += dpp(v, 3);
+    return v + __shfl_xor(v, 16, 64);
+}
+template <typename TO, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bf16_row32_kernel(const bf16_t* __restrict__ x, long x_row_stride,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float eps, TO* __restrict__ y, long rows, int D) {
+    const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int lane = threadIdx.x & 31;
+    if (row >= rows) return;
+    const bf16_t* xr = x + row * x_row_stride;
+    const int nch = D >> 3;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 32 * i;
+        if (c < nch) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e]; s += v[i][e]; }
+        }
+    }
+    const float mean = ln_row32_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 32 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; v[i][e] = c; q = fmaf(c, c, q); }
+        }
+    const float rstd = 1.f / sqrtf(ln_row32_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 32 * i;
+        if (c < nch) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = v[i][e] * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+            if constexpr (sizeof(TO) == 2) {
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)o[e];
+                *reinterpret_cast<bf16x8*>(y + row * D + c * 8) = ov;
+            } else {
+                *reinterpret_cast<f32x4*>(y + row * D + c * 8) = f32x4{o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<f32x4*>(y + row * D + c * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention, generic (any head_dim <= 128, any T, optional key padding mask): one wave per (b, head, query).
 // qkv [B, T, 3, heads, hd] -> out [B, T, heads*hd].  P is rounded to the storage type before P.V.
@@ -450,7 +517,10 @@ extern "C" int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const
     else {
         const bool vec = D % 8 == 0 && D <= 2048 && x_row_stride % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                          ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0;
-        if (vec && y_is_f32)
+        if (vec && !y_is_f32 && D <= 768 && rows >= 4096)                  // ViT-S/B token matrices
+            hipLaunchKernelGGL((layernorm_bf16_row32_kernel<bf16_t, 3>), dim3(cvcl_div_up(rows, 8)), dim3(256), 0, s, (const bf16_t*)x,
+                               x_row_stride, gamma, beta, eps, (bf16_t*)y, rows, D);
+        else if (vec && y_is_f32)
             hipLaunchKernelGGL((layernorm_bf16_vec_kernel<float>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
                                eps, (float*)y, rows, D);
         else if (vec)
