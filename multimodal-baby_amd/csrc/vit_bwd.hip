@@ -24,12 +24,11 @@ __device__ inline float row32_sum(float v) {            // sum over the 32 lanes
 //   xhat = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xhat mean(g xhat))  [+ add],  dgamma += dy xhat,  dbeta += dy
 // Row groups walk the rows with a fixed stride, so a lane always owns the same columns and accumulates their dgamma / dbeta
 // in registers; each group writes one partial row [2][D] at the end (summed in a fixed order by cvcl_colsum_f32).
-template <typename TDY>
+template <typename TDY, int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* __restrict__ x, long x_row_stride, const float* __restrict__ gamma,
                                                                  const TDY* __restrict__ dy, long dy_row_stride, float eps,
                                                                  const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, long dx_row_stride,
                                                                  float* __restrict__ partial, long rows, int D) {
-    constexpr int NCH = 4;
     const int lane = threadIdx.x & 31;
     const long group = (long)blockIdx.x * 8 + (threadIdx.x >> 5), ngroups = (long)gridDim.x * 8;
     const int nch = D >> 3;
@@ -175,7 +174,7 @@ int grid_1d(long n, int cap = 4096) {
 // number of partial rows ([2][D] each) cvcl_layernorm_bwd_rows writes for `rows` rows
 extern "C" int cvcl_layernorm_bwd_rows_partials(long rows) {
     long wgs = (rows + 7) / 8;
-    if (wgs > 512) wgs = 512;
+    if (wgs > 768) wgs = 768;                              // 3 workgroups per CU (register-limited residency); more only adds partial rows
     return (int)(wgs < 1 ? 8 : wgs * 8);
 }
 
@@ -189,11 +188,14 @@ extern "C" int cvcl_layernorm_bwd_rows(const void* x, long x_row_stride, const f
                    "cvcl_layernorm_bwd_rows: needs D %% 8 == 0, D <= 1024 and 16-byte aligned rows (D %d)", D);
     const int wgs = cvcl_layernorm_bwd_rows_partials(rows) / 8;
     CvclProfScope prof(stream, CVCL_K_LAYERNORM);
-    if (dy_is_f32)
-        hipLaunchKernelGGL(layernorm_bwd_rows_kernel<float>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
+    if (!dy_is_f32 && D <= 768)                               // ViT-S/B rows: 3 chunks per lane, fewer live registers
+        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<bf16_t, 3>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
+                           (const bf16_t*)dy, dy_row_stride, eps, (const bf16_t*)add, (bf16_t*)dx, dx_row_stride, partial, rows, D);
+    else if (dy_is_f32)
+        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<float, 4>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
                            (const float*)dy, dy_row_stride, eps, (const bf16_t*)add, (bf16_t*)dx, dx_row_stride, partial, rows, D);
     else
-        hipLaunchKernelGGL(layernorm_bwd_rows_kernel<bf16_t>, dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
+        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<bf16_t, 4>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
                            (const bf16_t*)dy, dy_row_stride, eps, (const bf16_t*)add, (bf16_t*)dx, dx_row_stride, partial, rows, D);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
