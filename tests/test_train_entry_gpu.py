@@ -325,3 +325,56 @@ def test_vit_finetune_through_train_entry(dev, tmp_path, monkeypatch):
         p = dict(vit.named_parameters())[n]
         assert torch.isfinite(p).all() and not torch.equal(p.detach().cpu(), ref[n]), n        # AdamW moved it
     assert (tmp_path / "checkpoints" / "vitft" / "epoch=0.ckpt").exists()
+
+
+def test_three_adamw_steps_match_the_oracle_step_fp32(dev):
+    """Three full train steps (forward with train-mode BatchNorm, InfoNCE, backward of the trainable set, AdamW) in the fp32 parity
+    mode against the oracle's CpuTrainStep on the same weights and batches: per-step losses, the updated fc / embedding
+    parameters and the frozen trunk's BatchNorm running statistics (updated even though the trunk is frozen: SURVEY 0.4)."""
+    import argparse, contextlib, io, math
+    import cvcl_oracle as O
+    from multimodal.multimodal import TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import read_vocab
+    from multimodal.multimodal_lit import MultiModalLitModel
+    args = argparse.Namespace(
+        embedding_type="flat", embedding_dim=64, pretrained_cnn=False, cnn_model="resnext50_32x4d", cnn_dino=False,
+        vit_dino=False, finetune_cnn=False, text_encoder="embedding", captioning=False, attention=False,
+        attention_gate=False, crange=1, dropout_i=0.0, dropout_o=0.0, pos_embed_type="no_pos_embed",
+        normalize_features=True, sim="max", temperature=0.07, fix_temperature=True, tie=True, bias=True, lr=1e-3,
+        weight_decay=0.1, lambda_mm=1.0, lambda_lm=0.0, lambda_ar=0.0, optimize_unused=True, lr_scheduler=False,
+        optimizer=torch.optim.AdamW)
+    torch.manual_seed(1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ve = VisionEncoder(args)
+        lit = MultiModalLitModel(ve, TextEncoder(read_vocab(), 2048, args), args)
+    sd = {k: v.detach().clone() for k, v in lit.model.state_dict().items()}
+    sd["logit_neg_log_temperature"] = torch.tensor(-math.log(0.07))
+    lit.to(dev).train()
+    lit.set_precision("32")
+    opt = lit.configure_optimizers()
+    cpu = O.CpuTrainStep(sd, lr=1e-3, weight_decay=0.1, normalize_features=True)
+    for s in range(3):
+        img, tok, ln = O.synthetic_batch(6, seed=10 + s)
+        want = cpu.step(img, tok, ln)
+        opt.zero_grad(set_to_none=True)
+        out = lit.training_step((img.to(dev), tok.to(dev), ln.to(dev), None), 0)
+        out["loss"].backward()
+        opt.step()
+        got = float(out["loss"].detach())
+        assert abs(got - want) < 2e-4 * max(1.0, abs(want)), (s, got, want)
+    now = {k: v.detach().float().cpu() for k, v in lit.model.state_dict().items()}
+    for k in O.TRAINABLE_FROZEN_CNN:
+        # AdamW's normalised step m / sqrt(v) is +-lr in the first steps whatever the gradient's size, so elements whose gradient
+        # is ~0 amplify 1e-7 differences to lr: compare the three-step UPDATE as a whole (direction and size), not element-wise
+        ua, ub = (now[k] - sd[k]).flatten().double(), (cpu.p[k].detach() - sd[k]).flatten().double()
+        assert float(ub.norm()) > 0                                            # it did move
+        cos = float(torch.nn.functional.cosine_similarity(ua, ub, dim=0))
+        rel = float((ua - ub).norm() / ub.norm())
+        assert cos > 0.9995 and rel < 3e-2, (k, cos, rel)
+    for k in ("image_embed.model.bn1.running_mean", "image_embed.model.layer1.0.bn3.running_var",
+              "image_embed.model.layer3.2.bn2.running_mean", "image_embed.model.layer4.2.bn3.running_var",
+              "image_embed.model.layer2.0.downsample.1.running_mean"):
+        a, b = now[k], cpu.p[k].detach()
+        assert float((a - b).abs().max()) < 2e-4 * max(1e-3, float(b.abs().max())), k
+        assert not torch.equal(b, sd[k])
+    assert int(now["image_embed.model.layer4.2.bn3.num_batches_tracked"]) == 3
