@@ -315,8 +315,8 @@ def test_vit_fp8_linears_vs_emulation_and_bf16(dev):
     assert float(cos_e.min()) > 0.995 and rel_e < 0.1 and float(cos_e.min()) >= float(cos.min()) - 1e-3
 
 
-@pytest.mark.parametrize("D,heads,depth,B", [(128, 2, 2, 3), (768, 12, 1, 2)])
-def test_vit_finetune_gradients_vs_oracle_autograd(dev, D, heads, depth, B):
+@pytest.mark.parametrize("D,heads,depth,B,patch", [(128, 2, 2, 3, 16), (768, 12, 1, 2, 16), (128, 2, 1, 2, 14)])
+def test_vit_finetune_gradients_vs_oracle_autograd(dev, D, heads, depth, B, patch):
     """--finetune_cnn with the ViT: vit_train.VitTrunk (forward that keeps activations + explicit backward kernels: attention
     backward, LayerNorm backward, GELU backward, data / weight-gradient GEMMs, token assembly backward) vs torch.autograd
     through the fp32 oracle on the same weights and images.  bf16 storage: every parameter gradient within cosine 0.99 /
@@ -324,7 +324,7 @@ def test_vit_finetune_gradients_vs_oracle_autograd(dev, D, heads, depth, B):
     import torch.nn.functional as F
     from multimodal import vision_transformer_dino_mugs as vits
     torch.manual_seed(D + depth)
-    m = vits.VisionTransformer(img_size=[224], patch_size=16, embed_dim=D, depth=depth, num_heads=heads, mlp_ratio=4, qkv_bias=True,
+    m = vits.VisionTransformer(img_size=[224], patch_size=patch, embed_dim=D, depth=depth, num_heads=heads, mlp_ratio=4, qkv_bias=True,
                                num_classes=0).to(dev)
     with torch.no_grad():                                   # non-trivial norms / biases so that every gradient is exercised
         for n, p in m.named_parameters():
@@ -352,7 +352,7 @@ def test_vit_finetune_gradients_vs_oracle_autograd(dev, D, heads, depth, B):
     assert torch.allclose(cls.detach(), frozen, rtol=2e-2, atol=2e-2)        # fused GELU epilogue vs separate pass: bf16 rounding points
     # oracle: fp32 autograd
     sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
-    yo = O.vit_forward(sd, x.cpu(), 16, heads)
+    yo = O.vit_forward(sd, x.cpu(), patch, heads)
     (yo * r.cpu()).sum().backward()
     assert maxrel(cls.detach(), yo.detach()) < 5e-2
     got = runs[0]
