@@ -354,7 +354,7 @@ struct GconvDev {
     int ablate;      // debug only ($CVCL_GCONV_ABLATE): 1 skip BN math, 2 skip MFMA loop, 4 skip stores, 8 skip LDS staging writes
 };
 
-template <bool WIDE>
+template <bool WIDE, int NPF>
 __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bf16_t* __restrict__ x = (const bf16_t*)p.x;
@@ -400,27 +400,31 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     char* s_out = smem + npix_in * GC_PIXB;                            // output band [TH * Wo pixels][GC_PIXB]
     // software pipeline over work items: the next band's pixels are loaded into registers (raw, no waiting) before
     // the current band is multiplied out of LDS; BN+ReLU and the LDS write happen one iteration later.
-    constexpr int NPF = 10;                          // >= ceil(max staged pixels / 32) (see gconv_plan)
+    // NPF = ceil(staged pixels / 32) rounded up to an even count (template parameter: every slot is loaded, see below)
     bf16x8 pf[NPF];
     bool pf_in[NPF];
+    // Every slot issues its load unconditionally from a clamped (always valid) address and the predicate only decides later whether
+    // the value or the zero padding is staged.  With the loads inside divergent `if`s the compiler put an s_waitcnt vmcnt(0) in
+    // front of each of them: ten serialized memory round trips per work item -- the kernel's phases simply added up (179 us for
+    // layer 1, of which 86 were this chain).
     auto prefetch = [&](int item) {
         const int b = item / p.bands, band = item - b * p.bands;
         const int iy0 = band * p.TH * p.stride - 1;
+        const bf16_t* xb = x + (long)b * p.H * p.W * p.C + c0 + s_chunk * 8;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int pi = s_pix0 + 32 * i;
-            pf_in[i] = false;
-            if (pi < npix_in) {
-                const int ry = pi / Wp, rx = pi - ry * Wp;
-                const int yin = iy0 + ry, xin = rx - 1;
-                if (yin >= 0 && yin < p.H && xin >= 0 && xin < p.W) {
-                    pf_in[i] = true;
-                    pf[i] = *reinterpret_cast<const bf16x8*>(x + (((long)b * p.H + yin) * p.W + xin) * p.C + c0 + s_chunk * 8);
-                }
-            }
+            const int ry = pi / Wp, rx = pi - ry * Wp;
+            const int yin = iy0 + ry, xin = rx - 1;
+            pf_in[i] = pi < npix_in && yin >= 0 && yin < p.H && xin >= 0 && xin < p.W;
+            const int yc = min(max(yin, 0), p.H - 1), xc = min(max(xin, 0), p.W - 1);
+            pf[i] = *reinterpret_cast<const bf16x8*>(xb + ((long)yc * p.W + xc) * p.C);
         }
     };
     const int n_items = p.B * p.bands;
+    // the weight fragments (loaded above) are ready from here on: without this the compiler, conservative across the loop's back
+    // edge, waits on vmcnt before the first MFMAs of every work item -- i.e. for the next item's prefetch just issued
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
     if ((int)blockIdx.x < n_items) prefetch(blockIdx.x);
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int b = item / p.bands, band = item - b * p.bands;
@@ -829,20 +833,22 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
         d.act_floor = act_floor;
         { const char* e = getenv("CVCL_GCONV_ABLATE"); d.ablate = e ? atoi(e) : 0; }
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void*)gconv_mfma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)gconv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);
+        CvclProfScope prof(stream, CVCL_K_GCONV);
+        auto launch = [&](auto kern) -> int {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
                 return CVCL_ELAUNCH;
             }
-            attr_set = true;
-        }
-        CvclProfScope prof(stream, CVCL_K_GCONV);
-        if (cg == 32)
-            hipLaunchKernelGGL(gconv_mfma_kernel<true>, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
-        else
-            hipLaunchKernelGGL(gconv_mfma_kernel<false>, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
+            hipLaunchKernelGGL(kern, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
+            return CVCL_OK;
+        };
+        int rc;
+        if (cg == 32) rc = slots <= 4 ? launch(gconv_mfma_kernel<true, 4>) : slots <= 6 ? launch(gconv_mfma_kernel<true, 6>)
+                         : slots <= 8 ? launch(gconv_mfma_kernel<true, 8>) : launch(gconv_mfma_kernel<true, 10>);
+        else rc = slots <= 4 ? launch(gconv_mfma_kernel<false, 4>) : slots <= 6 ? launch(gconv_mfma_kernel<false, 6>)
+                : slots <= 8 ? launch(gconv_mfma_kernel<false, 8>) : launch(gconv_mfma_kernel<false, 10>);
+        if (rc) return rc;
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }
