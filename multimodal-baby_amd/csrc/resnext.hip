@@ -555,13 +555,22 @@ __global__ __launch_bounds__(256) void bn_add_relu_kernel(const T* __restrict__ 
     const long total = rows * CC;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(i0 % CC) * EPC;
+    // per-channel affines as 16-byte loads from unconditional addresses (a `cond ? p[i] : 1.f` per element made the compiler emit
+    // one s_waitcnt vmcnt(0) per channel: eight dependent L2 round trips at the start of every workgroup)
     float sc[EPC], sh[EPC], isc[EPC], ish[EPC];
+    const float* isp = idn_scale ? idn_scale : scale;
+    const float* ihp = idn_scale ? idn_shift : shift;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        sc[e] = scale[c + e];
-        sh[e] = shift[c + e];
-        isc[e] = idn_scale ? idn_scale[c + e] : 1.f;
-        ish[e] = idn_scale ? idn_shift[c + e] : 0.f;
+    for (int v4 = 0; v4 < EPC / 4; ++v4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c + 4 * v4), b = *reinterpret_cast<const f32x4*>(shift + c + 4 * v4);
+        const f32x4 ia = *reinterpret_cast<const f32x4*>(isp + c + 4 * v4), ib = *reinterpret_cast<const f32x4*>(ihp + c + 4 * v4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[4 * v4 + e] = a[e];
+            sh[4 * v4 + e] = b[e];
+            isc[4 * v4 + e] = idn_scale ? ia[e] : 1.f;
+            ish[4 * v4 + e] = idn_scale ? ib[e] : 0.f;
+        }
     }
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = i0; i < total; i += 2 * stride) {          // two independent 16-B chunks in flight per thread
@@ -604,7 +613,11 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const T* __restrict_
     const int c = (int)(i0 % CC) * EPC;                 // fixed per thread: (grid * 256) % CC == 0 (see launcher)
     float sc[EPC], sh[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { sc[e] = scale[c + e]; sh[e] = shift[c + e]; }
+    for (int v4 = 0; v4 < EPC / 4; ++v4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(scale + c + 4 * v4), b = *reinterpret_cast<const f32x4*>(shift + c + 4 * v4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { sc[4 * v4 + e] = a[e]; sh[4 * v4 + e] = b[e]; }
+    }
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = i0; i < total; i += 2 * stride) {
         const long j = i + stride;
