@@ -38,9 +38,20 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int c = threadIdx.x & (NC - 1), sl = threadIdx.x / NC, ch = blockIdx.x * NC + c;
     double s = 0.0, q = 0.0;
     if (ch < C) {
-        for (int r = sl; r < rows; r += NS) {
-            s += (double)stats[((long)r * 2 + 0) * C + ch];
-            q += (double)stats[((long)r * 2 + 1) * C + ch];
+        // eight rows' loads are issued before the first is added (same summation order): one wait per eight rows instead of a
+        // dependent L2 round trip per row -- the kernel is nothing but latency
+        constexpr int UN = 8;
+        for (int r0 = sl; r0 < rows; r0 += NS * UN) {
+            float a[UN], b[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int r = min(r0 + NS * u, rows - 1);                       // clamped: always a valid address, no branch
+                a[u] = stats[((long)r * 2 + 0) * C + ch];
+                b[u] = stats[((long)r * 2 + 1) * C + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+                if (r0 + NS * u < rows) { s += (double)a[u]; q += (double)b[u]; }
         }
     }
     ps[sl][c] = s;
