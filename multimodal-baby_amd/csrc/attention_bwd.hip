@@ -47,11 +47,10 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const bf16_t* 
 
     for (int i = tid; i < Tpad * 8; i += 256) {
         const int j = i >> 3, c = i & 7;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (j < Tn) {
-            kv = *reinterpret_cast<const u32x4*>(base + (long)j * 3 * D + D + hh * 64 + c * 8);
-            vv = *reinterpret_cast<const u32x4*>(base + (long)j * 3 * D + 2 * D + hh * 64 + c * 8);
-        }
+        const int jc = min(j, Tn - 1);                     // unconditional loads from a clamped row, zeroed afterwards (no branch)
+        u32x4 kv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + D + hh * 64 + c * 8);
+        u32x4 vv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + 2 * D + hh * 64 + c * 8);
+        if (j >= Tn) { kv = u32x4{0u, 0u, 0u, 0u}; vv = u32x4{0u, 0u, 0u, 0u}; }
         *reinterpret_cast<u32x4*>(sK + j * AB_RP + c * 16) = kv;
         *reinterpret_cast<u32x4*>(sV + j * AB_RP + c * 16) = vv;
     }
@@ -153,11 +152,10 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_kernel(const bf16_t*
 
     for (int i = tid; i < Tpad * 8; i += 256) {
         const int j = i >> 3, c = i & 7;
-        u32x4 qv = {0u, 0u, 0u, 0u}, dv = {0u, 0u, 0u, 0u};
-        if (j < Tn) {
-            qv = *reinterpret_cast<const u32x4*>(base + (long)j * 3 * D + hh * 64 + c * 8);
-            dv = *reinterpret_cast<const u32x4*>(d_o + ((long)b * Tn + j) * D + hh * 64 + c * 8);
-        }
+        const int jc = min(j, Tn - 1);
+        u32x4 qv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + hh * 64 + c * 8);
+        u32x4 dv = *reinterpret_cast<const u32x4*>(d_o + ((long)b * Tn + jc) * D + hh * 64 + c * 8);
+        if (j >= Tn) { qv = u32x4{0u, 0u, 0u, 0u}; dv = u32x4{0u, 0u, 0u, 0u}; }
         *reinterpret_cast<u32x4*>(sQ + j * AB_RP + c * 16) = qv;
         *reinterpret_cast<u32x4*>(sO + j * AB_RP + c * 16) = dv;
     }
@@ -165,11 +163,12 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_kernel(const bf16_t*
     for (int i = tid; i < Tpad * 8; i += 256) {
         const int j = i >> 3, c = i & 7;
         float part = 0.f;
-        if (j < Tn) {
-            const long orow = ((long)b * Tn + j) * D + hh * 64 + c * 8;
+        {
+            const long orow = ((long)b * Tn + min(j, Tn - 1)) * D + hh * 64 + c * 8;
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(d_o + orow), bb = *reinterpret_cast<const bf16x8*>(o + orow);
 #pragma unroll
             for (int e = 0; e < 8; ++e) part = fmaf((float)a[e], (float)bb[e], part);
+            if (j >= Tn) part = 0.f;
         }
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);

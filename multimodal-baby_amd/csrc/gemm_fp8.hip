@@ -299,7 +299,8 @@ template <int LPR> __device__ inline float lanes_max(float v) {
     return v;
 }
 
-template <bool SRC_F32, int LPR, int NCH>
+// EXACT: K == 8 LPR NCH, every chunk exists -- no branch around a load (each branch costs a serializing s_waitcnt vmcnt(0))
+template <bool SRC_F32, int LPR, int NCH, bool EXACT>
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restrict__ xin, long x_row_stride, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, unsigned char* __restrict__ q,
                                                              float* __restrict__ scale, long rows, int K) {
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + LPR * i;
-        if (c < nch) {
+        if (EXACT || c < nch) {
             if (SRC_F32) {
                 const float* xr = (const float*)xin + row * x_row_stride + c * 8;
                 const f32x4 a = *reinterpret_cast<const f32x4*>(xr), b = *reinterpret_cast<const f32x4*>(xr + 4);
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
         float qq = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
-            if (lane + LPR * i < nch) {
+            if (EXACT || lane + LPR * i < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; v[i][e] = c; qq = fmaf(c, c, qq); }   // keep the centred value
             }
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + LPR * i;
-            if (c < nch) {
+            if (EXACT || c < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[i][e] = fmaf(v[i][e], rstd * gamma[c * 8 + e], beta[c * 8 + e]);
             }
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-        if (lane + LPR * i < nch) {
+        if (EXACT || lane + LPR * i < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
         }
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + LPR * i;
-        if (c < nch) {
+        if (EXACT || c < nch) {
             float t[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -403,12 +404,13 @@ extern "C" int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stri
     hipStream_t st = (hipStream_t)stream;
     unsigned char* qq = (unsigned char*)q;
     if (src_dtype == CVCL_F32) {
-        if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 32, 4>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
-        else hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 64, 8>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 32, 4, false>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<true, 64, 8, false>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
     } else {
-        if (K <= 768) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 3>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
-        else if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 4>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
-        else hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 64, 8>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        if (K == 768) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 3, true>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else if (K < 768) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 3, false>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else if (narrow) hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 32, 4, false>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
+        else hipLaunchKernelGGL((quant_rows_fp8_kernel<false, 64, 8, false>), grid, dim3(256), 0, st, x, x_row_stride, ln_gamma, ln_beta, ln_eps, qq, scale, rows, K);
     }
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;

@@ -335,17 +335,23 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
         float sc[8], sh[8], m[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; m[e] = 0.f; }  // relu output >= 0
-        for (int ky = 0; ky < 3; ++ky) {
-            const int yin = 2 * oy - 1 + ky;
-            if (yin < 0 || yin >= H) continue;
+        // all nine taps are loaded from clamped (always valid) addresses before any is used; a clamped tap repeats a pixel of the
+        // window, which leaves the maximum unchanged -- no branch around a load (branches made every tap wait for the previous one)
+        constexpr int EPC = ElemTraits<T>::kPerChunk, NC = 8 / EPC;              // 8 channels = 1 (bf16) or 2 (fp32) chunks
+        Chunk<T> tap[9][NC];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int xin = 2 * ox - 1 + kx;
-                if (xin < 0 || xin >= W) continue;
+                const int yin = min(max(2 * oy - 1 + ky, 0), H - 1), xin = min(max(2 * ox - 1 + kx, 0), W - 1);
                 const T* src = x + (((long)b * H + yin) * W + xin) * C + cc * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], fmaf(ElemTraits<T>::to_f(src[e]), sc[e], sh[e]));
+                for (int q = 0; q < NC; ++q) tap[ky * 3 + kx][q].load(src + q * EPC);
             }
-        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], fmaf(tap[t][e / EPC].get(e % EPC), sc[e], sh[e]));
         T* dst = y + (((long)b * Ho + oy) * Wo + ox) * C + cc * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) dst[e] = ElemTraits<T>::from_f(m[e]);

@@ -139,7 +139,8 @@ __device__ inline float ln_row32_sum(float v) {
     v += dpp(v, 0); v += dpp(v, 1); v += dpp(v, 2); v += dpp(v, 3);
     return v + __shfl_xor(v, 16, 64);
 }
-template <typename TO, int NCH>
+// EXACT: D == 256 NCH, every chunk exists -- no branch around the loads (a branch costs a serializing vmcnt(0) per chunk)
+template <typename TO, int NCH, bool EXACT>
 __global__ __launch_bounds__(256) void layernorm_bf16_row32_kernel(const bf16_t* __restrict__ x, long x_row_stride,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float eps, TO* __restrict__ y, long rows, int D) {
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_row32_kernel(const bf16_t*
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 32 * i;
-        if (c < nch) {
+        if (EXACT || c < nch) {
             const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + c * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e]; s += v[i][e]; }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_row32_kernel(const bf16_t*
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i)
-        if (lane + 32 * i < nch) {
+        if (EXACT || lane + 32 * i < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; v[i][e] = c; q = fmaf(c, c, q); }
         }
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_row32_kernel(const bf16_t*
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 32 * i;
-        if (c < nch) {
+        if (EXACT || c < nch) {
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + c * 8 + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c * 8), b1 = *reinterpret_cast<const f32x4*>(beta + c * 8 + 4);
             float o[8];
@@ -294,11 +295,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
 
     for (int i = tid; i < Tpad * 8; i += ATT_THREADS) {                     // 8 chunks of 16 B per row, zeros beyond Tn
         const int j = i >> 3, c = i & 7;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (j < Tn) {
-            kv = *reinterpret_cast<const u32x4*>(base + (long)j * 3 * D + D + hh * 64 + c * 8);
-            vv = *reinterpret_cast<const u32x4*>(base + (long)j * 3 * D + 2 * D + hh * 64 + c * 8);
-        }
+        // unconditional loads from a clamped row (a branch around them costs a vmcnt(0) per iteration), zeroed afterwards
+        const int jc = min(j, Tn - 1);
+        u32x4 kv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + D + hh * 64 + c * 8);
+        u32x4 vv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + 2 * D + hh * 64 + c * 8);
+        if (j >= Tn) { kv = u32x4{0u, 0u, 0u, 0u}; vv = u32x4{0u, 0u, 0u, 0u}; }
         *reinterpret_cast<u32x4*>(sK + j * ATT_KP + c * 16) = kv;
         *reinterpret_cast<u32x4*>(sV + j * ATT_VP + c * 16) = vv;
     }
@@ -518,8 +519,12 @@ extern "C" int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const
         const bool vec = D % 8 == 0 && D <= 2048 && x_row_stride % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                          ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0;
         if (vec && !y_is_f32 && D <= 768 && rows >= 4096)                  // ViT-S/B token matrices
-            hipLaunchKernelGGL((layernorm_bf16_row32_kernel<bf16_t, 3>), dim3(cvcl_div_up(rows, 8)), dim3(256), 0, s, (const bf16_t*)x,
-                               x_row_stride, gamma, beta, eps, (bf16_t*)y, rows, D);
+            if (D == 768)
+                hipLaunchKernelGGL((layernorm_bf16_row32_kernel<bf16_t, 3, true>), dim3(cvcl_div_up(rows, 8)), dim3(256), 0, s, (const bf16_t*)x,
+                                   x_row_stride, gamma, beta, eps, (bf16_t*)y, rows, D);
+            else
+                hipLaunchKernelGGL((layernorm_bf16_row32_kernel<bf16_t, 3, false>), dim3(cvcl_div_up(rows, 8)), dim3(256), 0, s, (const bf16_t*)x,
+                                   x_row_stride, gamma, beta, eps, (bf16_t*)y, rows, D);
         else if (vec && y_is_f32)
             hipLaunchKernelGGL((layernorm_bf16_vec_kernel<float>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
                                eps, (float*)y, rows, D);

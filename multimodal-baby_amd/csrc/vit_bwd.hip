@@ -24,7 +24,7 @@ __device__ inline float row32_sum(float v) {            // sum over the 32 lanes
 //   xhat = (x - mean) rstd,  g = dy gamma,  dx = rstd (g - mean(g) - xhat mean(g xhat))  [+ add],  dgamma += dy xhat,  dbeta += dy
 // Row groups walk the rows with a fixed stride, so a lane always owns the same columns and accumulates their dgamma / dbeta
 // in registers; each group writes one partial row [2][D] at the end (summed in a fixed order by cvcl_colsum_f32).
-template <typename TDY, int NCH>
+template <typename TDY, int NCH, bool EXACT>
 __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* __restrict__ x, long x_row_stride, const float* __restrict__ gamma,
                                                                  const TDY* __restrict__ dy, long dy_row_stride, float eps,
                                                                  const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, long dx_row_stride,
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* _
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 32 * i;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + row * x_row_stride + c * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { xv[i][e] = (float)a[e]; s += xv[i][e]; }
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* _
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
-            if (lane + 32 * i < nch) {
+            if (EXACT || lane + 32 * i < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float c = xv[i][e] - mean; xv[i][e] = c; q = fmaf(c, c, q); }
             }
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* _
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 32 * i;
-            if (c < nch) {
+            if (EXACT || c < nch) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xh = xv[i][e] * rstd, d = gv[i][e];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* _
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = lane + 32 * i;
-            if (c < nch) {
+            if (EXACT || c < nch) {
                 bf16x8 o;
                 bf16x8 ad;
                 if (add) ad = *reinterpret_cast<const bf16x8*>(add + row * dx_row_stride + c * 8);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* _
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 32 * i;
-        if (c < nch) {
+        if (EXACT || c < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 partial[(group * 2 + 0) * D + c * 8 + e] = dg[i][e];
@@ -188,14 +188,17 @@ extern "C" int cvcl_layernorm_bwd_rows(const void* x, long x_row_stride, const f
                    "cvcl_layernorm_bwd_rows: needs D %% 8 == 0, D <= 1024 and 16-byte aligned rows (D %d)", D);
     const int wgs = cvcl_layernorm_bwd_rows_partials(rows) / 8;
     CvclProfScope prof(stream, CVCL_K_LAYERNORM);
-    if (!dy_is_f32 && D <= 768)                               // ViT-S/B rows: 3 chunks per lane, fewer live registers
-        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<bf16_t, 3>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
+    if (!dy_is_f32 && D == 768)                               // ViT-B rows: exactly 3 chunks per lane, no branches around the loads
+        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<bf16_t, 3, true>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
+                           (const bf16_t*)dy, dy_row_stride, eps, (const bf16_t*)add, (bf16_t*)dx, dx_row_stride, partial, rows, D);
+    else if (!dy_is_f32 && D < 768)
+        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<bf16_t, 3, false>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
                            (const bf16_t*)dy, dy_row_stride, eps, (const bf16_t*)add, (bf16_t*)dx, dx_row_stride, partial, rows, D);
     else if (dy_is_f32)
-        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<float, 4>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
+        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<float, 4, false>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
                            (const float*)dy, dy_row_stride, eps, (const bf16_t*)add, (bf16_t*)dx, dx_row_stride, partial, rows, D);
     else
-        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<bf16_t, 4>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
+        hipLaunchKernelGGL((layernorm_bwd_rows_kernel<bf16_t, 4, false>), dim3(wgs), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, gamma,
                            (const bf16_t*)dy, dy_row_stride, eps, (const bf16_t*)add, (bf16_t*)dx, dx_row_stride, partial, rows, D);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
