@@ -45,14 +45,26 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dq_kernel(const bf16_t* 
     const int D = heads * 64;
     const bf16_t* base = qkv + (long)b * Tn * 3 * D;
 
-    for (int i = tid; i < Tpad * 8; i += 256) {
-        const int j = i >> 3, c = i & 7;
-        const int jc = min(j, Tn - 1);                     // unconditional loads from a clamped row, zeroed afterwards (no branch)
-        u32x4 kv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + D + hh * 64 + c * 8);
-        u32x4 vv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + 2 * D + hh * 64 + c * 8);
-        if (j >= Tn) { kv = u32x4{0u, 0u, 0u, 0u}; vv = u32x4{0u, 0u, 0u, 0u}; }
-        *reinterpret_cast<u32x4*>(sK + j * AB_RP + c * 16) = kv;
-        *reinterpret_cast<u32x4*>(sV + j * AB_RP + c * 16) = vv;
+    {   // all of a thread's staging loads are issued before the first LDS write (the plain loop paid a round trip per iteration)
+        constexpr int IT = (AB_TPAD_MAX_DKV * 8 + 255) / 256;
+        u32x4 kv[IT], vv[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = tid + it * 256;
+            const int jc = min(i >> 3, Tn - 1), c = i & 7;
+            kv[it] = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + D + hh * 64 + c * 8);
+            vv[it] = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + 2 * D + hh * 64 + c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = tid + it * 256;
+            const int j = i >> 3, c = i & 7;
+            if (i < Tpad * 8) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(sK + j * AB_RP + c * 16) = j < Tn ? kv[it] : z;
+                *reinterpret_cast<u32x4*>(sV + j * AB_RP + c * 16) = j < Tn ? vv[it] : z;
+            }
+        }
     }
     __syncthreads();
 
@@ -150,14 +162,26 @@ __global__ __launch_bounds__(256, 2) void attention_bwd_dkv_kernel(const bf16_t*
     const int D = heads * 64;
     const bf16_t* base = qkv + (long)b * Tn * 3 * D;
 
-    for (int i = tid; i < Tpad * 8; i += 256) {
-        const int j = i >> 3, c = i & 7;
-        const int jc = min(j, Tn - 1);
-        u32x4 qv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + hh * 64 + c * 8);
-        u32x4 dv = *reinterpret_cast<const u32x4*>(d_o + ((long)b * Tn + jc) * D + hh * 64 + c * 8);
-        if (j >= Tn) { qv = u32x4{0u, 0u, 0u, 0u}; dv = u32x4{0u, 0u, 0u, 0u}; }
-        *reinterpret_cast<u32x4*>(sQ + j * AB_RP + c * 16) = qv;
-        *reinterpret_cast<u32x4*>(sO + j * AB_RP + c * 16) = dv;
+    {
+        constexpr int IT = (AB_TPAD_MAX_DKV * 8 + 255) / 256;
+        u32x4 qv[IT], dv[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = tid + it * 256;
+            const int jc = min(i >> 3, Tn - 1), c = i & 7;
+            qv[it] = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + hh * 64 + c * 8);
+            dv[it] = *reinterpret_cast<const u32x4*>(d_o + ((long)b * Tn + jc) * D + hh * 64 + c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = tid + it * 256;
+            const int j = i >> 3, c = i & 7;
+            if (i < Tpad * 8) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(sQ + j * AB_RP + c * 16) = j < Tn ? qv[it] : z;
+                *reinterpret_cast<u32x4*>(sO + j * AB_RP + c * 16) = j < Tn ? dv[it] : z;
+            }
+        }
     }
     // D_i = sum_d dO_id O_id and the saved log-sum-exp, one query per 8 lanes (16 B of each row per lane)
     for (int i = tid; i < Tpad * 8; i += 256) {

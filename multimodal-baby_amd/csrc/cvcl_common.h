@@ -117,6 +117,23 @@ __device__ inline float block_max(float v, float* scratch) {
     return r;
 }
 
+// sum_{i < n} load(i), UN loads in flight per wait, additions in index order (same result as the plain loop, deterministic).
+// A `for (...) acc += p[i]` loop waits for every load before issuing the next (one L2 / HBM round trip per element): these
+// reductions are pure latency, so batching the loads is the whole optimisation.  load(i) must be valid for every i < n.
+template <int UN, typename ACC, typename F>
+__device__ inline ACC ordered_sum(int n, F load) {
+    ACC acc = (ACC)0;
+    for (int i0 = 0; i0 < n; i0 += UN) {
+        ACC v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) v[u] = (ACC)load(min(i0 + u, n - 1));
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (i0 + u < n) acc += v[u];
+    }
+    return acc;
+}
+
 // ---- GELU (erf form) with Abramowitz-Stegun 7.1.26 for erf (|error| < 1.5e-7, far below bf16 resolution) on v_rcp_f32 / v_exp_f32;
 // shared by the GEMM epilogues and the standalone passes so that fused and unfused paths round identically
 __device__ inline float gelu_erf_fast(float v) {

@@ -672,8 +672,7 @@ __global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restric
     __shared__ float part[64][16];
     const int c = threadIdx.x & 15, s = threadIdx.x >> 4, n = blockIdx.x * 16 + c;
     float acc = 0.f;
-    if (n < N)
-        for (int m = s; m < M; m += 64) acc += dY[(long)m * N + n];
+    if (n < N && s < M) acc = ordered_sum<8, float>((M - s + 63) / 64, [&](int j) { return dY[(long)(s + 64 * j) * N + n]; });
     part[s][c] = acc;
     __syncthreads();
     if (s == 0 && n < N) {

@@ -660,8 +660,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, f
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const long b = i / C;
-        float acc = 0.f;
-        for (int p = 0; p < HW; ++p) acc += ElemTraits<T>::to_f(x[(b * HW + p) * C + c]);
+        const float acc = ordered_sum<8, float>(HW, [&](int p) { return ElemTraits<T>::to_f(x[(b * HW + p) * C + c]); });
         out[i] = acc / (float)HW;
     }
 }

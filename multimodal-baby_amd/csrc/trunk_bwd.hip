@@ -109,11 +109,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     __shared__ double ss[8][32], sq[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, ch = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
-    if (ch < C)
-        for (int r = sl; r < prow; r += 8) {
-            s += (double)partial[((long)r * 2 + 0) * C + ch];
-            q += (double)partial[((long)r * 2 + 1) * C + ch];
-        }
+    if (ch < C && sl < prow) {
+        const int cnt = (prow - sl + 7) / 8;
+        s = ordered_sum<8, double>(cnt, [&](int j) { return partial[((long)(sl + 8 * j) * 2 + 0) * C + ch]; });
+        q = ordered_sum<8, double>(cnt, [&](int j) { return partial[((long)(sl + 8 * j) * 2 + 1) * C + ch]; });
+    }
     ss[sl][cl] = s;
     sq[sl][cl] = q;
     __syncthreads();
@@ -429,11 +429,11 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict
     __shared__ double ss[8][32], sq[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, ch = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
-    if (ch < C)
-        for (int r = sl; r < prow; r += 8) {
-            s += (double)stats[((long)r * 2 + 0) * C + ch];
-            q += (double)stats[((long)r * 2 + 1) * C + ch];
-        }
+    if (ch < C && sl < prow) {
+        const int cnt = (prow - sl + 7) / 8;
+        s = ordered_sum<8, double>(cnt, [&](int j) { return stats[((long)(sl + 8 * j) * 2 + 0) * C + ch]; });
+        q = ordered_sum<8, double>(cnt, [&](int j) { return stats[((long)(sl + 8 * j) * 2 + 1) * C + ch]; });
+    }
     ss[sl][cl] = s;
     sq[sl][cl] = q;
     __syncthreads();

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* __restrict
 constexpr int ATT_TPAD_MAX = 288;      // keys padded to a multiple of 32 (T <= 288 covers ViT-B/14 at 224: 257)
 constexpr int ATT_THREADS = 512;       // 8 waves: the 7 query tiles of a 197-token ViT-B/16 head run in ONE round (4 waves needed two, the
                                        // second half empty), two workgroups per CU = 4 waves per SIMD
+constexpr int ATT_STAGE_IT = (ATT_TPAD_MAX * 8 + ATT_THREADS - 1) / ATT_THREADS;   // staging chunks per thread (5 at 288 rows)
 constexpr int ATT_KP = 144;            // LDS bytes per K row (128 + 16)
 constexpr int ATT_VP = 192;            // LDS bytes per V row (128 + 64): the 4 rows x 64 B that 32 lanes touch in one
                                        // ds_read_b64_tr_b16 land on banks 0-15 / 48-63 / 32-47 / 16-31
@@ -293,15 +294,28 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
     const int D = heads * 64;
     const bf16_t* base = qkv + (long)b * Tn * 3 * D;
 
-    for (int i = tid; i < Tpad * 8; i += ATT_THREADS) {                     // 8 chunks of 16 B per row, zeros beyond Tn
-        const int j = i >> 3, c = i & 7;
-        // unconditional loads from a clamped row (a branch around them costs a vmcnt(0) per iteration), zeroed afterwards
-        const int jc = min(j, Tn - 1);
-        u32x4 kv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + D + hh * 64 + c * 8);
-        u32x4 vv = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + 2 * D + hh * 64 + c * 8);
-        if (j >= Tn) { kv = u32x4{0u, 0u, 0u, 0u}; vv = u32x4{0u, 0u, 0u, 0u}; }
-        *reinterpret_cast<u32x4*>(sK + j * ATT_KP + c * 16) = kv;
-        *reinterpret_cast<u32x4*>(sV + j * ATT_VP + c * 16) = vv;
+    // K and V rows -> LDS, 8 chunks of 16 B per row, zeros beyond Tn.  All of a thread's loads (<= ATT_STAGE_IT pairs) are issued
+    // before the first LDS write: the plain loop waited for each pair (a dependent L2 round trip per iteration, ~half of the
+    // workgroup's lifetime at 197 tokens)
+    {
+        u32x4 kv[ATT_STAGE_IT], vv[ATT_STAGE_IT];
+#pragma unroll
+        for (int it = 0; it < ATT_STAGE_IT; ++it) {
+            const int i = tid + it * ATT_THREADS;
+            const int jc = min(i >> 3, Tn - 1), c = i & 7;                       // clamped row: always a valid address, no branch
+            kv[it] = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + D + hh * 64 + c * 8);
+            vv[it] = *reinterpret_cast<const u32x4*>(base + (long)jc * 3 * D + 2 * D + hh * 64 + c * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < ATT_STAGE_IT; ++it) {
+            const int i = tid + it * ATT_THREADS;
+            const int j = i >> 3, c = i & 7;
+            if (i < Tpad * 8) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(sK + j * ATT_KP + c * 16) = j < Tn ? kv[it] : z;
+                *reinterpret_cast<u32x4*>(sV + j * ATT_VP + c * 16) = j < Tn ? vv[it] : z;
+            }
+        }
     }
     __syncthreads();
 

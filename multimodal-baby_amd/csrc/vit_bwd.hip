@@ -154,10 +154,16 @@ __global__ __launch_bounds__(256) void vit_tokens_bwd_kernel(const bf16_t* __res
 __global__ __launch_bounds__(256) void batch_sum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int B, long n) {
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n / 8; j += (long)gridDim.x * blockDim.x) {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int b = 0; b < B; ++b) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + (long)b * n + j * 8);
+        for (int b0 = 0; b0 < B; b0 += 8) {                  // eight rows' loads in flight per wait, added in batch order
+            bf16x8 a[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += (float)a[e];
+            for (int u = 0; u < 8; ++u) a[u] = *reinterpret_cast<const bf16x8*>(x + (long)min(b0 + u, B - 1) * n + j * 8);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (b0 + u < B) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)a[u][e];
+                }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) out[j * 8 + e] = acc[e];

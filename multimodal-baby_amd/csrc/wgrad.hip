@@ -237,9 +237,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     const long total = (long)N * k_keep;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i / k_keep), k = (int)(i % k_keep);
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a += P[((long)s * N + n) * K + k];
-        C[i] = a;
+        C[i] = ordered_sum<8, float>(S, [&](int s) { return P[((long)s * N + n) * K + k]; });
     }
 }
 
@@ -252,9 +250,7 @@ __global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __
         const int tap = (int)(i % 9), ci = (int)((i / 9) % cg), co = (int)(i / (9 * cg));
         const int cin = (co / cg) * cg + ci;
         const float* src = P + (((long)tap * S * tiles) + co / TN_T) * TN_T * TN_T + (long)(co % TN_T) * TN_T + (cin % TN_T);
-        float a = 0.f;
-        for (int s = 0; s < S; ++s) a += src[(long)s * tiles * TN_T * TN_T];
-        dw[i] = a;
+        dw[i] = ordered_sum<8, float>(S, [&](int s) { return src[(long)s * tiles * TN_T * TN_T]; });
     }
 }
 
@@ -413,9 +409,7 @@ namespace {
 __global__ __launch_bounds__(256) void tn_colsum_reduce_kernel(const float* __restrict__ CS, int S, int tiles, int N, float* __restrict__ out) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    double a = 0.0;
-    for (int s = 0; s < S; ++s) a += (double)CS[((long)s * tiles + n / TN_T) * TN_T + n % TN_T];      // fixed order: deterministic
-    out[n] = (float)a;
+    out[n] = (float)ordered_sum<8, double>(S, [&](int s) { return CS[((long)s * tiles + n / TN_T) * TN_T + n % TN_T]; });   // fixed order
 }
 size_t tn_colsum_off(const TnPlan& pl, int N, int K) { return (tn_ws_bytes(pl, N, K, 1, false) + 255) & ~(size_t)255; }
 }  // namespace
