@@ -174,7 +174,7 @@ constexpr int STEM_TH = 4;                 // output rows per work item
 constexpr int STEM_ROWS = 2 * STEM_TH + 5; // input rows per channel
 constexpr int STEM_PITCH = 144;            // dwords per patch row (288 bf16 >= 224 + 6 + 8 slack); 144 % 32 == 16
 
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
+__global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
                                                         bf16_t* __restrict__ y, float* __restrict__ stats,
                                                         int B, int Hin, int Win) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -207,31 +207,32 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         // either side were zeroed once and are never written).  All of a thread's 16-byte loads are issued before
         // the first LDS write so they overlap instead of paying one memory round trip each.
         {
+            // two batches of 5 x 16 B per thread (one batch of 10 kept 40 more registers live and the kernel at one workgroup per
+            // CU); loads are unconditional from clamped rows, rows outside the image are staged as zeros
             const int vec_per_row = Win / 4, nvec = 3 * STEM_ROWS * vec_per_row;
-            constexpr int NV = 10;                                   // ceil(39 * 56 / 256) for 224-wide inputs
-            f32x4 v[NV];
-            bool ok[NV];
+            constexpr int NV = 5;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int idx = tid + 256 * i;
-                ok[i] = idx < nvec;
-                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ok[i]) {
+            for (int half = 0; half < 2; ++half) {
+                f32x4 v[NV];
+                bool ok[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int idx = min(tid + 256 * (half * NV + i), nvec - 1);
                     const int r = idx / vec_per_row, j = idx - r * vec_per_row;
                     const int c = r / STEM_ROWS, iy = r - c * STEM_ROWS;
                     const int yin = 2 * oy0 - 3 + iy;
-                    if (yin >= 0 && yin < Hin)
-                        v[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + yin) * Win + 4 * j);
+                    ok[i] = yin >= 0 && yin < Hin;
+                    v[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + min(max(yin, 0), Hin - 1)) * Win + 4 * j);
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                if (ok[i]) {
-                    const int idx = tid + 256 * i;
-                    const int r = idx / vec_per_row, j = idx - r * vec_per_row;
-                    bf16_t* dst = (bf16_t*)(patch + r * STEM_PITCH) + 4 * j + 3;
+                for (int i = 0; i < NV; ++i) {
+                    const int idx = tid + 256 * (half * NV + i);
+                    if (idx < nvec) {
+                        const int r = idx / vec_per_row, j = idx - r * vec_per_row;
+                        bf16_t* dst = (bf16_t*)(patch + r * STEM_PITCH) + 4 * j + 3;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) dst[e] = (bf16_t)v[i][e];
+                        for (int e = 0; e < 4; ++e) dst[e] = ok[i] ? (bf16_t)v[i][e] : (bf16_t)0.f;
+                    }
                 }
             }
         }
