@@ -425,18 +425,26 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     // the value or the zero padding is staged.  With the loads inside divergent `if`s the compiler put an s_waitcnt vmcnt(0) in
     // front of each of them: ten serialized memory round trips per work item -- the kernel's phases simply added up (179 us for
     // layer 1, of which 86 were this chain).
+    // (row, column) of this thread's staging slots inside the band are the same for every work item: computed once (the division
+    // by the runtime row width is ~30 instructions per slot, and with the loads no longer serialized the staging phase is bound
+    // by instruction issue), packed row << 16 | column
+    int slot_rc[NPF];
+#pragma unroll
+    for (int i = 0; i < NPF; ++i) {
+        const int pi = s_pix0 + 32 * i;
+        const int ry = pi / Wp, rx = pi - ry * Wp;
+        slot_rc[i] = pi < npix_in ? ((ry << 16) | rx) : -1;
+    }
     auto prefetch = [&](int item) {
         const int b = item / p.bands, band = item - b * p.bands;
         const int iy0 = band * p.TH * p.stride - 1;
         const bf16_t* xb = x + (long)b * p.H * p.W * p.C + c0 + s_chunk * 8;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int pi = s_pix0 + 32 * i;
-            const int ry = pi / Wp, rx = pi - ry * Wp;
-            const int yin = iy0 + ry, xin = rx - 1;
-            pf_in[i] = pi < npix_in && yin >= 0 && yin < p.H && xin >= 0 && xin < p.W;
+            const int yin = iy0 + (slot_rc[i] >> 16), xin = (slot_rc[i] & 0xffff) - 1;
+            pf_in[i] = slot_rc[i] >= 0 && yin >= 0 && yin < p.H && xin >= 0 && xin < p.W;
             const int yc = min(max(yin, 0), p.H - 1), xc = min(max(xin, 0), p.W - 1);
-            pf[i] = *reinterpret_cast<const bf16x8*>(xb + ((long)yc * p.W + xc) * p.C);
+            pf[i] = *reinterpret_cast<const bf16x8*>(xb + (yc * p.W + xc) * p.C);
         }
     };
     const int n_items = p.B * p.bands;
