@@ -44,6 +44,10 @@ __device__ inline bf16x4 lds_tr_read(const char* p) {
     return __builtin_bit_cast(bf16x4, v);
 }
 
+// CONV: the B operand is gathered at a convolution tap (grouped 3x3 weight gradient); otherwise both operands are plain row-major
+// matrices and every load is unconditional from a clamped row / column (a branch around a load costs a serializing vmcnt(0), and the
+// tap path's index arithmetic -- 64-bit divisions per load -- otherwise sits in the plain GEMM's loop too)
+template <bool CONV>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnDev p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * TN_TILE_BYTES];
     char* sA = smem;
@@ -77,18 +81,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnDev p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     u32x4 ra[4], rb[4];
+    const int a_col = min(n0 + s_chunk * 8, p.N - 8), b_col = min(k0 + s_chunk * 8, p.K - 8);     // clamped: always a valid 16-byte chunk
     auto load_step = [&](long m0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long m = m0 + s_row0 + 16 * i;
             const u32x4 z = {0u, 0u, 0u, 0u};
-            ra[i] = z; rb[i] = z;
-            if (m < m_end) {
-                if (a_col_ok) ra[i] = *reinterpret_cast<const u32x4*>(p.A + m * p.lda + n0 + s_chunk * 8);
-                if (b_col_ok) {
-                    if (p.taps == 1) {
-                        rb[i] = *reinterpret_cast<const u32x4*>(p.B + m * p.ldb + k0 + s_chunk * 8);
-                    } else {
+            if constexpr (!CONV) {
+                const long mc = m < m_end ? m : m_end - 1;
+                const u32x4 va = *reinterpret_cast<const u32x4*>(p.A + mc * p.lda + a_col);
+                const u32x4 vb = *reinterpret_cast<const u32x4*>(p.B + mc * p.ldb + b_col);
+                ra[i] = (m < m_end && a_col_ok) ? va : z;
+                rb[i] = (m < m_end && b_col_ok) ? vb : z;
+            } else {
+                ra[i] = z; rb[i] = z;
+                if (m < m_end) {
+                    if (a_col_ok) ra[i] = *reinterpret_cast<const u32x4*>(p.A + m * p.lda + n0 + s_chunk * 8);
+                    if (b_col_ok) {
                         const int ox = (int)(m % p.Wo);
                         const long t = m / p.Wo;
                         const int oy = (int)(t % p.Ho);
@@ -392,7 +401,7 @@ extern "C" int cvcl_gemm_tn(int dtype, const void* A, int lda, const void* B, in
         d.A = (const bf16_t*)A; d.B = (const bf16_t*)B; d.P = (float*)workspace;
         d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.S = pl.S; d.chunk = pl.chunk;
         d.tiles_n = pl.tiles_n; d.tiles_k = pl.tiles_k; d.diag = 0; d.taps = 1;
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(pl.ntile * pl.S, 1), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, dim3(pl.ntile * pl.S, 1), dim3(256), 0, st, d);
     } else {
         TnF32Dev d = {(const float*)A, (const float*)B, (float*)workspace, M, N, K, lda, ldb, pl.S, pl.chunk, pl.tiles_k};
         hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3(pl.ntile, pl.S), dim3(256), 0, st, d);
@@ -439,7 +448,7 @@ extern "C" int cvcl_gemm_tn_colsum(const void* A, int lda, const void* B, int ld
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldb = ldb; d.S = pl.S; d.chunk = pl.chunk;
     d.tiles_n = pl.tiles_n; d.tiles_k = pl.tiles_k; d.diag = 0; d.taps = 1;
     d.colsum = (float*)((char*)workspace + tn_colsum_off(pl, N, K));
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(pl.ntile * pl.S, 1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, dim3(pl.ntile * pl.S, 1), dim3(256), 0, st, d);
     CVCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(tn_reduce_kernel, dim3(reduce_grid((long)N * k_keep)), dim3(256), 0, st, (const float*)workspace, C, pl.S, N, K, k_keep);
     hipLaunchKernelGGL(tn_colsum_reduce_kernel, dim3(cvcl_div_up(N, 256)), dim3(256), 0, st, (const float*)d.colsum, pl.S, pl.tiles_n, N, colsum);
@@ -474,7 +483,7 @@ extern "C" int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int
     d.M = M; d.N = C; d.K = C; d.lda = C; d.ldb = C; d.S = pl.S; d.chunk = pl.chunk;
     d.tiles_n = pl.tiles_n; d.tiles_k = pl.tiles_k; d.diag = 1;
     d.taps = 9; d.Ho = Ho; d.Wo = Wo; d.Hi = H; d.Wi = W; d.stride = stride;
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(pl.ntile * pl.S, 9), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, dim3(pl.ntile * pl.S, 9), dim3(256), 0, st, d);
     CVCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3(reduce_grid((long)C * cg * 9)), dim3(256), 0, st, (const float*)workspace, dw,
                        pl.S, C, cg);
@@ -526,7 +535,7 @@ extern "C" int cvcl_conv1x1_bn_stats_gram(const void* A, int lda, const void* W,
     d.M = M; d.N = K; d.K = K; d.lda = lda; d.ldb = lda; d.S = g.pl.S; d.chunk = g.pl.chunk;
     d.tiles_n = g.pl.tiles_n; d.tiles_k = g.pl.tiles_k; d.diag = 0; d.taps = 1;
     d.colsum = (float*)(ws + g.off_cs);
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(g.pl.ntile * g.pl.S, 1), dim3(256), 0, st, d);
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, dim3(g.pl.ntile * g.pl.S, 1), dim3(256), 0, st, d);
     CVCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(reduce_grid((long)K * K + K)), dim3(256), 0, st, (const float*)ws,
                        (const float*)(ws + g.off_cs), g.pl.S, K, g.pl.tiles_n, (float*)(ws + g.off_g), (float*)(ws + g.off_csr));
