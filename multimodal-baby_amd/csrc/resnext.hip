@@ -873,10 +873,15 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         { const char* e = getenv("CVCL_GCONV_ABLATE"); d.ablate = e ? atoi(e) : 0; }
         const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);
         CvclProfScope prof(stream, CVCL_K_GCONV);
+        static bool attr_set[2][11] = {};                    // per instantiation (wide, slots)
         auto launch = [&](auto kern) -> int {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
-                return CVCL_ELAUNCH;
+            bool& done = attr_set[cg == 32][slots <= 4 ? 4 : slots <= 6 ? 6 : slots <= 8 ? 8 : 10];
+            if (!done) {
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
+                    return CVCL_ELAUNCH;
+                }
+                done = true;
             }
             hipLaunchKernelGGL(kern, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
             return CVCL_OK;
