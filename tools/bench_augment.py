@@ -41,6 +41,7 @@ print(f"device transform: {ms * 1e3:.0f} us per batch of {a.batch} ({a.batch / m
       f"write); host draws {t_draw * 1e3:.1f} ms per batch")
 try:
     from PIL import Image, ImageFilter
+    torch.set_num_threads(1)                       # a DataLoader worker: one core per frame stream
     fr = frames[:a.cpu_frames].cpu().numpy()
     mean = torch.tensor([0.485, 0.456, 0.406]).view(3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(3, 1, 1)
