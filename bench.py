@@ -60,8 +60,10 @@ def synthetic_batch_on_device(batch, seed, device, vocab=2350):
 def gemm_algorithmic_work(B):
     """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode):
     every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
-    enqueues: conv1 and downsample (A + W + C); conv3 of layers 3-4 (A + W + C); conv3 of layers 1-2 twice -- a
-    statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C)."""
+    enqueues: conv1 and downsample (A + W + C); conv3 of layers 2-4 (A + W + C); conv3 of layer 1 twice -- a
+    statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The number of leading
+    stages that use the fused tail is the library's $CVCL_FUSED_TAIL_STAGES, default 1.)"""
+    fused_stages = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "1"))
     nbytes = flops = launches = 0
     inplanes, h = 64, 56
     for stage, blocks in enumerate((3, 4, 6, 3)):
@@ -74,13 +76,13 @@ def gemm_algorithmic_work(B):
             plain = [(m_in, width, inplanes)]                       # conv1
             if bi == 0:
                 plain.append((m_out, outc, inplanes))               # downsample
-            if stage >= 2:
+            if stage >= fused_stages:
                 plain.append((m_out, outc, width))                  # conv3, raw output materialised
             for (m, n, k) in plain:
                 nbytes += 2 * (m * k + n * k + m * n)
                 flops += 2 * m * n * k
                 launches += 1
-            if stage < 2:                                           # conv3 as statistics pass + fused tail pass
+            if stage < fused_stages:                                # conv3 as statistics pass + fused tail pass
                 m, n, k = m_out, outc, width
                 nbytes += 2 * (m * k + n * k) + 2 * (m * k + n * k + 2 * m * n)
                 flops += 2 * (2 * m * n * k)

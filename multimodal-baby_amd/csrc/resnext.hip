@@ -1076,12 +1076,15 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
             // (one pass) instead of in the GEMM operand load (once per 128-column output tile): see bn_relu_apply_kernel.
             if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
             char* dst = last ? (char*)layer4_out_nhwc : OUT;
-            // Layers 1-2 in bf16: conv3 is HBM-bound and cheap, so it runs twice -- a statistics-only pass (reads only
+            // Layer 1 in bf16 (CVCL_FUSED_TAIL_STAGES leading stages, default 1; measured 6.79 / 6.85 / 6.89 / 7.11 ms per step for
+            // 1 / 2 / 0 / 3 stages since bn_add_relu runs at the HBM rate): conv3 is HBM-bound and cheap, so it runs twice -- a
+            // statistics-only pass (reads only
             // the narrow operand), then a pass whose epilogue applies BN3 + identity / normalised downsample + ReLU
             // and writes the block output -- instead of materialising raw3 and re-reading it in bn_add_relu
             // (saves one write and one read of the wide tensor; results are bit-identical).
             // In eval mode there is no statistics pass at all, so the fused tail is used in every stage.
-            const bool fused_tail = dtype == CVCL_BF16 && (stage < 2 || !training);
+            static const int fused_stages = [] { const char* e = getenv("CVCL_FUSED_TAIL_STAGES"); return e ? atoi(e) : 1; }();
+            const bool fused_tail = dtype == CVCL_BF16 && (stage < fused_stages || !training);
             auto conv3_args = [&]() {
                 cvcl_gemm_args a = {};
                 a.A = R2; a.W = layers[l3].w;
