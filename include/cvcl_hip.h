@@ -199,6 +199,20 @@ size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W);
 int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
                        const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
                        void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream);
+/* The train-mode pass with its BatchNorm running-statistics update split off (no counterpart in the reference, which runs
+ * one pass at a time; same results).  Consecutive passes of a FROZEN trunk are independent except for those 53 EMA updates
+ * (torch.nn.BatchNorm2d train mode, reached from multimodal.py:88-104 because Lightning keeps .train()), so a host may enqueue
+ * pass k+1 on a second stream beside pass k and apply the updates in pass order:
+ *   cvcl_resnext50_fwd_deferred_stats  = cvcl_resnext50_fwd(training = 1) that writes every layer's batch (mean, unbiased
+ *       variance) to moments ([53][2][2048] floats = cvcl_resnext50_moments_floats()) and touches no BatchNorm buffer;
+ *   cvcl_resnext50_apply_moments       = the 53 updates r <- (1 - momentum) r + momentum x and num_batches_tracked += 1 in one
+ *       launch; enqueue it behind the previous pass's apply.  Bit-identical to the updates of cvcl_resnext50_fwd.          */
+size_t cvcl_resnext50_moments_floats(void);
+int cvcl_resnext50_fwd_deferred_stats(int dtype, int B, int H, int W, const float* x_nchw,
+                                      const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
+                                      void* layer4_out_nhwc, float* pooled, float eps, float* moments, void* stream);
+int cvcl_resnext50_apply_moments(const cvcl_convbn_params* layers, int n_layers, const float* moments, float momentum,
+                                 void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * DINO ViT image encoder (multimodal/vision_transformer_dino_mugs.py:87-250), the one-layer text

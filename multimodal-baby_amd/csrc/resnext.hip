@@ -26,11 +26,17 @@ constexpr int kMaxStatsRows = 1024;
 // ------------------------------------------------------------------------------------------------
 // stats [rows][2][C] partial sums -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale;
 // running_mean/var EMA with the unbiased variance (nn.BatchNorm2d train mode), num_batches_tracked += 1.
+// the running-statistics update r <- (1 - m) r + m x: one spelling, shared by the in-place and the deferred form (identical bits)
+__device__ inline float bn_ema(float r, float x, float m) { return fmaf(m, x, (1.f - m) * r); }
+
+// moments != NULL: the batch mean / unbiased variance are written there ([2][C]) and the running statistics are left alone --
+// `bn_apply_moments_kernel` applies them later (cvcl_resnext50_fwd_deferred_stats: passes pipelined on two streams).
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int rows, double count,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            int64_t* __restrict__ nbt, float momentum, float eps,
-                                                           float* __restrict__ scale, float* __restrict__ shift, int C) {
+                                                           float* __restrict__ scale, float* __restrict__ shift, int C,
+                                                           float* __restrict__ moments, int moments_ld) {
     // 16 channels x 64 row slices per workgroup (short dependent-load chains: the early layers have 512 partial rows and
     // only 64-256 channels); slices combined in a fixed order (deterministic)
     constexpr int NS = 64, NC = 16;
@@ -66,13 +72,31 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         const float sc = gamma[ch] / sqrtf((float)var + eps);
         scale[ch] = sc;
         shift[ch] = beta[ch] - (float)mean * sc;
-        if (running_mean) {
-            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-            running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * (float)mean;
-            running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * (float)unbiased;
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        if (moments) {
+            moments[ch] = (float)mean;
+            moments[moments_ld + ch] = (float)unbiased;
+        } else if (running_mean) {
+            running_mean[ch] = bn_ema(running_mean[ch], (float)mean, momentum);
+            running_var[ch] = bn_ema(running_var[ch], (float)unbiased, momentum);
         }
     }
-    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+    if (!moments && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+}
+
+// deferred running-statistics update of the whole trunk: all 53 layers in one launch, from the moments a pass left behind
+struct ApplyMomentsAll {
+    float* rm[53]; float* rv[53]; int64_t* nbt[53];
+    int C[53];
+};
+__global__ __launch_bounds__(256) void bn_apply_moments_kernel(ApplyMomentsAll t, const float* __restrict__ moments, float momentum) {
+    const int l = blockIdx.x;
+    const float* m = moments + (size_t)l * 4096;
+    for (int ch = threadIdx.x; ch < t.C[l]; ch += 256) {
+        t.rm[l][ch] = bn_ema(t.rm[l][ch], m[ch], momentum);
+        t.rv[l][ch] = bn_ema(t.rv[l][ch], m[2048 + ch], momentum);
+    }
+    if (threadIdx.x == 0 && t.nbt[l]) *t.nbt[l] += 1;
 }
 
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -685,16 +709,23 @@ int grid_for(long total, int per_block = 256, int cap = 4096) {
 // ================================================================================================
 // C ABI
 // ================================================================================================
-extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const float* gamma, const float* beta,
-                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                                float eps, float* scale, float* shift, int C, void* stream) {
+static int bn_finalize_launch(const float* stats, int rows, long count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                              float eps, float* scale, float* shift, int C, float* moments, int moments_ld, void* stream) {
     CVCL_CHECK_ARG(stats && gamma && beta && scale && shift && rows > 0 && count > 0 && C > 0, "cvcl_bn_finalize: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 16)), dim3(1024), 0, (hipStream_t)stream, stats, rows,
                        (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
-                       shift, C);
+                       shift, C, moments, moments_ld);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
+}
+
+extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                                float eps, float* scale, float* shift, int C, void* stream) {
+    return bn_finalize_launch(stats, rows, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                              scale, shift, C, nullptr, 0, stream);
 }
 
 extern "C" int cvcl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
@@ -987,9 +1018,9 @@ extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W)
            gram_ws_bytes(B, H, W);
 }
 
-extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
-                                  const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
-                                  void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream) {
+static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, const float* x_nchw,
+                              const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
+                              void* layer4_out_nhwc, float* pooled, float momentum, float eps, float* moments, void* stream) {
     CVCL_CHECK_ARG(x_nchw && layers && workspace && layer4_out_nhwc && pooled, "cvcl_resnext50_fwd: null pointer");
     CVCL_CHECK_ARG(n_layers == 53, "cvcl_resnext50_fwd: expected 53 conv+bn layers, got %d", n_layers);
     CVCL_CHECK_ARG(B > 0 && H % 32 == 0 && W % 32 == 0, "cvcl_resnext50_fwd: H, W must be multiples of 32");
@@ -1013,8 +1044,9 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
     auto finalize = [&](int l, int rows, long count, int C) -> int {
         const cvcl_convbn_params& L = layers[l];
         if (training)
-            return cvcl_bn_finalize(stats, rows, count, L.gamma, L.beta, L.running_mean, L.running_var,
-                                    L.num_batches_tracked, momentum, eps, scale_of(l), shift_of(l), C, stream);
+            return bn_finalize_launch(stats, rows, count, L.gamma, L.beta, L.running_mean, L.running_var, L.num_batches_tracked,
+                                      momentum, eps, scale_of(l), shift_of(l), C, moments ? moments + (size_t)l * 4096 : nullptr, 2048,
+                                      stream);
         return CVCL_OK;                                   // eval mode: every layer's affine was produced up front
     };
     if (!training) {
@@ -1139,4 +1171,53 @@ extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, 
         }
     }
     return cvcl_avgpool(dtype, layer4_out_nhwc, pooled, B, h * wd, 2048, stream);
+}
+
+extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
+                                  const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
+                                  void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream) {
+    return resnext50_fwd_impl(dtype, B, H, W, training, x_nchw, layers, n_layers, workspace, workspace_bytes, layer4_out_nhwc, pooled,
+                              momentum, eps, nullptr, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Train-mode pass with the running-statistics update split off, for passes pipelined on two streams: a frozen trunk's
+// consecutive passes are independent except for the BatchNorm running statistics (each pass normalises with its own batch
+// statistics), so pass k+1 may run beside pass k -- each fills the other's tail rounds, dependent-launch gaps and
+// MFMA-bound phases -- as long as the 53 EMA updates are applied in pass order.  The pass leaves (mean, unbiased variance) of
+// every layer in `moments` ([53][2][2048] floats) and touches no BatchNorm buffer; cvcl_resnext50_apply_moments, enqueued by
+// the caller behind the previous pass's apply (one event), performs the updates of cvcl_resnext50_fwd bit for bit.
+extern "C" size_t cvcl_resnext50_moments_floats(void) { return (size_t)53 * 2 * 2048; }
+
+extern "C" int cvcl_resnext50_fwd_deferred_stats(int dtype, int B, int H, int W, const float* x_nchw,
+                                                 const cvcl_convbn_params* layers, int n_layers, void* workspace,
+                                                 size_t workspace_bytes, void* layer4_out_nhwc, float* pooled, float eps,
+                                                 float* moments, void* stream) {
+    CVCL_CHECK_ARG(moments, "cvcl_resnext50_fwd_deferred_stats: moments is NULL");
+    return resnext50_fwd_impl(dtype, B, H, W, 1, x_nchw, layers, n_layers, workspace, workspace_bytes, layer4_out_nhwc, pooled,
+                              0.f, eps, moments, stream);
+}
+
+extern "C" int cvcl_resnext50_apply_moments(const cvcl_convbn_params* layers, int n_layers, const float* moments, float momentum,
+                                            void* stream) {
+    CVCL_CHECK_ARG(layers && moments && n_layers == 53, "cvcl_resnext50_apply_moments: expected 53 conv+bn layers and their moments");
+    ApplyMomentsAll t;
+    int l = 0;
+    auto put = [&](int C) {
+        t.rm[l] = layers[l].running_mean; t.rv[l] = layers[l].running_var; t.nbt[l] = layers[l].num_batches_tracked;
+        t.C[l] = C; ++l;
+    };
+    put(64);
+    for (int st = 0; st < 4; ++st)
+        for (int b = 0; b < kLayers[st]; ++b) {
+            const int pl = 64 << st;
+            put(pl * 2); put(pl * 2); put(pl * 4);
+            if (b == 0) put(pl * 4);
+        }
+    for (int i = 0; i < 53; ++i)
+        CVCL_CHECK_ARG(t.rm[i] && t.rv[i], "cvcl_resnext50_apply_moments: layer %d lacks running statistics", i);
+    CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
+    hipLaunchKernelGGL(bn_apply_moments_kernel, dim3(53), dim3(256), 0, (hipStream_t)stream, t, moments, momentum);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
 }

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -119,6 +120,8 @@ class ResNet(nn.Module):
             arr[i].running_mean = H.ptr(bn.running_mean, torch.float32)
             arr[i].running_var = H.ptr(bn.running_var, torch.float32)
             arr[i].num_batches_tracked = H.ptr(bn.num_batches_tracked, torch.int64)
+        if device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()   # packed once, then read by every stream that runs the trunk
         self._pack_cache["k"] = (key, (arr, keep))
         return arr, keep
 
@@ -139,9 +142,15 @@ class ResNet(nn.Module):
             return ts.wait(handle)
         return self._trunk_launch(x)
 
-    def enable_trunk_stream(self, device, inputs="caller", stream=None):
-        """Run the frozen trunk on a stream of its own so it overlaps the previous step's trainable tail (see H.TrunkStream)."""
-        self.__dict__["_trunk_stream"] = H.TrunkStream(device, inputs, stream) if inputs else None
+    def enable_trunk_stream(self, device, inputs="caller", stream=None, n_streams=None):
+        """Run the frozen trunk on a stream of its own so it overlaps the previous step's trainable tail (see H.TrunkStream).
+        n_streams = 2 (the default; $CVCL_TRUNK_STREAMS overrides): consecutive passes alternate between two streams and also
+        overlap each other -- each has its own workspace, and the BatchNorm running statistics are updated in pass order by
+        ``cvcl_resnext50_apply_moments`` (same values as the one-stream schedule, bit for bit)."""
+        if n_streams is None:
+            n_streams = 1 if stream is not None else int(os.environ.get("CVCL_TRUNK_STREAMS", "2"))
+        self.__dict__["_trunk_stream"] = H.TrunkStream(device, inputs, stream, n_streams) if inputs else None
+        self.__dict__["_ema_done"] = None
         return self.__dict__["_trunk_stream"]
 
     def _trunk_launch(self, x, slot=None):
@@ -151,12 +160,15 @@ class ResNet(nn.Module):
         with torch.no_grad():
             arr, _keep = self._packed_layers(dt, x.device)
             nb = lib.cvcl_resnext50_workspace_bytes(dt, B, Hh, Ww)
-            ws = self._ws_cache.get((nb, str(x.device)))
+            ts = self.__dict__.get("_trunk_stream")
+            piped = slot is not None and ts is not None and ts.n_streams > 1    # passes on two streams: scratch per stream
+            wkey = (nb, str(x.device), slot if piped else None)
+            ws = self._ws_cache.get(wkey)
             if ws is None:
-                for k in [k for k in self._ws_cache if not (isinstance(k, tuple) and k and k[0] == "out")]:
+                for k in [k for k in self._ws_cache if isinstance(k[0], int) and k[:2] != wkey[:2]]:    # other batch shapes' scratch
                     del self._ws_cache[k]
                 ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
-                self._ws_cache[(nb, str(x.device))] = ws
+                self._ws_cache[wkey] = ws
             if slot is None:
                 fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
                 pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
@@ -166,9 +178,29 @@ class ResNet(nn.Module):
                     self._ws_cache[key] = (torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device),
                                            torch.empty(B, 2048, dtype=torch.float32, device=x.device))
                 fmap, pooled = self._ws_cache[key]
-            H.check(lib.cvcl_resnext50_fwd(dt, B, Hh, Ww, int(self.training), H.ptr(x), arr, len(arr), H.ptr(ws), nb,
-                                           H.ptr(fmap), H.ptr(pooled), BN_MOMENTUM, BN_EPS, H.stream_ptr()),
-                    "cvcl_resnext50_fwd")
+            if piped and self.training:
+                # the pass leaves its batch moments behind; the 53 running-statistics updates run as one launch behind the
+                # previous pass's (other stream), so they are applied in pass order with the one-stream arithmetic
+                mkey = ("moments", slot, str(x.device))
+                if mkey not in self._ws_cache:
+                    self._ws_cache[mkey] = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=x.device)
+                moments = self._ws_cache[mkey]
+                H.check(lib.cvcl_resnext50_fwd_deferred_stats(dt, B, Hh, Ww, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap),
+                                                              H.ptr(pooled), BN_EPS, H.ptr(moments), H.stream_ptr()),
+                        "cvcl_resnext50_fwd_deferred_stats")
+                cur = torch.cuda.current_stream(x.device)
+                prev = self.__dict__.get("_ema_done")
+                if prev is not None:
+                    cur.wait_event(prev)
+                H.check(lib.cvcl_resnext50_apply_moments(arr, len(arr), H.ptr(moments), BN_MOMENTUM, H.stream_ptr()),
+                        "cvcl_resnext50_apply_moments")
+                done = torch.cuda.Event()
+                done.record(cur)
+                self.__dict__["_ema_done"] = done
+            else:
+                H.check(lib.cvcl_resnext50_fwd(dt, B, Hh, Ww, int(self.training), H.ptr(x), arr, len(arr), H.ptr(ws), nb,
+                                               H.ptr(fmap), H.ptr(pooled), BN_MOMENTUM, BN_EPS, H.stream_ptr()),
+                        "cvcl_resnext50_fwd")
         return pooled, fmap.permute(0, 3, 1, 2)
 
     # caches hold ctypes arrays / device buffers: never pickled (save_hyperparameters pickles whole encoder modules)
@@ -177,6 +209,7 @@ class ResNet(nn.Module):
         d["_pack_cache"], d["_ws_cache"] = {}, {}
         d["_pre_head_callback"] = None
         d["_trunk_stream"] = None
+        d["_ema_done"] = None
         return d
 
     def __setstate__(self, d):

@@ -102,10 +102,10 @@ class VisionTransformer(nn.Module):
         self.__dict__.setdefault("compute_dtype", torch.float32)
         self.__dict__.setdefault("_cache", {})
 
-    def enable_trunk_stream(self, device, inputs="caller", stream=None):
+    def enable_trunk_stream(self, device, inputs="caller", stream=None, n_streams=None):
         """Run the frozen ViT on a stream of its own so it overlaps the previous step's trainable tail (see H.TrunkStream)."""
         from . import vit_hip
-        return vit_hip.enable_trunk_stream(self, device, inputs, stream)
+        return vit_hip.enable_trunk_stream(self, device, inputs, stream, n_streams)
 
     def forward(self, x):
         """-> cls token after the final LayerNorm, [B, D] fp32 (reference :245-250)."""

@@ -6,6 +6,8 @@ the compute dtype (bf16 perf mode / fp32 parity mode).  Inference-only (the DINO
 configuration; ``--finetune_cnn`` with a ViT raises)."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _hip as H
@@ -51,6 +53,8 @@ def _packed(model, dt, device):
                 H.check(lib.cvcl_quant_rows_fp8(H.F32, H.ptr(wf), K, None, None, 0.0, H.ptr(q), H.ptr(sc), N, K, H.stream_ptr()),
                         "cvcl_quant_rows_fp8")
                 bw[name + "_q"], bw[name + "_s"] = q, sc
+    if torch.device(device).type == "cuda":
+        torch.cuda.current_stream(device).synchronize()      # packed once, then read by every stream that runs the trunk
     model._cache["w"] = (key, w)
     return w
 
@@ -93,8 +97,12 @@ def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
     return _vit_forward(model, x, None)
 
 
-def enable_trunk_stream(model, device, inputs="caller", stream=None):
-    model.__dict__["_trunk_stream"] = H.TrunkStream(device, inputs, stream) if inputs else None
+def enable_trunk_stream(model, device, inputs="caller", stream=None, n_streams=None):
+    """n_streams = 2 ($CVCL_VIT_TRUNK_STREAMS): consecutive passes of the frozen ViT alternate between two streams and overlap each
+    other (the forward keeps no state between passes: per-pass activations come from the stream's own allocator pool)."""
+    if n_streams is None:
+        n_streams = 1 if stream is not None else int(os.environ.get("CVCL_VIT_TRUNK_STREAMS", "1"))
+    model.__dict__["_trunk_stream"] = H.TrunkStream(device, inputs, stream, n_streams) if inputs else None
     return model.__dict__["_trunk_stream"]
 
 

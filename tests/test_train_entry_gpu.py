@@ -223,8 +223,9 @@ def test_eval_entry_batched_trials_match_reference_loop(dev, tmp_path, monkeypat
 
 
 def test_trunk_stream_overlap_is_bit_identical(dev):
-    """H.TrunkStream: the frozen trunk on its own stream (overlapping the previous step's trainable tail) gives the same losses
-    and the same parameters, bit for bit, as the single-stream schedule over several optimizer steps."""
+    """H.TrunkStream: the frozen trunk on its own stream (overlapping the previous step's trainable tail), and consecutive trunk
+    passes alternating between two streams (overlapping each other as well), give the same losses, parameters and BatchNorm
+    buffers, bit for bit, as the single-stream schedule over several optimizer steps."""
     import contextlib, io
     import bench
     from multimodal.multimodal import TextEncoder, VisionEncoder
@@ -245,7 +246,8 @@ def test_trunk_stream_overlap_is_bit_identical(dev):
         batches = [bench.synthetic_batch_on_device(16, seed=s, device=dev) + (None,) for s in range(3)]
         torch.cuda.synchronize()
         if stream_mode:
-            ve.model.enable_trunk_stream(dev, inputs="ready")
+            ts = ve.model.enable_trunk_stream(dev, inputs="ready", n_streams=stream_mode)
+            assert ts.n_streams == stream_mode
         losses = []
         for i in range(6):
             opt.zero_grad(set_to_none=True)
@@ -254,18 +256,22 @@ def test_trunk_stream_overlap_is_bit_identical(dev):
             opt.step()
             losses.append(out["loss"].detach())
         torch.cuda.synchronize()
-        return torch.stack(losses).cpu(), lit.vision_encoder.model.fc.weight.detach().cpu().clone(), \
-            lit.vision_encoder.model.bn1.running_mean.detach().cpu().clone()
+        # every BatchNorm buffer of the trunk: the two-stream schedule applies the running-statistics updates of consecutive
+        # passes in pass order (cvcl_resnext50_apply_moments), so all 53 x (mean, var, count) must match too
+        buffers = torch.cat([b.detach().double().flatten().cpu() for _, b in lit.vision_encoder.model.named_buffers()])
+        return torch.stack(losses).cpu(), lit.vision_encoder.model.fc.weight.detach().cpu().clone(), buffers
 
-    l0, w0, r0 = run(False)
-    l1, w1, r1 = run(True)
-    assert torch.equal(l0, l1) and torch.equal(w0, w1) and torch.equal(r0, r1)
+    l0, w0, r0 = run(0)
+    assert float(r0.abs().sum()) > 0
+    for n_streams in (1, 2):
+        l1, w1, r1 = run(n_streams)
+        assert torch.equal(l0, l1) and torch.equal(w0, w1) and torch.equal(r0, r1), n_streams
 
 
 def test_trainer_trunk_stream_flag_bit_identical(dev, tmp_path, monkeypatch):
     """train.py --trunk_stream True (batch copy + device frame transform + frozen trunk on their own stream, overlapping the
     previous step's tail; validation back on the main stream) trains to the same parameters and validation metrics, bit for
-    bit, as the single-stream run -- ResNeXt and ViT trunks."""
+    bit, as the single-stream run -- ResNeXt and ViT trunks, one and two trunk streams."""
     import contextlib, io
     import train
     import multimodal.multimodal as mm
@@ -281,7 +287,9 @@ def test_trainer_trunk_stream_flag_bit_identical(dev, tmp_path, monkeypatch):
             mm.load_model = lambda name, pretrained: vits.vit_base(patch_size=16, num_classes=0)
         try:
             res = []
-            for flag in ("False", "True"):
+            for flag, n_streams in (("False", "1"), ("True", "1"), ("True", "2")):
+                monkeypatch.setenv("CVCL_TRUNK_STREAMS", n_streams)          # two streams: consecutive trunk passes overlap too
+                monkeypatch.setenv("CVCL_VIT_TRUNK_STREAMS", n_streams)
                 torch.manual_seed(0)
                 with contextlib.redirect_stdout(io.StringIO()):
                     trainer, lit = train.main(base + extra + ["--trunk_stream", flag])
@@ -291,7 +299,8 @@ def test_trainer_trunk_stream_flag_bit_identical(dev, tmp_path, monkeypatch):
                             float(trainer.logged_metrics["val_loss"])))
         finally:
             mm.load_model = orig
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2], vit
+        for r in res[1:]:
+            assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) and res[0][2] == r[2], vit
 
 
 def test_vit_finetune_through_train_entry(dev, tmp_path, monkeypatch):

@@ -15,8 +15,8 @@ from bench import synthetic_batch_on_device
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=256); ap.add_argument("--patch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=10); ap.add_argument("--precision", default="bf16")
-ap.add_argument("--trunk-stream", action="store_true"); ap.add_argument("--finetune", action="store_true"); a = ap.parse_args()
-dev = torch.device("cuda:0")
+ap.add_argument("--trunk-stream", action="store_true"); ap.add_argument("--trunk-streams", type=int, default=1); ap.add_argument("--finetune", action="store_true"); a = ap.parse_args()
+dev = torch.device("cuda:0"); torch.manual_seed(0)
 args = argparse.Namespace(embedding_type="flat", embedding_dim=512, pretrained_cnn=False, cnn_dino=False, vit_dino=True,
                           finetune_cnn=a.finetune, text_encoder="transformer", crange=1, dropout_i=0.0, dropout_o=0.0,
                           pos_embed_type="learned", normalize_features=True, sim="max", temperature=0.07, fix_temperature=True,
@@ -31,7 +31,7 @@ lit.to(dev); lit.set_precision(a.precision); lit.train()
 opt = lit.configure_optimizers()
 if a.trunk_stream:
     from multimodal import vit_hip
-    vit_hip.enable_trunk_stream(ve.model, dev, inputs="ready")
+    vit_hip.enable_trunk_stream(ve.model, dev, inputs="ready", n_streams=a.trunk_streams)
 batch = synthetic_batch_on_device(a.batch, 0, dev) + (None,)
 def step():
     opt.zero_grad(set_to_none=True); out = lit.training_step(batch, 0); out["loss"].backward(); opt.step(); return out
