@@ -198,6 +198,9 @@ class ResNet(nn.Module):
                 done.record(cur)
                 self.__dict__["_ema_done"] = done
             else:
+                prev = self.__dict__.get("_ema_done")
+                if prev is not None and x.is_cuda:           # this pass reads / updates the running statistics in place: behind
+                    torch.cuda.current_stream(x.device).wait_event(prev)     # the last deferred update, whatever stream ran it
                 H.check(lib.cvcl_resnext50_fwd(dt, B, Hh, Ww, int(self.training), H.ptr(x), arr, len(arr), H.ptr(ws), nb,
                                                H.ptr(fmap), H.ptr(pooled), BN_MOMENTUM, BN_EPS, H.stream_ptr()),
                         "cvcl_resnext50_fwd")
