@@ -94,19 +94,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnDev p) {
                 ra[i] = (m < m_end && a_col_ok) ? va : z;
                 rb[i] = (m < m_end && b_col_ok) ? vb : z;
             } else {
-                ra[i] = z; rb[i] = z;
-                if (m < m_end) {
-                    if (a_col_ok) ra[i] = *reinterpret_cast<const u32x4*>(p.A + m * p.lda + n0 + s_chunk * 8);
-                    if (b_col_ok) {
-                        const int ox = (int)(m % p.Wo);
-                        const long t = m / p.Wo;
-                        const int oy = (int)(t % p.Ho);
-                        const long b = t / p.Ho;
-                        const int yi = oy * p.stride + ky, xi = ox * p.stride + kx;
-                        if (yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi)
-                            rb[i] = *reinterpret_cast<const u32x4*>(p.B + ((b * p.Hi + yi) * p.Wi + xi) * p.ldb + k0 + s_chunk * 8);
-                    }
-                }
+                // same rule for the gathered operand: both loads are issued unconditionally from clamped coordinates and the
+                // predicates (row inside the split, tap inside the image) select value or zero afterwards; M < 2^31 (checked by
+                // the host), so the pixel decomposition is 32-bit
+                const unsigned mc = (unsigned)(m < m_end ? m : m_end - 1);
+                const u32x4 va = *reinterpret_cast<const u32x4*>(p.A + (long)mc * p.lda + a_col);
+                const unsigned t = mc / (unsigned)p.Wo, ox = mc - t * (unsigned)p.Wo;
+                const unsigned b = t / (unsigned)p.Ho, oy = t - b * (unsigned)p.Ho;
+                const int yi = (int)oy * p.stride + ky, xi = (int)ox * p.stride + kx;
+                const bool inside = yi >= 0 && yi < p.Hi && xi >= 0 && xi < p.Wi;
+                const int yc = min(max(yi, 0), p.Hi - 1), xc = min(max(xi, 0), p.Wi - 1);
+                const u32x4 vb = *reinterpret_cast<const u32x4*>(p.B + (((long)b * p.Hi + yc) * p.Wi + xc) * p.ldb + b_col);
+                ra[i] = (m < m_end && a_col_ok) ? va : z;
+                rb[i] = (m < m_end && b_col_ok && inside) ? vb : z;
             }
         }
     };
@@ -471,6 +471,7 @@ extern "C" int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int
     CVCL_CHECK_ARG(C % TN_T == 0 && cg <= TN_T && TN_T % cg == 0, "cvcl_gconv3x3_wgrad: unsupported C=%d groups=%d", C, groups);
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long M = (long)B * Ho * Wo;
+    CVCL_CHECK_ARG(M < (1L << 31), "cvcl_gconv3x3_wgrad: B * Ho * Wo must be below 2^31");
     const TnPlan pl = tn_plan(M, C, C, 9, true, TN_T);
     if (workspace_bytes < tn_ws_bytes(pl, C, C, 9, true)) {
         cvcl_set_error("cvcl_gconv3x3_wgrad: workspace too small");
