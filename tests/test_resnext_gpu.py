@@ -232,6 +232,49 @@ def test_trunk_vs_oracle(H, dev, dt, training, B, S):
         assert int(sd["bn1.num_batches_tracked"]) == 0
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_deferred_statistics_pass_is_the_in_place_pass(H, dev, dt):
+    """cvcl_resnext50_fwd_deferred_stats + cvcl_resnext50_apply_moments (the form that lets two passes of a frozen trunk run on
+    two streams) against cvcl_resnext50_fwd(training = 1): same outputs, and after three passes the same 53 x (running_mean,
+    running_var, num_batches_tracked), bit for bit; the pass itself must leave the BatchNorm buffers untouched."""
+    import copy
+    from multimodal.resnext import ResNet, BN_MOMENTUM, BN_EPS
+    torch.manual_seed(3)
+    ref = ResNet().to(dev).train()
+    ref.compute_dtype = _t(dt)
+    for prm in ref.parameters():
+        prm.requires_grad_(False)
+    alt = copy.deepcopy(ref)
+    lib, cd = H.lib(), H.cvcl_dtype(_t(dt))
+    B, S = 3, 64
+    arr, _keep = alt._packed_layers(cd, dev)
+    nb = lib.cvcl_resnext50_workspace_bytes(cd, B, S, S)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    moments = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=dev)
+    for i in range(3):
+        x = torch.randn(B, 3, S, S, device=dev)
+        pooled_r, fmap_r = ref.trunk(x)
+        before = {k: v.clone() for k, v in alt.state_dict().items() if "running" in k or "tracked" in k}
+        fmap = torch.empty(B, S // 32, S // 32, 2048, dtype=_t(dt), device=dev)
+        pooled = torch.empty(B, 2048, dtype=torch.float32, device=dev)
+        H.check(lib.cvcl_resnext50_fwd_deferred_stats(cd, B, S, S, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap), H.ptr(pooled),
+                                                      BN_EPS, H.ptr(moments), H.stream_ptr()), "deferred")
+        after = alt.state_dict()
+        assert all(torch.equal(v, after[k]) for k, v in before.items())          # the pass wrote no BatchNorm buffer
+        H.check(lib.cvcl_resnext50_apply_moments(arr, len(arr), H.ptr(moments), BN_MOMENTUM, H.stream_ptr()), "apply")
+        assert torch.equal(pooled, pooled_r) and torch.equal(fmap.permute(0, 3, 1, 2), fmap_r)
+    sd_r, sd_a = ref.state_dict(), alt.state_dict()
+    n = 0
+    for k, v in sd_r.items():
+        if "running" in k or "tracked" in k:
+            assert torch.equal(v, sd_a[k]), k
+            n += 1
+    assert n == 53 * 3 and int(sd_a["layer4.2.bn3.num_batches_tracked"]) == 3
+    with pytest.raises(H.CvclError):
+        H.check(lib.cvcl_resnext50_fwd_deferred_stats(cd, B, S, S, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap), H.ptr(pooled),
+                                                      BN_EPS, None, H.stream_ptr()), "deferred")
+
+
 def test_trunk_properties_full_batch(H, dev):
     """BASELINE batch (256 x 224 x 224, bf16): eval-mode per-sample independence (a sample's features do not
     depend on its batch-mates) and determinism (bit-identical reruns)."""
