@@ -217,7 +217,13 @@ class TrunkStream:
             self.streams = [stream]
         else:
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n_streams)))]
-        self._step = 0                                     # launches so far: step k uses stream k % n and output slot k % 2
+        # launches so far: step k runs on stream k % n_streams (scratch is per stream: ``stream_index`` while fn runs) and writes
+        # output slot k % n_slots.  One slot more than streams: with as many slots as streams, step k+2's trunk would have to wait
+        # for step k's TAIL (the last reader of its slot) and each stream would idle for the length of a tail between its passes
+        self._step = 0
+        self.n_slots = len(self.streams) + 1
+        self.stream_index = 0
+        self._entries = []                                 # entry events of the last n_slots - 1 launches
 
     @property
     def n_streams(self):
@@ -234,22 +240,24 @@ class TrunkStream:
     def launch(self, fn, *inputs):
         """fn(slot) enqueues the trunk on the trunk stream and returns its output tensors; the caller's stream does NOT wait
         yet (``wait`` does), so work enqueued on it in between -- e.g. the deferred optimizer step of the previous batch --
-        overlaps the trunk too.  slot alternates 0 / 1: the trunk writes its outputs into one of two persistent buffer sets
-        (a fresh allocation per step would rotate through allocator blocks: the caller's stream holds each one until its
-        tail has run), so an output is valid until the step after next starts -- the trunk stream waits, before reusing a
-        slot, for the caller's stream to have passed the entry of the previous step, i.e. to have finished the tail that
-        read that slot.  (With two trunk streams slot k % 2 is also the stream index: scratch keyed by slot is private to a
-        stream.)"""
+        overlaps the trunk too.  slot cycles through n_slots persistent output buffer sets (a fresh allocation per step
+        would rotate through allocator blocks: the caller's stream holds each one until its tail has run), so an output is
+        valid until n_slots - 1 further steps have started -- the trunk stream waits, before reusing a slot, for the caller's
+        stream to have passed the entry of the step after the slot's last reader, i.e. to have finished the tail that read
+        it.  Scratch that must be private to a stream is keyed by ``self.stream_index`` (valid while fn runs)."""
         caller = torch.cuda.current_stream(self.device)
         stream = self.stream
         entry = torch.cuda.Event()
         entry.record(caller)                               # everything the caller enqueued for earlier steps precedes this
-        prev_entry, self._prev_entry = getattr(self, "_prev_entry", None), entry
+        # the last reader of this step's slot is the tail of step k - n_slots, which was enqueued before step k - n_slots + 1 entered
+        free = self._entries[0] if len(self._entries) == self.n_slots - 1 else None
+        self._entries = (self._entries + [entry])[-(self.n_slots - 1):]
         if self.inputs == "caller":
             stream.wait_stream(caller)
-        elif prev_entry is not None:
-            stream.wait_event(prev_entry)                  # the tail of two steps ago (last reader of this slot) is done
-        slot = self._step % 2
+        elif free is not None:
+            stream.wait_event(free)
+        slot = self._step % self.n_slots
+        self.stream_index = self._step % len(self.streams)
         self._step += 1
         with torch.cuda.stream(stream):
             outs = fn(slot)

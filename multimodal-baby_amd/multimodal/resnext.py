@@ -162,7 +162,8 @@ class ResNet(nn.Module):
             nb = lib.cvcl_resnext50_workspace_bytes(dt, B, Hh, Ww)
             ts = self.__dict__.get("_trunk_stream")
             piped = slot is not None and ts is not None and ts.n_streams > 1    # passes on two streams: scratch per stream
-            wkey = (nb, str(x.device), slot if piped else None)
+            sidx = ts.stream_index if piped else None
+            wkey = (nb, str(x.device), sidx)
             ws = self._ws_cache.get(wkey)
             if ws is None:
                 for k in [k for k in self._ws_cache if isinstance(k[0], int) and k[:2] != wkey[:2]]:    # other batch shapes' scratch
@@ -172,7 +173,7 @@ class ResNet(nn.Module):
             if slot is None:
                 fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
                 pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
-            else:                                         # side-stream mode: two persistent output sets (H.TrunkStream.run)
+            else:                                         # side-stream mode: a ring of persistent output sets (H.TrunkStream.launch)
                 key = ("out", slot, B, Hh, Ww, self.compute_dtype, str(x.device))
                 if key not in self._ws_cache:
                     self._ws_cache[key] = (torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device),
@@ -181,7 +182,7 @@ class ResNet(nn.Module):
             if piped and self.training:
                 # the pass leaves its batch moments behind; the 53 running-statistics updates run as one launch behind the
                 # previous pass's (other stream), so they are applied in pass order with the one-stream arithmetic
-                mkey = ("moments", slot, str(x.device))
+                mkey = ("moments", sidx, str(x.device))
                 if mkey not in self._ws_cache:
                     self._ws_cache[mkey] = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=x.device)
                 moments = self._ws_cache[mkey]

@@ -172,7 +172,7 @@ def _vit_forward(model, x: torch.Tensor, slot) -> torch.Tensor:
             H.gemm(mid, bw["fc2_w"], out=h, bias=bw["fc2_b"], residual=h)            # h = h + mlp(...)     (vit:147)
         if slot is None:
             cls = torch.empty(B, D, dtype=torch.float32, device=dev)
-        else:                                 # side-stream mode: two persistent outputs (see H.TrunkStream.run)
+        else:                                 # side-stream mode: a ring of persistent outputs (see H.TrunkStream.launch)
             ring = model.__dict__.setdefault("_trunk_out", {})
             key = (slot, B, D, str(dev))
             if key not in ring:
