@@ -13,6 +13,9 @@ with contextlib.redirect_stdout(io.StringIO()):
     args = c2_args(); ve = VisionEncoder(args); te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args)
     lit = MultiModalLitModel(ve, te, args)
 lit.to(dev); lit.set_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16"); lit.eval()
+n_streams = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # > 0: consecutive batches' trunk passes pipelined on that many HIP streams
+if n_streams:                                                 # (throughput of a feature-extraction loop, not the latency of one call)
+    torch.cuda.synchronize(); ve.model.enable_trunk_stream(dev, inputs="ready", n_streams=n_streams)
 for B in (1, 4, 16, 64, 256):
     x, y, yl = synthetic_batch_on_device(B, 0, dev)
     with torch.no_grad():
@@ -20,4 +23,4 @@ for B in (1, 4, 16, 64, 256):
         torch.cuda.synchronize(); t0 = time.perf_counter(); n = 30 if B <= 64 else 10
         for _ in range(n): out = lit.model(x, y, yl)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-    print(f"eval forward B={B}: {dt*1e3:.3f} ms  ({B/dt:.0f} images/s)")
+    print(f"eval forward B={B} trunk streams={n_streams}: {dt*1e3:.3f} ms  ({B/dt:.0f} images/s)")
