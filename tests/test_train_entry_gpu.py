@@ -263,7 +263,7 @@ def test_trunk_stream_overlap_is_bit_identical(dev):
 
     l0, w0, r0 = run(0)
     assert float(r0.abs().sum()) > 0
-    for n_streams in (1, 2):
+    for n_streams in (1, 2, 3):
         l1, w1, r1 = run(n_streams)
         assert torch.equal(l0, l1) and torch.equal(w0, w1) and torch.equal(r0, r1), n_streams
 
