@@ -21,6 +21,8 @@ There is no PyTorch-op fallback: CPU tensors raise in ``_hip.ptr``.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _hip as H
@@ -73,13 +75,72 @@ def _zero_stuff(dy: torch.Tensor) -> torch.Tensor:
     return z
 
 
+# ---- weight gradients on a stream of their own --------------------------------------------------------------------
+# In the backward pass only the data gradients are on the critical path (dX of layer l feeds layer l-1); a weight gradient is
+# needed by nobody before the optimizer step.  ``trunk_train`` therefore runs every weight-gradient kernel (TN GEMMs, the
+# grouped-conv tap GEMMs, the stem's im2col + GEMM: MFMA work) on a second HIP stream, beside the data-gradient chain and the
+# bandwidth-bound BatchNorm backward passes on the caller's stream.  The Function returns no gradient for the weight; the result
+# is parked and, when the backward pass ends (autograd engine callback), the caller's stream waits for the side stream once and
+# the gradients are stored / accumulated into ``param.grad`` -- the values autograd's own accumulation would have produced.
+# $CVCL_WGRAD_STREAM=0 keeps everything on one stream.
+_WGRAD_STREAMS: dict = {}
+_WGRAD_PENDING: list = []
+
+
+def _wgrad_stream(device) -> torch.cuda.Stream:
+    key = str(device)
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_STREAMS[key]
+
+
+def _wgrad_deferrable(weight) -> bool:
+    return (os.environ.get("CVCL_WGRAD_STREAM", "1") != "0" and isinstance(weight, torch.nn.Parameter) and weight.is_cuda
+            and weight.is_leaf and weight.requires_grad)
+
+
+def _flush_wgrads():
+    pending = list(_WGRAD_PENDING)
+    _WGRAD_PENDING.clear()
+    if not pending:
+        return
+    dev = pending[0][0].device
+    main = torch.cuda.current_stream(dev)
+    main.wait_stream(_wgrad_stream(dev))
+    for param, dw in pending:
+        dw.record_stream(main)                               # allocated on the side stream's pool, used here from now on
+        dw = dw.view(param.shape)
+        if param.grad is None:
+            param.grad = dw
+        else:
+            param.grad.add_(dw)
+
+
+def _defer_wgrad(param, compute, *reads):
+    """compute() -> dW (fp32) enqueued on the weight-gradient stream; ``reads``: tensors of the caller's stream it consumes."""
+    dev = param.device
+    main, side = torch.cuda.current_stream(dev), _wgrad_stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        dw = compute()
+    for t in reads:
+        t.record_stream(side)                                # their memory may be released on the caller's stream before the side stream is done
+    _WGRAD_PENDING.append((param, dw))
+    # one callback per deferral (the first to run flushes everything, the rest find nothing): a flag "already queued" would go
+    # stale if a backward pass died half way
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+
+
 class Conv1x1(torch.autograd.Function):
     """nn.Conv2d(cin, cout, 1, stride, bias=False) on NHWC: x [B,H,W,K] -> raw [B,Ho,Wo,N]."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int):
+    def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False):
         B, Hh, Ww, K = x.shape
         N = weight.shape[0]
+        ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
         wq = _pack(weight, H.PACK_DENSE, x.dtype).view(x.dtype).view(N, K)
         Ho, Wo = (Hh - 1) // stride + 1, (Ww - 1) // stride + 1
         out = torch.empty(B, Ho, Wo, N, dtype=x.dtype, device=x.device)
@@ -106,16 +167,20 @@ class Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = H.gemm(dy2, _transpose(wq)).view(B, Hh, Ww, K)
         if ctx.needs_input_grad[1]:
-            dw = _gemm_tn(dy2, x2).view(N, K, 1, 1)
-        return dx, dw, None
+            if ctx.param is not None:
+                _defer_wgrad(ctx.param, lambda: _gemm_tn(dy2, x2), dy2, x2)
+            else:
+                dw = _gemm_tn(dy2, x2).view(N, K, 1, 1)
+        return dx, dw, None, None
 
 
 class GroupedConv3x3(torch.autograd.Function):
     """nn.Conv2d(C, C, 3, stride, 1, groups=32, bias=False) on NHWC."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int):
+    def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False):
         B, Hh, Ww, Cn = x.shape
+        ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
         wp = _pack(weight, H.PACK_GCONV3, x.dtype)
         Ho, Wo = (Hh - 1) // stride + 1, (Ww - 1) // stride + 1
         out = torch.empty(B, Ho, Wo, Cn, dtype=x.dtype, device=x.device)
@@ -137,15 +202,22 @@ class GroupedConv3x3(torch.autograd.Function):
         dx = dw = None
         lib, s = H.lib(), H.stream_ptr()
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight, dtype=_F)
-            if x.dtype == torch.bfloat16:                 # 9 tap-shifted TN GEMMs on the diagonal channel slabs (MFMA)
-                nb = lib.cvcl_gconv3x3_wgrad_workspace_bytes(B, Hh, Ww, Cn, ctx.stride)
-                ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
-                H.check(lib.cvcl_gconv3x3_wgrad(H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, Cn, 32, ctx.stride, H.ptr(ws), nb, s),
-                        "cvcl_gconv3x3_wgrad")
+            def wgrad():
+                dw_ = torch.empty_like(weight, dtype=_F)
+                s_ = H.stream_ptr()
+                if x.dtype == torch.bfloat16:             # 9 tap-shifted TN GEMMs on the diagonal channel slabs (MFMA)
+                    nb = lib.cvcl_gconv3x3_wgrad_workspace_bytes(B, Hh, Ww, Cn, ctx.stride)
+                    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+                    H.check(lib.cvcl_gconv3x3_wgrad(H.ptr(x), H.ptr(dy), H.ptr(dw_), B, Hh, Ww, Cn, 32, ctx.stride, H.ptr(ws), nb, s_),
+                            "cvcl_gconv3x3_wgrad")
+                else:
+                    H.check(lib.cvcl_conv_wgrad_direct(_cd(x), H.ptr(x), H.ptr(dy), H.ptr(dw_), B, Hh, Ww, Cn, Cn, cg, 3, ctx.stride, 1, 0,
+                                                       s_), "cvcl_conv_wgrad_direct")
+                return dw_
+            if ctx.param is not None:
+                _defer_wgrad(ctx.param, wgrad, x, dy)
             else:
-                H.check(lib.cvcl_conv_wgrad_direct(_cd(x), H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, Cn, Cn, cg, 3, ctx.stride, 1, 0, s),
-                        "cvcl_conv_wgrad_direct")
+                dw = wgrad()
         if ctx.needs_input_grad[0]:
             wf = torch.empty_like(weight, dtype=_F)
             H.check(lib.cvcl_gconv_weight_dgrad(H.ptr(weight.detach().contiguous(), _F), H.ptr(wf), Cn, cg, s), "cvcl_gconv_weight_dgrad")
@@ -154,15 +226,16 @@ class GroupedConv3x3(torch.autograd.Function):
             dx = torch.empty_like(x)
             H.check(lib.cvcl_gconv3x3(_cd(x), H.ptr(z), None, None, H.ptr(wp), H.ptr(dx), None, 0, B, Hh, Ww, Cn, 32, 1, s),
                     "cvcl_gconv3x3")
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class StemConv(torch.autograd.Function):
     """conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False) on the NCHW fp32 images -> raw NHWC."""
 
     @staticmethod
-    def forward(ctx, x, weight, dtype):
+    def forward(ctx, x, weight, dtype, defer_wgrad: bool = False):
         B, _, Hh, Ww = x.shape
+        ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
         dt = H.cvcl_dtype(dtype)
         wp = _pack(weight, H.PACK_STEM7, dtype)
         out = torch.empty(B, Hh // 2, Ww // 2, 64, dtype=dtype, device=x.device)
@@ -179,15 +252,20 @@ class StemConv(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         B, _, Hh, Ww = x.shape
         dy = dy.contiguous()
-        if dy.dtype == torch.bfloat16:                    # patch matrix (bf16, 147 -> 160 columns) + TN GEMM on MFMA
-            P = B * (Hh // 2) * (Ww // 2)
-            col = torch.empty(P, 160, dtype=torch.bfloat16, device=x.device)
-            H.check(H.lib().cvcl_stem_im2col(H.ptr(x, _F), H.ptr(col), B, Hh, Ww, H.stream_ptr()), "cvcl_stem_im2col")
-            return None, _gemm_tn(dy.view(P, 64), col, 147).view(64, 3, 7, 7), None
-        dw = torch.empty(64, 3, 7, 7, dtype=_F, device=x.device)
-        H.check(H.lib().cvcl_conv_wgrad_direct(_cd(dy), H.ptr(x), H.ptr(dy), H.ptr(dw), B, Hh, Ww, 3, 64, 3, 7, 2, 3, 1,
-                                               H.stream_ptr()), "cvcl_conv_wgrad_direct")
-        return None, dw, None
+        def wgrad():
+            if dy.dtype == torch.bfloat16:                # patch matrix (bf16, 147 -> 160 columns) + TN GEMM on MFMA
+                P = B * (Hh // 2) * (Ww // 2)
+                col = torch.empty(P, 160, dtype=torch.bfloat16, device=x.device)
+                H.check(H.lib().cvcl_stem_im2col(H.ptr(x, _F), H.ptr(col), B, Hh, Ww, H.stream_ptr()), "cvcl_stem_im2col")
+                return _gemm_tn(dy.view(P, 64), col, 147).view(64, 3, 7, 7)
+            dw_ = torch.empty(64, 3, 7, 7, dtype=_F, device=x.device)
+            H.check(H.lib().cvcl_conv_wgrad_direct(_cd(dy), H.ptr(x), H.ptr(dy), H.ptr(dw_), B, Hh, Ww, 3, 64, 3, 7, 2, 3, 1,
+                                                   H.stream_ptr()), "cvcl_conv_wgrad_direct")
+            return dw_
+        if ctx.param is not None:
+            _defer_wgrad(ctx.param, wgrad, x, dy)
+            return None, None, None, None
+        return None, wgrad(), None, None
 
 
 def _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked):
@@ -353,17 +431,17 @@ def trunk_train(model, x: torch.Tensor):
         raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
     x = x.contiguous()
     cdt = model.compute_dtype
-    h = StemConv.apply(x, model.conv1.weight, cdt)
+    h = StemConv.apply(x, model.conv1.weight, cdt, True)
     h = _bn(h, model.bn1, True)
     h = MaxPool3x3s2.apply(h)
     for li in (1, 2, 3, 4):
         for blk in getattr(model, f"layer{li}"):
             idn = h
-            o = _bn(Conv1x1.apply(h, blk.conv1.weight, 1), blk.bn1, True)
-            o = _bn(GroupedConv3x3.apply(o, blk.conv2.weight, blk.conv2.stride[0]), blk.bn2, True)
+            o = _bn(Conv1x1.apply(h, blk.conv1.weight, 1, True), blk.bn1, True)
+            o = _bn(GroupedConv3x3.apply(o, blk.conv2.weight, blk.conv2.stride[0], True), blk.bn2, True)
             if blk.downsample is not None:
-                idn = _bn(Conv1x1.apply(h, blk.downsample[0].weight, blk.downsample[0].stride[0]), blk.downsample[1], False)
-            raw3, st3 = Conv1x1.apply(o, blk.conv3.weight, 1)
+                idn = _bn(Conv1x1.apply(h, blk.downsample[0].weight, blk.downsample[0].stride[0], True), blk.downsample[1], False)
+            raw3, st3 = Conv1x1.apply(o, blk.conv3.weight, 1, True)
             b3 = blk.bn3
             h = BnAddRelu.apply(raw3, st3, b3.weight, b3.bias, b3.running_mean, b3.running_var, b3.num_batches_tracked, idn)
     pooled = AvgPool.apply(h)

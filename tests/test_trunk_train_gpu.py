@@ -303,6 +303,43 @@ def test_trunk_bf16_grads_finite_deterministic(dev):
         assert cos > 0.8, (k, cos)
 
 
+@pytest.mark.parametrize("cdt", [torch.float32, torch.bfloat16])
+def test_weight_gradient_stream_is_bit_identical(dev, monkeypatch, cdt):
+    """trunk_train runs the weight-gradient kernels on their own HIP stream and stores them into param.grad when the backward
+    pass ends ($CVCL_WGRAD_STREAM, default on): same gradients, bit for bit, as the one-stream form where autograd accumulates
+    them -- including accumulation over two backward passes -- and torch.autograd.grad on the Functions themselves still works."""
+    from multimodal.resnext import ResNet
+    from multimodal import trunk_train as TT
+    torch.manual_seed(1)
+    model = ResNet().to(dev).train()
+    model.compute_dtype = cdt
+    x = torch.randn(6, 3, 96, 96, device=dev)
+    dp = torch.randn(6, 2048, device=dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CVCL_WGRAD_STREAM", mode)
+        model.zero_grad(set_to_none=True)
+        for _ in range(2):                                        # the second pass accumulates into existing .grad tensors
+            with torch.no_grad():
+                for m in model.modules():
+                    if isinstance(m, torch.nn.BatchNorm2d):
+                        m.reset_running_stats()
+            pooled, _ = model.trunk(x)
+            pooled.backward(dp)
+        torch.cuda.synchronize()
+        assert not TT._WGRAD_PENDING
+        res[mode] = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    assert len(res["0"]) == len(res["1"]) == 159
+    for k, v in res["0"].items():
+        assert v.shape == dict(model.named_parameters())[k].shape and torch.equal(v, res["1"][k]), k
+    # the Functions called directly (no deferral requested) still return the weight gradient through autograd
+    w = torch.nn.Parameter(torch.randn(64, 128, 1, 1, device=dev))
+    xx = torch.randn(2, 8, 8, 128, device=dev).to(cdt)
+    y, _ = TT.Conv1x1.apply(xx, w, 1)
+    (gw,) = torch.autograd.grad(y, w, torch.ones_like(y))
+    assert gw.shape == w.shape and torch.isfinite(gw).all()
+
+
 def test_finetune_cnn_training_step(dev):
     """reference config with --finetune_cnn (multimodal.py:175-179): the trunk's parameters receive gradients and an
     AdamW step changes them; the default (frozen) configuration leaves them untouched."""

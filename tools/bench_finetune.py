@@ -13,7 +13,7 @@ from bench import c2_args, synthetic_batch_on_device
 
 ap = argparse.ArgumentParser(); ap.add_argument("--batch", type=int, default=64); ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--dtype", default="bf16"); a = ap.parse_args()
-dev = torch.device("cuda:0")
+dev = torch.device("cuda:0"); torch.manual_seed(0)
 args = c2_args(); args.finetune_cnn = True
 with contextlib.redirect_stdout(io.StringIO()):
     ve = VisionEncoder(args); te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args); lit = MultiModalLitModel(ve, te, args)
