@@ -213,8 +213,8 @@ def main():
     if not a.no_roofline:
         # further passes of the same steps with HIP events around every launch (on the launch stream).  The roofline figures come
         # from a pass with ONE trunk pass in flight: with two trunk streams a launch shares the CUs and HBM with the other pass's
-        # kernels and its event-timed duration is no longer the kernel's own (rocprofv3 --kernel-trace serialises dispatches, so
-        # its per-kernel averages for this command are the one-at-a-time durations as well); the durations seen under the
+        # kernels and its event-timed duration is no longer the kernel's own (in the rocprofv3 --kernel-trace run of this command
+        # the per-kernel averages come out as the one-at-a-time durations too: profiles/r01_bench_c2_kernel_stats.csv); the durations seen under the
         # two-stream schedule are reported beside them (roofline.concurrent).
         def instrumented(n):
             for _ in range(2):
@@ -268,7 +268,7 @@ def main():
             c_ms, c_n = conc["gemm"]
             c_avg = c_ms / max(c_n, 1) * 1e-3
             roofline["measured"] = ("one trunk pass in flight (CVCL_TRUNK_STREAMS=1 schedule): the kernel's own launch duration, "
-                                    "which is also what rocprofv3 --kernel-trace reports for this command (it serialises dispatches)")
+                                    "which is also what the rocprofv3 --kernel-trace run of this command reports (profiles/r01_bench_c2_kernel_stats.csv)")
             roofline["concurrent"] = {"note": "the timed region keeps two trunk passes in flight on two HIP streams; event-timed "
                                               "there, a launch's duration includes the time it shares the GPU with the other "
                                               "pass's kernels -- per-kernel figures are not meaningful, the step time is",

@@ -1,7 +1,6 @@
 #!/bin/bash
-# round-end profile refresh: rocprofv3 --kernel-trace --stats of bench.py (C2; kernel tracing serialises dispatches, so the
-# per-kernel averages are one-at-a-time durations even though the command keeps two trunk passes in flight), the C5 fp8 probe
-# and the frame transform
+# round-end profile refresh: rocprofv3 --kernel-trace --stats of bench.py (C2; under the tracer the per-kernel averages come
+# out as one-at-a-time durations although the command keeps two trunk passes in flight), the C5 fp8 probe and the frame transform
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_end
