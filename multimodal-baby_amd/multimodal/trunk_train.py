@@ -174,6 +174,46 @@ class Conv1x1(torch.autograd.Function):
         return dx, dw, None, None
 
 
+class Conv1x1Skip(torch.autograd.Function):
+    """The stride-1 1x1 convolution at the head of a Bottleneck, which also hands its input on to the block's other consumer
+    (the identity of the residual add, or the downsample convolution): -> (raw, stats, x).  Autograd would add the two gradients
+    of the block input with an element-wise kernel of its own (one more read-read-write pass over the widest tensor of the
+    block); here the gradient arriving through the second output rides the data-gradient GEMM as its residual operand:
+    dX = round(round(dY W) + d_skip) -- the same two roundings as GEMM + add, one pass less."""
+
+    @staticmethod
+    def forward(ctx, x, weight, defer_wgrad: bool = False):
+        B, Hh, Ww, K = x.shape
+        N = weight.shape[0]
+        ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
+        wq = _pack(weight, H.PACK_DENSE, x.dtype).view(x.dtype).view(N, K)
+        out = torch.empty(B, Hh, Ww, N, dtype=x.dtype, device=x.device)
+        M = B * Hh * Ww
+        st = torch.empty(H.gemm_grid_m(_cd(x), M, N), 2, N, dtype=_F, device=x.device)      # BN statistics from the epilogue
+        H.gemm(x, wq, out=out, M=M, lda=K, stats=st)
+        ctx.save_for_backward(x, wq)
+        ctx.mark_non_differentiable(st)
+        return out, st, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, _dst, d_skip):
+        x, wq = ctx.saved_tensors
+        B, Hh, Ww, K = x.shape
+        N = wq.shape[0]
+        M = B * Hh * Ww
+        dy2, x2 = dy.contiguous().view(M, N), x.view(M, K)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            res = None if d_skip is None else d_skip.contiguous().view(M, K)
+            dx = H.gemm(dy2, _transpose(wq), residual=res).view(B, Hh, Ww, K)
+        if ctx.needs_input_grad[1]:
+            if ctx.param is not None:
+                _defer_wgrad(ctx.param, lambda: _gemm_tn(dy2, x2), dy2, x2)
+            else:
+                dw = _gemm_tn(dy2, x2).view(N, K, 1, 1)
+        return dx, dw, None
+
+
 class GroupedConv3x3(torch.autograd.Function):
     """nn.Conv2d(C, C, 3, stride, 1, groups=32, bias=False) on NHWC."""
 
@@ -436,11 +476,11 @@ def trunk_train(model, x: torch.Tensor):
     h = MaxPool3x3s2.apply(h)
     for li in (1, 2, 3, 4):
         for blk in getattr(model, f"layer{li}"):
-            idn = h
-            o = _bn(Conv1x1.apply(h, blk.conv1.weight, 1, True), blk.bn1, True)
+            raw1, st1, idn = Conv1x1Skip.apply(h, blk.conv1.weight, True)      # idn = h, its gradient folded into conv1's dX GEMM
+            o = _bn((raw1, st1), blk.bn1, True)
             o = _bn(GroupedConv3x3.apply(o, blk.conv2.weight, blk.conv2.stride[0], True), blk.bn2, True)
             if blk.downsample is not None:
-                idn = _bn(Conv1x1.apply(h, blk.downsample[0].weight, blk.downsample[0].stride[0], True), blk.downsample[1], False)
+                idn = _bn(Conv1x1.apply(idn, blk.downsample[0].weight, blk.downsample[0].stride[0], True), blk.downsample[1], False)
             raw3, st3 = Conv1x1.apply(o, blk.conv3.weight, 1, True)
             b3 = blk.bn3
             h = BnAddRelu.apply(raw3, st3, b3.weight, b3.bias, b3.running_mean, b3.running_var, b3.num_batches_tracked, idn)
