@@ -138,6 +138,7 @@ class Conv1x1(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False):
+        ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, Hh, Ww, K = x.shape
         N = weight.shape[0]
         ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
@@ -183,6 +184,7 @@ class Conv1x1Skip(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, defer_wgrad: bool = False):
+        ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, Hh, Ww, K = x.shape
         N = weight.shape[0]
         ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
@@ -219,6 +221,7 @@ class GroupedConv3x3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False):
+        ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, Hh, Ww, Cn = x.shape
         ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
         wp = _pack(weight, H.PACK_GCONV3, x.dtype)
@@ -274,6 +277,7 @@ class StemConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, dtype, defer_wgrad: bool = False):
+        ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, _, Hh, Ww = x.shape
         ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
         dt = H.cvcl_dtype(dtype)
