@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, global_negatives, out):
+def _worker(rank, world, port, global_negatives, out, deferred=False):
     for p in (os.path.join(ROOT, "multimodal-baby_amd"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -47,7 +47,10 @@ def _worker(rank, world, port, global_negatives, out):
                                                   global_negatives=global_negatives).attach(mod)
     assert parallel.world_size() == world and len(engine.buckets) >= 2      # several buckets -> exercises bucketing
     sl = slice(rank * B, (rank + 1) * B)
-    fi = O.l2_normalize(x_all[sl] @ proj.t())
+    # deferred: proj's gradient does not come through autograd's accumulation (no post-accumulate hook fires) but is stored into
+    # .grad when the backward pass is over -- what trunk_train does with the weight gradients it computes on a side stream
+    proj_used = proj.detach().clone().requires_grad_(True) if deferred else proj
+    fi = O.l2_normalize(x_all[sl] @ proj_used.t())
     ft = O.l2_normalize(O.embedding_meanpool(table, tok_all[sl], len_all[sl])[0])
     if global_negatives:
         fi, ft = parallel.gather_features(fi, ft)
@@ -55,6 +58,8 @@ def _worker(rank, world, port, global_negatives, out):
     lpi, lpt = O.similarity_logits(fi, ft, nlt)
     loss = O.contrastive_loss(lpi, lpt)[0]
     loss.backward()
+    if deferred:
+        proj.grad = proj_used.grad
     engine.reduce_gradients()
     out.put((rank, float(loss), proj.grad.clone(), table.grad.clone(), nlt.grad.clone()))
     dist.barrier()
@@ -89,13 +94,13 @@ def _single_process_reference(world, global_negatives):
     return float(loss), proj.grad, table.grad, nlt.grad
 
 
-@pytest.mark.parametrize("global_negatives", [True, False])
-def test_world2_gradients_equal_single_process(global_negatives):
+@pytest.mark.parametrize("global_negatives,deferred", [(True, False), (False, False), (True, True)])
+def test_world2_gradients_equal_single_process(global_negatives, deferred):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, global_negatives, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, global_negatives, q, deferred)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in range(world)]
