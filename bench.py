@@ -190,8 +190,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Schedule choice with more than one rank (untimed, before the warm-up): the two-trunk-stream schedule has only been
+    # measured on one GPU; with RCCL's own streams in the process a trunk stream could end up sharing a hardware queue with a
+    # collective.  So, unless $CVCL_TRUNK_STREAMS pins it, both schedules run a few steps and every rank keeps the faster one
+    # (the slowest rank's time decides, all ranks agree through an all-reduce).  Same numbers either way.
+    ts0 = ve.model.__dict__.get("_trunk_stream")
+    trunk_streams = ts0.n_streams if ts0 is not None else 0
+    if world > 1 and ts0 is not None and "CVCL_TRUNK_STREAMS" not in os.environ:
+        trial = {}
+        for n in (2, 1):
+            torch.cuda.synchronize()
+            ve.model.enable_trunk_stream(device, inputs="ready", n_streams=n)
+            for _ in range(3):
+                step()
+            upd.flush()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                step()
+            upd.flush()
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[n] = float(t.item())
+        trunk_streams = 2 if trial[2] <= trial[1] else 1
+        torch.cuda.synchronize()
+        ve.model.enable_trunk_stream(device, inputs="ready", n_streams=trunk_streams)
+
     for _ in range(a.warmup):
         out = step()
+    if upd is not None:
+        upd.flush()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -288,7 +317,7 @@ def main():
                                        "bwd(fc, embedding) + AdamW",
                            "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,
                            "negatives": "global (RCCL all-gather)" if world > 1 else "local (single GPU)",
-                           "parallelism": f"dp{world}"},
+                           "parallelism": f"dp{world}", "trunk_streams": trunk_streams},
                 "final_loss": round(loss, 5)}
         if roofline is not None:
             line["roofline"] = roofline
