@@ -100,9 +100,8 @@ def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
 def enable_trunk_stream(model, device, inputs="caller", stream=None, n_streams=None):
     """n_streams = 2 ($CVCL_VIT_TRUNK_STREAMS): consecutive passes of the frozen ViT alternate between two streams and overlap each
     other (the forward keeps no state between passes: per-pass activations come from the stream's own allocator pool)."""
-    if n_streams is None:                     # measured at B = 256: fp8 linears 10.12 -> 9.57 ms/step with two, bf16 14.3 -> 14.4
-        default = "2" if getattr(model, "fp8_linears", False) else "1"
-        n_streams = 1 if stream is not None else int(os.environ.get("CVCL_VIT_TRUNK_STREAMS", default))
+    if n_streams is None:                     # measured at B = 256 with two: fp8 linears 10.03 -> 9.33 ms/step, bf16 14.47 -> 14.28
+        n_streams = 1 if stream is not None else int(os.environ.get("CVCL_VIT_TRUNK_STREAMS", "2"))
     model.__dict__["_trunk_stream"] = H.TrunkStream(device, inputs, stream, n_streams) if inputs else None
     return model.__dict__["_trunk_stream"]
 
