@@ -475,6 +475,7 @@ def trunk_train(model, x: torch.Tensor):
         raise H.CvclError(f"expected NCHW fp32 images, got {tuple(x.shape)} {x.dtype}")
     x = x.contiguous()
     cdt = model.compute_dtype
+    _WGRAD_PENDING.clear()                  # leftovers of a backward pass that died half way must not reach the next one
     h = StemConv.apply(x, model.conv1.weight, cdt, True)
     h = _bn(h, model.bn1, True)
     h = MaxPool3x3s2.apply(h)
