@@ -1,22 +1,32 @@
-"""CVCL contrastive train-step benchmark on MI355X (driver contract: see the task prompt / DESIGN.md).
+"""CVCL contrastive train-step benchmark on MI355X (driver contract: see the task prompt / DESIGN.md section 7).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c4|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one batch of synthetic input already resident in HBM: ResNeXt-50
-forward (bf16 MFMA trunk, BN in train mode), embedding mean-pool, L2 normalise, [RCCL feature all-gather],
-similarity logits, symmetric InfoNCE, backward of the trainable set (fc + embedding), [RCCL gradient
-all-reduce], AdamW.  Workload = BASELINE.json configs[1] (C2), weak scaling (256 pairs per GPU).
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment starts that torch.distributed.run command itself as a
+child process (before this process has touched the GPU) and exits with its code.
 
-Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant kernel (timed live with
-HIP events on the launch stream in a second pass of the same steps, so the events do not perturb the
-headline number) and a CPU baseline (the oracle restatement on the host cores, bounded sample).
+A step = one pass of the hot path over one batch of synthetic input already resident in HBM: image trunk forward,
+text encoder, L2 normalise, [RCCL feature all-gather], similarity logits, symmetric InfoNCE, backward of the trainable
+set, [RCCL gradient all-reduce], AdamW.  Weak scaling (the per-GPU batch is fixed).
+
+    c2 (default)  BASELINE.json configs[1]: frozen ResNeXt-50 32x4d (BN train mode) + embedding text encoder, bf16, 256 / GPU
+    c4            configs[3]: frozen DINO ViT-B/16 (bf16 MFMA linears) + trainable transformer text encoder, 256 / GPU
+    c5            configs[4]: c4 with e4m3 weights / activations in the ViT linears (scaled MFMA); --batch grows the per-GPU batch
+
+Rank 0 prints ONE JSON line with the throughput, the measured deviation of the benchmarked precision from the exact-fp32
+parity mode on the same batch (``logits_rel_vs_fp32``), the roofline of the dominant kernel (timed live with HIP events on
+the launch stream in a second pass of the same steps, so the events do not perturb the headline number) and a CPU
+baseline (the oracle restatement of the reference step on the host cores, bounded sample).
 """
 import argparse
+import contextlib
+import io
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,12 +39,24 @@ import torch.distributed as dist               # noqa: E402
 METRIC = "image-text pairs/sec, CVCL ResNeXt+embed 224², bs256, 1/2/4/8 MI355X"
 PER_GPU_BATCH = 256
 EMBEDDING_DIM = 512
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA)
+PROFILE_ROUND = "r02"
+
+WORKLOADS = {
+    "c2": "C2 = BASELINE configs[1]: CVCL saycam_contrastive, frozen random-init ResNeXt-50 32x4d (BN train mode) + embedding "
+          "mean-pool text encoder, E=512, L2-normalised, fixed tau 0.07, 224x224 frames + 3-word utterances; full step = fwd + "
+          "InfoNCE + bwd(fc, embedding) + AdamW",
+    "c4": "C4 = BASELINE configs[3]: saycam_contrastive_transformer, frozen random-init DINO ViT-B/16 (bf16 MFMA linears) + "
+          "trainable one-layer transformer text encoder (learned positions, dropout 0.1), E=512, L2-normalised, fixed tau 0.07; "
+          "full step = fwd + InfoNCE + bwd(head, text encoder) + AdamW",
+    "c5": "C5 = BASELINE configs[4]: C4 with e4m3 weights (per-channel scales) and e4m3 activations (per-token / MX block "
+          "scales) in the four linears of every ViT block on v_mfma_scale_f32_32x32x64_f8f6f4; bf16 residual stream",
+}
 
 
 def c2_args():
-    import types
     return argparse.Namespace(
         embedding_type="flat", embedding_dim=EMBEDDING_DIM, pretrained_cnn=False, cnn_model="resnext50_32x4d",
         cnn_dino=False, vit_dino=False, finetune_cnn=False, text_encoder="embedding", captioning=False,
@@ -42,6 +64,38 @@ def c2_args():
         normalize_features=True, sim="max", temperature=0.07, fix_temperature=True, tie=True, bias=True,
         optimizer=torch.optim.AdamW, lr=1e-4, weight_decay=0.1, lr_scheduler=False, lambda_mm=1.0, lambda_lm=0.0,
         lambda_ar=0.0, optimize_unused=True, local_negatives=False)
+
+
+def c4_args():
+    a = c2_args()
+    a.vit_dino, a.text_encoder, a.pos_embed_type, a.dropout_i = True, "transformer", "learned", 0.0
+    return a
+
+
+def build_model(config, device, precision=None, seed=0, patch=16):
+    """The benchmarked module with random-init weights: -> (lit, vision_encoder, optimizer).  ``precision`` None = the
+    configuration's own (bf16; fp8 linears for c5)."""
+    import multimodal.multimodal as mm
+    from multimodal import vision_transformer_dino_mugs as vits
+    from multimodal.multimodal import TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import read_vocab
+    from multimodal.multimodal_lit import MultiModalLitModel
+    torch.manual_seed(seed)
+    args = c2_args() if config == "c2" else c4_args()
+    orig = mm.load_model
+    if config != "c2":      # BASELINE names ViT-B/16; the reference hard-codes vitb14 (multimodal.py:135), vit_base(16) exists (:287)
+        mm.load_model = lambda name, pretrained: vits.vit_base(patch_size=patch, num_classes=0)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            ve = VisionEncoder(args)
+            te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args)
+            lit = MultiModalLitModel(ve, te, args)
+    finally:
+        mm.load_model = orig
+    lit.to(device)
+    lit.set_precision(precision or ("fp8" if config == "c5" else "bf16"))
+    lit.train()                                           # Lightning keeps .train(): BN uses batch statistics
+    return lit, ve, lit.configure_optimizers()
 
 
 def synthetic_batch_on_device(batch, seed, device, vocab=2350):
@@ -57,7 +111,41 @@ def synthetic_batch_on_device(batch, seed, device, vocab=2350):
     return img, tok.contiguous(), ln
 
 
-def gemm_algorithmic_work(B):
+def logits_vs_fp32(lit, batch, precision):
+    """Deviation of the benchmarked precision from the exact-fp32 parity mode (the mode that meets the 1e-3 gate against the
+    reference forward, multimodal.py:746-794) on the SAME weights and batch, module in train mode as benchmarked (BatchNorm on
+    batch statistics): the rank-local logits matrix and InfoNCE loss.  The BatchNorm buffers are restored afterwards."""
+    from multimodal import ops
+    x, y, ln = batch[0], batch[1], batch[2]
+    model = lit.model
+    keep = {k: v.clone() for k, v in lit.state_dict().items() if "running_" in k or "num_batches_tracked" in k}
+    was_training, gn = lit.training, model.global_negatives
+    model.global_negatives = False                          # rank-local B x B logits (no collective in this check)
+    te = model.text_embed
+    out = {}
+    try:
+        lit.train()
+        te.eval()                                           # dropout off (it would draw different masks in the two runs)
+        res = {}
+        with torch.no_grad():
+            for p in ("32", precision):
+                lit.set_precision(p)
+                li, _lt = model(x, y, ln)
+                loss, _m = ops.infonce(li)
+                res[p] = (li.float().clone(), float(loss))
+        a, b = res[precision][0].double(), res["32"][0].double()
+        out = {"logits_rel_vs_fp32": float((a - b).abs().max() / b.abs().max()),
+               "logits_cosine_vs_fp32": float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0)),
+               "loss_abs_vs_fp32": abs(res[precision][1] - res["32"][1]), "loss_fp32": res["32"][1]}
+    finally:
+        model.global_negatives = gn
+        lit.set_precision(precision)
+        lit.train(was_training)
+        lit.load_state_dict(keep, strict=False)
+    return out
+
+
+def resnext_gemm_work(B):
     """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode):
     every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
     enqueues: conv1 and downsample (A + W + C); conv3 of layers 2-4 (A + W + C); conv3 of layer 1 twice -- a
@@ -91,41 +179,85 @@ def gemm_algorithmic_work(B):
     return nbytes, flops, launches
 
 
-def cpu_baseline(sample_batch=64, steps=2):
-    """The oracle (CPU restatement of the reference step: fwd + InfoNCE + bwd(trainable) + AdamW) timed on the
-    host cores on a bounded sample of the same workload: `steps` steps at batch `sample_batch`."""
+def vit_gemm_work(B, patch=16, D=768, depth=12, mlp=3072, operand_bytes=2):
+    """Algorithmic flops / bytes of the ViT-B GEMM launches of one forward at batch B: the patch embedding and the four
+    linears of every block (qkv, proj, fc1, fc2).  Bytes: A + W at the operand width, C in bf16."""
+    T = (224 // patch) ** 2 + 1
+    M = B * T
+    shapes = [(B * (T - 1), D, (3 * patch * patch + 7) // 8 * 8)]
+    for _ in range(depth):
+        shapes += [(M, 3 * D, D), (M, D, D), (M, mlp, D), (M, D, mlp)]
+    flops = sum(2 * m * n * k for m, n, k in shapes)
+    nbytes = sum(operand_bytes * (m * k + n * k) + 2 * m * n for m, n, k in shapes)
+    return nbytes, flops, len(shapes)
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference step: fwd + InfoNCE + bwd(trainable) + AdamW, BatchNorm through
+    F.batch_norm as nn.BatchNorm2d runs it) timed on the host cores as SURVEY.md 8(d) prescribes: C1 (B = 8, E = 128,
+    learned temperature, no normalise) for 5 steps and C2 (B = 256, E = 512) for 2 steps, all host threads."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cvcl_oracle as O
     threads = torch.get_num_threads()
-    p = O.cvcl_random_params(EMBEDDING_DIM, seed=0)
-    step = O.CpuTrainStep(p, lr=1e-4, weight_decay=0.1, normalize_features=True)
-    img, tok, ln = O.synthetic_batch(sample_batch, seed=0)
-    step.step(img, tok, ln)                                   # untimed warm-up
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step.step(img, tok, ln)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_batch * steps / dt, 2), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} train steps at batch {sample_batch} (same per-pair work as the batch-256 step: "
-                      f"ResNeXt-50 fwd with train-mode BN + embedding + InfoNCE + bwd + AdamW), fp32, torch "
-                      f"{torch.__version__} CPU, {threads} threads of {os.cpu_count()} cpus, {dt:.1f}s"}
+
+    def run(batch, steps, embed, normalize, warm):
+        p = O.cvcl_random_params(embed, seed=0)
+        step = O.CpuTrainStep(p, lr=1e-4, weight_decay=0.1, normalize_features=normalize, bn_impl="torch",
+                              learn_temperature=not normalize)         # C1 (run.sh:12) learns the temperature, C2 fixes it
+        img, tok, ln = O.synthetic_batch(batch, seed=0)
+        for _ in range(warm):
+            step.step(img, tok, ln)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step.step(img, tok, ln)
+        return time.perf_counter() - t0
+
+    t1 = run(8, 5, 128, False, 1)                             # also warms the thread pool / allocator for the C2 sample
+    t2 = run(PER_GPU_BATCH, 2, EMBEDDING_DIM, True, 0)
+    host = f"fp32, torch {torch.__version__} CPU, {threads} threads of {os.cpu_count()} cpus"
+    return {"value": round(PER_GPU_BATCH * 2 / t2, 2), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"C2: 2 train steps at batch {PER_GPU_BATCH} (ResNeXt-50 fwd with train-mode BN + embedding + InfoNCE + "
+                      f"bwd + AdamW), {host}, {t2:.1f}s",
+            "c1": {"value": round(8 * 5 / t1, 2), "unit": "pairs/s", "cores": threads,
+                   "sample": f"C1 = BASELINE configs[0]: 5 train steps at batch 8, E=128 (after 1 untimed), {host}, {t1:.1f}s"}}
 
 
-def main():
+def spawn_ranks(a, argv):
+    """``python bench.py --gpus N`` outside torch.distributed.run: start N fresh ranks as a child process.  Nothing in this
+    process has initialised the GPU at this point (torch.cuda.device_count() does not), and the child is a child -- no exec."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 256; c5: see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "32"])
-    a = ap.parse_args()
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--precision", default=None, choices=["bf16", "32", "fp8"])
+    a = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and not (a.gpus == 1 and world == 1):
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a, argv))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the CVCL hot path has no CPU fallback")
     device = torch.device("cuda", local_rank % torch.cuda.device_count())
@@ -137,35 +269,36 @@ def main():
 
     from multimodal import _hip as H
     from multimodal import parallel
-    from multimodal.multimodal import TextEncoder, VisionEncoder
-    from multimodal.multimodal_data_module import read_vocab
-    from multimodal.multimodal_lit import MultiModalLitModel
 
-    torch.manual_seed(0)
-    args = c2_args()
-    import io, contextlib
-    with contextlib.redirect_stdout(io.StringIO()):
-        ve = VisionEncoder(args)
-        te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args)
-        lit = MultiModalLitModel(ve, te, args)
-    lit.to(device)
-    lit.set_precision(a.precision)
-    lit.train()                                           # Lightning keeps .train(): BN uses batch statistics
-    opt = lit.configure_optimizers()
+    cfg = a.config
+    precision = a.precision or ("fp8" if cfg == "c5" else "bf16")
+    batch_size = a.batch or PER_GPU_BATCH
+    steps = a.steps if a.steps is not None else (50 if batch_size <= 1024 else 5)
+    warmup = a.warmup if a.warmup is not None else (10 if batch_size <= 1024 else 2)
+    lit, ve, opt = build_model(cfg, device, precision)
     engine = parallel.DataParallelEngine(device, global_negatives=True).attach(lit)
-    batch = synthetic_batch_on_device(PER_GPU_BATCH, seed=rank, device=device) + (None,)
-    # the frozen trunk runs on its own HIP stream (H.TrunkStream; CVCL_TRUNK_STREAM=0 restores the single-stream schedule):
-    # step k+1's trunk overlaps step k's trainable tail -- fc, text, loss, backward, AdamW, and with world > 1 the feature
-    # all-gathers, the larger global-negatives loss and the deferred all-reduce wait + optimizer step -- which stays on the
-    # main stream.  Every step does the same work with the same numbers (bit-identical, tests/test_train_entry_gpu.py), and
-    # all of it is complete when the clock stops (torch.cuda.synchronize() waits for both streams).  One GPU: 7.42 -> 7.38
-    # ms/step (the tail is only 0.26 ms there and the cross-stream events cost 0.1 ms).
-    # With two trunk streams ($CVCL_TRUNK_STREAMS, default 2) consecutive trunk passes -- independent for a frozen trunk except
-    # for the BatchNorm running statistics, which are still updated in step order -- also overlap each other: each fills the
-    # other's tail rounds, dependent-launch gaps and MFMA-bound phases (6.40 -> 5.96 ms per pass).
-    if os.environ.get("CVCL_TRUNK_STREAM", "1") != "0":
-        torch.cuda.synchronize()
-        ve.model.enable_trunk_stream(device, inputs="ready")          # the benchmark batch is resident and never rewritten
+    batch = synthetic_batch_on_device(batch_size, seed=rank, device=device) + (None,)
+
+    # The frozen trunk runs on its own HIP stream(s) (H.TrunkStream): step k+1's trunk overlaps step k's trainable tail -- head,
+    # text encoder, loss, backward, AdamW, and with world > 1 the feature all-gathers, the global-negatives loss and the deferred
+    # all-reduce wait + optimizer step -- which stays on the main stream; with two trunk streams consecutive passes of the frozen
+    # trunk also overlap each other (BatchNorm running statistics still updated in step order).  Every step does the same work
+    # with the same numbers (bit-identical, tests/test_train_entry_gpu.py), all of it complete when the clock stops.  The number
+    # of trunk streams is fixed up front -- $CVCL_TRUNK_STREAMS (ResNeXt) / $CVCL_VIT_TRUNK_STREAMS (ViT), default 2, 0 = the
+    # single-stream schedule -- and reported in config.trunk_streams; nothing is auto-selected at run time.
+    env_name = "CVCL_TRUNK_STREAMS" if cfg == "c2" else "CVCL_VIT_TRUNK_STREAMS"
+    trunk_streams = int(os.environ.get(env_name, "2"))
+    if os.environ.get("CVCL_TRUNK_STREAM", "1") == "0":
+        trunk_streams = 0
+    torch.cuda.synchronize()
+
+    def set_trunk_streams(n):
+        if cfg == "c2":
+            ve.model.enable_trunk_stream(device, inputs="ready" if n else None, n_streams=max(n, 1))
+        else:
+            from multimodal import vit_hip
+            vit_hip.enable_trunk_stream(ve.model, device, inputs="ready" if n else None, n_streams=max(n, 1))
+    set_trunk_streams(trunk_streams)              # the benchmark batch is resident and never rewritten: inputs="ready"
 
     # multi-GPU: the all-reduce + optimizer step of step k are enqueued behind the frozen trunk of step k+1
     # (parallel.OverlappedUpdate; same parameter sequence as the sequential schedule); flushed before the clock stops
@@ -185,48 +318,23 @@ def main():
         upd.step_done()
         return out
 
+    def flush():
+        if upd is not None:
+            upd.flush()
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Schedule choice with more than one rank (untimed, before the warm-up): the two-trunk-stream schedule has only been
-    # measured on one GPU; with RCCL's own streams in the process a trunk stream could end up sharing a hardware queue with a
-    # collective.  So, unless $CVCL_TRUNK_STREAMS pins it, both schedules run a few steps and every rank keeps the faster one
-    # (the slowest rank's time decides, all ranks agree through an all-reduce).  Same numbers either way.
-    ts0 = ve.model.__dict__.get("_trunk_stream")
-    trunk_streams = ts0.n_streams if ts0 is not None else 0
-    if world > 1 and ts0 is not None and "CVCL_TRUNK_STREAMS" not in os.environ:
-        trial = {}
-        for n in (2, 1):
-            torch.cuda.synchronize()
-            ve.model.enable_trunk_stream(device, inputs="ready", n_streams=n)
-            for _ in range(3):
-                step()
-            upd.flush()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(8):
-                step()
-            upd.flush()
-            barrier()
-            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            trial[n] = float(t.item())
-        trunk_streams = 2 if trial[2] <= trial[1] else 1
-        torch.cuda.synchronize()
-        ve.model.enable_trunk_stream(device, inputs="ready", n_streams=trunk_streams)
-
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         out = step()
-    if upd is not None:
-        upd.flush()
+    flush()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out = step()
-    if upd is not None:
-        upd.flush()
+    flush()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -234,95 +342,108 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(out["loss"].detach())
-    pairs = world * PER_GPU_BATCH * a.steps
-    value = pairs / elapsed
+    value = world * batch_size * steps / elapsed
 
-    roofline = None
-    breakdown = None
+    roofline = breakdown = None
     if not a.no_roofline:
         # further passes of the same steps with HIP events around every launch (on the launch stream).  The roofline figures come
         # from a pass with ONE trunk pass in flight: with two trunk streams a launch shares the CUs and HBM with the other pass's
-        # kernels and its event-timed duration is no longer the kernel's own (in the rocprofv3 --kernel-trace run of this command
-        # the per-kernel averages come out as the one-at-a-time durations too: profiles/r01_bench_c2_kernel_stats.csv); the durations seen under the
-        # two-stream schedule are reported beside them (roofline.concurrent).
+        # kernels and its event-timed duration is no longer the kernel's own (the rocprofv3 --kernel-trace run of this command
+        # reports the one-at-a-time durations too); the durations seen under the two-stream schedule are reported beside them.
         def instrumented(n):
             for _ in range(2):
                 step()
-            if upd is not None:
-                upd.flush()
+            flush()
             torch.cuda.synchronize()
             H.prof_enable(True)
             for _ in range(n):
                 step()
-            if upd is not None:
-                upd.flush()
+            flush()
             torch.cuda.synchronize()
             out_ = H.prof_collect()
             H.prof_enable(False)
             return out_
 
-        nprof = min(a.steps, 10)
-        ts_now = ve.model.__dict__.get("_trunk_stream")
-        conc, nconc = None, min(a.steps, 5)
-        if ts_now is not None and ts_now.n_streams > 1:
+        nprof, nconc, conc = min(steps, 10), min(steps, 5), None
+        if trunk_streams > 1:
             conc = instrumented(nconc)
-            ve.model.enable_trunk_stream(device, inputs="ready", n_streams=1)
+            set_trunk_streams(1)
         prof = instrumented(nprof)
         breakdown = {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1] > 0}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
-        nbytes, flops, launches = gemm_algorithmic_work(PER_GPU_BATCH)
         g_ms, g_n = prof["gemm"]
         avg_s = g_ms / max(g_n, 1) * 1e-3
-        per_launch_bytes = nbytes / launches
-        achieved = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3
-        # --pmc passes of this same command: tools/pmc_bench.sh -> profiles/r01_pmc_hbm_traffic.json)
+        if cfg == "c2":
+            nbytes, flops, launches = resnext_gemm_work(batch_size)
+        else:
+            nbytes, flops, launches = vit_gemm_work(batch_size, operand_bytes=1 if precision == "fp8" else 2)
+        per_launch_bytes, per_launch_flops = nbytes / launches, flops / launches
+        gbs = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
+        tfs = per_launch_flops / avg_s / 1e12 if avg_s > 0 else 0.0
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                pm = json.load(f)["gemm_glds_kernel"]
-            traffic = int((pm["hbm_read_bytes_per_step_corrected_x2"] + pm["hbm_write_bytes_per_step"]) / pm["launches_per_step"])
-        except Exception:
-            pass
-        roofline = {"kernel": "gemm_glds_kernel (bf16 1x1-conv MFMA GEMM, direct-to-LDS operand loads; epilogues: BN statistics / "
-                              "fused BN3+identity+ReLU Bottleneck tail)",
-                    "dominant_class_by_time": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_note": "PMC HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)",
-                    "launches_per_step": g_n // nprof, "avg_launch_us": round(avg_s * 1e6, 2),
-                    "algorithmic_bytes_per_launch": int(per_launch_bytes),
-                    "mfma_tflops": round(flops / launches / avg_s / 1e12, 1) if avg_s > 0 else 0.0,
-                    "mfma_frac_of_bf16_dense_peak": round(flops / launches / avg_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if avg_s > 0 else 0.0}
+        if cfg == "c2":
+            # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc
+            # passes of this same command: tools/pmc_bench.sh -> profiles/<round>_pmc_hbm_traffic.json)
+            for rnd in (PROFILE_ROUND, "r01"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.json")) as f:
+                        pm = json.load(f)["gemm_glds_kernel"]
+                    traffic = int((pm["hbm_read_bytes_per_step_corrected_x2"] + pm["hbm_write_bytes_per_step"]) / pm["launches_per_step"])
+                    break
+                except Exception:
+                    continue
+            roofline = {"kernel": "gemm_glds_kernel (bf16 1x1-conv MFMA GEMM, direct-to-LDS operand loads; epilogues: BN statistics / "
+                                  "fused BN3+identity+ReLU Bottleneck tail)",
+                        "dominant_class_by_time": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_note": "PMC HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)",
+                        "mfma_tflops": round(tfs, 1), "mfma_frac_of_bf16_dense_peak": round(tfs / MFMA_BF16_PEAK_TFLOPS, 4)}
+        else:
+            peak = MFMA_FP8_PEAK_TFLOPS if precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
+            roofline = {"kernel": ("gemm_fp8_kernel (e4m3 x e4m3 ViT linears on v_mfma_scale_f32_32x32x64_f8f6f4)" if precision == "fp8"
+                                   else "gemm_glds_kernel<linear epilogue> (bf16 ViT linears: bias / GELU / residual)"),
+                        "dominant_class_by_time": dom, "bound": "mfma", "achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(tfs / peak, 4), "traffic": None, "algorithmic_GBps": round(gbs, 1)}
+        roofline.update({"launches_per_step": g_n // nprof, "avg_launch_us": round(avg_s * 1e6, 2),
+                         "algorithmic_bytes_per_launch": int(per_launch_bytes), "algorithmic_flops_per_launch": int(per_launch_flops)})
         if conc is not None:
             c_ms, c_n = conc["gemm"]
-            c_avg = c_ms / max(c_n, 1) * 1e-3
-            roofline["measured"] = ("one trunk pass in flight (CVCL_TRUNK_STREAMS=1 schedule): the kernel's own launch duration, "
-                                    "which is also what the rocprofv3 --kernel-trace run of this command reports (profiles/r01_bench_c2_kernel_stats.csv)")
+            roofline["measured"] = ("one trunk pass in flight (single-trunk-stream schedule): the kernel's own launch duration, "
+                                    "which is also what the rocprofv3 --kernel-trace run of this command reports (profiles/)")
             roofline["concurrent"] = {"note": "the timed region keeps two trunk passes in flight on two HIP streams; event-timed "
                                               "there, a launch's duration includes the time it shares the GPU with the other "
                                               "pass's kernels -- per-kernel figures are not meaningful, the step time is",
-                                      "avg_launch_us": round(c_avg * 1e6, 2),
+                                      "avg_launch_us": round(c_ms / max(c_n, 1) * 1e3, 2),
                                       "kernel_ms_per_step": {k: round(v[0] / nconc, 4) for k, v in conc.items() if v[1] > 0}}
         if world > 1:
             dist.barrier()
 
+    parity = None
+    if not a.no_parity and precision != "32" and batch_size <= 1024:
+        flush()
+        torch.cuda.synchronize()
+        set_trunk_streams(0)
+        parity = logits_vs_fp32(lit, batch, precision)
+
     if rank == 0:
-        line = {"metric": METRIC, "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": a.steps,
-                "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
+        line = {"metric": METRIC if cfg == "c2" else f"image-text pairs/sec, CVCL ViT-B/16+transformer text 224², {cfg.upper()}, MI355X",
+                "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": steps,
+                "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "32": "f32", "fp8": "fp8-e4m3"}[precision],
                 "data": "synthetic",
-                "config": {"workload": "C2 = BASELINE configs[1]: CVCL saycam_contrastive, frozen random-init ResNeXt-50 "
-                                       "32x4d (BN train mode) + embedding mean-pool text encoder, E=512, L2-normalised, "
-                                       "fixed tau 0.07, 224x224 frames + 3-word utterances; full step = fwd + InfoNCE + "
-                                       "bwd(fc, embedding) + AdamW",
-                           "per_gpu_batch": PER_GPU_BATCH, "global_batch": PER_GPU_BATCH * world,
+                "config": {"workload": WORKLOADS[cfg], "per_gpu_batch": batch_size, "global_batch": batch_size * world,
                            "negatives": "global (RCCL all-gather)" if world > 1 else "local (single GPU)",
                            "parallelism": f"dp{world}", "trunk_streams": trunk_streams},
                 "final_loss": round(loss, 5)}
+        if parity is not None:
+            line.update({k: float(f"{v:.4g}") for k, v in parity.items()})
+            line["parity_note"] = ("same weights and batch through the exact-fp32 parity mode (the mode held to the 1e-3 logits gate "
+                                   "against the reference forward) and the benchmarked precision, train-mode BatchNorm; yardstick: "
+                                   "PyTorch CPU bf16 autocast deviates ~1e-2 on the reference path (SURVEY.md 0.6)")
         if roofline is not None:
             line["roofline"] = roofline
             line["kernel_ms_per_step"] = breakdown
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and cfg == "c2":
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -199,6 +199,15 @@ size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W);
 int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
                        const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
                        void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream);
+/* ONE Bottleneck of that trunk (torchvision.models.resnet.Bottleneck.forward, reached from multimodal.py:101), enqueued as
+ * exactly the launch sequence cvcl_resnext50_fwd uses for it -- the unit the teacher-forced parity tests drive: feed the
+ * oracle's block input, compare the block output.  stage 0..3 = layer1..layer4; first != 0 for the stage's first block
+ * (downsample branch, stride 2 when stage > 0); layers = conv1, conv2, conv3[, downsample] of the block (3 or 4 entries);
+ * x_nhwc [B,h,w,Cin] -> out_nhwc [B,h/s,w/s,256 << stage].                                                              */
+size_t cvcl_resnext50_block_workspace_bytes(int dtype, int B, int h, int w, int stage);
+int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stage, int first, int training, const void* x_nhwc,
+                             const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
+                             void* out_nhwc, float momentum, float eps, void* stream);
 /* The train-mode pass with its BatchNorm running-statistics update split off (no counterpart in the reference, which runs
  * one pass at a time; same results).  Consecutive passes of a FROZEN trunk are independent except for those 53 EMA updates
  * (torch.nn.BatchNorm2d train mode, reached from multimodal.py:88-104 because Lightning keeps .train()), so a host may enqueue

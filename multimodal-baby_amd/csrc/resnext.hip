@@ -1018,6 +1018,158 @@ extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W)
            gram_ws_bytes(B, H, W);
 }
 
+// ------------------------------------------------------------------------------------------------
+// One Bottleneck (torchvision Bottleneck.forward: conv1-bn1-relu, conv2(grouped 3x3, stride)-bn2-relu, conv3-bn3,
+// + identity / downsample, relu) as the launch sequence the whole-trunk call uses.  L = this block's layers
+// (conv1, conv2, conv3[, downsample]); aff = their (scale, shift) scratch, 4096 floats per layer; mom = where the
+// deferred-statistics pass leaves the batch moments (or NULL: running statistics updated in place).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct BlockCtx {
+    int dtype, B, training;
+    float momentum, eps;
+    float* stats;
+    char* gram_ws; size_t gram_bytes;
+    void* stream;
+};
+
+int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, const char* X, char* R1, char* R2, char* R3, char* RD,
+                   char* dst, const cvcl_convbn_params* L, float* aff, float* mom) {
+    const int dtype = c.dtype, B = c.B, training = c.training;
+    float* stats = c.stats;
+    void* stream = c.stream;
+    const int planes = 64 << stage, width = planes * 2, outc = planes * 4;
+    const int inplanes = first ? (stage == 0 ? 64 : outc / 2) : outc;
+    const int stride = (stage > 0 && first) ? 2 : 1;
+    const int ho = h / stride, wo = wd / stride;
+    const long m_in = (long)B * h * wd, m_out = (long)B * ho * wo;
+    const int l1 = 0, l2 = 1, l3 = 2, ld = 3;
+    int rc;
+    auto scale_of = [&](int l) { return aff + (size_t)l * 4096; };
+    auto shift_of = [&](int l) { return aff + (size_t)l * 4096 + 2048; };
+    auto finalize = [&](int l, int rows, long count, int C) -> int {
+        if (training)
+            return bn_finalize_launch(stats, rows, count, L[l].gamma, L[l].beta, L[l].running_mean, L[l].running_var,
+                                      L[l].num_batches_tracked, c.momentum, c.eps, scale_of(l), shift_of(l), C,
+                                      mom ? mom + (size_t)l * 4096 : nullptr, 2048, stream);
+        return CVCL_OK;                                   // eval mode: every layer's affine was produced up front
+    };
+    // conv1 1x1: X [m_in, inplanes] -> R1 [m_in, width]
+    {
+        cvcl_gemm_args a = {};
+        a.A = X; a.W = L[l1].w; a.C = R1;
+        a.M = (int)m_in; a.N = width; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = width;
+        a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+        if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
+        if ((rc = finalize(l1, cvcl_gemm_stats_rows(dtype, &a), m_in, width))) return rc;
+    }
+    // conv2 grouped 3x3 (stride here): R1 -> R2 [m_out, width], BN1+ReLU fused into the load
+    if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), L[l2].w, R2, training ? stats : nullptr,
+                            kMaxStatsRows, B, h, wd, width, 32, stride, stream))) return rc;
+    if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, width, stride), m_out, width))) return rc;
+    // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  BN2+ReLU is applied to the narrow tensor in place first
+    // (one pass) instead of in the GEMM operand load (once per 128-column output tile): see bn_relu_apply_kernel.
+    if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
+    // Layer 1 in bf16 (CVCL_FUSED_TAIL_STAGES leading stages, default 1; measured 6.79 / 6.85 / 6.89 / 7.11 ms per step for
+    // 1 / 2 / 0 / 3 stages since bn_add_relu runs at the HBM rate): conv3 is HBM-bound and cheap, so it runs twice -- a
+    // statistics-only pass (reads only
+    // the narrow operand), then a pass whose epilogue applies BN3 + identity / normalised downsample + ReLU
+    // and writes the block output -- instead of materialising raw3 and re-reading it in bn_add_relu
+    // (saves one write and one read of the wide tensor; results are bit-identical).
+    // In eval mode there is no statistics pass at all, so the fused tail is used in every stage.
+    static const int fused_stages = [] { const char* e = getenv("CVCL_FUSED_TAIL_STAGES"); return e ? atoi(e) : 1; }();
+    const bool fused_tail = dtype == CVCL_BF16 && (stage < fused_stages || !training);
+    auto conv3_args = [&]() {
+        cvcl_gemm_args a = {};
+        a.A = R2; a.W = L[l3].w;
+        a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
+        return a;
+    };
+    // opt-in ($CVCL_BN3_GRAM=1): measured SLOWER than the statistics-only GEMM pass on MI355X at B=256 (8.14 vs 7.74
+    // ms/step: the Gram TN GEMM runs at ~400 TFLOP/s and needs two small follow-up kernels), kept as an experiment
+    static const bool use_gram = [] { const char* e = getenv("CVCL_BN3_GRAM"); return e && e[0] == '1'; }();
+    if (fused_tail && training && use_gram && c.gram_ws) {
+        // BN3 statistics from the Gram matrix of conv3's (narrow) input: one read of R2 instead of a statistics-only
+        // GEMM pass (the conv is linear: sum_y = W colsum(R2), sum_y2[n] = w_n^T (R2^T R2) w_n)
+        if ((rc = cvcl_conv1x1_bn_stats_gram(R2, width, L[l3].w, width, m_out, outc, width, stats, c.gram_ws,
+                                             c.gram_bytes, stream))) return rc;
+        if ((rc = finalize(l3, 1, m_out, outc))) return rc;
+    } else if (!fused_tail || training) {
+        cvcl_gemm_args a = conv3_args();
+        a.C = fused_tail ? nullptr : R3;
+        a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+        if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
+        if ((rc = finalize(l3, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
+    } else {
+        if ((rc = finalize(l3, 0, m_out, outc))) return rc;              // eval mode: affine from the running stats
+    }
+    if (first) {
+        // downsample 1x1 stride s: X -> RD [m_out, outc]
+        cvcl_gemm_args a = {};
+        a.A = X; a.W = L[ld].w; a.C = RD;
+        a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
+        if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
+        a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+        if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
+        if ((rc = finalize(ld, cvcl_gemm_stats_rows(dtype, &a), m_out, outc))) return rc;
+    }
+    if (fused_tail) {
+        cvcl_gemm_args a = conv3_args();
+        a.C = dst; a.act = CVCL_ACT_RELU;
+        a.c_scale = scale_of(l3); a.c_shift = shift_of(l3);
+        a.R = first ? RD : X; a.ldr = outc;
+        if (first) { a.r_scale = scale_of(ld); a.r_shift = shift_of(ld); }
+        if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
+    } else if (first) {
+        if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), RD, scale_of(ld), shift_of(ld), dst, m_out,
+                                   outc, stream))) return rc;
+    } else {
+        if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), X, nullptr, nullptr, dst, m_out, outc,
+                                   stream))) return rc;
+    }
+    return CVCL_OK;
+}
+
+// block-level scratch: R1 / R2 / R3 / RD, statistics rows, 4 affines
+inline size_t block_act_bytes(int dtype, int B, int h, int w, int stage) {
+    const size_t es = dtype == CVCL_BF16 ? 2 : 4;
+    const size_t outc = (size_t)256 << stage;
+    return al256((size_t)B * h * w * outc * es);          // >= every intermediate of the block (R1 is [B,h,w,outc/2])
+}
+}  // namespace
+
+extern "C" size_t cvcl_resnext50_block_workspace_bytes(int dtype, int B, int h, int w, int stage) {
+    return 3 * block_act_bytes(dtype, B, h, w, stage) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)4 * 4096 * 4);
+}
+
+extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stage, int first, int training, const void* x_nhwc,
+                                        const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
+                                        void* out_nhwc, float momentum, float eps, void* stream) {
+    CVCL_CHECK_ARG(x_nhwc && layers && workspace && out_nhwc, "cvcl_resnext50_block_fwd: null pointer");
+    CVCL_CHECK_ARG(stage >= 0 && stage < 4 && n_layers == (first ? 4 : 3), "cvcl_resnext50_block_fwd: stage %d with %d layers", stage, n_layers);
+    CVCL_CHECK_ARG(B > 0 && h > 0 && w > 0 && (!(stage > 0 && first) || (h % 2 == 0 && w % 2 == 0)), "cvcl_resnext50_block_fwd: bad shape");
+    if (workspace_bytes < cvcl_resnext50_block_workspace_bytes(dtype, B, h, w, stage)) {
+        cvcl_set_error("cvcl_resnext50_block_fwd: workspace too small");
+        return CVCL_EWORKSPACE;
+    }
+    char* p = (char*)workspace;
+    const size_t ab = block_act_bytes(dtype, B, h, w, stage);
+    char* R1 = p; char* R2 = p + ab; char* RD = p + 2 * ab; p += 3 * ab;
+    float* stats = (float*)p; p += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
+    float* aff = (float*)p;
+    if (!training) {                                      // eval mode: affines from the running statistics
+        const int planes = 64 << stage;
+        const int Cs[4] = {planes * 2, planes * 2, planes * 4, planes * 4};
+        for (int l = 0; l < n_layers; ++l) {
+            int rc = cvcl_bn_eval_affine(layers[l].gamma, layers[l].beta, layers[l].running_mean, layers[l].running_var, eps,
+                                         aff + (size_t)l * 4096, aff + (size_t)l * 4096 + 2048, Cs[l], stream);
+            if (rc) return rc;
+        }
+    }
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, nullptr, 0, stream};
+    return bottleneck_fwd(ctx, stage, first != 0, h, w, (const char*)x_nhwc, R1, R2, R1, RD, (char*)out_nhwc, layers, aff, nullptr);
+}
+
 static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, const float* x_nchw,
                               const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
                               void* layer4_out_nhwc, float* pooled, float momentum, float eps, float* moments, void* stream) {
@@ -1081,93 +1233,17 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     if ((rc = cvcl_bn_relu_maxpool(dtype, RAW, scale_of(0), shift_of(0), X, B, h, wd, 64, stream))) return rc;
     h /= 2; wd /= 2;
     li = 1;
-    int inplanes = 64;
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, gram_bytes, stream};
     for (int stage = 0; stage < 4; ++stage) {
-        const int planes = 64 << stage, width = planes * 2, outc = planes * 4;
         for (int bi = 0; bi < kLayers[stage]; ++bi) {
             const int stride = (stage > 0 && bi == 0) ? 2 : 1;
-            const int ho = h / stride, wo = wd / stride;
-            const long m_in = (long)B * h * wd, m_out = (long)B * ho * wo;
-            const int l1 = li, l2 = li + 1, l3 = li + 2, ld = li + 3;
-            char *R1 = buf[2], *R2 = buf[3], *R3 = buf[2], *RD = buf[4];
             const bool last = (stage == 3 && bi == kLayers[3] - 1);
-            // conv1 1x1: X [m_in, inplanes] -> R1 [m_in, width]
-            {
-                cvcl_gemm_args a = {};
-                a.A = X; a.W = layers[l1].w; a.C = R1;
-                a.M = (int)m_in; a.N = width; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = width;
-                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
-                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-                if ((rc = finalize(l1, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_in, width))) return rc;
-            }
-            // conv2 grouped 3x3 (stride here): R1 -> R2 [m_out, width], BN1+ReLU fused into the load
-            if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), layers[l2].w, R2, training ? stats : nullptr,
-                                    kMaxStatsRows, B, h, wd, width, 32, stride, stream))) return rc;
-            if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, width, stride), m_out, width))) return rc;
-            // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  BN2+ReLU is applied to the narrow tensor in place first
-            // (one pass) instead of in the GEMM operand load (once per 128-column output tile): see bn_relu_apply_kernel.
-            if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
             char* dst = last ? (char*)layer4_out_nhwc : OUT;
-            // Layer 1 in bf16 (CVCL_FUSED_TAIL_STAGES leading stages, default 1; measured 6.79 / 6.85 / 6.89 / 7.11 ms per step for
-            // 1 / 2 / 0 / 3 stages since bn_add_relu runs at the HBM rate): conv3 is HBM-bound and cheap, so it runs twice -- a
-            // statistics-only pass (reads only
-            // the narrow operand), then a pass whose epilogue applies BN3 + identity / normalised downsample + ReLU
-            // and writes the block output -- instead of materialising raw3 and re-reading it in bn_add_relu
-            // (saves one write and one read of the wide tensor; results are bit-identical).
-            // In eval mode there is no statistics pass at all, so the fused tail is used in every stage.
-            static const int fused_stages = [] { const char* e = getenv("CVCL_FUSED_TAIL_STAGES"); return e ? atoi(e) : 1; }();
-            const bool fused_tail = dtype == CVCL_BF16 && (stage < fused_stages || !training);
-            auto conv3_args = [&]() {
-                cvcl_gemm_args a = {};
-                a.A = R2; a.W = layers[l3].w;
-                a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
-                return a;
-            };
-            // opt-in ($CVCL_BN3_GRAM=1): measured SLOWER than the statistics-only GEMM pass on MI355X at B=256 (8.14 vs 7.74
-            // ms/step: the Gram TN GEMM runs at ~400 TFLOP/s and needs two small follow-up kernels), kept as an experiment
-            static const bool use_gram = [] { const char* e = getenv("CVCL_BN3_GRAM"); return e && e[0] == '1'; }();
-            if (fused_tail && training && use_gram) {
-                // BN3 statistics from the Gram matrix of conv3's (narrow) input: one read of R2 instead of a statistics-only
-                // GEMM pass (the conv is linear: sum_y = W colsum(R2), sum_y2[n] = w_n^T (R2^T R2) w_n)
-                if ((rc = cvcl_conv1x1_bn_stats_gram(R2, width, layers[l3].w, width, m_out, outc, width, stats, gram_ws,
-                                                     gram_bytes, stream))) return rc;
-                if ((rc = finalize(l3, 1, m_out, outc))) return rc;
-            } else if (!fused_tail || training) {
-                cvcl_gemm_args a = conv3_args();
-                a.C = fused_tail ? nullptr : R3;
-                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
-                if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
-                if ((rc = finalize(l3, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_out, outc))) return rc;
-            } else {
-                if ((rc = finalize(l3, 0, m_out, outc))) return rc;              // eval mode: affine from the running stats
-            }
-            if (bi == 0) {
-                // downsample 1x1 stride s: X -> RD [m_out, outc]
-                cvcl_gemm_args a = {};
-                a.A = X; a.W = layers[ld].w; a.C = RD;
-                a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
-                if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
-                a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
-                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-                if ((rc = finalize(ld, cvcl_gemm_grid_m(dtype, a.M, a.N, 0), m_out, outc))) return rc;
-            }
-            if (fused_tail) {
-                cvcl_gemm_args a = conv3_args();
-                a.C = dst; a.act = CVCL_ACT_RELU;
-                a.c_scale = scale_of(l3); a.c_shift = shift_of(l3);
-                a.R = bi == 0 ? RD : X; a.ldr = outc;
-                if (bi == 0) { a.r_scale = scale_of(ld); a.r_shift = shift_of(ld); }
-                if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-            } else if (bi == 0) {
-                if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), RD, scale_of(ld), shift_of(ld), dst, m_out,
-                                           outc, stream))) return rc;
-            } else {
-                if ((rc = cvcl_bn_add_relu(dtype, R3, scale_of(l3), shift_of(l3), X, nullptr, nullptr, dst, m_out, outc,
-                                           stream))) return rc;
-            }
+            if ((rc = bottleneck_fwd(ctx, stage, bi == 0, h, wd, X, buf[2], buf[3], buf[2], buf[4], dst, layers + li,
+                                     affine + (size_t)li * 4096, moments ? moments + (size_t)li * 4096 : nullptr))) return rc;
             li += bi == 0 ? 4 : 3;
             char* t = X; X = dst; OUT = (t == (char*)layer4_out_nhwc) ? OUT : t;
-            h = ho; wd = wo; inplanes = outc;
+            h /= stride; wd /= stride;
         }
     }
     return cvcl_avgpool(dtype, layer4_out_nhwc, pooled, B, h * wd, 2048, stream);

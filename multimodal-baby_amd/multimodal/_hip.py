@@ -148,6 +148,8 @@ SIGNATURES = {
     "cvcl_gemm_fp8": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
+    "cvcl_resnext50_block_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
+    "cvcl_resnext50_block_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _F, _F, _P]),
     "cvcl_resnext50_moments_floats": (_SZ, []),
     "cvcl_resnext50_fwd_deferred_stats": (_I, [_I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _P, _P]),
     "cvcl_resnext50_apply_moments": (_I, [C.POINTER(ConvBnParams), _I, _P, _F, _P]),

@@ -92,10 +92,14 @@ class LightningModule(nn.Module):
         model.load_state_dict(ckpt["state_dict"])
         return model
 
-    def checkpoint_dict(self, trainer=None, optimizer=None):
+    def checkpoint_dict(self, trainer=None, optimizer=None, scheduler=None):
+        """Lightning's checkpoint keys: weights, hyper-parameters, loop position, optimizer / lr-scheduler / callback state."""
+        callbacks = {type(cb).__name__: cb.state_dict() for cb in getattr(trainer, "callbacks", []) if hasattr(cb, "state_dict")}
         return {"state_dict": self.state_dict(), "hyper_parameters": dict(self.hparams),
                 "epoch": getattr(trainer, "current_epoch", 0), "global_step": getattr(trainer, "global_step", 0),
                 "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
+                "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else [],
+                "callbacks": callbacks,
                 "pytorch-lightning_version": "1.6.0-shim"}
 
 
@@ -158,7 +162,9 @@ class Trainer:
                 raise RuntimeError("--gpus > 0 but no GPU is visible")
             # one process per GPU; the modulo only matters when more ranks than GPUs are started on purpose
             # (CVCL_DIST_BACKEND=gloo smoke runs of the N > 1 path on a single-GPU box)
-            return torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1))
+            torch.cuda.set_device(device)      # libcvcl_hip launches on the CURRENT device's current stream: rank r > 0 must not
+            return device                      # enqueue on cuda:0 (validate()/test() never reach DataParallelEngine.from_env)
         return torch.device("cpu")
 
     def _eval_loop(self, model, loaders, step_name, epoch_end_name, device, datamodule=None):
@@ -211,7 +217,13 @@ class Trainer:
     def fit(self, model, datamodule=None, ckpt_path=None):
         from . import parallel
         device = self._device()
-        engine = parallel.DataParallelEngine.from_env(device)
+        # --local_negatives: per-rank B x B loss, gradients AVERAGED (Lightning DDP); default: global negatives, gradients SUMMED
+        global_negatives = bool(getattr(getattr(model, "model", None), "global_negatives", True))
+        engine = parallel.DataParallelEngine.from_env(device, global_negatives=global_negatives)
+        if parallel.is_distributed():
+            # replicas were initialised from the same seed (identical weights); from here on every rank draws its own dropout
+            # masks / augmentation parameters, and the data module hands it its own shard of every global batch
+            seed_everything(int(os.environ.get("PL_GLOBAL_SEED", torch.initial_seed() % (2 ** 31))) + parallel.rank())
         model.trainer = self
         datamodule.prepare_data()
         datamodule.setup()
@@ -223,11 +235,19 @@ class Trainer:
         if isinstance(opt, dict):
             sched, opt = opt.get("lr_scheduler"), opt["optimizer"]
         start_epoch = 0
-        if ckpt_path is not None and os.path.exists(str(ckpt_path)):
+        if ckpt_path is not None:
+            if not os.path.isfile(str(ckpt_path)):
+                raise FileNotFoundError(f"Checkpoint at {ckpt_path} not found. Aborting training.")     # as Lightning does
             ckpt = torch.load(str(ckpt_path), map_location="cpu", weights_only=False)
             model.load_state_dict(ckpt["state_dict"])
             if ckpt.get("optimizer_states"):
                 opt.load_state_dict(ckpt["optimizer_states"][0])
+            if sched is not None and ckpt.get("lr_schedulers"):
+                sched["scheduler"].load_state_dict(ckpt["lr_schedulers"][0])
+            for cb in self.callbacks:
+                st = (ckpt.get("callbacks") or {}).get(type(cb).__name__)
+                if st is not None and hasattr(cb, "load_state_dict"):
+                    cb.load_state_dict(st)
             start_epoch, self.global_step = int(ckpt.get("epoch", -1)) + 1, int(ckpt.get("global_step", 0))
         engine.attach(model)
         upd = None
@@ -242,6 +262,9 @@ class Trainer:
         for epoch in range(start_epoch, self.max_epochs):
             self.current_epoch = epoch
             model.train()
+            model._reset_epoch_logs()          # epoch means start from zero (also when validation is skipped this epoch)
+            if hasattr(datamodule, "set_epoch"):
+                datamodule.set_epoch(epoch)
             outs = []
             if ts is not None:
                 ts.inputs = "ready"            # the batch is produced on the trunk stream itself (below)
@@ -289,7 +312,7 @@ class Trainer:
             if self.enable_checkpointing and parallel.rank() == 0:
                 for cb in self.callbacks:
                     if hasattr(cb, "save"):
-                        cb.save(self, model, opt)
+                        cb.save(self, model, opt, sched["scheduler"] if sched is not None else None)
         return self
 
 
@@ -301,18 +324,25 @@ class ModelCheckpoint:
         self.monitor, self.save_last, self.save_top_k = monitor, save_last, save_top_k
         self.dirpath, self.filename = str(dirpath), filename
 
-    def save(self, trainer, model, optimizer):
+    def state_dict(self):
+        return {"best_k": list(self.__dict__.get("best_k", [])), "best_model_path": getattr(self, "best_model_path", ""),
+                "best_model_score": getattr(self, "best_model_score", None)}
+
+    def load_state_dict(self, st):
+        self.__dict__["best_k"] = [tuple(b) for b in st.get("best_k", [])]
+        if st.get("best_model_path"):
+            self.best_model_path, self.best_model_score = st["best_model_path"], st.get("best_model_score")
+
+    def save(self, trainer, model, optimizer, scheduler=None):
         """``last.ckpt`` every epoch; ``epoch=N.ckpt`` kept for the ``save_top_k`` best values of ``monitor`` (min mode, as
         for val_loss; every epoch counts as best when the monitored metric was not logged)."""
         os.makedirs(self.dirpath, exist_ok=True)
-        ckpt = model.checkpoint_dict(trainer, optimizer)
         if self.save_top_k != 0:
             score = trainer.logged_metrics.get(self.monitor) if self.monitor else None
             score = float(score) if score is not None else float(-trainer.current_epoch)     # no metric: newest wins
             path = os.path.join(self.dirpath, self.filename.format(epoch=f"epoch={trainer.current_epoch}") + ".ckpt")
             best = self.__dict__.setdefault("best_k", [])
             if self.save_top_k < 0 or len(best) < self.save_top_k or score < max(b[0] for b in best):
-                torch.save(ckpt, path)
                 best.append((score, path))
                 best.sort(key=lambda t: t[0])
                 while 0 < self.save_top_k < len(best):
@@ -320,5 +350,7 @@ class ModelCheckpoint:
                     if os.path.exists(worst) and worst != path:
                         os.remove(worst)
                 self.best_model_path, self.best_model_score = best[0][1], best[0][0]
+                if any(b[1] == path for b in best):      # (the checkpoint records this callback's state: build it afterwards)
+                    torch.save(model.checkpoint_dict(trainer, optimizer, scheduler), path)
         if self.save_last:
-            torch.save(ckpt, os.path.join(self.dirpath, "last.ckpt"))
+            torch.save(model.checkpoint_dict(trainer, optimizer, scheduler), os.path.join(self.dirpath, "last.ckpt"))

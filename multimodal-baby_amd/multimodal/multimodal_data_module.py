@@ -179,7 +179,8 @@ class SyntheticDataModule(MultiModalDataModule):
 
     def __init__(self, args=None, n_items: int = 64):
         super().__init__(args)
-        self.n_items = max(n_items, 2 * self.batch_size)
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.n_items = max(n_items, 2 * self.batch_size) * max(world, 1)          # the same number of steps per rank
         self.seed = self.args.get("seed", 0)
 
     def prepare_data(self, *a, **k):
@@ -199,8 +200,20 @@ class SyntheticDataModule(MultiModalDataModule):
                           "test": SyntheticEvalTrials(n_trials, v, seed=self.seed + 4, eval_include_sos_eos=sos_eos, raw_frames=raw,
                                                       eval_type=et)}
 
+    def set_epoch(self, epoch: int):
+        self._epoch = int(epoch)
+
     def train_dataloader(self):
-        return torch.utils.data.DataLoader(self.train_set, batch_size=self.batch_size, shuffle=False,
+        """One process per GPU: every rank reads its own shard of each global batch (DistributedSampler, as Lightning's DDP
+        strategy injects into the reference's loaders) -- identical batches on every rank would make each positive a
+        ``world``-fold negative of itself under global negatives."""
+        sampler = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(
+                self.train_set, num_replicas=torch.distributed.get_world_size(), rank=torch.distributed.get_rank(),
+                shuffle=False, drop_last=True)
+            sampler.set_epoch(getattr(self, "_epoch", 0))
+        return torch.utils.data.DataLoader(self.train_set, batch_size=self.batch_size, shuffle=False, sampler=sampler,
                                            collate_fn=multiModalDataset_collate_fn, drop_last=self.drop_last)
 
     def _val_test(self, pairs, trials):

@@ -12,7 +12,7 @@ import os
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, parallel
 from .lightning import LightningModule
 from .multimodal import LanguageModel, MultiModalModel
 from .multimodal_data_module import (EOS_TOKEN_ID, MAX_LEN_UTTERANCE, N_VAL_DATALOADERS_PER_SPLIT, PAD_TOKEN_ID,
@@ -181,7 +181,11 @@ class MultiModalLitModel(LightningModule):
                 ret[f"n_tokens{suffix}"] = counts[i]
         else:
             lm_ce_loss = 0.
-        loss = self.lambda_mm * infonce_loss + self.lambda_lm * lm_ce_loss
+        # data-parallel, global negatives: InfoNCE is the replicated full-batch loss and per-rank gradients are SUMMED; the LM
+        # cross entropy is a mean over this rank's tokens only, so it enters with 1 / world (sum over ranks = global mean).
+        # The logged / returned ce_loss values stay the rank's own means.
+        lm_scale = parallel.local_term_scale(self.model.global_negatives) if (self.training and self.lambda_lm) else 1.0
+        loss = self.lambda_mm * infonce_loss + (self.lambda_lm * lm_scale) * lm_ce_loss
         log(f"{stage}_loss", loss)
         ret.update({"loss": loss})
         return ret

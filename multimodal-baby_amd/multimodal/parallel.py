@@ -17,7 +17,15 @@ Gradients are reduced in size-capped buckets launched from post-accumulate-grad 
 is complete, so the RCCL all-reduce of early buckets runs on RCCL's stream while the rest of backward is
 still executing; ``reduce_gradients`` waits and scatters the results back.  xGMI is point-to-point (7
 links of ~153 GB/s per GPU): few large buckets keep the ring per-link efficient; the frozen-CNN step has
-only ~9 MB of gradients, i.e. a single bucket.
+only ~9 MB of gradients, i.e. a single bucket.  With ``--finetune_cnn`` the trunk's weight gradients do not
+come through autograd's accumulation (trunk_train computes them on a side stream and stores them when the
+backward pass ends), so trunk_train reports each one as it is enqueued (``grad_ready``): it is copied into
+its bucket on the stream that produced it and a complete bucket's all-reduce starts behind that stream --
+the ~100 MB of ResNeXt gradients are reduced while the data-gradient chain is still running.
+
+Terms of the loss that are rank-local means (the language-model cross entropy of ``lambda_lm > 0``) are
+divided by the world size in global-negatives mode (``local_term_scale``), so that the SUM over ranks is
+the mean over the global batch, like the replicated InfoNCE term.
 """
 from __future__ import annotations
 
@@ -61,6 +69,13 @@ class _AllGatherRows(torch.autograd.Function):
         return grad[r * ctx.rows:(r + 1) * ctx.rows].contiguous()
 
 
+def local_term_scale(global_negatives: bool) -> float:
+    """Factor for a loss term that is a mean over the RANK'S OWN samples when gradients are summed over ranks (global
+    negatives): 1 / world, so that the summed gradient is the gradient of the mean over all ranks' samples.  1.0 otherwise
+    (single process; local negatives, where the engine averages every gradient)."""
+    return 1.0 / world_size() if (global_negatives and is_distributed()) else 1.0
+
+
 def gather_features(image_features: torch.Tensor, text_features: torch.Tensor):
     """[B,E] per rank -> [world*B, E] on every rank (rank-major row order)."""
     if not is_distributed():
@@ -77,6 +92,7 @@ class DataParallelEngine:
         self.global_negatives = global_negatives
         self.buckets = []            # list of dict(params, buf, pending, handle)
         self._hooks = []
+        self._bucket_of = {}
 
     @classmethod
     def from_env(cls, device, **kw):
@@ -91,7 +107,8 @@ class DataParallelEngine:
     def attach(self, module: torch.nn.Module):
         for h in self._hooks:
             h.remove()
-        self._hooks, self.buckets = [], []
+        self._hooks, self.buckets, self._bucket_of = [], [], {}
+        self._listen(False)
         if not is_distributed():
             return self
         params = [p for p in module.parameters() if p.requires_grad]
@@ -106,36 +123,70 @@ class DataParallelEngine:
             cur_bytes += nb
         if cur:
             self._new_bucket(cur)
+        self._listen(True)
         return self
+
+    def _listen(self, on: bool):
+        """Receive the weight gradients trunk_train computes outside autograd's accumulation (fine-tuning path)."""
+        try:
+            from . import trunk_train
+        except Exception:                                   # pragma: no cover - CPU-only host-logic tests without the library
+            return
+        if on:
+            trunk_train._WGRAD_LISTENER = self.grad_ready
+        elif getattr(trunk_train, "_WGRAD_LISTENER", None) is not None and \
+                getattr(trunk_train._WGRAD_LISTENER, "__self__", None) is self:
+            trunk_train._WGRAD_LISTENER = None
 
     def _new_bucket(self, params):
         total = sum(p.numel() for p in params)
+        offs, off = {}, 0
+        for p in params:
+            offs[id(p)] = off
+            off += p.numel()
         b = {"params": list(params), "buf": torch.zeros(total, dtype=params[0].dtype, device=params[0].device),
-             "pending": len(params), "handle": None, "seen": set()}
+             "pending": len(params), "handle": None, "seen": set(), "offs": offs}
         self.buckets.append(b)
         for p in params:
+            self._bucket_of[id(p)] = b
             self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+
+    def _arrive(self, b, p, grad):
+        """Gradient of p is final: into the bucket (on the current stream); the last arrival launches the all-reduce."""
+        if id(p) in b["seen"]:
+            return
+        b["seen"].add(id(p))
+        off = b["offs"][id(p)]
+        b["buf"][off:off + p.numel()].copy_(grad.reshape(-1))
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
 
     def _make_hook(self, b):
         def hook(p):
-            if id(p) in b["seen"]:
-                return
-            b["seen"].add(id(p))
-            b["pending"] -= 1
-            if b["pending"] == 0:
-                self._launch(b)
+            self._arrive(b, p, p.grad)
         return hook
 
+    def grad_ready(self, p, grad):
+        """A gradient produced outside autograd's accumulation (trunk_train._defer_wgrad), called on the stream that
+        computes it: the collective of a completed bucket is enqueued behind THAT stream, not behind the backward pass."""
+        b = self._bucket_of.get(id(p))
+        if b is None or not is_distributed():
+            return
+        if p.grad is not None:                               # accumulating over several backward passes: reduce the total
+            b.setdefault("late", set()).add(id(p))           # at reduce_gradients() time instead
+            return
+        self._arrive(b, p, grad)
+
     def _launch(self, b):
-        off = 0
-        b["had_grad"] = [p.grad is not None for p in b["params"]]
-        for p in b["params"]:
-            n = p.numel()
-            if p.grad is not None:
-                b["buf"][off:off + n].copy_(p.grad.reshape(-1))
-            else:
-                b["buf"][off:off + n].zero_()
-            off += n
+        b["had_grad"] = [id(p) in b["seen"] or p.grad is not None for p in b["params"]]
+        for p in b["params"]:                                # parameters without a gradient this step contribute zeros
+            if id(p) not in b["seen"] or id(p) in b.get("late", ()):
+                off = b["offs"][id(p)]
+                if p.grad is not None:
+                    b["buf"][off:off + p.numel()].copy_(p.grad.reshape(-1))
+                else:
+                    b["buf"][off:off + p.numel()].zero_()
         b["handle"] = dist.all_reduce(b["buf"], op=dist.ReduceOp.SUM, async_op=True)
 
     def reduce_gradients(self):
@@ -147,16 +198,15 @@ class DataParallelEngine:
             if b["handle"] is None:                         # some parameter received no gradient this step
                 self._launch(b)
             b["handle"].wait()
-            off = 0
             for p, had in zip(b["params"], b["had_grad"]):
-                n = p.numel()
-                if had:      # a parameter no rank produced a gradient for keeps grad=None (the optimizer skips it,
-                    g = b["buf"][off:off + n].view_as(p)        # as in the single-process reference)
+                if had and p.grad is not None:   # a parameter no rank produced a gradient for keeps grad=None (the optimizer
+                    off = b["offs"][id(p)]       # skips it, as in the single-process reference)
+                    g = b["buf"][off:off + p.numel()].view_as(p)
                     averaged = (not self.global_negatives) or getattr(p, "_cvcl_replicated_grad", False)
                     p.grad.copy_(g / world if averaged else g)
-                off += n
             b["pending"], b["handle"] = len(b["params"]), None
             b["seen"].clear()
+            b.pop("late", None)
 
 
 class OverlappedUpdate:

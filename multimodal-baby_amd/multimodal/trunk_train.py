@@ -85,6 +85,9 @@ def _zero_stuff(dy: torch.Tensor) -> torch.Tensor:
 # $CVCL_WGRAD_STREAM=0 keeps everything on one stream.
 _WGRAD_STREAMS: dict = {}
 _WGRAD_PENDING: list = []
+# parallel.DataParallelEngine.grad_ready when data-parallel: called with (param, dW) on the side stream right after dW is
+# enqueued, so that the bucketed all-reduce of the trunk's gradients starts during the backward pass instead of after it
+_WGRAD_LISTENER = None
 
 
 def _wgrad_stream(device) -> torch.cuda.Stream:
@@ -125,6 +128,8 @@ def _defer_wgrad(param, compute, *reads):
     side.wait_event(ready)
     with torch.cuda.stream(side):
         dw = compute()
+        if _WGRAD_LISTENER is not None:
+            _WGRAD_LISTENER(param, dw)
     for t in reads:
         t.record_stream(side)                                # their memory may be released on the caller's stream before the side stream is done
     _WGRAD_PENDING.append((param, dw))

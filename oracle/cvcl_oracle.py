@@ -349,13 +349,23 @@ def bn_name_of(conv_name: str) -> str:
 
 
 def batch_norm(x: Tensor, p: Dict[str, Tensor], name: str, training: bool,
-               stats_out: Optional[Dict[str, Tensor]] = None) -> Tensor:
+               stats_out: Optional[Dict[str, Tensor]] = None, impl: str = "explicit") -> Tensor:
     """``nn.BatchNorm2d`` (eps 1e-5, momentum 0.1): batch statistics + running-stat EMA with
     the unbiased variance in training mode, running statistics in eval mode.  ``stats_out``
     receives the *updated* running buffers (the reference mutates them in place, also when the
-    CNN is frozen: SURVEY 0.4)."""
+    CNN is frozen: SURVEY 0.4).  ``impl="torch"`` runs the same layer through ``F.batch_norm`` on
+    copies of the running buffers -- exactly what ``nn.BatchNorm2d.forward`` executes on the host;
+    the CPU baseline uses it so that it times what the reference would run (tests/test_oracle_golden.py
+    checks the two forms against each other)."""
     w, b = p[name + ".weight"], p[name + ".bias"]
     rm, rv = p[name + ".running_mean"], p[name + ".running_var"]
+    if impl == "torch":
+        rm2, rv2 = rm.detach().clone(), rv.detach().clone()
+        y = F.batch_norm(x, rm2, rv2, w, b, training, BN_MOMENTUM, BN_EPS)
+        if training and stats_out is not None:
+            stats_out[name + ".running_mean"], stats_out[name + ".running_var"] = rm2, rv2
+            stats_out[name + ".num_batches_tracked"] = p[name + ".num_batches_tracked"] + 1
+        return y
     if training:
         n = x.numel() // x.shape[1]
         mean = x.mean(dim=(0, 2, 3))
@@ -371,31 +381,31 @@ def batch_norm(x: Tensor, p: Dict[str, Tensor], name: str, training: bool,
     return x * scale[None, :, None, None] + shift[None, :, None, None]
 
 
-def _conv_bn(pp, inp, name, stride, pad, groups, relu, training, quant, stats_out, taps):
+def _conv_bn(pp, inp, name, stride, pad, groups, relu, training, quant, stats_out, taps, bn_impl="explicit"):
     y = F.conv2d(_q(quant, inp), _q(quant, pp[name + ".weight"]), None, stride, pad, 1, groups)
     y = _q(quant, y)                                        # raw conv output as stored
     if taps is not None:
         taps[name + ".raw"] = y
-    y = batch_norm(y, pp, bn_name_of(name), training, stats_out)
+    y = batch_norm(y, pp, bn_name_of(name), training, stats_out, bn_impl)
     return torch.relu(y) if relu else y
 
 
-def resnext50_stem(pp, x, training, quant: Quant = None, stats_out=None, taps=None) -> Tensor:
+def resnext50_stem(pp, x, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit") -> Tensor:
     """conv1 7x7/2 -> bn1 -> relu -> maxpool 3x3/2 pad 1."""
-    h = _conv_bn(pp, x, "conv1", 2, 3, 1, True, training, quant, stats_out, taps)
+    h = _conv_bn(pp, x, "conv1", 2, 3, 1, True, training, quant, stats_out, taps, bn_impl)
     h = _q(quant, F.max_pool2d(h, 3, 2, 1))
     if taps is not None:
         taps["maxpool"] = h
     return h
 
 
-def resnext50_stage(pp, h, li: int, training, quant: Quant = None, stats_out=None, taps=None) -> Tensor:
+def resnext50_stage(pp, h, li: int, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit") -> Tensor:
     """``layer{li}``: Bottleneck x RESNEXT_LAYERS[li-1] (1x1 -> grouped 3x3 (stride here, v1.5) -> 1x1,
     + identity / 1x1-stride-s downsample on the first block, ReLU after the add)."""
     for bi in range(RESNEXT_LAYERS[li - 1]):
         pre = f"layer{li}.{bi}."
         stride = 2 if (li > 1 and bi == 0) else 1
-        a = (training, quant, stats_out, taps)
+        a = (training, quant, stats_out, taps, bn_impl)
         o = _q(quant, _conv_bn(pp, h, pre + "conv1", 1, 0, 1, True, *a))
         o = _q(quant, _conv_bn(pp, o, pre + "conv2", stride, 1, RESNEXT_GROUPS, True, *a))
         o = _conv_bn(pp, o, pre + "conv3", 1, 0, 1, False, *a)
@@ -408,7 +418,7 @@ def resnext50_stage(pp, h, li: int, training, quant: Quant = None, stats_out=Non
 
 def resnext50_forward(p: Dict[str, Tensor], x: Tensor, training: bool, quant: Quant = None,
                       prefix: str = "", stats_out: Optional[Dict[str, Tensor]] = None,
-                      taps: Optional[Dict[str, Tensor]] = None):
+                      taps: Optional[Dict[str, Tensor]] = None, bn_impl: str = "explicit"):
     """torchvision ``ResNet.forward`` for resnext50_32x4d up to and including avgpool+flatten.
 
     Returns (pooled [B,2048] fp32, layer4 feature map [B,2048,7,7]).  The ``fc`` is applied
@@ -419,9 +429,9 @@ def resnext50_forward(p: Dict[str, Tensor], x: Tensor, training: bool, quant: Qu
     ``stats_out`` keys carry no prefix.
     """
     pp = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)} if prefix else p
-    h = resnext50_stem(pp, x, training, quant, stats_out, taps)
+    h = resnext50_stem(pp, x, training, quant, stats_out, taps, bn_impl)
     for li in (1, 2, 3, 4):
-        h = resnext50_stage(pp, h, li, training, quant, stats_out, taps)
+        h = resnext50_stage(pp, h, li, training, quant, stats_out, taps, bn_impl)
     pooled = h.mean(dim=(2, 3))
     return pooled, h
 
@@ -501,13 +511,13 @@ def vit_forward(p: Dict[str, Tensor], x: Tensor, patch: int, num_heads: int, qua
 def cvcl_forward(p: Dict[str, Tensor], image: Tensor, text: Tensor, text_len: Tensor, *,
                  vision: str = "resnext", text_encoder: str = "embedding", normalize_features: bool,
                  training: bool, quant: Quant = None, vit_patch: int = 14, vit_heads: int = 12,
-                 pos_embed_type: str = "no_pos_embed", stats_out=None):
+                 pos_embed_type: str = "no_pos_embed", stats_out=None, bn_impl: str = "explicit"):
     """``MultiModalModel.forward(..., return_image_features=True, return_text_outputs=True)``
     (multimodal.py:746-794), flat embedding branch.  ``p`` uses ``MultiModalModel.state_dict()``
     names: ``image_embed.model.*``, ``text_embed.*``, ``logit_neg_log_temperature``."""
     ip = "image_embed.model."
     if vision == "resnext":
-        pooled, fmap = resnext50_forward(p, image, training, quant, ip, stats_out)
+        pooled, fmap = resnext50_forward(p, image, training, quant, ip, stats_out, bn_impl=bn_impl)
         img = linear(pooled, p[ip + "fc.weight"], p[ip + "fc.bias"])           # multimodal.py:101,192
     else:
         cls = vit_forward(p, image, vit_patch, vit_heads, quant, ip)
@@ -579,10 +589,11 @@ class CpuTrainStep:
     (BN in train mode: SURVEY 0.4), InfoNCE, backward of the trainable set, AdamW
     (multimodal_lit.py:112-114, 227-261, 445-447).  Used by bench.py's cpu_baseline leg."""
 
-    def __init__(self, p, lr=1e-4, weight_decay=0.1, normalize_features=True):
+    def __init__(self, p, lr=1e-4, weight_decay=0.1, normalize_features=True, bn_impl="explicit", learn_temperature=False):
         self.p = dict(p)
         self.normalize = normalize_features
-        self.train = [k for k in TRAINABLE_FROZEN_CNN]
+        self.bn_impl = bn_impl
+        self.train = [k for k in TRAINABLE_FROZEN_CNN] + (["logit_neg_log_temperature"] if learn_temperature else [])
         for k in self.train:
             self.p[k] = self.p[k].clone().requires_grad_(True)
         self.opt = torch.optim.AdamW([self.p[k] for k in self.train], lr=lr, weight_decay=weight_decay)
@@ -590,7 +601,7 @@ class CpuTrainStep:
     def step(self, image, text, text_len):
         stats = {}
         out = cvcl_contrastive_loss(self.p, image, text, text_len, normalize_features=self.normalize,
-                                    training=True, stats_out=stats)
+                                    training=True, stats_out=stats, bn_impl=self.bn_impl)
         loss = out[0]
         self.opt.zero_grad(set_to_none=True)
         loss.backward()

@@ -156,3 +156,29 @@ def test_resnext_anchors():
     full = torch.nn.functional.conv2d(h, w, None, 1, 1, 1, 32)
     g3 = torch.nn.functional.conv2d(h[:, 12:16], w[12:16], None, 1, 1)
     assert maxrel(g3, full[:, 12:16]) < 1e-5
+
+
+def test_batch_norm_forms_agree():
+    """The explicit BatchNorm of the oracle and its F.batch_norm form (what nn.BatchNorm2d executes; used by the CPU
+    baseline) give the same outputs and the same updated running statistics, in train and eval mode."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(6, 16, 9, 7, generator=g) * 1.7 + 0.3
+    p = {"bn.weight": torch.rand(16, generator=g) + 0.5, "bn.bias": torch.randn(16, generator=g),
+         "bn.running_mean": torch.randn(16, generator=g), "bn.running_var": torch.rand(16, generator=g) + 0.5,
+         "bn.num_batches_tracked": torch.tensor(7)}
+    for training in (True, False):
+        s1, s2 = {}, {}
+        y1 = O.batch_norm(x, p, "bn", training, s1)
+        y2 = O.batch_norm(x, p, "bn", training, s2, impl="torch")
+        assert float((y1 - y2).abs().max()) < 1e-5
+        assert set(s1) == set(s2)
+        for k in s1:
+            assert float((s1[k].double() - s2[k].double()).abs().max()) < 1e-5, k
+    assert int(s1.get("bn.num_batches_tracked", torch.tensor(8))) == 8 or not s1
+    # and through the whole train step of the ResNeXt + embedding configuration (tiny frames)
+    pr = O.cvcl_random_params(32, seed=2)
+    img, tok, ln = O.synthetic_batch(3, seed=4)
+    img = img[:, :, :64, :64].contiguous()
+    a = O.cvcl_contrastive_loss(pr, img, tok, ln, normalize_features=True, training=True)
+    b = O.cvcl_contrastive_loss(pr, img, tok, ln, normalize_features=True, training=True, bn_impl="torch")
+    assert abs(float(a[0]) - float(b[0])) < 1e-4

@@ -58,7 +58,10 @@ def _worker(rank, world, port, global_negatives, out, deferred=False):
     lpi, lpt = O.similarity_logits(fi, ft, nlt)
     loss = O.contrastive_loss(lpi, lpt)[0]
     loss.backward()
-    if deferred:
+    if deferred == "listener":        # trunk_train reports the gradient while the backward pass is still running (grad_ready),
+        engine.grad_ready(proj, proj_used.grad)          # and stores it into .grad when the pass is over
+        proj.grad = proj_used.grad
+    elif deferred:
         proj.grad = proj_used.grad
     engine.reduce_gradients()
     out.put((rank, float(loss), proj.grad.clone(), table.grad.clone(), nlt.grad.clone()))
@@ -94,7 +97,8 @@ def _single_process_reference(world, global_negatives):
     return float(loss), proj.grad, table.grad, nlt.grad
 
 
-@pytest.mark.parametrize("global_negatives,deferred", [(True, False), (False, False), (True, True)])
+@pytest.mark.parametrize("global_negatives,deferred", [(True, False), (False, False), (True, True), (True, "listener"),
+                                                       (False, "listener")])
 def test_world2_gradients_equal_single_process(global_negatives, deferred):
     world = 2
     ctx = mp.get_context("spawn")

@@ -1,0 +1,173 @@
+"""GPU, two ranks on one device over gloo (RCCL refuses two ranks per GPU; the collectives' call pattern is the same):
+the data-parallel path end to end, through the product's own entry points.
+
+* one C2 step at 256 pairs per rank through DataParallelEngine + OverlappedUpdate with global negatives (N = 512) against
+  the oracle's single-process loss / gradients on the concatenated features (SURVEY.md 8e parity definition: reference
+  calculate_contrastive_loss math, multimodal.py:796-822, applied to cat_r(features_r); gradients = SUM over ranks);
+* ``train.py --gpus 2`` (Trainer.fit: per-rank data shards, per-rank RNG, --local_negatives / lambda_lm handling) against the
+  single-process run on the 2B batch."""
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import cvcl_oracle as O
+from conftest import ROOT, maxrel
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(args, world=2, timeout=600):
+    env = dict(os.environ)
+    env.update(CVCL_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), WORKER] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_two_ranks_global_negatives_n512_vs_oracle(tmp_path):
+    _run_ranks(["bench_step", str(tmp_path)])
+    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in range(2)]
+    pooled = torch.cat([r[0]["pooled"], r[1]["pooled"]]).float()
+    tok, ln = torch.cat([r[0]["tok"], r[1]["tok"]]), torch.cat([r[0]["len"], r[1]["len"]])
+    assert pooled.shape == (512, 2048) and not torch.equal(r[0]["pooled"], r[1]["pooled"])       # ranks saw different shards
+    names = {"fc.weight": "vision_encoder.model.fc.weight", "fc.bias": "vision_encoder.model.fc.bias",
+             "emb": "text_encoder.embedding.weight"}
+    for k in names.values():
+        assert torch.equal(r[0]["before"][k], r[1]["before"][k]), k                               # replicas start identical
+    w = r[0]["before"][names["fc.weight"]].clone().requires_grad_()
+    b = r[0]["before"][names["fc.bias"]].clone().requires_grad_()
+    emb = r[0]["before"][names["emb"]].clone().requires_grad_()
+    fi = O.l2_normalize(O.linear(pooled, w, b))
+    ft = O.l2_normalize(O.embedding_meanpool(emb, tok, ln)[0])
+    lpi, lpt = O.similarity_logits(fi, ft, torch.tensor(-math.log(0.07)))
+    loss = O.contrastive_loss(lpi, lpt)[0]
+    loss.backward()
+    for i in range(2):
+        assert abs(r[i]["losses"][0] - float(loss)) < 2e-4 * abs(float(loss)), (i, r[i]["losses"], float(loss))
+        g = r[i]["grads"]
+        assert maxrel(g[names["fc.weight"]], w.grad) < 2e-4, i
+        assert maxrel(g[names["fc.bias"]], b.grad) < 2e-4, i
+        assert maxrel(g[names["emb"]], emb.grad) < 2e-4, i
+    for k in names.values():                                                                      # replicas stay bit-identical
+        assert torch.equal(r[0]["grads"][k], r[1]["grads"][k]), k
+        assert torch.equal(r[0]["after1"][k], r[1]["after1"][k]) and not torch.equal(r[0]["after1"][k], r[0]["before"][k]), k
+    assert r[0]["losses"] == r[1]["losses"] and r[0]["losses"][1] < r[0]["losses"][0] + 0.5
+
+
+COMMON = ("--dataset synthetic --text_encoder embedding --embedding_dim 64 --vit_dino --normalize_features --fix_temperature "
+          "--optimize_unused --checkpoint_callback False --logger False --max_epochs 1 --limit_train_batches 2 "
+          "--check_val_every_n_epoch 100 --lr 1e-3 --weight_decay 0.1 --precision 32 --seed 3")
+
+
+def _single_process(tmp_path, extra, batch):
+    out = tmp_path / "single"
+    out.mkdir()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, WORKER, "train", str(out), "--"] + (COMMON + f" --gpus 1 --batch_size {batch} " + extra).split()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return torch.load(out / "rank0.pt", weights_only=False)
+
+
+@pytest.mark.parametrize("extra", ["--lambda_lm 0", "--lambda_lm 0.5"])
+def test_trainer_fit_two_ranks_equals_single_process_on_the_global_batch(tmp_path, extra):
+    """Frozen ViT trunk (no BatchNorm: a rank's features do not depend on its shard-mates), global negatives: two ranks x B
+    take exactly the optimizer steps of one process on the 2B batch -- each rank reads its own shard (DistributedSampler),
+    InfoNCE gradients are summed, and the rank-local LM mean enters with 1 / world."""
+    B = 4
+    two = tmp_path / "two"
+    two.mkdir()
+    _run_ranks(["train", str(two), "--"] + (COMMON + f" --gpus 2 --batch_size {B} " + extra).split())
+    r = [torch.load(two / f"rank{i}.pt", weights_only=False) for i in range(2)]
+    ref = _single_process(tmp_path, extra, 2 * B)
+    assert r[0]["global_step"] == r[1]["global_step"] == ref["global_step"] == 2
+    for k, v in ref["params"].items():
+        assert torch.equal(r[0]["params"][k], r[1]["params"][k]), k
+        d = float((r[0]["params"][k] - v).abs().max())
+        assert d < 2e-5 * max(1.0, float(v.abs().max())), (k, d)
+
+
+def test_trainer_fit_local_negatives_averages_gradients(tmp_path):
+    """--local_negatives = Lightning-DDP semantics: each rank's own B x B loss, gradients averaged.  Same update as a single
+    process that averages the two half-batch gradients (computed here with the product itself, one half at a time)."""
+    import contextlib
+    import io
+    B = 4
+    two = tmp_path / "two"
+    two.mkdir()
+    argv = (COMMON + f" --gpus 2 --batch_size {B} --lambda_lm 0 --local_negatives --limit_train_batches 1").split()
+    _run_ranks(["train", str(two), "--"] + argv)
+    r = [torch.load(two / f"rank{i}.pt", weights_only=False) for i in range(2)]
+    # single-process emulation: build the same model, run the two shards, average, step
+    import train as train_entry
+    from multimodal import lightning as pl
+    from multimodal.multimodal import TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import SyntheticDataModule
+    from multimodal.multimodal_lit import MultiModalLitModel
+    args = train_entry._setup_parser().parse_args((COMMON + f" --gpus 1 --batch_size {B} --lambda_lm 0 --local_negatives").split())
+    pl.seed_everything(args.seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        data = SyntheticDataModule(args)
+        ve = VisionEncoder(args=args)
+        lit = MultiModalLitModel(ve, TextEncoder(data.read_vocab(), ve.last_cnn_out_dim, args=args), args)
+    dev = torch.device("cuda:0")
+    lit.to(dev).train()
+    lit.set_precision("32")
+    opt = lit.configure_optimizers()
+    data.setup()
+    from multimodal.multimodal_data_module import multiModalDataset_collate_fn
+    shards = [[data.train_set[rk + 2 * i] for i in range(B)] for rk in range(2)]                   # DistributedSampler(shuffle=False)
+    grads = []
+    for items in shards:
+        x, y, ln, raw = multiModalDataset_collate_fn(items)
+        opt.zero_grad(set_to_none=True)
+        out = lit.training_step((x.to(dev), y.to(dev), ln.to(dev), raw), 0)
+        out["loss"].backward()
+        grads.append({k: v.grad.clone() for k, v in lit.named_parameters() if v.grad is not None})
+    opt.zero_grad(set_to_none=True)
+    for k, v in lit.named_parameters():
+        if k in grads[0]:
+            v.grad = (grads[0][k] + grads[1][k]) / 2
+    opt.step()
+    for k, v in lit.named_parameters():
+        if v.requires_grad and k in r[0]["params"]:
+            assert torch.equal(r[0]["params"][k], r[1]["params"][k]), k
+            d = float((r[0]["params"][k] - v.detach().cpu()).abs().max())
+            assert d < 2e-5 * max(1.0, float(v.abs().max())), (k, d)
+
+
+def test_bench_spawns_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` outside torch.distributed.run starts two fresh ranks itself (before touching the GPU) and
+    rank 0 prints the one JSON line with the whole-job throughput."""
+    import json
+    env = dict(os.environ)
+    env.update(CVCL_DIST_BACKEND="gloo", CVCL_TRUNK_STREAMS="1")          # two ranks share this box's one GPU
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["config"]["trunk_streams"] == 1
+    assert line["value"] > 0 and line["config"]["negatives"].startswith("global") and "logits_rel_vs_fp32" in line
