@@ -327,6 +327,15 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # deviation of the benchmarked precision from the exact-fp32 parity mode: the benchmark's weights (random init, before any
+    # optimizer step) and the benchmark's batch; BatchNorm buffers restored, so the timed steps start from the initial state
+    parity = None
+    if not a.no_parity and precision != "32" and batch_size <= 1024:
+        set_trunk_streams(0)
+        parity = logits_vs_fp32(lit, batch, precision)
+        torch.cuda.synchronize()
+        set_trunk_streams(trunk_streams)
+
     for _ in range(warmup):
         out = step()
     flush()
@@ -418,13 +427,6 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
 
-    parity = None
-    if not a.no_parity and precision != "32" and batch_size <= 1024:
-        flush()
-        torch.cuda.synchronize()
-        set_trunk_streams(0)
-        parity = logits_vs_fp32(lit, batch, precision)
-
     if rank == 0:
         line = {"metric": METRIC if cfg == "c2" else f"image-text pairs/sec, CVCL ViT-B/16+transformer text 224², {cfg.upper()}, MI355X",
                 "value": round(value, 1), "unit": "pairs/s", "n_gpus": world, "steps": steps,
@@ -437,9 +439,11 @@ def main(argv=None):
                 "final_loss": round(loss, 5)}
         if parity is not None:
             line.update({k: float(f"{v:.4g}") for k, v in parity.items()})
-            line["parity_note"] = ("same weights and batch through the exact-fp32 parity mode (the mode held to the 1e-3 logits gate "
-                                   "against the reference forward) and the benchmarked precision, train-mode BatchNorm; yardstick: "
-                                   "PyTorch CPU bf16 autocast deviates ~1e-2 on the reference path (SURVEY.md 0.6)")
+            line["parity_note"] = ("the benchmark's random-init weights and batch through the exact-fp32 parity mode (the mode held to the "
+                                   "1e-3 logits gate against the reference forward) and through the benchmarked precision, train-mode "
+                                   "BatchNorm, before the first optimizer step; logits_rel = max |d logit| / max |logit|.  iid-noise frames "
+                                   "through a random-init trunk: BatchNorm divides by a small per-channel spread and amplifies every bf16 "
+                                   "storage rounding (tests/test_c2_parity_gpu.py measures it per block); DESIGN.md section 3")
         if roofline is not None:
             line["roofline"] = roofline
             line["kernel_ms_per_step"] = breakdown

@@ -131,11 +131,15 @@ int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);
  * (args->stats / stats_rows are ignored).  With a smaller buffer sized by cvcl_gemm_grid_m the 128-tile kernel runs and
  * writes cvcl_gemm_grid_m rows.                                                                          */
 int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* args);
-/* the 256 x 256 phase-interleaved bf16 kernel behind cvcl_gemm's dispatcher (epi 0: conv + statistics, 1: bias /
- * activation / residual); exposed for tests and tuning                                                   */
-int cvcl_gemm256(int epi, const cvcl_gemm_args* args, void* stream);
-int cvcl_gemm256_supported(int M, int N, int K, int lda, int ldw, int ldc);
-int cvcl_gemm256_stats_rows(int M);
+/* The 8-wave 256 (224) x 256 bf16 kernel the dispatcher of cvcl_gemm selects for the MFMA-bound shapes (ResNeXt layers 2-4 1x1
+ * convolutions, ViT linears; N % 256 == 0, K % 128 == 0), callable directly with the same argument block.
+ * epi 0 = convolution epilogue (round + BN partial sums; C may be NULL), epi 1 = bias / activation / residual.
+ * cvcl_gemm8w_tile_rows: the tile height (256 or 224) the epi-0 launch uses for an [M, N] output; cvcl_gemm8w_stats_rows: the
+ * number of BN-statistics rows it writes.                                                                                */
+int cvcl_gemm8w(int epi, const cvcl_gemm_args* args, void* stream);
+int cvcl_gemm8w_supported(int M, int N, int K, int lda, int ldw, int ldc);
+int cvcl_gemm8w_tile_rows(int M, int N);
+int cvcl_gemm8w_stats_rows(int M, int N);
 
 /* out[c][r] = in[r][c], f32 (operand re-layout for the weight-gradient GEMMs). */
 int cvcl_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);

@@ -821,32 +821,37 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
 
 
 }  // namespace
-extern "C" int cvcl_gemm256(int epi, const cvcl_gemm_args* a, void* stream);
-extern "C" int cvcl_gemm256_supported(int M, int N, int K, int lda, int ldw, int ldc);
-extern "C" int cvcl_gemm256_stats_rows(int M);
+extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream);
+extern "C" int cvcl_gemm8w_supported(int M, int N, int K, int lda, int ldw, int ldc);
+extern "C" int cvcl_gemm8w_stats_rows(int M, int N);
 namespace {
 
-// Policy for the 256 x 256 phase-interleaved kernel (gemm256.hip).  OPT-IN ($CVCL_GEMM256=1): measured on MI355X it wins
-// only when K is long (4096^3: 1046 vs 949 TFLOP/s, 8192^3: 961 vs 888); on this workload's shapes (K = 512 .. 3072, one
-// workgroup per CU so nothing overlaps a tile's epilogue) it is equal or slower (ResNeXt layers 3-4: 590-690 vs 640-710
-// TFLOP/s; ViT-B linears with bias/GELU/residual: 365-640 vs 500-740) -- tools/gemm_bench.py.  When selected: K >= 512,
-// enough tiles to fill the chip, plain operands, and -- when BN statistics are requested -- a statistics buffer sized by
-// cvcl_gemm_stats_rows.  Returns -1 (not selected) or the epilogue id.
-inline int pick_gemm256(int dtype, const cvcl_gemm_args* a) {
-    static const bool on = [] { const char* e = getenv("CVCL_GEMM256"); return e && e[0] == '1'; }();
+// Policy for the 8-wave 256 (224) x 256 kernel (gemm8w.hip): the MFMA-bound shapes -- K >= 256, N a multiple of 256, enough
+// 256-row tiles to occupy the chip at one workgroup per CU, plain operands (no BN prologue, no strided gather, no output
+// scale, no Bottleneck-tail / GELU-backward epilogue) -- and, when BN statistics are requested, a statistics buffer sized by
+// cvcl_gemm_stats_rows.  Measured on MI355X (tools/gemm_lab, profiles/r02_gemm_lab.txt): ResNeXt layer-3/4 1x1 convolutions
+// and ViT-B linears 10-25 % faster than the 128 x 128 kernel below; $CVCL_GEMM8W=0 switches it off.
+// Returns -1 (not selected) or the epilogue id.
+inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
+    static const bool on = [] { const char* e = getenv("CVCL_GEMM8W"); return !(e && e[0] == '0'); }();
     if (!on || dtype != CVCL_BF16) return -1;
-    if (!cvcl_gemm256_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) || a->K < 512) return -1;
+    if (!cvcl_gemm8w_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) || a->K < 256) return -1;
     if (a->a_scale || a->gather_stride > 1 || a->exp_scale || a->c_scale || a->C_pre || a->G) return -1;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!al16(a->A) || !al16(a->W) || !al16(a->C) || !al16(a->R) || !al16(a->bias) || (a->R && a->ldr % 8)) return -1;
-    if ((long)cvcl_div_up(a->M, 256) * (a->N / 256) < 128) return -1;
+    if ((long)a->M * a->lda >= (1L << 31) || (long)a->N * a->ldw >= (1L << 31)) return -1;
+    if ((long)cvcl_div_up(a->M, 256) * (a->N / 256) < 96) return -1;
+    // bandwidth-bound shapes stay with the 128 x 128 kernel (two workgroups per CU keep more bytes in flight): layer-2 block-0
+    // conv1, M 802816 x N 256 x K 256, measured 176 us there vs 191-197 us here; N K / (N + K) = flop per byte of A + C traffic
+    if ((long)a->N * a->K < 170L * (a->N + a->K)) return -1;
     const bool plain = !a->bias && !a->R && a->act == CVCL_ACT_NONE;
     if (a->stats) {
-        if (!plain || a->stats_rows < cvcl_gemm256_stats_rows(a->M)) return -1;
+        if (!plain || a->stats_rows < cvcl_gemm8w_stats_rows(a->M, a->N)) return -1;
         return 0;
     }
+    if (plain) return 0;
     if (!a->C) return -1;
-    return plain ? 0 : 1;
+    return 1;
 }
 
 inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
@@ -892,8 +897,8 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.C2 = nullptr;
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
-        const int e256 = pick_gemm256(CVCL_BF16, a);
-        if (e256 >= 0) return cvcl_gemm256(e256, a, stream);
+        const int e8 = pick_gemm8w(CVCL_BF16, a);
+        if (e8 >= 0) return cvcl_gemm8w(e8, a, stream);
         static const bool use_glds = [] { const char* e = getenv("CVCL_GEMM_GLDS"); return !(e && e[0] == '0'); }();
         if (use_glds && a->c_scale) {                // Bottleneck tail epilogue: only the direct-to-LDS kernel implements it
             CVCL_CHECK_ARG(d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && a->R && a->c_shift &&
@@ -968,7 +973,7 @@ extern "C" int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* a) {
     static float dummy;
     t.stats = &dummy;
     t.stats_rows = 1 << 30;
-    if (pick_gemm256(dtype, &t) == 0) return cvcl_gemm256_stats_rows(a->M);
+    if (pick_gemm8w(dtype, &t) == 0) return cvcl_gemm8w_stats_rows(a->M, a->N);
     return cvcl_gemm_grid_m(dtype, a->M, a->N, 0);
 }
 

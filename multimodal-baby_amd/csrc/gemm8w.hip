@@ -1,0 +1,116 @@
+// Host side of the 8-wave 256 (224) x 256 bf16 GEMM (gemm8w_kernel.h): shape support, tile-height choice, launch.
+// Same interface as cvcl_gemm (include/cvcl_hip.h); selected by the dispatcher in gemm.hip for the MFMA-bound shapes --
+// the 1x1 convolutions of ResNeXt layers 2-4 (reference call site multimodal/multimodal.py:101) and the ViT linears
+// (multimodal/vision_transformer_dino_mugs.py:92-94,113-115).
+#include <cstdlib>
+
+#include "gemm8w_kernel.h"
+
+namespace {
+
+int g8_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+// grid rows (workgroups per column tile): a multiple of 8 so that the column tiles of one m-tile share an XCD, at most one
+// workgroup per CU in total, no more than there are m-tiles (rounded up to 8)
+int g8_grid_m(int tiles_m, int ncol) {
+    int gm = (g8_num_cus() / ncol) & ~7;
+    if (gm < 8) gm = 8;
+    const int need = (tiles_m + 7) & ~7;
+    return gm > need ? need : gm;
+}
+
+template <int MI, int EPI>
+int g8_launch(const g8w::Dev& d, int grid, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES) != hipSuccess) {
+            cvcl_set_error("cvcl_gemm8w: cannot raise the dynamic LDS limit to %d", g8w::LDS_BYTES);
+            return CVCL_ELAUNCH;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, 2>), dim3(grid), dim3(512), g8w::LDS_BYTES, stream, d);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+}  // namespace
+
+// shapes the kernel accepts (the dispatcher adds its own policy on top)
+extern "C" int cvcl_gemm8w_supported(int M, int N, int K, int lda, int ldw, int ldc) {
+    return M >= 1 && N % 256 == 0 && N / 256 <= 32 && N <= g8w::MAX_BIAS_N && K % 128 == 0 && K >= 128 && lda % 8 == 0 && ldw % 8 == 0 &&
+           ldc % 8 == 0;
+}
+
+// Tile height for an [M, N] output: 256 rows (MI 8) or 224 (MI 7).  M of the ResNeXt activations is 49 * 2^k: 224 = 7 * 32
+// divides it and leaves 7/8 of the workgroup slots busy in the last round where 256-row tiles leave ~5/8.  Picks the height
+// with the smaller (rounds x height); ties -> 256.
+extern "C" int cvcl_gemm8w_tile_rows(int M, int N) {
+    const int ncol = N / 256;
+    int best = 256;
+    long best_cost = -1;
+    for (int bm : {256, 224}) {
+        const int tiles = cvcl_div_up(M, bm), gm = g8_grid_m(tiles, ncol);
+        const long cost = (long)cvcl_div_up(tiles, gm) * bm;
+        if (best_cost < 0 || cost < best_cost) { best = bm; best_cost = cost; }
+    }
+    return best;
+}
+
+// BN-statistics rows cvcl_gemm8w writes for an [M, N] output (one per grid row)
+extern "C" int cvcl_gemm8w_stats_rows(int M, int N) {
+    const int bm = cvcl_gemm8w_tile_rows(M, N);
+    return g8_grid_m(cvcl_div_up(M, bm), N / 256);
+}
+
+// epi 0: convolution epilogue (round + BN partial sums; C may be NULL = statistics only); epi 1: bias / activation / residual
+extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
+    CVCL_CHECK_ARG(a && a->A && a->W && (a->C || a->stats), "cvcl_gemm8w: null operand");
+    CVCL_CHECK_ARG(cvcl_gemm8w_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) && !a->a_scale && !(a->gather_stride > 1) &&
+                       !a->exp_scale && !a->c_scale && !a->C_pre && !a->G,
+                   "cvcl_gemm8w: unsupported shape / options (M %d N %d K %d)", a->M, a->N, a->K);
+    CVCL_CHECK_ARG(epi == 0 || epi == 1, "cvcl_gemm8w: epilogue %d", epi);
+    CVCL_CHECK_ARG(epi == 1 || (!a->bias && !a->R && a->act == CVCL_ACT_NONE), "cvcl_gemm8w: epilogue 0 takes no bias / activation / residual");
+    CVCL_CHECK_ARG(epi == 0 || (a->C && !a->stats), "cvcl_gemm8w: epilogue 1 writes C and takes no statistics");
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    CVCL_CHECK_ARG(al16(a->A) && al16(a->W) && al16(a->C) && al16(a->R) && al16(a->bias) && (!a->R || a->ldr % 8 == 0),
+                   "cvcl_gemm8w: operands must be 16-byte aligned");
+    CVCL_CHECK_ARG((long)a->M * a->lda < (1L << 31) && (long)a->N * a->ldw < (1L << 31), "cvcl_gemm8w: operand offsets must fit 31 bits");
+    g8w::Dev d;
+    d.A = (const bf16_t*)a->A; d.W = (const bf16_t*)a->W; d.C = (bf16_t*)a->C; d.R = (const bf16_t*)a->R;
+    d.bias = a->bias; d.stats = a->stats;
+    d.M = a->M; d.N = a->N; d.K = a->K; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr; d.act = a->act;
+    d.ncol = a->N / 256;
+    int bm, grid;
+    if (epi == 0) {                                          // column-fixed mapping: grid_m workgroups per column tile
+        bm = cvcl_gemm8w_tile_rows(a->M, a->N);
+        d.tiles_m = cvcl_div_up(a->M, bm);
+        d.grid_m = g8_grid_m(d.tiles_m, d.ncol);
+        if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= d.grid_m, "cvcl_gemm8w: stats_rows %d < %d", a->stats_rows, d.grid_m);
+        grid = d.grid_m * d.ncol;
+    } else {                                                 // flat mapping: every CU takes tiles q, q + grid, ... of the column-fastest list
+        bm = 256;
+        long best = -1;
+        for (int h : {256, 224}) {
+            const long total = (long)cvcl_div_up(a->M, h) * d.ncol;
+            const long g = total < g8_num_cus() ? ((total + 7) & ~7L) : (g8_num_cus() & ~7);
+            const long cost = ((total + g - 1) / g) * h;
+            if (best < 0 || cost < best) { best = cost; bm = h; }
+        }
+        d.tiles_m = cvcl_div_up(a->M, bm);
+        const long total = (long)d.tiles_m * d.ncol;
+        grid = total < g8_num_cus() ? (int)((total + 7) & ~7L) : (g8_num_cus() & ~7);
+        d.grid_m = 0;
+    }
+    CvclProfScope prof(stream, CVCL_K_GEMM);
+    if (bm == 256) return epi == 0 ? g8_launch<8, 0>(d, grid, (hipStream_t)stream) : g8_launch<8, 1>(d, grid, (hipStream_t)stream);
+    return epi == 0 ? g8_launch<7, 0>(d, grid, (hipStream_t)stream) : g8_launch<7, 1>(d, grid, (hipStream_t)stream);
+}

@@ -1,0 +1,351 @@
+// 256 (224 / 192) x 256 bf16 GEMM tile for the MFMA-bound shapes: one 8-wave workgroup per CU, (16 MI) x 64 per wave.
+//
+//      C[M,N] = A[M,K] . W[N,K]^T          (A, W row-major, K contiguous; N % 256 == 0, K % 128 == 0)
+//
+// Why: the 128 x 128 x 64 two-buffer kernel of gemm.hip reads 1 LDS fragment per MFMA, pulls 64 B/clk/CU through the L1 fill
+// path and meets a workgroup barrier every 16 MFMAs (512 cycles) with one K tile of prefetch -- it sits at ~0.3 of the bf16
+// peak on K >= 512 shapes (profiles/r01_pmc_gemm_sq.json).  Here a wave owns a (16 MI) x 64 block of the output on
+// v_mfma_f32_16x16x32_bf16 (MI x 4 accumulator tiles = 128 registers at MI = 8, two waves per SIMD): 0.375 fragment reads per
+// MFMA, 32 B/clk/CU of operand traffic, one barrier per 32 MFMAs of a wave (1024 cycles of a SIMD's matrix pipe).
+//
+// Pipeline (per workgroup, persistent over its output tiles; "stage" = 32 k = 64 bytes per operand row):
+//   * 4-stage LDS ring, 32 KiB per stage (A: 256 rows x 64 B, W: 256 rows x 64 B), filled by global_load_lds_dwordx4.
+//     A wave instruction lands 16 rows x 64 B; the 16-byte chunk c of row r sits at chunk position c ^ swz((r >> 2) & 3)
+//     (swizzle applied on the SOURCE address, the LDS image stays lane-linear), which makes the ds_read_b128 fragment reads
+//     of a 16-row block (lane -> row lane & 15, chunk lane >> 4) conflict-free.
+//   * fragments are double-buffered in registers.  Iteration g multiplies stage g out of registers; in its middle it waits
+//     (counted vmcnt) for stage g+1, passes the one barrier of the iteration, issues the fragment reads of stage g+1 and the
+//     loads of stage g+4 (into the buffer stage g occupied: every wave finished reading it before the barrier), and the second
+//     half of the MFMAs covers those latencies.  3.5 stages of loads are in flight.
+//   * vmcnt retires in issue order for loads and stores alike: the wait for stage g+1 allows exactly the 8 younger load
+//     instructions (+ the epilogue's stores when one was issued in between).  Stages past the end of the workgroup's work are
+//     issued as harmless re-loads so that the count stays constant.
+//   * epilogue per 16-row block through 2 KiB of wave-private LDS: rounded to bf16, written as full 128-byte row segments,
+//     BN partial sums of the stored values accumulated per lane (8 fixed columns) across all tiles of the workgroup.
+#pragma once
+#include <type_traits>
+
+#include "cvcl_common.h"
+
+namespace g8w {
+
+constexpr int BN = 256;
+constexpr int BK = 32;
+constexpr int NSTAGE = 4;
+constexpr int A_BYTES = 16384;                    // 256 rows x 64 B
+constexpr int STAGE_BYTES = 2 * A_BYTES;          // + W: 256 rows x 64 B
+constexpr int STG_BYTES = 2048;                   // per-wave epilogue staging: 16 rows x 128 B
+constexpr int ACC_OFF = NSTAGE * STAGE_BYTES + 8 * STG_BYTES;       // [8 waves][2][64] f32 BN partial sums / [N] f32 bias
+constexpr int LDS_BYTES = 160 * 1024;                               // everything: 128 KiB ring + 16 KiB staging + 16 KiB
+constexpr int MAX_BIAS_N = (LDS_BYTES - ACC_OFF) / 4;               // 4096
+
+// EPI 0: C = round(acc) (+ BN partial sums when stats != nullptr; C may be nullptr: statistics only)
+// EPI 1: C = round(round(act(acc + bias)) + R)      (nn.Linear: bias / ReLU / GELU / residual)
+struct Dev {
+    const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
+    const float* bias; float* stats;
+    int M, N, K, lda, ldw, ldc, ldr, act;
+    int tiles_m, grid_m, ncol;
+};
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS swizzle: the 16-byte chunk c of row r sits at chunk position c ^ swz((r >> 2) & 3), swz = {0, 2, 3, 1}.  A fragment read
+// (ds_read_b128: lane -> row lane & 15, chunk lane >> 4) is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+// and the same + 32: each group holds the four 4-row sets g = 0..3 with chunks (c, c, c+1, c+1) in the order (0, 3, 1, 2) or
+// (c+1 for 0, 3; c for 1, 2); with this permutation the four sets land on four different chunk positions, i.e. the 16 lanes hit
+// the 16 different 16-byte slots of a 256-byte bank row.  (The plain c ^ g -- right for the 32-row fragments of the 32x32 MFMA --
+// is 2-way conflicted here: SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE.)
+__device__ __forceinline__ int swz(int g) { return (0x78 >> (2 * g)) & 3; }
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "add the literal");
+}
+
+// VAR (experiment switches): bit 0 = s_setprio(1) around the MFMA halves; bit 1 = the post-barrier fragment reads and stage
+// loads are interleaved with the second half's MFMAs (sched_group_barrier) instead of being issued ahead of them
+template <int MI, int EPI, int VAR>
+__global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
+    constexpr int BM = MI * 32;
+    constexpr int ESTORES = MI * 2;                        // global stores per lane per full tile epilogue
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                 // waves w and w + 4 (one SIMD) own the two row halves of a column strip
+
+    // ---- this workgroup's output tiles ----
+    // EPI 0 (BN statistics per column): fixed column tile j, m-tiles i, i + grid_m, ...; blocks of one XCD (blockIdx % 8) hold
+    //   the column tiles of the same m-tiles, so an m-tile's A rows are fetched into one L2 once.
+    // EPI 1 (linear epilogue): the tiles in column-fastest order, q, q + G, ... with q = this block's rank in XCD-major order
+    //   (consecutive q = consecutive tiles = same A rows = same XCD); every CU busy whatever N / 256 is.
+    constexpr bool FLAT = EPI == 1;
+    const int b = blockIdx.x;
+    const int G = gridDim.x;
+    int ti, tj, nt;
+    if constexpr (FLAT) {
+        const int q = (b & 7) * (G >> 3) + (b >> 3);
+        const int total = p.tiles_m * p.ncol;
+        nt = q < total ? (total - q + G - 1) / G : 0;
+        ti = q / p.ncol;
+        tj = q - ti * p.ncol;
+    } else {
+        const int xcd = b & 7, s = b >> 3;
+        tj = s % p.ncol;
+        ti = (s / p.ncol) * 8 + xcd;
+        nt = ti < p.tiles_m ? (p.tiles_m - ti + p.grid_m - 1) / p.grid_m : 0;
+    }
+    const int KS = p.K / BK;
+    const int S = nt * KS;
+    if (S == 0) {                                            // more workgroup rows than m-tiles: an all-zero statistics row
+        if (EPI == 0 && p.stats && ti < p.grid_m && tid < BN) {
+            p.stats[((long)ti * 2 + 0) * p.N + tj * BN + tid] = 0.f;
+            p.stats[((long)ti * 2 + 1) * p.N + tj * BN + tid] = 0.f;
+        }
+        return;
+    }
+    // tile k of this workgroup -> the step to tile k + 1 in (m-tile, column tile); FLAT: G tiles further in column-fastest order
+    const int step_i = FLAT ? G / p.ncol : p.grid_m;         // (FLAT: + 1 more m-tile when the column index wraps)
+    const int step_j = FLAT ? G - step_i * p.ncol : 0;
+
+    const bf16_t* __restrict__ A = p.A;
+    const bf16_t* __restrict__ W = p.W;
+
+    // ---- staging: wave w lands row blocks 2w, 2w+1 (16 rows x 64 B each) of both operands per stage ----
+    const int srow = lane >> 2;
+    const int slog = (lane & 3) ^ swz((lane >> 4) & 3);     // logical chunk fetched by this lane (it lands at chunk lane & 3)
+    unsigned w_off[2], a_raw[2];                            // element offsets of this lane's two rows of W / of A (current load tile)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        w_off[j] = (unsigned)(tj * BN + (wave * 2 + j) * 16 + srow) * (unsigned)p.ldw + slog * 8;
+        int r = (wave * 2 + j) * 16 + srow;
+        if (r >= BM) r = BM - 1;                            // BM < 256: rows of the unused part of the A region
+        a_raw[j] = (unsigned)(ti * BM + r) * (unsigned)p.lda + slog * 8;
+    }
+    // the next tile is a uniform step further; rows past M (ragged last tile) are clamped to an address inside the last row
+    // (any valid address will do: those rows are masked at the store) -- no per-lane state beyond the offsets
+    const unsigned a_unit = (unsigned)BM * (unsigned)p.lda, w_unit = (unsigned)BN * (unsigned)p.ldw;
+    const unsigned a_lim = (unsigned)(p.M - 1) * (unsigned)p.lda + 24;
+    int l_t = 0, l_ks = 0, l_j = tj;                         // (tile, k stage) of the next stage to load; its column tile
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        char* base = smem + buf * STAGE_BYTES + wave * 2048;
+        const int k0 = l_ks * BK;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(A + min(a_raw[j], a_lim) + k0, base + j * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) glds16(W + w_off[j] + k0, base + A_BYTES + j * 1024);
+    };
+    // next stage to load; kept apart from issue() so that its branch does not split the loads from the MFMAs around them.
+    // Past the end of the workgroup's work the last tile is re-loaded (never read)
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++l_ks == KS) {
+            l_ks = 0;
+            if (l_t + 1 < nt) {
+                ++l_t;
+                int di = step_i, dj = step_j;
+                if constexpr (FLAT) {
+                    if (l_j + dj >= p.ncol) { dj -= p.ncol; ++di; }
+                    l_j += dj;
+                }
+                const unsigned da = (unsigned)di * a_unit, dw = (unsigned)dj * w_unit;      // (dj < 0 wraps modulo 2^32: fine)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { a_raw[j] += da; w_off[j] += dw; }
+            }
+        }
+    };
+
+    // ---- fragment addressing: lane -> row lane & 15 of a 16-row block, logical chunk lane >> 4 ----
+    const int f_off = (lane & 15) * 64 + (((lane >> 4) ^ swz((lane >> 2) & 3)) << 4);
+    const int a_base = wm * (BM / 2) * 64 + f_off;
+    const int w_base = A_BYTES + wn * 64 * 64 + f_off;
+
+    bf16x8 fa[2][MI], fw[2][4];
+    f32x4 acc[4][MI];
+    auto read_frags = [&](int buf, auto P) __attribute__((always_inline)) {
+        constexpr int q = decltype(P)::value;
+        const char* sb = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fw[q][ni] = *reinterpret_cast<const bf16x8*>(sb + w_base + ni * 1024);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[q][mi] = *reinterpret_cast<const bf16x8*>(sb + a_base + mi * 1024);
+    };
+    auto mma_half = [&](auto P, auto HALF) __attribute__((always_inline)) {
+        constexpr int q = decltype(P)::value, h = decltype(HALF)::value;
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ni = 2 * h; ni < 2 * h + 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[q][ni], fa[q][mi], acc[ni][mi], 0, 0, 0);
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
+    };
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Per-wave LDS slots next to the ring (registers are all spoken for: 128 accumulators + 96 fragment registers per lane):
+    // EPI 0: BN partial sums [wave][2][64], added to once per tile in a fixed order (deterministic);
+    // EPI 1: the column tile's 256 bias values, read back in the accumulator layout by the epilogue.
+    float* lds_acc = reinterpret_cast<float*>(smem + ACC_OFF);
+    if constexpr (EPI == 1) {                                // the whole bias vector (N <= 4096 floats fit beside the ring)
+        for (int i = tid; i < p.N; i += 512) lds_acc[i] = p.bias ? p.bias[i] : 0.f;
+    } else {
+        lds_acc[tid] = 0.f;
+        lds_acc[tid + 512] = 0.f;
+    }
+    // (ordered before the first epilogue by the prologue's barrier)
+
+    char* stg = smem + NSTAGE * STAGE_BYTES + wave * STG_BYTES;
+    const int e_row = lane & 15;                             // accumulator layout: m = mi*16 + (lane & 15), n = ni*16 + (lane >> 4)*4 + e
+    const int e_wchunk = lane >> 5, e_wsub = ((lane >> 4) & 1) * 8;
+    const int e_wsw = (e_row >> 1) & 7;
+    const int r_chunk = lane & 7, r_row0 = lane >> 3;        // read-back: row 8j + (lane >> 3), 16-byte chunk lane & 7
+
+    // -> a lower bound on the VMEM instructions this call issued (exact for a full tile with stores and no residual)
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) -> int {
+        const bool full = m0 + BM <= p.M;
+        float st_sum[8], st_sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                bf16x4 q;
+                if constexpr (EPI == 1) {
+                    const f32x4 bias_r = *reinterpret_cast<const f32x4*>(lds_acc + n0 + wn * 64 + ni * 16 + (lane >> 4) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[ni][mi][e] + bias_r[e];
+                        if (p.act == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (p.act == CVCL_ACT_GELU) v = gelu_erf_fast(v);
+                        q[e] = (bf16_t)v;
+                    }
+                } else {
+                    q = bf16x4{(bf16_t)acc[ni][mi][0], (bf16_t)acc[ni][mi][1], (bf16_t)acc[ni][mi][2], (bf16_t)acc[ni][mi][3]};
+                }
+                acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};         // ready for the next output tile
+                const int chunk = ni * 2 + e_wchunk;
+                *reinterpret_cast<bf16x4*>(stg + e_row * 128 + ((chunk ^ e_wsw) << 4) + e_wsub) = q;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = j * 8 + r_row0;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((r_chunk ^ ((row >> 1) & 7)) << 4));
+                const int m = m0 + wm * (BM / 2) + mi * 16 + row, n = n0 + wn * 64 + r_chunk * 8;
+                if (full || m < p.M) {
+                    if constexpr (EPI == 1) {
+                        if (p.R) {
+                            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
+                        }
+                        __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[e];
+                            st_sum[e] += f;
+                            st_sq[e] = fmaf(f, f, st_sq[e]);
+                        }
+                        if (p.C) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                    }
+                }
+            }
+        }
+        if (EPI == 0 && p.stats) {                           // this tile's column sums into the wave's slot, fixed order
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = 8; o <= 32; o <<= 1) {
+                    st_sum[e] += __shfl_xor(st_sum[e], o, 64);
+                    st_sq[e] += __shfl_xor(st_sq[e], o, 64);
+                }
+            }
+            if (lane < 8) {
+                float* s0 = lds_acc + (wave * 2 + 0) * 64 + lane * 8;
+                float* s1 = lds_acc + (wave * 2 + 1) * 64 + lane * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s0[e] += st_sum[e]; s1[e] += st_sq[e]; }
+            }
+        }
+        return (full && p.C != nullptr) ? ESTORES : 0;
+    };
+
+    // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----
+    issue(0); advance(); issue(1); advance(); issue(2); advance(); issue(3); advance();
+    wait_vm<12>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, std::integral_constant<int, 0>{});
+
+    // stores issued by an epilogue sit between stage loads in the in-order vmcnt queue for the next three waits
+    // (the count passed to s_waitcnt must not exceed the number of younger instructions; a smaller one only waits longer)
+    int after_epi = 0;          // iterations left in which the last epilogue's stores are younger than the awaited stage
+    int epi_ops = 0;            // lower bound on what that epilogue issued: ESTORES or 0
+    int c_ks = 0, c_i = ti, c_j = tj;                        // k stage / (m-tile, column tile) of the tile being multiplied
+    auto step = [&](int g, auto P) __attribute__((always_inline)) {
+        constexpr int q = decltype(P)::value;
+        mma_half(P, std::integral_constant<int, 0>{});
+        // stage g+1 has landed (this wave's part); the fragment reads of stage g are complete
+        if (after_epi > 0 && epi_ops == ESTORES) wait_vm<8 + ESTORES>();
+        else wait_vm<8>();
+        if (after_epi > 0) --after_epi;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
+        issue(g & 3);                                       // stage g+4 into the buffer stage g occupied
+        mma_half(P, std::integral_constant<int, 1>{});
+        if constexpr (VAR & 2) {                            // one MFMA between any two of the 4 + MI reads / 4 loads
+#pragma unroll
+            for (int i = 0; i < 4 + MI; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+        }
+        advance();
+        if (++c_ks == KS) {
+            c_ks = 0;
+            epi_ops = epilogue(c_i * BM, c_j * BN);
+            after_epi = 3;
+            c_i += step_i;
+            if constexpr (FLAT) {
+                c_j += step_j;
+                if (c_j >= p.ncol) { c_j -= p.ncol; ++c_i; }
+            }
+        }
+    };
+    for (int g = 0; g < S; g += 2) {
+        step(g, std::integral_constant<int, 0>{});
+        step(g + 1, std::integral_constant<int, 1>{});
+    }
+    wait_vm<0>();                                            // the re-loads past the end must not outlive the workgroup
+
+    if (EPI == 0 && p.stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int wn_ = tid >> 6, c = tid & 63, n = tj * BN + tid;   // column strip wn_: waves wn_ (upper rows) and wn_ + 4
+            const float sv = lds_acc[((wn_) * 2 + 0) * 64 + c] + lds_acc[((wn_ + 4) * 2 + 0) * 64 + c];
+            const float qv = lds_acc[((wn_) * 2 + 1) * 64 + c] + lds_acc[((wn_ + 4) * 2 + 1) * 64 + c];
+            p.stats[((long)ti * 2 + 0) * p.N + n] = sv;
+            p.stats[((long)ti * 2 + 1) * p.N + n] = qv;
+        }
+    }
+}
+
+}  // namespace g8w

@@ -120,9 +120,10 @@ SIGNATURES = {
     "cvcl_conv1x1_bn_stats_gram_workspace_bytes": (C.c_size_t, [C.c_long, _I]),
     "cvcl_conv1x1_bn_stats_gram": (_I, [_P, _I, _P, _I, C.c_long, _I, _I, _P, _P, C.c_size_t, _P]),
     "cvcl_gemm_stats_rows": (_I, [_I, _P]),
-    "cvcl_gemm256": (_I, [_I, _P, _P]),
-    "cvcl_gemm256_supported": (_I, [_I, _I, _I, _I, _I, _I]),
-    "cvcl_gemm256_stats_rows": (_I, [_I]),
+    "cvcl_gemm8w": (_I, [_I, _P, _P]),
+    "cvcl_gemm8w_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cvcl_gemm8w_tile_rows": (_I, [_I, _I]),
+    "cvcl_gemm8w_stats_rows": (_I, [_I, _I]),
     "cvcl_bf16_to_f32": (_I, [_P, _P, C.c_long, _P]),
     "cvcl_spatial_max_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_spatial_max_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -349,6 +350,16 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
 
 def gemm_grid_m(dtype: int, M: int, N: int, has_prologue: bool = False) -> int:
     return lib().cvcl_gemm_grid_m(dtype, M, N, int(has_prologue))
+
+
+def gemm_stats_rows(dtype: int, M: int, N: int, K: int, gather=None) -> int:
+    """BN-statistics rows ``gemm(..., stats=...)`` writes for a plain [M, K] x [N, K]^T product of this dtype (depends on
+    which kernel the dispatcher picks: cvcl_gemm_stats_rows)."""
+    a = GemmArgs()
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
+    if gather is not None:
+        a.gather_ho, a.gather_wo, a.gather_hi, a.gather_wi, a.gather_stride = gather
+    return lib().cvcl_gemm_stats_rows(dtype, C.byref(a))
 
 
 def prof_enable(on: bool):

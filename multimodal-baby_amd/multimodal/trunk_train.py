@@ -152,7 +152,7 @@ class Conv1x1(torch.autograd.Function):
         out = torch.empty(B, Ho, Wo, N, dtype=x.dtype, device=x.device)
         gather = (Ho, Wo, Hh, Ww, stride) if stride > 1 else None
         M = B * Ho * Wo
-        st = torch.empty(H.gemm_grid_m(_cd(x), M, N), 2, N, dtype=_F, device=x.device)      # BN statistics from the epilogue
+        st = torch.empty(H.gemm_stats_rows(_cd(x), M, N, K, gather), 2, N, dtype=_F, device=x.device)   # BN statistics from the epilogue
         H.gemm(x, wq, out=out, gather=gather, M=M, lda=K, stats=st)
         ctx.save_for_backward(x, wq)
         ctx.stride = stride
@@ -196,7 +196,7 @@ class Conv1x1Skip(torch.autograd.Function):
         wq = _pack(weight, H.PACK_DENSE, x.dtype).view(x.dtype).view(N, K)
         out = torch.empty(B, Hh, Ww, N, dtype=x.dtype, device=x.device)
         M = B * Hh * Ww
-        st = torch.empty(H.gemm_grid_m(_cd(x), M, N), 2, N, dtype=_F, device=x.device)      # BN statistics from the epilogue
+        st = torch.empty(H.gemm_stats_rows(_cd(x), M, N, K), 2, N, dtype=_F, device=x.device)   # BN statistics from the epilogue
         H.gemm(x, wq, out=out, M=M, lda=K, stats=st)
         ctx.save_for_backward(x, wq)
         ctx.mark_non_differentiable(st)

@@ -101,6 +101,13 @@ class VisionTransformer(nn.Module):
         self.__dict__.update(d)
         self.__dict__.setdefault("compute_dtype", torch.float32)
         self.__dict__.setdefault("_cache", {})
+        # instances pickled by the reference's own class (hyper_parameters of its Lightning checkpoints) carry only what
+        # reference :174-197 sets: recover the two attributes the HIP forward reads from the submodules
+        mods = self.__dict__.get("_modules", {})
+        if "patch_size" not in self.__dict__ and "patch_embed" in mods:
+            self.__dict__["patch_size"] = int(mods["patch_embed"].patch_size)
+        if "num_heads" not in self.__dict__ and len(mods.get("blocks", ())) > 0:
+            self.__dict__["num_heads"] = int(mods["blocks"][0].attn.num_heads)
 
     def enable_trunk_stream(self, device, inputs="caller", stream=None, n_streams=None):
         """Run the frozen ViT on a stream of its own so it overlaps the previous step's trainable tail (see H.TrunkStream)."""

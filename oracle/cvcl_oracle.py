@@ -381,8 +381,8 @@ def batch_norm(x: Tensor, p: Dict[str, Tensor], name: str, training: bool,
     return x * scale[None, :, None, None] + shift[None, :, None, None]
 
 
-def _conv_bn(pp, inp, name, stride, pad, groups, relu, training, quant, stats_out, taps, bn_impl="explicit"):
-    y = F.conv2d(_q(quant, inp), _q(quant, pp[name + ".weight"]), None, stride, pad, 1, groups)
+def _conv_bn(pp, inp, name, stride, pad, groups, relu, training, quant, stats_out, taps, bn_impl="explicit", conv_fn=None):
+    y = (conv_fn or F.conv2d)(_q(quant, inp), _q(quant, pp[name + ".weight"]), None, stride, pad, 1, groups)
     y = _q(quant, y)                                        # raw conv output as stored
     if taps is not None:
         taps[name + ".raw"] = y
@@ -399,20 +399,29 @@ def resnext50_stem(pp, x, training, quant: Quant = None, stats_out=None, taps=No
     return h
 
 
+def resnext50_block(pp, h, li: int, bi: int, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit",
+                   conv_fn=None) -> Tensor:
+    """One torchvision ``Bottleneck`` of ``layer{li}``: 1x1 -> grouped 3x3 (stride here, v1.5) -> 1x1, + identity /
+    1x1-stride-s downsample on the first block, ReLU after the add.  ``conv_fn`` (tests only) replaces ``F.conv2d`` -- e.g.
+    by the same convolution with its input channels visited in another order, to measure what fp32 summation order alone
+    does to a block's output."""
+    pre = f"layer{li}.{bi}."
+    stride = 2 if (li > 1 and bi == 0) else 1
+    a = (training, quant, stats_out, taps, bn_impl, conv_fn)
+    o = _q(quant, _conv_bn(pp, h, pre + "conv1", 1, 0, 1, True, *a))
+    o = _q(quant, _conv_bn(pp, o, pre + "conv2", stride, 1, RESNEXT_GROUPS, True, *a))
+    o = _conv_bn(pp, o, pre + "conv3", 1, 0, 1, False, *a)
+    idn = _conv_bn(pp, h, pre + "downsample.0", stride, 0, 1, False, *a) if bi == 0 else h
+    h = _q(quant, torch.relu(o + idn))
+    if taps is not None:
+        taps[pre + "out"] = h
+    return h
+
+
 def resnext50_stage(pp, h, li: int, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit") -> Tensor:
-    """``layer{li}``: Bottleneck x RESNEXT_LAYERS[li-1] (1x1 -> grouped 3x3 (stride here, v1.5) -> 1x1,
-    + identity / 1x1-stride-s downsample on the first block, ReLU after the add)."""
+    """``layer{li}``: Bottleneck x RESNEXT_LAYERS[li-1]."""
     for bi in range(RESNEXT_LAYERS[li - 1]):
-        pre = f"layer{li}.{bi}."
-        stride = 2 if (li > 1 and bi == 0) else 1
-        a = (training, quant, stats_out, taps, bn_impl)
-        o = _q(quant, _conv_bn(pp, h, pre + "conv1", 1, 0, 1, True, *a))
-        o = _q(quant, _conv_bn(pp, o, pre + "conv2", stride, 1, RESNEXT_GROUPS, True, *a))
-        o = _conv_bn(pp, o, pre + "conv3", 1, 0, 1, False, *a)
-        idn = _conv_bn(pp, h, pre + "downsample.0", stride, 0, 1, False, *a) if bi == 0 else h
-        h = _q(quant, torch.relu(o + idn))
-        if taps is not None:
-            taps[pre + "out"] = h
+        h = resnext50_block(pp, h, li, bi, training, quant, stats_out, taps, bn_impl)
     return h
 
 

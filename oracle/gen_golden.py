@@ -430,6 +430,80 @@ def case_cvcl_step(mm, lit_mod):
          shapes=np.array([list(sd[k].shape) + [0] * (4 - sd[k].dim()) for k in names]))
 
 
+
+def periodic_fill_(t: torch.Tensor, tag: int, std: float, period: int = 1021):
+    """Weights that survive gzip: a seeded normal table of `period` values repeated over the flattened tensor (exactly
+    periodic data deflates ~1000:1, so a 31 MB checkpoint becomes a fixture of a few hundred KiB)."""
+    g = torch.Generator().manual_seed(1000 + tag)
+    table = torch.randn(period, generator=g) * std
+    idx = torch.arange(t.numel()) % period
+    with torch.no_grad():
+        t.copy_(table[idx].reshape(t.shape))
+
+
+def case_reference_checkpoint(mm, lit_mod, vits):
+    """f1: a Lightning-layout checkpoint WRITTEN BY THE REFERENCE'S OWN CLASSES (multimodal_lit.py:74 save_hyperparameters ->
+    hyper_parameters = the constructor arguments, i.e. the pickled VisionEncoder / TextEncoder modules and the args
+    namespace; :134-149 load_from_checkpoint reads it back) + the logits the reference computes from it.  pytorch_lightning
+    is absent, so the dict Lightning 1.6 would write is assembled here key by key; every object inside it is an instance of
+    the reference's classes (multimodal.multimodal.VisionEncoder / TextEncoder, the vendored VisionTransformer), pickled by
+    their dotted names.  The ViT is one ViT-B-wide block on 32 x 32 frames (VisionEncoder hard-codes the 768-wide head,
+    multimodal.py:118-122), weights periodic so the file compresses."""
+    import gzip
+    import shutil
+    import tempfile
+    with open(os.path.join(REF, "multimodal", "vocab.json")) as f:
+        vocab = json.load(f)
+    args = argparse.Namespace(
+        embedding_type="flat", embedding_dim=32, pretrained_cnn=False, cnn_model="models/TC-S-resnext.tar",
+        cnn_dino=False, vit_dino=True, finetune_cnn=False, text_encoder="embedding", captioning=False,
+        attention=False, attention_gate=False, crange=1, dropout_i=0.0, dropout_o=0.0,
+        pos_embed_type="no_pos_embed", normalize_features=True, sim="max", temperature=0.07,
+        fix_temperature=False, tie=True, bias=True, lr=1e-4, weight_decay=0.1, lambda_mm=1.0, lambda_lm=0.0,
+        lambda_ar=0.0, optimize_unused=True, lr_scheduler=False, optimizer=torch.optim.AdamW, seed=0)
+    orig = mm.load_model
+    mm.load_model = lambda name, pretrained: vits.VisionTransformer(
+        img_size=[32], patch_size=16, embed_dim=768, depth=1, num_heads=12, mlp_ratio=4, qkv_bias=True,
+        norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    try:
+        torch.manual_seed(5)
+        ve = mm.VisionEncoder(args)
+        te = mm.TextEncoder(vocab, ve.last_cnn_out_dim, args)
+        lit = lit_mod.MultiModalLitModel(ve, te, args)
+    finally:
+        mm.load_model = orig
+    for i, (n_, p_) in enumerate(lit.named_parameters()):
+        if p_.numel() >= 4096:
+            periodic_fill_(p_.data, i, 0.03 if "embedding" not in n_ else 0.5)
+        elif p_.dim() >= 1:
+            with torch.no_grad():
+                p_.copy_(torch.randn(p_.shape, generator=torch.Generator().manual_seed(2000 + i)) * 0.1 + (1.0 if "norm" in n_ and n_.endswith("weight") else 0.0))
+    with torch.no_grad():
+        lit.model.text_embed.embedding.weight[0].zero_()          # padding row
+    lit.eval()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 3, 32, 32, generator=g)
+    tok, ln = lit.tokenize(["ball", "look at the ball", "car"])
+    with torch.no_grad():
+        lpi, lpt = lit(x, tok, ln)
+        fi, ft = lit.encode_image(x), lit.encode_text(tok, ln)
+    ckpt = {"epoch": 3, "global_step": 120, "pytorch-lightning_version": "1.6.0",
+            "state_dict": lit.state_dict(),
+            "hyper_parameters": {"vision_encoder": ve, "text_encoder": te, "args": args},
+            "optimizer_states": [], "lr_schedulers": [], "callbacks": {}}
+    with tempfile.TemporaryDirectory() as d:
+        raw = os.path.join(d, "ref.ckpt")
+        torch.save(ckpt, raw)
+        dst = os.path.join(OUT, "ref_lit_vit.ckpt.gz")
+        with open(raw, "rb") as fi_, gzip.GzipFile(dst, "wb", compresslevel=9, mtime=0) as fo_:
+            shutil.copyfileobj(fi_, fo_)
+        print(f"  wrote ref_lit_vit.ckpt.gz ({os.path.getsize(raw)/2**20:.1f} MiB raw -> {os.path.getsize(dst)/1024:.1f} KiB)")
+    sd = lit.state_dict()
+    save("ref_lit_vit_io", x=x, tokens=tok, lengths=ln, logits_per_image=lpi, logits_per_text=lpt, image_features=fi,
+         text_features=ft, keys=np.array(sorted(sd.keys())), temperature=sd["model.logit_neg_log_temperature"].reshape(1),
+         n_params=np.array([sum(p_.numel() for p_ in lit.parameters())]))
+
+
 def case_tokenizer(lit_mod):
     with open(os.path.join(REF, "multimodal", "vocab.json")) as f:
         vocab = json.load(f)
@@ -536,6 +610,7 @@ def main():
     case_vit(vits)
     case_tokenizer(lit_mod)
     case_cvcl_step(mm, lit_mod)
+    case_reference_checkpoint(mm, lit_mod, vits)
     print("golden fixtures written to", OUT)
 
 

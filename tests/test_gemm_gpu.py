@@ -136,7 +136,7 @@ def test_bn_stats_from_gram_matrix(dev, M, K, N):
     assert float(((var_got - var_ref).abs() / var_ref).max()) < 2e-4       # what BatchNorm consumes
 
 
-def _gemm256(H, epi, A, W, C=None, stats=None, bias=None, act=0, R=None):
+def _gemm8w(H, epi, A, W, C=None, stats=None, bias=None, act=0, R=None):
     import ctypes as Cc
     a = H.GemmArgs()
     M, K = A.shape
@@ -150,30 +150,34 @@ def _gemm256(H, epi, A, W, C=None, stats=None, bias=None, act=0, R=None):
     a.act = act
     if R is not None:
         a.R, a.ldr = H.ptr(R), N
-    H.check(H.lib().cvcl_gemm256(epi, Cc.byref(a), H.stream_ptr()), "cvcl_gemm256")
+    H.check(H.lib().cvcl_gemm8w(epi, Cc.byref(a), H.stream_ptr()), "cvcl_gemm8w")
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1000, 512, 512), (12544, 2048, 1024), (50176, 512, 1024), (777, 768, 3072),
-                                   (4099, 256, 2048)])
-def test_gemm256_exact_on_small_integers_and_race_free(dev, M, N, K):
-    """256 x 256 phase-interleaved kernel, conv epilogue: with small-integer operands every partial sum is exact, so C must
-    equal the float64 product bit for bit -- any half-tile read before its global_load_lds landed, a wrong swizzle or a
-    quadrant mix-up shows up as a wrong integer.  Repeated launches (different timing) must agree; BN statistics rows
-    (2 per 256-row tile) must sum to the column sums of what was stored."""
+                                   (4099, 256, 2048), (200704, 256, 512), (50400, 1024, 256)])
+def test_gemm8w_exact_on_small_integers_and_race_free(dev, M, N, K):
+    """8-wave 256 (224) x 256 kernel with the 4-stage global_load_lds ring, conv epilogue: with small-integer operands every
+    partial sum is exact, so C must equal the float64 product bit for bit -- any stage read before its loads landed or
+    overwritten before every wave had read it, a wrong swizzle or a fragment mix-up shows up as a wrong integer.  Repeated
+    launches (different timing) must agree; the BN statistics rows must sum to the column sums of what was stored; the
+    statistics-only form (C = NULL) must give the same rows."""
     from multimodal import _hip as H
     g = torch.Generator().manual_seed(M + N + K)
     a = torch.randint(-2, 3, (M, K), generator=g).float()
     w = torch.randint(-2, 3, (N, K), generator=g).float()
     ref = (a.double() @ w.double().t())
     ad, wd = a.bfloat16().to(dev), w.bfloat16().to(dev)
-    rows = H.lib().cvcl_gemm256_stats_rows(M)
+    rows = H.lib().cvcl_gemm8w_stats_rows(M, N)
     outs = []
     for _ in range(4):
         C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
         st = torch.full((rows, 2, N), float("nan"), device=dev)
-        _gemm256(H, 0, ad, wd, C, st)
+        _gemm8w(H, 0, ad, wd, C, st)
         outs.append((C, st))
+    st_only = torch.full((rows, 2, N), float("nan"), device=dev)
+    _gemm8w(H, 0, ad, wd, None, st_only)
     torch.cuda.synchronize()
+    assert torch.equal(st_only, outs[0][1])
     C0, st0 = outs[0]
     assert all(torch.equal(C0, c) and torch.equal(st0, s) for c, s in outs[1:])
     want = ref.float().bfloat16()                                            # the kernel rounds the exact sum to bf16
@@ -184,11 +188,10 @@ def test_gemm256_exact_on_small_integers_and_race_free(dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,act,res", [(1024, 768, 768, 0, True), (3000, 3072, 768, 2, False), (5000, 768, 3072, 0, True),
-                                           (600, 2304, 768, 0, False)])
-def test_gemm256_linear_epilogue_matches_128_tile_kernel(dev, M, N, K, act, res):
-    """EPI 1 (bias + activation + residual, the ViT linears): bit-identical to the 128-tile kernel on random data
-    (same products, same fp32 accumulation order per output is NOT guaranteed across tilings -> compare with tolerance to
-    float64 and require both kernels to be equally close)."""
+                                           (600, 2304, 768, 0, False), (50432, 768, 768, 1, True), (9000, 2304, 768, 0, False)])
+def test_gemm8w_linear_epilogue(dev, M, N, K, act, res):
+    """EPI 1 (bias + activation + residual, the ViT linears; flat tile order over all column tiles, bias vector in LDS): vs
+    float64 of the same bf16 operands within 1 bf16 ulp, deterministic, and -- with small-integer operands -- exact."""
     from multimodal import _hip as H
     g = torch.Generator().manual_seed(N + K)
     a = torch.randn(M, K, generator=g).bfloat16()
@@ -196,6 +199,8 @@ def test_gemm256_linear_epilogue_matches_128_tile_kernel(dev, M, N, K, act, res)
     bias = torch.randn(N, generator=g)
     r = torch.randn(M, N, generator=g).bfloat16() if res else None
     y = a.double() @ w.double().t() + bias.double()
+    if act == 1:
+        y = torch.relu(y)
     if act == 2:
         y = 0.5 * y * (1 + torch.erf(y / 2 ** 0.5))
     y = y.float().bfloat16().double()
@@ -204,11 +209,25 @@ def test_gemm256_linear_epilogue_matches_128_tile_kernel(dev, M, N, K, act, res)
     ad, wd, bd = a.to(dev), w.to(dev), bias.to(dev)
     rd = r.to(dev) if res else None
     C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    _gemm256(H, 1, ad, wd, C, None, bd, act, rd)
+    _gemm8w(H, 1, ad, wd, C, None, bd, act, rd)
     C2 = torch.empty_like(C)
-    _gemm256(H, 1, ad, wd, C2, None, bd, act, rd)
+    _gemm8w(H, 1, ad, wd, C2, None, bd, act, rd)
     assert torch.equal(C, C2)
     assert maxrel(C.float(), y.float()) < 8e-3
+    if act != 2:                                    # exact on small integers (GELU is not an integer map)
+        ai = torch.randint(-2, 3, (M, K), generator=g).float()
+        wi = torch.randint(-2, 3, (N, K), generator=g).float()
+        bi = torch.randint(-3, 4, (N,), generator=g).float()
+        ri = torch.randint(-3, 4, (M, N), generator=g).float() if res else None
+        yi = ai.double() @ wi.double().t() + bi.double()
+        if act == 1:
+            yi = torch.relu(yi)
+        yi = yi.float().bfloat16().double()
+        if res:
+            yi = (yi + ri.double()).float().bfloat16().double()
+        Ci = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        _gemm8w(H, 1, ai.bfloat16().to(dev), wi.bfloat16().to(dev), Ci, None, bi.to(dev), act, ri.bfloat16().to(dev) if res else None)
+        assert torch.equal(Ci.double().cpu(), yi)
 
 
 def _quant_rows_ref(y):

@@ -1,0 +1,158 @@
+// Standalone bench / checker for GEMM kernel variants (no torch): build here with hipcc, run on the GPU box.
+//   lab <variant> <M> <N> <K> [iters] [fill]     variant: old (cvcl_gemm of libcvcl_hip.so) | w8 | w7 | w6 (gemm8w MI = 8 / 7 / 6)
+//   fill: 0 = uniform [-1, 1) (timing + tolerance check), 1 = small integers (exact check)
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <functional>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../multimodal-baby_amd/csrc/gemm8w_kernel.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+void cvcl_set_error(const char*, ...) {}
+bool cvcl_prof_on() { return false; }
+void* cvcl_prof_begin(void*, int) { return nullptr; }
+void cvcl_prof_end(void*, void*) {}
+
+__global__ void ref_rows_kernel(const bf16_t* A, const bf16_t* W, float* out, const int* rows, int nrows, int N, int K) {
+    const int r = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows || n >= N) return;
+    const bf16_t* a = A + (long)rows[r] * K;
+    const bf16_t* w = W + (long)n * K;
+    double acc = 0;
+    for (int k = 0; k < K; ++k) acc += (double)(float)a[k] * (double)(float)w[k];
+    out[(long)r * N + n] = (float)acc;
+}
+
+static unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
+
+template <int MI, int EPI, int VAR>
+static void launch_w(const g8w::Dev& d, int grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES)); attr = true; }
+    hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, VAR>), dim3(grid), dim3(512), g8w::LDS_BYTES, st, d);
+}
+
+typedef int (*gemm_fn)(int, const cvcl_gemm_args*, void*);
+typedef int (*rows_fn)(int, const cvcl_gemm_args*);
+
+int main(int argc, char** argv) {
+    if (argc < 5) { printf("usage: lab variant M N K [iters] [fill] [stats]\n"); return 1; }
+    std::string var = argv[1];
+    const int M = atoi(argv[2]), N = atoi(argv[3]), K = atoi(argv[4]);
+    const int iters = argc > 5 ? atoi(argv[5]) : 20, fill = argc > 6 ? atoi(argv[6]) : 0, want_stats = argc > 7 ? atoi(argv[7]) : 0;
+    std::vector<bf16_t> hA((size_t)M * K), hW((size_t)N * K);
+    unsigned s = 12345;
+    for (auto& v : hA) v = fill ? (bf16_t)(float)((int)(lcg(s) >> 28) - 8) : (bf16_t)((float)(lcg(s) >> 8) / 8388608.f - 1.f);
+    for (auto& v : hW) v = fill ? (bf16_t)(float)((int)(lcg(s) >> 29) - 4) : (bf16_t)((float)(lcg(s) >> 8) / 8388608.f - 1.f);
+    bf16_t *dA, *dW, *dC;
+    float* dStats;
+    CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&dC, (size_t)M * N * 2));
+    CK(hipMalloc(&dStats, (size_t)2048 * 2 * N * 4));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemset(dC, 0xff, (size_t)M * N * 2));
+    hipStream_t st; CK(hipStreamCreate(&st));
+
+    int stats_rows = 0;
+    std::function<void()> run;
+    void* lib = nullptr;
+    if (var == "old") {
+        lib = dlopen("multimodal-baby_amd/lib/libcvcl_hip.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) { printf("dlopen: %s\n", dlerror()); return 2; }
+        gemm_fn g = (gemm_fn)dlsym(lib, "cvcl_gemm");
+        rows_fn rf = (rows_fn)dlsym(lib, "cvcl_gemm_stats_rows");
+        static cvcl_gemm_args a;
+        memset(&a, 0, sizeof(a));
+        a.A = dA; a.W = dW; a.C = dC; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N;
+        if (want_stats) { a.stats = dStats; a.stats_rows = 2048; stats_rows = rf(CVCL_BF16, &a); }
+        run = [=]() { int rc = g(CVCL_BF16, &a, st); if (rc) { printf("cvcl_gemm rc %d\n", rc); exit(3); } };
+    } else {
+        // w<MI>[abc]: a = setprio, b = interleaved reads, c = both
+        const int mi = var[0] == 'w' ? var[1] - '0' : 0;
+        const int vv = var.size() > 2 ? (var[2] == 'a' ? 1 : var[2] == 'b' ? 2 : 3) : 0;
+        if (mi < 6 || mi > 8 || N % 256 || K % 128) { printf("bad variant / shape\n"); return 1; }
+        static g8w::Dev d;
+        memset(&d, 0, sizeof(d));
+        d.A = dA; d.W = dW; d.C = dC; d.M = M; d.N = N; d.K = K; d.lda = K; d.ldw = K; d.ldc = N;
+        d.stats = want_stats ? dStats : nullptr;
+        const int BM = mi * 32;
+        d.tiles_m = (M + BM - 1) / BM;
+        d.ncol = N / 256;
+        int dev = 0, cus = 256;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int gm = (cus / d.ncol) & ~7;
+        if (gm < 8) gm = 8;
+        const int need = (d.tiles_m + 7) & ~7;
+        if (gm > need) gm = need;
+        d.grid_m = gm;
+        stats_rows = gm;
+        const int grid = gm * d.ncol;
+        printf("  tiles_m %d ncol %d grid_m %d grid %d rounds %.2f\n", d.tiles_m, d.ncol, gm, grid, (double)d.tiles_m / gm);
+#define PICK(MI_) \
+        if (mi == MI_) { if (vv == 0) run = [=]() { launch_w<MI_, 0, 0>(d, grid, st); }; else if (vv == 1) run = [=]() { launch_w<MI_, 0, 1>(d, grid, st); }; \
+                         else if (vv == 2) run = [=]() { launch_w<MI_, 0, 2>(d, grid, st); }; else run = [=]() { launch_w<MI_, 0, 3>(d, grid, st); }; }
+        PICK(8) PICK(7) PICK(6)
+    }
+    run();
+    CK(hipStreamSynchronize(st));
+    CK(hipGetLastError());
+    // ---- check: 96 rows spread over M (first / last tiles included), all N
+    const int nrows = 96;
+    std::vector<int> rows(nrows);
+    for (int i = 0; i < nrows; ++i) rows[i] = (int)(((long)i * (M - 1)) / (nrows - 1));
+    rows[1] = 1; rows[2] = M - 2; rows[3] = M / 2 + 113;
+    int* dRows; float* dRef;
+    CK(hipMalloc(&dRows, nrows * 4)); CK(hipMalloc(&dRef, (size_t)nrows * N * 4));
+    CK(hipMemcpy(dRows, rows.data(), nrows * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_rows_kernel, dim3((N + 255) / 256, nrows), dim3(256), 0, st, dA, dW, dRef, dRows, nrows, N, K);
+    CK(hipStreamSynchronize(st));
+    std::vector<float> ref((size_t)nrows * N);
+    std::vector<bf16_t> got((size_t)N);
+    CK(hipMemcpy(ref.data(), dRef, ref.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0; long bad = 0;
+    for (int i = 0; i < nrows; ++i) {
+        CK(hipMemcpy(got.data(), dC + (size_t)rows[i] * N, (size_t)N * 2, hipMemcpyDeviceToHost));
+        for (int n = 0; n < N; ++n) {
+            const float r = ref[(size_t)i * N + n], g = (float)got[n];
+            const float rr = (float)(bf16_t)r;
+            const double err = fill ? fabs((double)g - rr) : fabs((double)g - r) / (fabs(r) * (1.0 / 128) + sqrt((double)K) * 2e-3);
+            if (err > worst) worst = err;
+            if (fill ? (g != rr) : (err > 1.0)) ++bad;
+        }
+    }
+    if (want_stats) {          // column sums of the stored tensor vs a host sum over all rows
+        std::vector<float> hs((size_t)stats_rows * 2 * N);
+        CK(hipMemcpy(hs.data(), dStats, hs.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<bf16_t> hC((size_t)M * N);
+        CK(hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost));
+        double w2 = 0;
+        for (int n = 0; n < N; n += 37) {
+            double s1 = 0, s2 = 0, g1 = 0, g2 = 0;
+            for (int m = 0; m < M; ++m) { const double v = (float)hC[(size_t)m * N + n]; s1 += v; s2 += v * v; }
+            for (int r = 0; r < stats_rows; ++r) { g1 += hs[((size_t)r * 2 + 0) * N + n]; g2 += hs[((size_t)r * 2 + 1) * N + n]; }
+            w2 = fmax(w2, fabs(g1 - s1) / (fabs(s1) + 1e-3 * sqrt((double)M)));
+            w2 = fmax(w2, fabs(g2 - s2) / (fabs(s2) + 1e-9));
+        }
+        printf("  stats rel err %.3e (%d rows)\n", w2, stats_rows);
+    }
+    // ---- timing
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) run();
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) run();
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("%-4s M %7d N %5d K %5d fill %d: %8.2f us  %7.1f TFLOP/s  check: worst %.3g bad %ld %s\n", var.c_str(), M, N, K, fill, us, tf, worst, bad,
+           bad ? "FAIL" : "ok");
+    return bad ? 4 : 0;
+}

@@ -1,0 +1,15 @@
+#!/bin/bash
+# GEMM lab sweep (run from the repo root on the GPU box): correctness first, then the workload's MFMA-bound shapes
+L=tools/gemm_lab/lab
+echo "== exact checks (small integers) =="
+for v in w8 w7 w6; do
+  $L $v 1000 256 128 2 1 1
+  $L $v 4096 512 256 2 1 1
+  $L $v 777 768 384 2 1 0
+done
+echo "== timing =="
+for shape in "4096 4096 4096" "8192 8192 8192" "65536 512 1024" "50176 512 1024" "50176 1024 512" "12544 1024 2048" "12544 2048 1024" "200704 256 512" "200704 512 256" "50176 1024 1024" "200704 512 512" "50432 2304 768" "50432 768 768" "50432 3072 768" "50432 768 3072"; do
+  for v in old w8 w7; do
+    $L $v $shape 20 0 0 | grep -v tiles_m
+  done
+done
