@@ -137,6 +137,12 @@ int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* args);
  * cvcl_gemm8w_tile_rows: the tile height (256 or 224) the epi-0 launch uses for an [M, N] output; cvcl_gemm8w_stats_rows: the
  * number of BN-statistics rows it writes.                                                                                */
 int cvcl_gemm8w(int epi, const cvcl_gemm_args* args, void* stream);
+/* The bandwidth-bound form cvcl_gemm selects when the operand carries the producer's BatchNorm + ReLU (a_scale / a_shift /
+ * a_relu) and K = 128 | 256, N % 256 == 0 (conv3 of ResNeXt layers 1-2 on the raw grouped-convolution output: torchvision
+ * Bottleneck.forward conv3(relu(bn2(.)))): statistics only (C NULL), C + statistics, or the Bottleneck tail (c_scale ...).    */
+int cvcl_gemm_pro(const cvcl_gemm_args* args, void* stream);
+int cvcl_gemm_pro_supported(const cvcl_gemm_args* args);
+int cvcl_gemm_pro_stats_rows(int M, int N);
 int cvcl_gemm8w_supported(int M, int N, int K, int lda, int ldw, int ldc);
 int cvcl_gemm8w_tile_rows(int M, int N);
 int cvcl_gemm8w_stats_rows(int M, int N);

@@ -821,6 +821,9 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
 
 
 }  // namespace
+extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream);
+extern "C" int cvcl_gemm_pro_supported(const cvcl_gemm_args* a);
+extern "C" int cvcl_gemm_pro_stats_rows(int M, int N);
 extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream);
 extern "C" int cvcl_gemm8w_supported(int M, int N, int K, int lda, int ldw, int ldc);
 extern "C" int cvcl_gemm8w_stats_rows(int M, int N);
@@ -852,6 +855,14 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
     if (plain) return 0;
     if (!a->C) return -1;
     return 1;
+}
+
+// Bandwidth-bound 1x1 convolution with the producer's BN + ReLU on its input (gemm_pro.hip): conv3 of ResNeXt layers 1-2.
+// $CVCL_GEMM_PRO=0 refuses it (callers then have to normalise the operand themselves).
+inline bool pick_gemm_pro(int dtype, const cvcl_gemm_args* a) {
+    static const bool on = [] { const char* e = getenv("CVCL_GEMM_PRO"); return !(e && e[0] == '0'); }();
+    if (!on || dtype != CVCL_BF16 || !cvcl_gemm_pro_supported(a)) return false;
+    return !a->stats || a->stats_rows >= cvcl_gemm_pro_stats_rows(a->M, a->N);
 }
 
 inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
@@ -897,6 +908,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.C2 = nullptr;
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
+        if (pick_gemm_pro(CVCL_BF16, a)) return cvcl_gemm_pro(a, stream);
         const int e8 = pick_gemm8w(CVCL_BF16, a);
         if (e8 >= 0) return cvcl_gemm8w(e8, a, stream);
         static const bool use_glds = [] { const char* e = getenv("CVCL_GEMM_GLDS"); return !(e && e[0] == '0'); }();
@@ -973,6 +985,7 @@ extern "C" int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* a) {
     static float dummy;
     t.stats = &dummy;
     t.stats_rows = 1 << 30;
+    if (pick_gemm_pro(dtype, &t)) return cvcl_gemm_pro_stats_rows(a->M, a->N);
     if (pick_gemm8w(dtype, &t) == 0) return cvcl_gemm8w_stats_rows(a->M, a->N);
     return cvcl_gemm_grid_m(dtype, a->M, a->N, 0);
 }

@@ -1,0 +1,335 @@
+// Bandwidth-bound 1x1 convolution with the PRODUCER's BatchNorm + ReLU applied to its input on the way in:
+//
+//      C[M, N] = relu(A[M, K] * a_scale[K] + a_shift[K]) . W[N, K]^T          K = 128 | 256,  N % 256 == 0,  bf16
+//
+// = conv3 of a ResNeXt Bottleneck in layers 1-2 (torchvision Bottleneck.forward: conv3(relu(bn2(conv2(..)))), reached from
+// multimodal/multimodal.py:101), whose input is the RAW grouped-convolution output.  BN2's batch statistics exist only after
+// the whole grouped convolution has run, so its normalisation cannot ride the producer; the round-1 trunk ran an in-place
+// bn_relu_apply pass over the tensor (one read + one write of it, 2.8 GB per step) ahead of a plain GEMM, because applying it in
+// the 128-wide GEMM's operand load repeats the work in every column-tile workgroup and costs more than it saves.  These
+// layers are HBM-bound (K <= 256: 64..170 flop per byte), so this kernel is built around the byte stream instead of the MFMA:
+//
+//   * a workgroup (8 waves, one per CU, persistent) owns a 256-column strip of W and keeps it IN REGISTERS as MFMA fragments
+//     (4 x K/32 fragments per wave: 64 / 128 VGPRs) for its whole life; nothing of W ever sits in LDS;
+//   * A arrives in 64-row tiles through registers: 16-byte chunks, transformed (scale, shift, ReLU, round to bf16 -- the value
+//     the oracle's storage-point model feeds conv3) exactly once per element and written to a swizzled LDS tile, double
+//     buffered: one barrier per tile; the next tile's chunks and the residual rows are in flight while the current tile is
+//     multiplied (32 / 64 MFMAs per wave -- a fraction of the tile's HBM time);
+//   * three epilogues: statistics only (BN partial sums of the rounded output straight from the accumulators, nothing
+//     stored), store + statistics, and the Bottleneck tail relu(bn3(.) + identity | bn_d(downsample)) with the block output
+//     written as full 128-byte row segments through wave-private LDS.
+#include <cstdlib>
+
+#include "cvcl_common.h"
+
+namespace {
+
+constexpr int PM = 64;                     // rows per tile
+constexpr int PN = 256;                    // columns per workgroup
+
+struct ProDev {
+    const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
+    const float* a_scale; const float* a_shift; const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;
+    float* stats;
+    int M, N, lda, ldw, ldc, ldr;
+    int tiles;
+};
+
+enum { PRO_STATS = 0, PRO_STORE = 1, PRO_TAIL = 2 };
+
+template <int KT> constexpr int pro_lds_bytes() { return 2 * PM * KT * 64 + 8 * 4096 + 4 * PN * 4; }
+
+template <int KT, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
+    constexpr int K = KT * 32;
+    constexpr int PITCH = K * 2;                        // LDS row pitch of the A tile in bytes (256 | 512)
+    constexpr int CPR = K / 8;                          // 16-byte chunks per row (16 | 32)
+    constexpr int NCH = PM * CPR / 512;                 // chunks staged per thread per tile (2 | 4)
+    constexpr int RPP = 512 / CPR;                      // rows per staging pass (32 | 16)
+    constexpr int ABUF = PM * PITCH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;            // wave tile: rows wm*32 .. +31, columns wn*64 .. +63 of the strip
+    const int n0 = blockIdx.y * PN;
+
+    // ---- W strip as MFMA A-operand fragments: fw[ni][ks] = rows n0 + wn*64 + ni*16 + (lane & 15), k = ks*32 + (lane >> 4)*8 .. +7
+    bf16x8 fw[4][KT];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks)
+            fw[ni][ks] = *reinterpret_cast<const bf16x8*>(p.W + (long)(n0 + wn * 64 + ni * 16 + (lane & 15)) * p.ldw + ks * 32 + (lane >> 4) * 8);
+
+    // ---- staging role: chunk s_c of rows s_r + RPP * i; this thread's 8 channels never change
+    const int s_c = tid % CPR, s_r = tid / CPR;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = p.a_scale[s_c * 8 + e]; sh[e] = p.a_shift[s_c * 8 + e]; }
+    bf16x8 araw[NCH];
+    auto load_a = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            int m = tile * PM + s_r + RPP * i;
+            if (m >= p.M) m = p.M - 1;                   // ragged last tile: any valid row, masked at the store
+            araw[i] = *reinterpret_cast<const bf16x8*>(p.A + (long)m * p.lda + s_c * 8);
+        }
+    };
+    auto stage_a = [&](int buf) __attribute__((always_inline)) {
+        char* dst = smem + buf * ABUF;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int r = s_r + RPP * i;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)araw[i][e], sc[e], sh[e]), 0.f);
+            *reinterpret_cast<bf16x8*>(dst + r * PITCH + ((s_c ^ (r & 15)) << 4)) = v;
+        }
+    };
+    // fragment read: row (lane & 15) of a 16-row block, chunk 4 ks + (lane >> 4), XOR-swizzled by the row
+    const int f_row = lane & 15, f_kc = lane >> 4;
+
+    // ---- epilogue state
+    // TAIL / STORE read-back: lane -> row 8 j + (lane >> 3), 16-byte chunk lane & 7 of the wave's 64-column strip: 8 fixed channels
+    const int r_chunk = lane & 7, r_row0 = lane >> 3;
+    // the strip's BN3 / downsample-BN affines sit in LDS ([4][256] floats) and are fetched per tile: 32 registers that would
+    // otherwise be live across the MFMA phase (K = 256 holds 128 registers of W fragments)
+    float* aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096);
+    if constexpr (MODE == PRO_TAIL) {
+        if (tid < PN) {
+            aff[tid] = p.c_scale[n0 + tid];
+            aff[PN + tid] = p.c_shift[n0 + tid];
+            aff[2 * PN + tid] = p.r_scale ? p.r_scale[n0 + tid] : 1.f;
+            aff[3 * PN + tid] = p.r_scale ? p.r_shift[n0 + tid] : 0.f;
+        }
+    }                                                    // (visible after the first tile's barrier)
+    bf16x8 rres[4];                                      // residual rows of the current tile (TAIL)
+    auto load_r = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int m = tile * PM + wm * 32 + j * 8 + r_row0;
+            if (m >= p.M) m = p.M - 1;
+            rres[j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + r_chunk * 8);
+        }
+    };
+    // STATS: per-lane partial sums in the accumulator layout: column wn*64 + ni*16 + (lane >> 4)*4 + e
+    // STORE: per-lane partial sums of the read-back layout: column wn*64 + (lane & 7)*8 + e
+    float st_sum[16], st_sq[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+
+    char* stg = smem + 2 * ABUF + wave * 4096;           // wave-private: 32 rows x 128 B
+    const int e_row = lane & 15, e_wchunk = lane >> 5, e_wsub = ((lane >> 4) & 1) * 8;
+
+    const int first = blockIdx.x;
+    if (first < p.tiles) {
+        load_a(first);
+        if constexpr (MODE == PRO_TAIL) load_r(first);
+    }
+    int buf = 0;
+    for (int tile = first; tile < p.tiles; tile += gridDim.x) {
+        stage_a(buf);
+        __syncthreads();                                 // tile staged by everyone; the other buffer's readers (tile - 2) are long done
+        const int next = tile + gridDim.x;
+        if (next < p.tiles) load_a(next);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* ab = smem + buf * ABUF + (wm * 32 + f_row) * PITCH;
+#pragma unroll
+        for (int ks = 0; ks < KT; ++ks) {
+            bf16x8 fa[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                fa[mi] = *reinterpret_cast<const bf16x8*>(ab + mi * 16 * PITCH + (((ks * 4 + f_kc) ^ f_row) << 4));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni][ks], fa[mi], acc[ni][mi], 0, 0, 0);
+        }
+        const int m0 = tile * PM + wm * 32;
+        if constexpr (MODE == PRO_STATS) {
+            // sums of the ROUNDED outputs (what a stored tensor would hold), rows past M excluded
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const bool ok = m0 + mi * 16 + e_row < p.M;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float f = ok ? (float)(bf16_t)acc[ni][mi][e] : 0.f;
+                        st_sum[ni * 4 + e] += f;
+                        st_sq[ni * 4 + e] = fmaf(f, f, st_sq[ni * 4 + e]);
+                    }
+            }
+        } else {
+            // accumulator layout (m = mi*16 + (lane & 15), n = ni*16 + (lane >> 4)*4 + e) -> rows of 128 B in the wave's staging
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const bf16x4 q = {(bf16_t)acc[ni][mi][0], (bf16_t)acc[ni][mi][1], (bf16_t)acc[ni][mi][2], (bf16_t)acc[ni][mi][3]};
+                    const int row = mi * 16 + e_row, chunk = ni * 2 + e_wchunk;
+                    *reinterpret_cast<bf16x4*>(stg + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + e_wsub) = q;
+                }
+            float cs[8], cb[8], rs[8], rb[8];
+            if constexpr (MODE == PRO_TAIL) {
+                const float* t = aff + wn * 64 + r_chunk * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { cs[e] = t[e]; cb[e] = t[PN + e]; rs[e] = t[2 * PN + e]; rb[e] = t[3 * PN + e]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 8 + r_row0;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((r_chunk ^ ((row >> 1) & 7)) << 4));
+                const int m = m0 + row, n = n0 + wn * 64 + r_chunk * 8;
+                if (m < p.M) {
+                    if constexpr (MODE == PRO_TAIL) {
+                        const bf16x8 r = rres[j];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float y = fmaf((float)v[e], cs[e], cb[e]);
+                            const float idv = p.r_scale ? fmaf((float)r[e], rs[e], rb[e]) : (float)r[e];
+                            v[e] = (bf16_t)fmaxf(y + idv, 0.f);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[e];
+                            st_sum[e] += f;
+                            st_sq[e] = fmaf(f, f, st_sq[e]);
+                        }
+                    }
+                    __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                }
+            }
+            if constexpr (MODE == PRO_TAIL) {
+                if (next < p.tiles) load_r(next);
+            }
+        }
+        buf ^= 1;
+    }
+
+    if (MODE != PRO_TAIL && p.stats) {
+        __syncthreads();
+        float* red = (float*)smem;                       // [8 waves][2][64]
+        if constexpr (MODE == PRO_STATS) {
+            // reduce over the 16 row lanes (lane & 15); lane >> 4 selects the 4-column group
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    st_sum[e] += __shfl_xor(st_sum[e], o, 64);
+                    st_sq[e] += __shfl_xor(st_sq[e], o, 64);
+                }
+            }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        red[(wave * 2 + 0) * 64 + ni * 16 + (lane >> 4) * 4 + e] = st_sum[ni * 4 + e];
+                        red[(wave * 2 + 1) * 64 + ni * 16 + (lane >> 4) * 4 + e] = st_sq[ni * 4 + e];
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = 8; o <= 32; o <<= 1) {
+                    st_sum[e] += __shfl_xor(st_sum[e], o, 64);
+                    st_sq[e] += __shfl_xor(st_sq[e], o, 64);
+                }
+            }
+            if (lane < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[(wave * 2 + 0) * 64 + lane * 8 + e] = st_sum[e];
+                    red[(wave * 2 + 1) * 64 + lane * 8 + e] = st_sq[e];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < PN) {
+            const int wn_ = tid >> 6, c = tid & 63, n = n0 + tid;
+            p.stats[((long)blockIdx.x * 2 + 0) * p.N + n] = red[(wn_ * 2 + 0) * 64 + c] + red[((wn_ + 4) * 2 + 0) * 64 + c];
+            p.stats[((long)blockIdx.x * 2 + 1) * p.N + n] = red[(wn_ * 2 + 1) * 64 + c] + red[((wn_ + 4) * 2 + 1) * 64 + c];
+        }
+    }
+}
+
+int pro_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+template <int KT, int MODE>
+int pro_launch(const ProDev& d, dim3 grid, hipStream_t stream) {
+    static bool attr = false;
+    constexpr int lds = pro_lds_bytes<KT>();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)gemm_pro_kernel<KT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            cvcl_set_error("cvcl_gemm_pro: cannot raise the dynamic LDS limit to %d", lds);
+            return CVCL_ELAUNCH;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_pro_kernel<KT, MODE>), grid, dim3(512), lds, stream, d);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+}  // namespace
+
+// the cvcl_gemm argument blocks this kernel takes: bf16, BN + ReLU operand prologue, K = 128 | 256, N % 256 == 0, and one of
+// {statistics only, C + statistics, Bottleneck tail (c_scale / c_shift + residual)}
+extern "C" int cvcl_gemm_pro_supported(const cvcl_gemm_args* a) {
+    if (!a || !a->a_scale || !a->a_shift || !a->a_relu) return 0;
+    if ((a->K != 128 && a->K != 256) || a->N % PN != 0 || a->M < 1) return 0;
+    if (a->lda % 8 || a->ldw % 8 || (a->C && a->ldc % 8) || a->gather_stride > 1 || a->exp_scale || a->bias || a->C_pre || a->G) return 0;
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    if (!al16(a->A) || !al16(a->W) || !al16(a->C) || !al16(a->R)) return 0;
+    if (a->c_scale) return a->c_shift && a->R && a->C && !a->stats && a->ldr % 8 == 0 && a->act == CVCL_ACT_RELU &&
+                           (a->r_scale == nullptr) == (a->r_shift == nullptr);
+    return !a->R && a->act == CVCL_ACT_NONE && (a->C || a->stats);
+}
+
+// statistics rows written: one per workgroup row (grid.x)
+extern "C" int cvcl_gemm_pro_stats_rows(int M, int N) {
+    const int tiles = cvcl_div_up(M, PM), ncol = N / PN;
+    int g = pro_num_cus() / (ncol > 0 ? ncol : 1);
+    if (g < 1) g = 1;
+    return g > tiles ? tiles : g;
+}
+
+extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream) {
+    CVCL_CHECK_ARG(cvcl_gemm_pro_supported(a), "cvcl_gemm_pro: unsupported argument block");
+    ProDev d;
+    d.A = (const bf16_t*)a->A; d.W = (const bf16_t*)a->W; d.C = (bf16_t*)a->C; d.R = (const bf16_t*)a->R;
+    d.a_scale = a->a_scale; d.a_shift = a->a_shift; d.c_scale = a->c_scale; d.c_shift = a->c_shift;
+    d.r_scale = a->r_scale; d.r_shift = a->r_shift; d.stats = a->stats;
+    d.M = a->M; d.N = a->N; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr;
+    d.tiles = cvcl_div_up(a->M, PM);
+    const int gx = cvcl_gemm_pro_stats_rows(a->M, a->N);
+    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gx, "cvcl_gemm_pro: stats_rows %d < %d", a->stats_rows, gx);
+    dim3 grid(gx, a->N / PN);
+    const int mode = a->c_scale ? PRO_TAIL : (a->C ? PRO_STORE : PRO_STATS);
+    CvclProfScope prof(stream, CVCL_K_GEMM);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->K == 128) {
+        if (mode == PRO_TAIL) return pro_launch<4, PRO_TAIL>(d, grid, st);
+        if (mode == PRO_STORE) return pro_launch<4, PRO_STORE>(d, grid, st);
+        return pro_launch<4, PRO_STATS>(d, grid, st);
+    }
+    if (mode == PRO_TAIL) return pro_launch<8, PRO_TAIL>(d, grid, st);
+    if (mode == PRO_STORE) return pro_launch<8, PRO_STORE>(d, grid, st);
+    return pro_launch<8, PRO_STATS>(d, grid, st);
+}

@@ -1067,9 +1067,15 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), L[l2].w, R2, training ? stats : nullptr,
                             kMaxStatsRows, B, h, wd, width, 32, stride, stream))) return rc;
     if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, width, stride), m_out, width))) return rc;
-    // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  BN2+ReLU is applied to the narrow tensor in place first
-    // (one pass) instead of in the GEMM operand load (once per 128-column output tile): see bn_relu_apply_kernel.
-    if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
+    // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  Layers 1-2 (K = width <= 256, bandwidth-bound): BN2 + ReLU rides conv3's
+    // operand load (gemm_pro.hip: applied once per element, W resident in registers) -- no pass of its own over the tensor.
+    // Layers 3-4 (MFMA-bound, 4-8 column-tile workgroups per A tile): BN2 + ReLU is applied in place first (one pass over the
+    // narrow tensor), which is cheaper than repeating it in every column tile's operand path.
+    static const int pro_stages = [] { const char* e = getenv("CVCL_CONV3_PRO_STAGES"); return e ? atoi(e) : 2; }();
+    const bool pro = dtype == CVCL_BF16 && stage < pro_stages && (width == 128 || width == 256);
+    if (!pro) {
+        if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
+    }
     // Layer 1 in bf16 (CVCL_FUSED_TAIL_STAGES leading stages, default 1; measured 6.79 / 6.85 / 6.89 / 7.11 ms per step for
     // 1 / 2 / 0 / 3 stages since bn_add_relu runs at the HBM rate): conv3 is HBM-bound and cheap, so it runs twice -- a
     // statistics-only pass (reads only
@@ -1083,6 +1089,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         cvcl_gemm_args a = {};
         a.A = R2; a.W = L[l3].w;
         a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
+        if (pro) { a.a_scale = scale_of(l2); a.a_shift = shift_of(l2); a.a_relu = 1; }
         return a;
     };
     // opt-in ($CVCL_BN3_GRAM=1): measured SLOWER than the statistics-only GEMM pass on MI355X at B=256 (8.14 vs 7.74

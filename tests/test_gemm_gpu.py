@@ -395,3 +395,99 @@ def test_gemm_training_gelu_epilogues_match_separate_passes(dev):
     torch.nn.functional.gelu(uu).backward(dg.double().cpu())
     err = float((du_ref.double().cpu() - uu.grad).abs().max() / uu.grad.abs().max())
     assert err < 1e-2, err
+
+
+def _gemm_args(H, A, W, C=None, stats=None, a_scale=None, a_shift=None, c_scale=None, c_shift=None, R=None, r_scale=None, r_shift=None):
+    a = H.GemmArgs()
+    M, K = A.shape
+    N = W.shape[0]
+    a.A, a.W, a.C = H.ptr(A), H.ptr(W), H.ptr(C)
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
+    if a_scale is not None:
+        a.a_scale, a.a_shift, a.a_relu = H.ptr(a_scale), H.ptr(a_shift), 1
+    if stats is not None:
+        a.stats, a.stats_rows = H.ptr(stats), stats.shape[0]
+    if c_scale is not None:
+        a.c_scale, a.c_shift, a.act = H.ptr(c_scale), H.ptr(c_shift), H.ACT_RELU
+        a.R, a.ldr = H.ptr(R), N
+        if r_scale is not None:
+            a.r_scale, a.r_shift = H.ptr(r_scale), H.ptr(r_shift)
+    return a
+
+
+@pytest.mark.parametrize("M,N,K", [(12544, 256, 128), (5000, 512, 256), (63, 256, 128), (100352, 256, 128), (7777, 768, 256)])
+def test_gemm_pro_bn_relu_operand_three_epilogues(dev, M, N, K):
+    """cvcl_gemm with the producer's BatchNorm + ReLU on the operand and K = 128 | 256 (conv3 of ResNeXt layers 1-2 on the raw
+    grouped-convolution output) runs the bandwidth-bound kernel of gemm_pro.hip: statistics only / store + statistics /
+    Bottleneck tail, against float64 of the storage-point model (operand rounded to bf16 after the affine + ReLU, output rounded,
+    statistics of the rounded output), ragged M included; deterministic."""
+    import ctypes as Cc
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 2 + 0.5).bfloat16()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    act = torch.relu(a.float() * sc + sh).bfloat16()                          # what conv3 consumes (storage-point model)
+    y = (act.double() @ w.double().t()).float().bfloat16()
+    ad, wd, scd, shd = a.to(dev), w.to(dev), sc.to(dev), sh.to(dev)
+    rows = H.lib().cvcl_gemm_pro_stats_rows(M, N)
+    probe = torch.empty(rows, 2, N, device=dev)
+    args = _gemm_args(H, ad, wd, None, probe, scd, shd)
+    assert H.lib().cvcl_gemm_pro_supported(Cc.byref(args)) == 1
+    assert rows == H.lib().cvcl_gemm_stats_rows(H.BF16, Cc.byref(args))
+    # store + statistics
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+    st = torch.full((rows, 2, N), float("nan"), device=dev)
+    H.check(H.lib().cvcl_gemm(H.BF16, Cc.byref(_gemm_args(H, ad, wd, C, st, scd, shd)), H.stream_ptr()), "cvcl_gemm")
+    err = (C.double().cpu() - y.double()).abs() / (y.double().abs() + float(y.abs().max()) * 5e-2)
+    assert float(err.max()) < 8e-3
+    s = st.double().sum(0).cpu()
+    cd = C.double().cpu()
+    assert maxrel(s[0], cd.sum(0)) < 1e-5 and maxrel(s[1], (cd * cd).sum(0)) < 1e-5
+    # statistics only: same rows as sums of the same rounded outputs (other per-workgroup split is allowed: compare totals)
+    st2 = torch.full((rows, 2, N), float("nan"), device=dev)
+    H.check(H.lib().cvcl_gemm(H.BF16, Cc.byref(_gemm_args(H, ad, wd, None, st2, scd, shd)), H.stream_ptr()), "cvcl_gemm")
+    s2 = st2.double().sum(0).cpu()
+    assert maxrel(s2[0], cd.sum(0)) < 1e-5 and maxrel(s2[1], (cd * cd).sum(0)) < 1e-5
+    st3 = torch.empty_like(st2)
+    H.check(H.lib().cvcl_gemm(H.BF16, Cc.byref(_gemm_args(H, ad, wd, None, st3, scd, shd)), H.stream_ptr()), "cvcl_gemm")
+    assert torch.equal(st2, st3)
+    # Bottleneck tail: relu(bn3(round(acc)) + identity) and + normalised downsample branch
+    cs, cb = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    rs, rb = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g).bfloat16()
+    for with_ds in (False, True):
+        idn = r.double() * rs.double() + rb.double() if with_ds else r.double()
+        ref = torch.relu(cd * cs.double() + cb.double() + idn).float().bfloat16()
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        args = _gemm_args(H, ad, wd, out, None, scd, shd, cs.to(dev), cb.to(dev), r.to(dev),
+                          rs.to(dev) if with_ds else None, rb.to(dev) if with_ds else None)
+        keep = (args, )
+        H.check(H.lib().cvcl_gemm(H.BF16, Cc.byref(args), H.stream_ptr()), "cvcl_gemm")
+        e = (out.double().cpu() - ref.double()).abs() / (ref.double().abs() + float(ref.abs().max()) * 5e-2)
+        assert float(e.max()) < 8e-3, with_ds
+
+
+def test_gemm_pro_exact_on_small_integers(dev):
+    """Identity affine + ReLU on integer operands: every product and partial sum is exact -> bit-exact output (pins the W-in-
+    registers fragment layout, the A-tile swizzle and the double buffering across many tiles per workgroup)."""
+    import ctypes as Cc
+    from multimodal import _hip as H
+    M, N, K = 40000, 512, 256
+    g = torch.Generator().manual_seed(3)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    ref = (torch.relu(a).double() @ w.double().t()).float().bfloat16()
+    one, zero = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+    ad, wd = a.bfloat16().to(dev), w.bfloat16().to(dev)
+    rows = H.lib().cvcl_gemm_pro_stats_rows(M, N)
+    outs = []
+    for _ in range(3):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        st = torch.full((rows, 2, N), float("nan"), device=dev)
+        H.check(H.lib().cvcl_gemm(H.BF16, Cc.byref(_gemm_args(H, ad, wd, C, st, one, zero)), H.stream_ptr()), "cvcl_gemm")
+        outs.append((C, st))
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0][0], c) and torch.equal(outs[0][1], s) for c, s in outs[1:])
+    assert torch.equal(outs[0][0].cpu(), ref)
+    assert torch.equal(outs[0][1][:, 0].double().sum(0).cpu(), ref.double().sum(0))
