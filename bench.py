@@ -148,10 +148,10 @@ def logits_vs_fp32(lit, batch, precision):
 def resnext_gemm_work(B):
     """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode):
     every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
-    enqueues: conv1 and downsample (A + W + C); conv3 of layers 2-4 (A + W + C); conv3 of layer 1 twice -- a
+    enqueues: conv1 and downsample (A + W + C); conv3 of layers 3-4 (A + W + C); conv3 of layers 1-2 twice -- a
     statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The number of leading
-    stages that use the fused tail is the library's $CVCL_FUSED_TAIL_STAGES, default 1.)"""
-    fused_stages = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "1"))
+    stages that use the fused tail is the library's $CVCL_FUSED_TAIL_STAGES, default 2.)"""
+    fused_stages = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "2"))
     nbytes = flops = launches = 0
     inplanes, h = 64, 56
     for stage, blocks in enumerate((3, 4, 6, 3)):
@@ -380,7 +380,9 @@ def main(argv=None):
         prof = instrumented(nprof)
         breakdown = {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1] > 0}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
-        g_ms, g_n = prof["gemm"]
+        GEMM_CLASSES = ("gemm", "gemm8w", "gemm_pro")          # the bf16 MFMA GEMM kernels: 128 x 128 glds / 8-wave 256 x 256 / BN-prologue
+        g_ms = sum(prof[c][0] for c in GEMM_CLASSES)
+        g_n = sum(prof[c][1] for c in GEMM_CLASSES)
         avg_s = g_ms / max(g_n, 1) * 1e-3
         if cfg == "c2":
             nbytes, flops, launches = resnext_gemm_work(batch_size)
@@ -389,34 +391,37 @@ def main(argv=None):
         per_launch_bytes, per_launch_flops = nbytes / launches, flops / launches
         gbs = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         tfs = per_launch_flops / avg_s / 1e12 if avg_s > 0 else 0.0
+        split = {c: {"ms_per_step": round(prof[c][0] / nprof, 4), "launches_per_step": prof[c][1] // nprof} for c in GEMM_CLASSES if prof[c][1]}
         traffic = None
         if cfg == "c2":
             # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc
             # passes of this same command: tools/pmc_bench.sh -> profiles/<round>_pmc_hbm_traffic.json)
-            for rnd in (PROFILE_ROUND, "r01"):
-                try:
-                    with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.json")) as f:
-                        pm = json.load(f)["gemm_glds_kernel"]
-                    traffic = int((pm["hbm_read_bytes_per_step_corrected_x2"] + pm["hbm_write_bytes_per_step"]) / pm["launches_per_step"])
-                    break
-                except Exception:
-                    continue
-            roofline = {"kernel": "gemm_glds_kernel (bf16 1x1-conv MFMA GEMM, direct-to-LDS operand loads; epilogues: BN statistics / "
-                                  "fused BN3+identity+ReLU Bottleneck tail)",
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_hbm_traffic.json")) as f:
+                    pm = json.load(f)["conv_gemm_all"]
+                traffic = int((pm["hbm_read_bytes_per_step_corrected_x2"] + pm["hbm_write_bytes_per_step"]) / pm["launches_per_step"])
+            except Exception:
+                traffic = None
+            roofline = {"kernel": "the bf16 1x1-convolution MFMA GEMMs of the trunk: gemm_glds_kernel (128 x 128 tiles, direct-to-LDS loads; "
+                                  "layer-1/2 conv1 + downsamples), gemm8w_kernel (8-wave 256|224 x 256 tiles, 4-stage LDS ring; the MFMA-bound "
+                                  "layers 2-4) and gemm_pro_kernel (conv3 of layers 1-2 with BN2+ReLU on the operand load: statistics pass "
+                                  "and fused BN3+identity+ReLU tail)",
                         "dominant_class_by_time": dom, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "traffic_note": "PMC HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, profiles/)",
-                        "mfma_tflops": round(tfs, 1), "mfma_frac_of_bf16_dense_peak": round(tfs / MFMA_BF16_PEAK_TFLOPS, 4)}
+                        "traffic_note": "PMC L2<->fabric bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes, profiles/)",
+                        "mfma_tflops": round(tfs, 1), "mfma_frac_of_bf16_dense_peak": round(tfs / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "by_kernel": split}
         else:
             peak = MFMA_FP8_PEAK_TFLOPS if precision == "fp8" else MFMA_BF16_PEAK_TFLOPS
             roofline = {"kernel": ("gemm_fp8_kernel (e4m3 x e4m3 ViT linears on v_mfma_scale_f32_32x32x64_f8f6f4)" if precision == "fp8"
-                                   else "gemm_glds_kernel<linear epilogue> (bf16 ViT linears: bias / GELU / residual)"),
+                                   else "gemm8w_kernel<linear epilogue> (bf16 ViT linears: bias / GELU / residual; 8-wave 256|224 x 256 tiles)"),
                         "dominant_class_by_time": dom, "bound": "mfma", "achieved": round(tfs, 1), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(tfs / peak, 4), "traffic": None, "algorithmic_GBps": round(gbs, 1)}
+                        "frac": round(tfs / peak, 4), "traffic": None, "algorithmic_GBps": round(gbs, 1), "by_kernel": split}
         roofline.update({"launches_per_step": g_n // nprof, "avg_launch_us": round(avg_s * 1e6, 2),
                          "algorithmic_bytes_per_launch": int(per_launch_bytes), "algorithmic_flops_per_launch": int(per_launch_flops)})
         if conc is not None:
-            c_ms, c_n = conc["gemm"]
+            c_ms = sum(conc[c][0] for c in GEMM_CLASSES)
+            c_n = sum(conc[c][1] for c in GEMM_CLASSES)
             roofline["measured"] = ("one trunk pass in flight (single-trunk-stream schedule): the kernel's own launch duration, "
                                     "which is also what the rocprofv3 --kernel-trace run of this command reports (profiles/)")
             roofline["concurrent"] = {"note": "the timed region keeps two trunk passes in flight on two HIP streams; event-timed "

@@ -42,7 +42,7 @@ const char* cvcl_last_error(void);
 enum { CVCL_K_GEMM = 0, CVCL_K_GCONV = 1, CVCL_K_STEM = 2, CVCL_K_BN_FINALIZE = 3, CVCL_K_BN_ADD_RELU = 4,
        CVCL_K_MAXPOOL = 5, CVCL_K_AVGPOOL = 6, CVCL_K_HEAD = 7, CVCL_K_OTHER = 8, CVCL_K_ATTENTION = 9,
        CVCL_K_LAYERNORM = 10, CVCL_K_LSTM = 11, CVCL_K_GEMM_F32 = 12, CVCL_K_BN_APPLY = 13, CVCL_K_BN_BWD = 14,
-       CVCL_K_WGRAD = 15, CVCL_K_NCLASSES = 16 };
+       CVCL_K_WGRAD = 15, CVCL_K_GEMM8W = 16, CVCL_K_GEMM_PRO = 17, CVCL_K_NCLASSES = 18 };
 int cvcl_prof_enable(int on);
 int cvcl_prof_collect(double* ms_per_class, long* launches_per_class, int n_classes);
 

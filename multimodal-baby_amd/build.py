@@ -21,7 +21,12 @@ LIB = os.path.join(LIBDIR, "libcvcl_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=off"]
+         "-ffp-contract=off"] + os.environ.get("CVCL_EXTRA_FLAGS", "").split()
+# experiments: CVCL_EXTRA_FLAGS=-DCVCL_PLAIN_STORES CVCL_LIB_SUFFIX=_plain python build.py -> lib/libcvcl_hip_plain.so ($CVCL_HIP_LIB)
+SUFFIX = os.environ.get("CVCL_LIB_SUFFIX", "")
+if SUFFIX:
+    LIB = os.path.join(LIBDIR, f"libcvcl_hip{SUFFIX}.so")
+    OBJDIR = os.path.join(HERE, "build" + SUFFIX)
 
 
 def sources():
@@ -42,7 +47,7 @@ def _digest():
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "libcvcl_hip.stamp")
+    stamp = os.path.join(LIBDIR, f"libcvcl_hip{SUFFIX}.stamp")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB

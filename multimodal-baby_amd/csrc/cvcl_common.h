@@ -84,6 +84,16 @@ template <> struct Chunk<bf16_t> {
     __device__ inline void set(int i, float f) { v[i] = (bf16_t)f; }
 };
 
+// streamed-out results: nontemporal by default (the L2 keeps the operands); -DCVCL_PLAIN_STORES builds the same kernels with
+// ordinary stores (experiment: does the consumer find the tensor in the Infinity Cache?)
+template <typename V> __device__ __forceinline__ void stream_store(V v, V* dst) {
+#ifdef CVCL_PLAIN_STORES
+    *dst = v;
+#else
+    __builtin_nontemporal_store(v, dst);
+#endif
+}
+
 // ---- wave / block reductions ---------------------------------------------------------------
 __device__ inline float wave_sum(float v) {
 #pragma unroll

@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                         st_sq[e] = fmaf(f, f, st_sq[e]);
                     }
                 }
-                if (EPI != 0 || C) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n));   // streamed out: keep L2 for the operands
+                if (EPI != 0 || C) stream_store(v, reinterpret_cast<bf16x8*>(C + (long)m * p.ldc + n));   // streamed out: keep L2 for the operands
             }
         }
         // the next loop iteration's vmcnt wait + barrier orders these staging reads before the buffer is refilled

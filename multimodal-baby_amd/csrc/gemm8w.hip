@@ -89,6 +89,9 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     d.bias = a->bias; d.stats = a->stats;
     d.M = a->M; d.N = a->N; d.K = a->K; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr; d.act = a->act;
     d.ncol = a->N / 256;
+    // experiment: $CVCL_GEMM8W_REV=1 visits the m-tiles last-to-first (the producer's freshest rows first)
+    static const int rev = [] { const char* e = getenv("CVCL_GEMM8W_REV"); return (e && e[0] == '1') ? 1 : 0; }();
+    d.rev = rev;
     int bm, grid;
     if (epi == 0) {                                          // column-fixed mapping: grid_m workgroups per column tile
         bm = cvcl_gemm8w_tile_rows(a->M, a->N);
@@ -110,7 +113,7 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
         grid = total < g8_num_cus() ? (int)((total + 7) & ~7L) : (g8_num_cus() & ~7);
         d.grid_m = 0;
     }
-    CvclProfScope prof(stream, CVCL_K_GEMM);
+    CvclProfScope prof(stream, CVCL_K_GEMM8W);
     if (bm == 256) return epi == 0 ? g8_launch<8, 0>(d, grid, (hipStream_t)stream) : g8_launch<8, 1>(d, grid, (hipStream_t)stream);
     return epi == 0 ? g8_launch<7, 0>(d, grid, (hipStream_t)stream) : g8_launch<7, 1>(d, grid, (hipStream_t)stream);
 }

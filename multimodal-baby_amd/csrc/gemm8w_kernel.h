@@ -46,6 +46,7 @@ struct Dev {
     const float* bias; float* stats;
     int M, N, K, lda, ldw, ldc, ldr, act;
     int tiles_m, grid_m, ncol;
+    int rev;                        // m-tiles are visited from the last to the first (the rows the producer wrote last are read first)
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         w_off[j] = (unsigned)(tj * BN + (wave * 2 + j) * 16 + srow) * (unsigned)p.ldw + slog * 8;
         int r = (wave * 2 + j) * 16 + srow;
         if (r >= BM) r = BM - 1;                            // BM < 256: rows of the unused part of the A region
-        a_raw[j] = (unsigned)(ti * BM + r) * (unsigned)p.lda + slog * 8;
+        a_raw[j] = (unsigned)((p.rev ? p.tiles_m - 1 - ti : ti) * BM + r) * (unsigned)p.lda + slog * 8;
     }
     // the next tile is a uniform step further; rows past M (ragged last tile) are clamped to an address inside the last row
     // (any valid address will do: those rows are masked at the store) -- no per-lane state beyond the offsets
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                     if (l_j + dj >= p.ncol) { dj -= p.ncol; ++di; }
                     l_j += dj;
                 }
-                const unsigned da = (unsigned)di * a_unit, dw = (unsigned)dj * w_unit;      // (dj < 0 wraps modulo 2^32: fine)
+                const unsigned da = (unsigned)(p.rev ? -di : di) * a_unit, dw = (unsigned)dj * w_unit;   // (negative steps wrap modulo 2^32: fine)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { a_raw[j] += da; w_off[j] += dw; }
             }
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                         }
-                        __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                        stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                             st_sum[e] += f;
                             st_sq[e] = fmaf(f, f, st_sq[e]);
                         }
-                        if (p.C) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                        if (p.C) stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
                     }
                 }
             }
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         advance();
         if (++c_ks == KS) {
             c_ks = 0;
-            epi_ops = epilogue(c_i * BM, c_j * BN);
+            epi_ops = epilogue((p.rev ? p.tiles_m - 1 - c_i : c_i) * BM, c_j * BN);
             after_epi = 3;
             c_i += step_i;
             if constexpr (FLAT) {

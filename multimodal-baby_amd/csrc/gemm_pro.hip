@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
                             st_sq[e] = fmaf(f, f, st_sq[e]);
                         }
                     }
-                    __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                    stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
                 }
             }
             if constexpr (MODE == PRO_TAIL) {
@@ -322,7 +322,7 @@ extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream) {
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gx, "cvcl_gemm_pro: stats_rows %d < %d", a->stats_rows, gx);
     dim3 grid(gx, a->N / PN);
     const int mode = a->c_scale ? PRO_TAIL : (a->C ? PRO_STORE : PRO_STATS);
-    CvclProfScope prof(stream, CVCL_K_GEMM);
+    CvclProfScope prof(stream, CVCL_K_GEMM_PRO);
     hipStream_t st = (hipStream_t)stream;
     if (a->K == 128) {
         if (mode == PRO_TAIL) return pro_launch<4, PRO_TAIL>(d, grid, st);

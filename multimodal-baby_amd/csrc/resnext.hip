@@ -854,8 +854,9 @@ GconvPlan gconv_plan(int B, int H, int W, int C, int stride) {
     // output rows per work item: staged input band + output band within ~52 KiB (3 workgroups per CU) and the
     // input pixel count within the 10 x 32 register-prefetch slots of the kernel
     auto bytes = [&](int th) { return (size_t)(((th - 1) * stride + 3) * Wp + th * Wo) * GC_PIXB; };
+    static const int lds_kb = [] { const char* e = getenv("CVCL_GCONV_LDS_KB"); return e ? atoi(e) : 52; }();
     int TH = Ho;
-    while (TH > 1 && (bytes(TH) > 52 * 1024 || ((TH - 1) * stride + 3) * Wp > 10 * 32)) TH = (TH + 1) / 2;
+    while (TH > 1 && (bytes(TH) > (size_t)lds_kb * 1024 || ((TH - 1) * stride + 3) * Wp > 10 * 32)) TH = (TH + 1) / 2;
     g.TH = TH;
     g.bands = cvcl_div_up(Ho, TH);
     g.rows_in = (TH - 1) * stride + 3;
@@ -1076,14 +1077,14 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     if (!pro) {
         if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
     }
-    // Layer 1 in bf16 (CVCL_FUSED_TAIL_STAGES leading stages, default 1; measured 6.79 / 6.85 / 6.89 / 7.11 ms per step for
-    // 1 / 2 / 0 / 3 stages since bn_add_relu runs at the HBM rate): conv3 is HBM-bound and cheap, so it runs twice -- a
-    // statistics-only pass (reads only
-    // the narrow operand), then a pass whose epilogue applies BN3 + identity / normalised downsample + ReLU
-    // and writes the block output -- instead of materialising raw3 and re-reading it in bn_add_relu
-    // (saves one write and one read of the wide tensor; results are bit-identical).
+    // Layers 1-2 in bf16 ($CVCL_FUSED_TAIL_STAGES leading stages, default 2): conv3 is HBM-bound and cheap there, so it runs
+    // twice -- a statistics-only pass (reads only the narrow operand), then a pass whose epilogue applies BN3 + identity /
+    // normalised downsample + ReLU and writes the block output -- instead of materialising raw3 and re-reading it in
+    // bn_add_relu (saves one write and one read of the wide tensor; results are bit-identical).  Both passes apply BN2 + ReLU
+    // on the operand load (gemm_pro.hip).  Measured per step at B = 256 (round 2, with gemm_pro): 1 stage 5.47 ms, 2 stages
+    // 5.46 ms and 1.2 GB less HBM traffic; layers 3-4 are MFMA-bound and keep the materialised form.
     // In eval mode there is no statistics pass at all, so the fused tail is used in every stage.
-    static const int fused_stages = [] { const char* e = getenv("CVCL_FUSED_TAIL_STAGES"); return e ? atoi(e) : 1; }();
+    static const int fused_stages = [] { const char* e = getenv("CVCL_FUSED_TAIL_STAGES"); return e ? atoi(e) : 2; }();
     const bool fused_tail = dtype == CVCL_BF16 && (stage < fused_stages || !training);
     auto conv3_args = [&]() {
         cvcl_gemm_args a = {};

@@ -20,7 +20,7 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 ABI_VERSION = 1
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
-                  "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply", "bn_bwd", "wgrad")
+                  "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply", "bn_bwd", "wgrad", "gemm8w", "gemm_pro")
 
 
 class CvclError(RuntimeError):

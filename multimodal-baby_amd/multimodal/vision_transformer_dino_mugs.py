@@ -80,6 +80,7 @@ class VisionTransformer(nn.Module):
         self.apply(self._init_weights)
         self.compute_dtype = torch.float32
         self._cache = {}
+        self._pre_head_callback = None                  # parallel.OverlappedUpdate: runs between the trunk and the head
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
@@ -93,6 +94,7 @@ class VisionTransformer(nn.Module):
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_cache"] = {}
+        d["_pre_head_callback"] = None
         d.pop("_trunk_stream", None)          # streams / ring buffers of H.TrunkStream are never pickled
         d.pop("_trunk_out", None)
         return d
@@ -101,6 +103,7 @@ class VisionTransformer(nn.Module):
         self.__dict__.update(d)
         self.__dict__.setdefault("compute_dtype", torch.float32)
         self.__dict__.setdefault("_cache", {})
+        self.__dict__.setdefault("_pre_head_callback", None)
         # instances pickled by the reference's own class (hyper_parameters of its Lightning checkpoints) carry only what
         # reference :174-197 sets: recover the two attributes the HIP forward reads from the submodules
         mods = self.__dict__.get("_modules", {})

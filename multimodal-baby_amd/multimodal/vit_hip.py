@@ -91,10 +91,17 @@ def vit_forward(model, x: torch.Tensor) -> torch.Tensor:
         from .vit_train import vit_trunk_train         # --finetune_cnn: differentiable twin (saves activations)
         return vit_trunk_train(model, x)
     ts = model.__dict__.get("_trunk_stream")
+    cb = model.__dict__.get("_pre_head_callback")        # parallel.OverlappedUpdate: the previous step's all-reduce wait + optimizer
     if ts is not None and x.is_cuda:          # frozen ViT on its own stream: overlaps the previous step's text encoder / loss /
         x = x.contiguous()                    # backward / optimizer, which stay on the caller's stream (H.TrunkStream)
-        return ts.run(lambda slot: _vit_forward(model, x, slot), x)
-    return _vit_forward(model, x, None)
+        handle = ts.launch(lambda slot: _vit_forward(model, x, slot), x)
+        if cb is not None:
+            cb()                              # ... enqueued on the caller's stream while the trunk runs on its own
+        return ts.wait(handle)
+    out = _vit_forward(model, x, None)
+    if cb is not None:
+        cb()
+    return out
 
 
 def enable_trunk_stream(model, device, inputs="caller", stream=None, n_streams=None):

@@ -83,6 +83,7 @@ int main(int argc, char** argv) {
         memset(&d, 0, sizeof(d));
         d.A = dA; d.W = dW; d.C = dC; d.M = M; d.N = N; d.K = K; d.lda = K; d.ldw = K; d.ldc = N;
         d.stats = want_stats ? dStats : nullptr;
+        d.rev = getenv("LAB_REV") ? 1 : 0;
         const int BM = mi * 32;
         d.tiles_m = (M + BM - 1) / BM;
         d.ncol = N / 256;

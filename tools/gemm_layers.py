@@ -3,7 +3,7 @@
 import csv, os, sys
 trace = sys.argv[1]
 out = sys.argv[2] if len(sys.argv) > 2 else None
-fused = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "1"))
+fused = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "2"))
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def is_conv_gemm(n):
