@@ -146,13 +146,25 @@ def logits_vs_fp32(lit, batch, precision):
 
 
 def resnext_gemm_work(B):
-    """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode):
-    every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
+    """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode), per
+    kernel: every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
     enqueues: conv1 and downsample (A + W + C); conv3 of layers 3-4 (A + W + C); conv3 of layers 1-2 twice -- a
     statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The number of leading
-    stages that use the fused tail is the library's $CVCL_FUSED_TAIL_STAGES, default 2.)"""
+    stages that use the fused tail is the library's $CVCL_FUSED_TAIL_STAGES, default 2.)  Which kernel runs a launch mirrors
+    the dispatcher of csrc/gemm.hip: gemm_pro = conv3 with the BN2+ReLU operand prologue (layers 1-2), gemm8w = plain operands,
+    K >= 256, N % 256 == 0, >= 96 tiles of 256 x 256, N K >= 170 (N + K), no strided gather; the rest on gemm_glds ("gemm").
+    -> {kernel: [bytes, flops, launches]} and the totals."""
     fused_stages = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "2"))
-    nbytes = flops = launches = 0
+    pro_stages = int(os.environ.get("CVCL_CONV3_PRO_STAGES", "2"))
+    per = {"gemm": [0, 0, 0], "gemm8w": [0, 0, 0], "gemm_pro": [0, 0, 0]}
+
+    def add(kernel, nbytes, flops):
+        per[kernel][0] += nbytes; per[kernel][1] += flops; per[kernel][2] += 1
+
+    def plain_kernel(m, n, k, gather):
+        ok = (k >= 256 and k % 128 == 0 and n % 256 == 0 and not gather and -(-m // 256) * (n // 256) >= 96 and n * k >= 170 * (n + k)
+              and os.environ.get("CVCL_GEMM8W", "1") != "0")
+        return "gemm8w" if ok else "gemm"
     inplanes, h = 64, 56
     for stage, blocks in enumerate((3, 4, 6, 3)):
         planes = 64 << stage
@@ -161,22 +173,22 @@ def resnext_gemm_work(B):
             stride = 2 if (stage > 0 and bi == 0) else 1
             ho = h // stride
             m_in, m_out = B * h * h, B * ho * ho
-            plain = [(m_in, width, inplanes)]                       # conv1
-            if bi == 0:
-                plain.append((m_out, outc, inplanes))               # downsample
-            if stage >= fused_stages:
-                plain.append((m_out, outc, width))                  # conv3, raw output materialised
-            for (m, n, k) in plain:
-                nbytes += 2 * (m * k + n * k + m * n)
-                flops += 2 * m * n * k
-                launches += 1
-            if stage < fused_stages:                                # conv3 as statistics pass + fused tail pass
-                m, n, k = m_out, outc, width
-                nbytes += 2 * (m * k + n * k) + 2 * (m * k + n * k + 2 * m * n)
-                flops += 2 * (2 * m * n * k)
-                launches += 2
+            m, n, k = m_in, width, inplanes                          # conv1
+            add(plain_kernel(m, n, k, False), 2 * (m * k + n * k + m * n), 2 * m * n * k)
+            if bi == 0:                                              # downsample
+                m, n, k = m_out, outc, inplanes
+                add(plain_kernel(m, n, k, stride > 1), 2 * (m * k + n * k + m * n), 2 * m * n * k)
+            m, n, k = m_out, outc, width                             # conv3
+            pro = stage < pro_stages and width in (128, 256)
+            kern = "gemm_pro" if pro else plain_kernel(m, n, k, False)
+            if stage < fused_stages:                                 # statistics pass + fused tail pass
+                add(kern if pro else "gemm", 2 * (m * k + n * k), 2 * m * n * k)
+                add(kern if pro else "gemm", 2 * (m * k + n * k + 2 * m * n), 2 * m * n * k)
+            else:
+                add(kern, 2 * (m * k + n * k + m * n), 2 * m * n * k)
             h, inplanes = ho, outc
-    return nbytes, flops, launches
+    tot = [sum(v[i] for v in per.values()) for i in range(3)]
+    return per, tot[0], tot[1], tot[2]
 
 
 def vit_gemm_work(B, patch=16, D=768, depth=12, mlp=3072, operand_bytes=2):
@@ -384,14 +396,23 @@ def main(argv=None):
         g_ms = sum(prof[c][0] for c in GEMM_CLASSES)
         g_n = sum(prof[c][1] for c in GEMM_CLASSES)
         avg_s = g_ms / max(g_n, 1) * 1e-3
+        per_kernel = None
         if cfg == "c2":
-            nbytes, flops, launches = resnext_gemm_work(batch_size)
+            per_kernel, nbytes, flops, launches = resnext_gemm_work(batch_size)
         else:
             nbytes, flops, launches = vit_gemm_work(batch_size, operand_bytes=1 if precision == "fp8" else 2)
         per_launch_bytes, per_launch_flops = nbytes / launches, flops / launches
         gbs = per_launch_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
         tfs = per_launch_flops / avg_s / 1e12 if avg_s > 0 else 0.0
         split = {c: {"ms_per_step": round(prof[c][0] / nprof, 4), "launches_per_step": prof[c][1] // nprof} for c in GEMM_CLASSES if prof[c][1]}
+        if per_kernel is not None:                             # each kernel against its own algorithmic work (when the launch lists agree)
+            for c, v in split.items():
+                pb, pf, pn = per_kernel[c]
+                if pn == v["launches_per_step"] and v["ms_per_step"] > 0:
+                    v.update({"avg_launch_us": round(v["ms_per_step"] * 1e3 / pn, 2), "algorithmic_GBps": round(pb / v["ms_per_step"] / 1e6, 1),
+                              "tflops": round(pf / v["ms_per_step"] / 1e9, 1),
+                              "hbm_frac": round(pb / v["ms_per_step"] / 1e6 / HBM_PEAK_GBS, 4),
+                              "mfma_frac": round(pf / v["ms_per_step"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)})
         traffic = None
         if cfg == "c2":
             # HBM bytes per launch from the PMC counters (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc
