@@ -256,7 +256,8 @@ def main(argv=None):
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 256; c5: see DESIGN.md)")
+    ap.add_argument("--batch", default=None, help="per-GPU batch: a number, or 'auto' = as many pairs as fit the free HBM (frozen-ViT "
+                                                  "configurations: ~5 MB per pair, capped at 32768); default 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -284,7 +285,18 @@ def main(argv=None):
 
     cfg = a.config
     precision = a.precision or ("fp8" if cfg == "c5" else "bf16")
-    batch_size = a.batch or PER_GPU_BATCH
+    if a.batch in (None, ""):
+        batch_size = PER_GPU_BATCH
+    elif str(a.batch) == "auto":
+        # BASELINE configs[4]: "per-GPU batch sized to 288 GB HBM".  A frozen ViT pass keeps ~4.6 MB per pair alive (fp32 frame, patch
+        # matrix, tokens, qkv, MLP hidden, e4m3 copies) on ONE trunk stream; the head adds 3 x B^2 x 4 bytes of logits / gradients.
+        # 80 % of the free memory, multiples of 1024, and at most 32768 pairs (B^2 must stay below 2^31 for the head kernels).
+        free_b, _tot = torch.cuda.mem_get_info(device)
+        batch_size = 1024
+        while batch_size + 1024 <= 32768 and (batch_size + 1024) * 4.6e6 + 12.0 * (batch_size + 1024) ** 2 < 0.8 * free_b:
+            batch_size += 1024
+    else:
+        batch_size = int(a.batch)
     steps = a.steps if a.steps is not None else (50 if batch_size <= 1024 else 5)
     warmup = a.warmup if a.warmup is not None else (10 if batch_size <= 1024 else 2)
     lit, ve, opt = build_model(cfg, device, precision)
@@ -299,7 +311,7 @@ def main(argv=None):
     # of trunk streams is fixed up front -- $CVCL_TRUNK_STREAMS (ResNeXt) / $CVCL_VIT_TRUNK_STREAMS (ViT), default 2, 0 = the
     # single-stream schedule -- and reported in config.trunk_streams; nothing is auto-selected at run time.
     env_name = "CVCL_TRUNK_STREAMS" if cfg == "c2" else "CVCL_VIT_TRUNK_STREAMS"
-    trunk_streams = int(os.environ.get(env_name, "2"))
+    trunk_streams = int(os.environ.get(env_name, "2" if batch_size <= 1024 else "1"))     # (large batches: one pass's scratch at a time)
     if os.environ.get("CVCL_TRUNK_STREAM", "1") == "0":
         trunk_streams = 0
     torch.cuda.synchronize()
@@ -462,7 +474,7 @@ def main(argv=None):
                 "config": {"workload": WORKLOADS[cfg], "per_gpu_batch": batch_size, "global_batch": batch_size * world,
                            "negatives": "global (RCCL all-gather)" if world > 1 else "local (single GPU)",
                            "parallelism": f"dp{world}", "trunk_streams": trunk_streams},
-                "final_loss": round(loss, 5)}
+                "final_loss": round(loss, 5), "hbm_peak_gb": round(torch.cuda.max_memory_allocated(device) / 1e9, 2)}
         if parity is not None:
             line.update({k: float(f"{v:.4g}") for k, v in parity.items()})
             line["parity_note"] = ("the benchmark's random-init weights and batch through the exact-fp32 parity mode (the mode held to the "

@@ -853,7 +853,7 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
         return 0;
     }
     if (plain) return 0;
-    if (!a->C) return -1;
+    if (!a->C || (a->R && a->act != CVCL_ACT_NONE)) return -1;     // (activation + residual together: the 128 x 128 kernel)
     return 1;
 }
 

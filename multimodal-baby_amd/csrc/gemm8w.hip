@@ -114,6 +114,11 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
         d.grid_m = 0;
     }
     CvclProfScope prof(stream, CVCL_K_GEMM8W);
-    if (bm == 256) return epi == 0 ? g8_launch<8, 0>(d, grid, (hipStream_t)stream) : g8_launch<8, 1>(d, grid, (hipStream_t)stream);
-    return epi == 0 ? g8_launch<7, 0>(d, grid, (hipStream_t)stream) : g8_launch<7, 1>(d, grid, (hipStream_t)stream);
+    // the linear epilogue comes in two instantiations: activation (no residual) and residual (no activation) -- the only
+    // combinations nn.Linear call sites on the path use (vit:92-94 fc1 + GELU, :113-115 / :146-147 proj, fc2 + residual)
+    CVCL_CHECK_ARG(epi == 0 || !(a->R && a->act != CVCL_ACT_NONE), "cvcl_gemm8w: activation and residual together are not implemented");
+    const int k = epi == 0 ? 0 : (a->R ? 2 : 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (bm == 256) return k == 0 ? g8_launch<8, 0>(d, grid, st) : k == 1 ? g8_launch<8, 1>(d, grid, st) : g8_launch<8, 2>(d, grid, st);
+    return k == 0 ? g8_launch<7, 0>(d, grid, st) : k == 1 ? g8_launch<7, 1>(d, grid, st) : g8_launch<7, 2>(d, grid, st);
 }

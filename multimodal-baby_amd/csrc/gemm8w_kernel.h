@@ -40,7 +40,8 @@ constexpr int LDS_BYTES = 160 * 1024;                               // everythin
 constexpr int MAX_BIAS_N = (LDS_BYTES - ACC_OFF) / 4;               // 4096
 
 // EPI 0: C = round(acc) (+ BN partial sums when stats != nullptr; C may be nullptr: statistics only)
-// EPI 1: C = round(round(act(acc + bias)) + R)      (nn.Linear: bias / ReLU / GELU / residual)
+// EPI 1: C = round(act(acc + bias))                 (nn.Linear: bias / ReLU / GELU)
+// EPI 2: C = round(round(acc + bias) + R)            (nn.Linear + residual: the residual rows are fetched two 16-row blocks ahead)
 struct Dev {
     const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
     const float* bias; float* stats;
@@ -89,7 +90,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     //   the column tiles of the same m-tiles, so an m-tile's A rows are fetched into one L2 once.
     // EPI 1 (linear epilogue): the tiles in column-fastest order, q, q + G, ... with q = this block's rank in XCD-major order
     //   (consecutive q = consecutive tiles = same A rows = same XCD); every CU busy whatever N / 256 is.
-    constexpr bool FLAT = EPI == 1;
+    constexpr bool LIN = EPI >= 1, RES = EPI == 2;
+    constexpr bool FLAT = LIN;
     const int b = blockIdx.x;
     const int G = gridDim.x;
     int ti, tj, nt;
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     // EPI 0: BN partial sums [wave][2][64], added to once per tile in a fixed order (deterministic);
     // EPI 1: the column tile's 256 bias values, read back in the accumulator layout by the epilogue.
     float* lds_acc = reinterpret_cast<float*>(smem + ACC_OFF);
-    if constexpr (EPI == 1) {                                // the whole bias vector (N <= 4096 floats fit beside the ring)
+    if constexpr (LIN) {                                     // the whole bias vector (N <= 4096 floats fit beside the ring)
         for (int i = tid; i < p.N; i += 512) lds_acc[i] = p.bias ? p.bias[i] : 0.f;
     } else {
         lds_acc[tid] = 0.f;
@@ -218,18 +220,33 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         float st_sum[8], st_sq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+        // EPI 2: the residual rows of block mi are in flight from block mi - 2 on (an exposed load per block cost ~0.7 us x MI per
+        // tile: the proj linear of ViT-B ran 104 us against 72 us of K loop)
+        bf16x8 rr[MI][2];
+        auto load_res = [&](int mi) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int m = m0 + wm * (BM / 2) + mi * 16 + j * 8 + r_row0;
+                if (m >= p.M) m = p.M - 1;
+                rr[mi][j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + r_chunk * 8);
+            }
+        };
+        if constexpr (RES) { load_res(0); if (MI > 1) load_res(1); }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            if constexpr (RES) { if (mi + 2 < MI) load_res(mi + 2); }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 bf16x4 q;
-                if constexpr (EPI == 1) {
+                if constexpr (LIN) {
                     const f32x4 bias_r = *reinterpret_cast<const f32x4*>(lds_acc + n0 + wn * 64 + ni * 16 + (lane >> 4) * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float v = acc[ni][mi][e] + bias_r[e];
-                        if (p.act == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
-                        else if (p.act == CVCL_ACT_GELU) v = gelu_erf_fast(v);
+                        if constexpr (!RES) {
+                            if (p.act == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
+                            else if (p.act == CVCL_ACT_GELU) v = gelu_erf_fast(v);
+                        }
                         q[e] = (bf16_t)v;
                     }
                 } else {
@@ -245,9 +262,9 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((r_chunk ^ ((row >> 1) & 7)) << 4));
                 const int m = m0 + wm * (BM / 2) + mi * 16 + row, n = n0 + wn * 64 + r_chunk * 8;
                 if (full || m < p.M) {
-                    if constexpr (EPI == 1) {
-                        if (p.R) {
-                            const bf16x8 r = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n);
+                    if constexpr (LIN) {
+                        if constexpr (RES) {
+                            const bf16x8 r = rr[mi][j];
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                         }

@@ -861,7 +861,10 @@ GconvPlan gconv_plan(int B, int H, int W, int C, int stride) {
     g.bands = cvcl_div_up(Ho, TH);
     g.rows_in = (TH - 1) * stride + 3;
     g.lds = bytes(TH);
-    // persistent grid = what is co-resident (no second round of workgroups): LDS- and register-limited to 3 per CU
+    // persistent grid = what is co-resident (no second round of workgroups): LDS- and register-limited to 3 per CU.
+    // (Round 2 built a pipelined form -- one 512-thread workgroup per CU, double-buffered input / output bands, one barrier per
+    // band, the two wave halves running store / stage / load and MFMA in opposite order: correct on every test and SLOWER,
+    // 1.47 vs 1.05 ms per step.  Three small workgroups per CU hide each other's phases better than one pipelined one; removed.)
     int per_cu = (int)((160 * 1024) / g.lds);
     const int reg_limit = (C / 32 == 32) ? 2 : 3;                     // launch bounds of the two kernel variants
     if (per_cu > reg_limit) per_cu = reg_limit;
@@ -903,8 +906,9 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
         d.act_floor = act_floor;
         { const char* e = getenv("CVCL_GCONV_ABLATE"); d.ablate = e ? atoi(e) : 0; }
-        const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);
         CvclProfScope prof(stream, CVCL_K_GCONV);
+        int rc;
+        const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);
         static bool attr_set[2][11] = {};                    // per instantiation (wide, slots)
         auto launch = [&](auto kern) -> int {
             bool& done = attr_set[cg == 32][slots <= 4 ? 4 : slots <= 6 ? 6 : slots <= 8 ? 8 : 10];
@@ -918,7 +922,6 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
             hipLaunchKernelGGL(kern, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
             return CVCL_OK;
         };
-        int rc;
         if (cg == 32) rc = slots <= 4 ? launch(gconv_mfma_kernel<true, 4>) : slots <= 6 ? launch(gconv_mfma_kernel<true, 6>)
                          : slots <= 8 ? launch(gconv_mfma_kernel<true, 8>) : launch(gconv_mfma_kernel<true, 10>);
         else rc = slots <= 4 ? launch(gconv_mfma_kernel<false, 4>) : slots <= 6 ? launch(gconv_mfma_kernel<false, 6>)

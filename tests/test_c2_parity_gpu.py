@@ -207,4 +207,6 @@ def test_loss_trajectory_bf16_vs_fp32(dev, finetune, B, lr):
         # frozen trunk (the benchmarked configuration): the curves coincide step by step.  With every trunk parameter training
         # the first AdamW steps (lr / sqrt(v) normalised) move 25 M weights at once and the loss falls 100x within ~7 steps, so
         # the curves are compared by pace (above) and end point, not pointwise
-        assert gap < 0.01 * f32[0] + 0.02
+        # (through the steep part of the descent -- lr 2e-3, the loss halves every few steps -- the curves differ by their local
+        # noise: measured |gap| <= 0.09 at loss ~1, 0.002 on the plateau before and 0.004 at the end)
+        assert all(abs(a - b) <= 0.1 * max(a, b) + 0.02 for a, b in zip(f32, b16)), gap
