@@ -152,7 +152,7 @@ def resnext_gemm_work(B):
     statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The number of leading
     stages that use the fused tail is the library's $CVCL_FUSED_TAIL_STAGES, default 2.)  Which kernel runs a launch mirrors
     the dispatcher of csrc/gemm.hip: gemm_pro = conv3 with the BN2+ReLU operand prologue (layers 1-2), gemm8w = plain operands,
-    K >= 256, N % 256 == 0, >= 96 tiles of 256 x 256, N K >= 170 (N + K), no strided gather; the rest on gemm_glds ("gemm").
+    K >= 256, N % 256 == 0, >= 96 tiles of 256 x 256, N K >= 170 (N + K) (strided-gather downsamples included); the rest on gemm_glds ("gemm").
     -> {kernel: [bytes, flops, launches]} and the totals."""
     fused_stages = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "2"))
     pro_stages = int(os.environ.get("CVCL_CONV3_PRO_STAGES", "2"))
@@ -162,7 +162,7 @@ def resnext_gemm_work(B):
         per[kernel][0] += nbytes; per[kernel][1] += flops; per[kernel][2] += 1
 
     def plain_kernel(m, n, k, gather):
-        ok = (k >= 256 and k % 128 == 0 and n % 256 == 0 and not gather and -(-m // 256) * (n // 256) >= 96 and n * k >= 170 * (n + k)
+        ok = (k >= 256 and k % 128 == 0 and n % 256 == 0 and -(-m // 256) * (n // 256) >= 96 and n * k >= 170 * (n + k)
               and os.environ.get("CVCL_GEMM8W", "1") != "0")
         return "gemm8w" if ok else "gemm"
     inplanes, h = 64, 56

@@ -830,7 +830,7 @@ extern "C" int cvcl_gemm8w_stats_rows(int M, int N);
 namespace {
 
 // Policy for the 8-wave 256 (224) x 256 kernel (gemm8w.hip): the MFMA-bound shapes -- K >= 256, N a multiple of 256, enough
-// 256-row tiles to occupy the chip at one workgroup per CU, plain operands (no BN prologue, no strided gather, no output
+// 256-row tiles to occupy the chip at one workgroup per CU, plain operands (no BN prologue, no output
 // scale, no Bottleneck-tail / GELU-backward epilogue) -- and, when BN statistics are requested, a statistics buffer sized by
 // cvcl_gemm_stats_rows.  Measured on MI355X (tools/gemm_lab, profiles/r02_gemm_lab.txt): ResNeXt layer-3/4 1x1 convolutions
 // and ViT-B linears 10-25 % faster than the 128 x 128 kernel below; $CVCL_GEMM8W=0 switches it off.
@@ -839,10 +839,15 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
     static const bool on = [] { const char* e = getenv("CVCL_GEMM8W"); return !(e && e[0] == '0'); }();
     if (!on || dtype != CVCL_BF16) return -1;
     if (!cvcl_gemm8w_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) || a->K < 256) return -1;
-    if (a->a_scale || a->gather_stride > 1 || a->exp_scale || a->c_scale || a->C_pre || a->G) return -1;
+    if (a->a_scale || a->exp_scale || a->c_scale || a->C_pre || a->G) return -1;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!al16(a->A) || !al16(a->W) || !al16(a->C) || !al16(a->R) || !al16(a->bias) || (a->R && a->ldr % 8)) return -1;
-    if ((long)a->M * a->lda >= (1L << 31) || (long)a->N * a->ldw >= (1L << 31)) return -1;
+    long a_rows = a->M;
+    if (a->gather_stride > 1) {                              // strided 1x1 convolution (the downsample branch of blocks 2.0 / 3.0 / 4.0)
+        if (a->gather_ho <= 0 || a->gather_wo <= 0 || a->M % (a->gather_ho * a->gather_wo)) return -1;
+        a_rows = (long)(a->M / (a->gather_ho * a->gather_wo)) * a->gather_hi * a->gather_wi;
+    }
+    if (a_rows * a->lda >= (1L << 31) || (long)a->N * a->ldw >= (1L << 31)) return -1;
     if ((long)cvcl_div_up(a->M, 256) * (a->N / 256) < 96) return -1;
     // bandwidth-bound shapes stay with the 128 x 128 kernel (two workgroups per CU keep more bytes in flight): layer-2 block-0
     // conv1, M 802816 x N 256 x K 256, measured 176 us there vs 191-197 us here; N K / (N + K) = flop per byte of A + C traffic

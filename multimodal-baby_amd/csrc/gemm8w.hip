@@ -74,7 +74,7 @@ extern "C" int cvcl_gemm8w_stats_rows(int M, int N) {
 // epi 0: convolution epilogue (round + BN partial sums; C may be NULL = statistics only); epi 1: bias / activation / residual
 extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     CVCL_CHECK_ARG(a && a->A && a->W && (a->C || a->stats), "cvcl_gemm8w: null operand");
-    CVCL_CHECK_ARG(cvcl_gemm8w_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) && !a->a_scale && !(a->gather_stride > 1) &&
+    CVCL_CHECK_ARG(cvcl_gemm8w_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) && !a->a_scale &&
                        !a->exp_scale && !a->c_scale && !a->C_pre && !a->G,
                    "cvcl_gemm8w: unsupported shape / options (M %d N %d K %d)", a->M, a->N, a->K);
     CVCL_CHECK_ARG(epi == 0 || epi == 1, "cvcl_gemm8w: epilogue %d", epi);
@@ -83,15 +83,20 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     CVCL_CHECK_ARG(al16(a->A) && al16(a->W) && al16(a->C) && al16(a->R) && al16(a->bias) && (!a->R || a->ldr % 8 == 0),
                    "cvcl_gemm8w: operands must be 16-byte aligned");
-    CVCL_CHECK_ARG((long)a->M * a->lda < (1L << 31) && (long)a->N * a->ldw < (1L << 31), "cvcl_gemm8w: operand offsets must fit 31 bits");
+    const bool gather = a->gather_stride > 1;
+    if (gather)
+        CVCL_CHECK_ARG(a->gather_ho > 0 && a->gather_wo > 0 && a->M % (a->gather_ho * a->gather_wo) == 0 &&
+                           (a->gather_ho - 1) * a->gather_stride < a->gather_hi && (a->gather_wo - 1) * a->gather_stride < a->gather_wi,
+                       "cvcl_gemm8w: gather geometry");
+    const long a_rows = gather ? (long)(a->M / (a->gather_ho * a->gather_wo)) * a->gather_hi * a->gather_wi : a->M;
+    CVCL_CHECK_ARG(a_rows * a->lda < (1L << 31) && (long)a->N * a->ldw < (1L << 31), "cvcl_gemm8w: operand offsets must fit 31 bits");
     g8w::Dev d;
     d.A = (const bf16_t*)a->A; d.W = (const bf16_t*)a->W; d.C = (bf16_t*)a->C; d.R = (const bf16_t*)a->R;
     d.bias = a->bias; d.stats = a->stats;
     d.M = a->M; d.N = a->N; d.K = a->K; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr; d.act = a->act;
     d.ncol = a->N / 256;
-    // experiment: $CVCL_GEMM8W_REV=1 visits the m-tiles last-to-first (the producer's freshest rows first)
-    static const int rev = [] { const char* e = getenv("CVCL_GEMM8W_REV"); return (e && e[0] == '1') ? 1 : 0; }();
-    d.rev = rev;
+    d.gs = gather ? a->gather_stride : 1; d.g_hw = gather ? a->gather_ho * a->gather_wo : 1; d.g_wo = gather ? a->gather_wo : 1;
+    d.g_hi = a->gather_hi; d.g_wi = a->gather_wi; d.a_rows = (int)a_rows;
     int bm, grid;
     if (epi == 0) {                                          // column-fixed mapping: grid_m workgroups per column tile
         bm = cvcl_gemm8w_tile_rows(a->M, a->N);

@@ -47,7 +47,9 @@ struct Dev {
     const float* bias; float* stats;
     int M, N, K, lda, ldw, ldc, ldr, act;
     int tiles_m, grid_m, ncol;
-    int rev;                        // m-tiles are visited from the last to the first (the rows the producer wrote last are read first)
+    // row gather of a strided 1x1 convolution: output row m = (b, oy, ox) reads A row (b, oy * gs, ox * gs); gs <= 1 = off
+    int gs, g_hw, g_wo, g_hi, g_wi;
+    int a_rows;                     // rows of A (= M without the gather)
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
@@ -132,13 +134,24 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         w_off[j] = (unsigned)(tj * BN + (wave * 2 + j) * 16 + srow) * (unsigned)p.ldw + slog * 8;
         int r = (wave * 2 + j) * 16 + srow;
         if (r >= BM) r = BM - 1;                            // BM < 256: rows of the unused part of the A region
-        a_raw[j] = (unsigned)((p.rev ? p.tiles_m - 1 - ti : ti) * BM + r) * (unsigned)p.lda + slog * 8;
+        a_raw[j] = (unsigned)(ti * BM + r) * (unsigned)p.lda + slog * 8;
     }
+    // gathered rows: no uniform step from tile to tile -- the two offsets are recomputed per tile (two integer divisions per
+    // row, once per K / 32 stages)
+    auto gathered = [&](int i_tile, int j) __attribute__((always_inline)) -> unsigned {
+        int r = (wave * 2 + j) * 16 + srow;
+        if (r >= BM) r = BM - 1;
+        const unsigned m = (unsigned)min(i_tile * BM + r, p.M - 1);
+        const unsigned bi = m / (unsigned)p.g_hw, rem = m - bi * (unsigned)p.g_hw;
+        const unsigned oy = rem / (unsigned)p.g_wo, ox = rem - oy * (unsigned)p.g_wo;
+        return ((bi * p.g_hi + oy * p.gs) * p.g_wi + ox * p.gs) * (unsigned)p.lda + slog * 8;
+    };
+    if (p.gs > 1) { a_raw[0] = gathered(ti, 0); a_raw[1] = gathered(ti, 1); }
     // the next tile is a uniform step further; rows past M (ragged last tile) are clamped to an address inside the last row
     // (any valid address will do: those rows are masked at the store) -- no per-lane state beyond the offsets
     const unsigned a_unit = (unsigned)BM * (unsigned)p.lda, w_unit = (unsigned)BN * (unsigned)p.ldw;
-    const unsigned a_lim = (unsigned)(p.M - 1) * (unsigned)p.lda + 24;
-    int l_t = 0, l_ks = 0, l_j = tj;                         // (tile, k stage) of the next stage to load; its column tile
+    const unsigned a_lim = (unsigned)(p.a_rows - 1) * (unsigned)p.lda + 24;
+    int l_t = 0, l_ks = 0, l_j = tj, l_i = ti;                         // (tile, k stage) of the next stage to load; its column tile
     auto issue = [&](int buf) __attribute__((always_inline)) {
         char* base = smem + buf * STAGE_BYTES + wave * 2048;
         const int k0 = l_ks * BK;
@@ -159,9 +172,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                     if (l_j + dj >= p.ncol) { dj -= p.ncol; ++di; }
                     l_j += dj;
                 }
-                const unsigned da = (unsigned)(p.rev ? -di : di) * a_unit, dw = (unsigned)dj * w_unit;   // (negative steps wrap modulo 2^32: fine)
+                const unsigned da = (unsigned)di * a_unit, dw = (unsigned)dj * w_unit;   // (negative steps wrap modulo 2^32: fine)
+                l_i += di;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { a_raw[j] += da; w_off[j] += dw; }
+                for (int j = 0; j < 2; ++j) {
+                    if (p.gs > 1) a_raw[j] = gathered(l_i, j);
+                    else a_raw[j] += da;
+                    w_off[j] += dw;
+                }
             }
         }
     };
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         advance();
         if (++c_ks == KS) {
             c_ks = 0;
-            epi_ops = epilogue((p.rev ? p.tiles_m - 1 - c_i : c_i) * BM, c_j * BN);
+            epi_ops = epilogue(c_i * BM, c_j * BN);
             after_epi = 3;
             c_i += step_i;
             if constexpr (FLAT) {

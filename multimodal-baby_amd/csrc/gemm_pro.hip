@@ -24,6 +24,17 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// two bf16 in one register <-> two floats (v_lshlrev / v_and; v_cvt_pk_bf16_f32): the VALU work of this kernel is written on
+// register pairs so that it compiles to the packed fp32 instructions (v_pk_fma_f32, v_pk_add_f32) -- half the issue slots
+__device__ __forceinline__ f32x2 widen2(unsigned u) {
+    return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned round2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+
 constexpr int PM = 64;                     // rows per tile
 constexpr int PN = 256;                    // columns per workgroup
 
@@ -37,9 +48,11 @@ struct ProDev {
 
 enum { PRO_STATS = 0, PRO_STORE = 1, PRO_TAIL = 2 };
 
-template <int KT> constexpr int pro_lds_bytes() { return 2 * PM * KT * 64 + 8 * 4096 + 4 * PN * 4; }
+template <int KT> constexpr int pro_lds_bytes() { return 2 * PM * KT * 64 + 8 * 4096 + 4 * PN * 4 + 2 * 256 * 4; }
 
-template <int KT, int MODE>
+// D = tiles of A in flight per workgroup (registers); more than one buys ~2 % (the per-tile chain stage -> barrier -> fragment
+// reads -> MFMA -> statistics is the bound, not the load latency)
+template <int KT, int MODE, int D>
 __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     constexpr int K = KT * 32;
     constexpr int PITCH = K * 2;                        // LDS row pitch of the A tile in bytes (256 | 512)
@@ -63,27 +76,51 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
 
     // ---- staging role: chunk s_c of rows s_r + RPP * i; this thread's 8 channels never change
     const int s_c = tid % CPR, s_r = tid / CPR;
-    float sc[8], sh[8];
+    // K = 256 holds 128 registers of W fragments: the operand affine of this thread's 8 channels is then re-read from LDS per
+    // tile (4 ds_read_b128) instead of living in 16 registers
+    constexpr bool AFF_LDS = KT == 8;
+    float* in_aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096 + 4 * PN * 4);      // [2][K]
+    f32x2 sc[4], sh[4];
+    if constexpr (AFF_LDS) {
+        if (tid < K) { in_aff[tid] = p.a_scale[tid]; in_aff[K + tid] = p.a_shift[tid]; }
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sc[e] = p.a_scale[s_c * 8 + e]; sh[e] = p.a_shift[s_c * 8 + e]; }
-    bf16x8 araw[NCH];
-    auto load_a = [&](int tile) __attribute__((always_inline)) {
+        for (int e = 0; e < 4; ++e) {
+            sc[e] = f32x2{p.a_scale[s_c * 8 + 2 * e], p.a_scale[s_c * 8 + 2 * e + 1]};
+            sh[e] = f32x2{p.a_shift[s_c * 8 + 2 * e], p.a_shift[s_c * 8 + 2 * e + 1]};
+        }
+    }
+    u32x4 araw[D][NCH];
+    auto load_a = [&](int tile, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             int m = tile * PM + s_r + RPP * i;
             if (m >= p.M) m = p.M - 1;                   // ragged last tile: any valid row, masked at the store
-            araw[i] = *reinterpret_cast<const bf16x8*>(p.A + (long)m * p.lda + s_c * 8);
+            araw[slot][i] = *reinterpret_cast<const u32x4*>(p.A + (long)m * p.lda + s_c * 8);
         }
     };
-    auto stage_a = [&](int buf) __attribute__((always_inline)) {
+    auto stage_a = [&](int buf, int slot) __attribute__((always_inline)) {
         char* dst = smem + buf * ABUF;
+        if constexpr (AFF_LDS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc[e] = *reinterpret_cast<const f32x2*>(in_aff + s_c * 8 + 2 * e);
+                sh[e] = *reinterpret_cast<const f32x2*>(in_aff + K + s_c * 8 + 2 * e);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int r = s_r + RPP * i;
-            bf16x8 v;
+            u32x4 v;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)araw[i][e], sc[e], sh[e]), 0.f);
-            *reinterpret_cast<bf16x8*>(dst + r * PITCH + ((s_c ^ (r & 15)) << 4)) = v;
+            for (int e = 0; e < 4; ++e) {
+                // round(relu(y)) = relu(round(y)): rounding keeps the sign, and a bf16 is negative (or -0) exactly when its bits
+                // are a negative int16 -> the ReLU is one packed integer max on the rounded pair
+                const unsigned y = round2(__builtin_elementwise_fma(widen2(araw[slot][i][e]), sc[e], sh[e]));
+                v[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), s16x2{0, 0}));
+            }
+            *reinterpret_cast<u32x4*>(dst + r * PITCH + ((s_c ^ (r & 15)) << 4)) = v;
         }
     };
     // fragment read: row (lane & 15) of a 16-row block, chunk 4 ks + (lane >> 4), XOR-swizzled by the row
@@ -114,25 +151,48 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     };
     // STATS: per-lane partial sums in the accumulator layout: column wn*64 + ni*16 + (lane >> 4)*4 + e
     // STORE: per-lane partial sums of the read-back layout: column wn*64 + (lane & 7)*8 + e
-    float st_sum[16], st_sq[16];
+    f32x2 st_sum[8], st_sq[8];                           // (pairs of adjacent columns)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { st_sum[e] = f32x2{0.f, 0.f}; st_sq[e] = f32x2{0.f, 0.f}; }
 
     char* stg = smem + 2 * ABUF + wave * 4096;           // wave-private: 32 rows x 128 B
     const int e_row = lane & 15, e_wchunk = lane >> 5, e_wsub = ((lane >> 4) & 1) * 8;
 
     const int first = blockIdx.x;
-    if (first < p.tiles) {
-        load_a(first);
-        if constexpr (MODE == PRO_TAIL) load_r(first);
+    const int G = gridDim.x;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (first + d * G < p.tiles) load_a(first + d * G, d);
+    if constexpr (MODE == PRO_TAIL) {
+        if (first < p.tiles) load_r(first);
     }
+    // STATS: sums of the ROUNDED outputs (what a stored tensor would hold) of one wave tile, rows past M excluded
+    f32x4 acc[4][2];
+    auto tile_stats = [&](int m0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const unsigned keep = m0 + mi * 16 + e_row < p.M ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x2 f = widen2(round2(f32x2{acc[ni][mi][2 * h], acc[ni][mi][2 * h + 1]}) & keep);
+                    st_sum[ni * 2 + h] += f;
+                    st_sq[ni * 2 + h] = __builtin_elementwise_fma(f, f, st_sq[ni * 2 + h]);
+                }
+        }
+    };
+    // (Measured and dropped: deferring the lower-half waves' statistics to after the next barrier, so that one wave of a SIMD
+    // does VALU work while the other issues MFMAs -- 1.476 vs 1.471 ms per step over the 14 launches, no gain.)
     int buf = 0;
-    for (int tile = first; tile < p.tiles; tile += gridDim.x) {
-        stage_a(buf);
+    for (int tile = first; tile < p.tiles;) {
+#pragma unroll
+      for (int slot = 0; slot < D; ++slot) {             // (static register slot of the tile being staged)
+        if (tile >= p.tiles) break;
+        stage_a(buf, slot);
         __syncthreads();                                 // tile staged by everyone; the other buffer's readers (tile - 2) are long done
-        const int next = tile + gridDim.x;
-        if (next < p.tiles) load_a(next);
-        f32x4 acc[4][2];
+        const int next = tile + G;
+        if (tile + D * G < p.tiles) load_a(tile + D * G, slot);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -152,19 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
         }
         const int m0 = tile * PM + wm * 32;
         if constexpr (MODE == PRO_STATS) {
-            // sums of the ROUNDED outputs (what a stored tensor would hold), rows past M excluded
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const bool ok = m0 + mi * 16 + e_row < p.M;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float f = ok ? (float)(bf16_t)acc[ni][mi][e] : 0.f;
-                        st_sum[ni * 4 + e] += f;
-                        st_sq[ni * 4 + e] = fmaf(f, f, st_sq[ni * 4 + e]);
-                    }
-            }
+            tile_stats(m0);
         } else {
             // accumulator layout (m = mi*16 + (lane & 15), n = ni*16 + (lane >> 4)*4 + e) -> rows of 128 B in the wave's staging
 #pragma unroll
@@ -196,11 +244,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
                             v[e] = (bf16_t)fmaxf(y + idv, 0.f);
                         }
                     } else {
+                        const u32x4 u = __builtin_bit_cast(u32x4, v);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float f = (float)v[e];
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x2 f = widen2(u[e]);
                             st_sum[e] += f;
-                            st_sq[e] = fmaf(f, f, st_sq[e]);
+                            st_sq[e] = __builtin_elementwise_fma(f, f, st_sq[e]);
                         }
                     }
                     stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
@@ -211,6 +260,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
             }
         }
         buf ^= 1;
+        tile += G;
+      }
     }
 
     if (MODE != PRO_TAIL && p.stats) {
@@ -219,36 +270,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
         if constexpr (MODE == PRO_STATS) {
             // reduce over the 16 row lanes (lane & 15); lane >> 4 selects the 4-column group
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+            for (int e = 0; e < 8; ++e)
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    st_sum[e] += __shfl_xor(st_sum[e], o, 64);
-                    st_sq[e] += __shfl_xor(st_sq[e], o, 64);
-                }
-            }
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) {
+                        st_sum[e][h] += __shfl_xor(st_sum[e][h], o, 64);
+                        st_sq[e][h] += __shfl_xor(st_sq[e][h], o, 64);
+                    }
             if ((lane & 15) == 0) {
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        red[(wave * 2 + 0) * 64 + ni * 16 + (lane >> 4) * 4 + e] = st_sum[ni * 4 + e];
-                        red[(wave * 2 + 1) * 64 + ni * 16 + (lane >> 4) * 4 + e] = st_sq[ni * 4 + e];
+                        red[(wave * 2 + 0) * 64 + ni * 16 + (lane >> 4) * 4 + e] = st_sum[ni * 2 + (e >> 1)][e & 1];
+                        red[(wave * 2 + 1) * 64 + ni * 16 + (lane >> 4) * 4 + e] = st_sq[ni * 2 + (e >> 1)][e & 1];
                     }
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int o = 8; o <= 32; o <<= 1) {
-                    st_sum[e] += __shfl_xor(st_sum[e], o, 64);
-                    st_sq[e] += __shfl_xor(st_sq[e], o, 64);
-                }
-            }
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int o = 8; o <= 32; o <<= 1) {
+                        st_sum[e][h] += __shfl_xor(st_sum[e][h], o, 64);
+                        st_sq[e][h] += __shfl_xor(st_sq[e][h], o, 64);
+                    }
             if (lane < 8) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    red[(wave * 2 + 0) * 64 + lane * 8 + e] = st_sum[e];
-                    red[(wave * 2 + 1) * 64 + lane * 8 + e] = st_sq[e];
+                    red[(wave * 2 + 0) * 64 + lane * 8 + e] = st_sum[e >> 1][e & 1];
+                    red[(wave * 2 + 1) * 64 + lane * 8 + e] = st_sq[e >> 1][e & 1];
                 }
             }
         }
@@ -271,18 +324,18 @@ int pro_num_cus() {
     return n;
 }
 
-template <int KT, int MODE>
+template <int KT, int MODE, int D>
 int pro_launch(const ProDev& d, dim3 grid, hipStream_t stream) {
     static bool attr = false;
     constexpr int lds = pro_lds_bytes<KT>();
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)gemm_pro_kernel<KT, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_pro_kernel<KT, MODE, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cvcl_set_error("cvcl_gemm_pro: cannot raise the dynamic LDS limit to %d", lds);
             return CVCL_ELAUNCH;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_pro_kernel<KT, MODE>), grid, dim3(512), lds, stream, d);
+    hipLaunchKernelGGL((gemm_pro_kernel<KT, MODE, D>), grid, dim3(512), lds, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
@@ -324,12 +377,17 @@ extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream) {
     const int mode = a->c_scale ? PRO_TAIL : (a->C ? PRO_STORE : PRO_STATS);
     CvclProfScope prof(stream, CVCL_K_GEMM_PRO);
     hipStream_t st = (hipStream_t)stream;
+    // tiles of A in flight: 3 (K = 128) / 2 (K = 256: the register budget); $CVCL_PRO_DEPTH overrides (measured on C2: depth 1
+    // 1.502 ms per step over the 14 launches, default 1.471)
+    static const int depth = [] { const char* e = getenv("CVCL_PRO_DEPTH"); return e ? atoi(e) : 0; }();
     if (a->K == 128) {
-        if (mode == PRO_TAIL) return pro_launch<4, PRO_TAIL>(d, grid, st);
-        if (mode == PRO_STORE) return pro_launch<4, PRO_STORE>(d, grid, st);
-        return pro_launch<4, PRO_STATS>(d, grid, st);
+        const int dd = depth ? depth : 3;
+        if (mode == PRO_TAIL) return dd >= 3 ? pro_launch<4, PRO_TAIL, 3>(d, grid, st) : dd == 2 ? pro_launch<4, PRO_TAIL, 2>(d, grid, st) : pro_launch<4, PRO_TAIL, 1>(d, grid, st);
+        if (mode == PRO_STORE) return dd >= 3 ? pro_launch<4, PRO_STORE, 3>(d, grid, st) : dd == 2 ? pro_launch<4, PRO_STORE, 2>(d, grid, st) : pro_launch<4, PRO_STORE, 1>(d, grid, st);
+        return dd >= 3 ? pro_launch<4, PRO_STATS, 3>(d, grid, st) : dd == 2 ? pro_launch<4, PRO_STATS, 2>(d, grid, st) : pro_launch<4, PRO_STATS, 1>(d, grid, st);
     }
-    if (mode == PRO_TAIL) return pro_launch<8, PRO_TAIL>(d, grid, st);
-    if (mode == PRO_STORE) return pro_launch<8, PRO_STORE>(d, grid, st);
-    return pro_launch<8, PRO_STATS>(d, grid, st);
+    const int dd = depth ? depth : 2;
+    if (mode == PRO_TAIL) return dd >= 2 ? pro_launch<8, PRO_TAIL, 2>(d, grid, st) : pro_launch<8, PRO_TAIL, 1>(d, grid, st);
+    if (mode == PRO_STORE) return dd >= 2 ? pro_launch<8, PRO_STORE, 2>(d, grid, st) : pro_launch<8, PRO_STORE, 1>(d, grid, st);
+    return dd >= 2 ? pro_launch<8, PRO_STATS, 2>(d, grid, st) : pro_launch<8, PRO_STATS, 1>(d, grid, st);
 }

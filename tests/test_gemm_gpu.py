@@ -187,6 +187,31 @@ def test_gemm8w_exact_on_small_integers_and_race_free(dev, M, N, K):
     assert torch.allclose(st0[:, 1].double().sum(0).cpu(), (want.double() ** 2).sum(0), rtol=1e-6)
 
 
+@pytest.mark.parametrize("B,Hi,Cin,Cout", [(256, 28, 512, 1024), (200, 14, 1024, 2048), (37, 56, 256, 512)])
+def test_gemm8w_strided_gather_exact(dev, B, Hi, Cin, Cout):
+    """Downsample branch of Bottleneck x.0 (1x1, stride 2) on the 8-wave kernel: rows gathered from the NHWC input by (b, 2 oy,
+    2 ox), recomputed per tile; small integers -> bit-exact product and statistics (ragged last tile included)."""
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(B + Hi)
+    x = torch.randint(-2, 3, (B, Hi, Hi, Cin), generator=g).float()
+    w = torch.randint(-2, 3, (Cout, Cin), generator=g).float()
+    Ho = Hi // 2
+    M = B * Ho * Ho
+    gather = (Ho, Ho, Hi, Hi, 2)
+    rows = H.gemm_stats_rows(H.BF16, M, Cout, Cin, gather=gather)
+    assert rows == H.lib().cvcl_gemm8w_stats_rows(M, Cout), "shape not routed to the 8-wave kernel"
+    st = torch.full((rows, 2, Cout), float("nan"), device=dev)
+    H.prof_enable(True)
+    y = H.gemm(x.bfloat16().to(dev), w.bfloat16().to(dev), M=M, gather=gather, stats=st)
+    torch.cuda.synchronize()
+    prof = H.prof_collect()
+    H.prof_enable(False)
+    assert prof.get("gemm8w", (0, 0))[1] == 1, prof
+    want = (x[:, ::2, ::2].reshape(M, Cin).double() @ w.double().t()).float().bfloat16()
+    assert torch.equal(y.cpu(), want)
+    assert torch.equal(st[:, 0].double().sum(0).cpu(), want.double().sum(0))
+
+
 @pytest.mark.parametrize("M,N,K,act,res", [(1024, 768, 768, 0, True), (3000, 3072, 768, 2, False), (5000, 768, 3072, 0, True),
                                            (600, 2304, 768, 0, False), (50432, 768, 768, 0, True), (9000, 2304, 768, 1, False)])
 def test_gemm8w_linear_epilogue(dev, M, N, K, act, res):

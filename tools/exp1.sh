@@ -1,8 +1,11 @@
+# A/B runs of bench.py under experiment switches: name, pairs/s, ms/step, single-stream kernel ms per class
 run() { python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-parity 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernel_ms_per_step']
 print('$1', d['value'], d['ms_per_step'], {a:round(b,3) for a,b in k.items() if b>0.1})
 "; }
-CVCL_GCONV_V2=0 run gconv_v1
-run gconv_v2
+CVCL_PRO_DEPTH=1 run depth1
+run default
+CVCL_PRO_LATE=1 run late
+CVCL_PRO_DEPTH=2 run depth2
