@@ -77,7 +77,17 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 }
 
 // VAR (experiment switches): bit 0 = s_setprio(1) around the MFMA halves; bit 1 = the post-barrier fragment reads and stage
-// loads are interleaved with the second half's MFMAs (sched_group_barrier) instead of being issued ahead of them
+// loads are interleaved with the second half's MFMAs (sched_group_barrier) instead of being issued ahead of them.
+// Ablations for tools/gemm_lab only (WRONG results, timing of what is left): bit 2 = no per-stage barrier, bit 3 = no stage
+// loads, bit 4 = no fragment reads.  The library instantiates VAR = 2.
+// What the ablations say (tools/gemm_lab/ablate.sh, 4096^3: 110 us = 1.25 PFLOP/s as is): without the barrier 112 us (the
+// barrier costs nothing), without the stage loads 94, without the fragment reads 93, without all three 72 us = 1.92 PFLOP/s
+// (MFMAs + epilogue alone: the clock-limited ceiling).  The loss is the LDS traffic itself (96 KB of fragment reads + 32 KB of
+// DMA writes per 32-deep stage), not its latency: a variant with the reads of stage g+1 spread over the whole of step g (one A
+// fragment set refilled row block by row block behind the MFMAs that used it, two barriers per stage, hand-placed
+// s_waitcnt lgkmcnt(n) around inline-asm reads so that no wait ever covered a recent read) was bit-exact and SLOWER:
+// 1.09-1.13 PFLOP/s at 4096^3, equal or -3 % on the workload's shapes.  Fewer LDS bytes per flop needs a 128 x 128 tile per
+// wave (256 accumulators), which this compiler spills (round-2 notes in DESIGN.md).
 template <int MI, int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     constexpr int BM = MI * 32;
@@ -153,6 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     const unsigned a_lim = (unsigned)(p.a_rows - 1) * (unsigned)p.lda + 24;
     int l_t = 0, l_ks = 0, l_j = tj, l_i = ti;                         // (tile, k stage) of the next stage to load; its column tile
     auto issue = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (VAR & 8) return;
         char* base = smem + buf * STAGE_BYTES + wave * 2048;
         const int k0 = l_ks * BK;
 #pragma unroll
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     f32x4 acc[4][MI];
     auto read_frags = [&](int buf, auto P) __attribute__((always_inline)) {
         constexpr int q = decltype(P)::value;
+        if constexpr (VAR & 16) return;
         const char* sb = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) fw[q][ni] = *reinterpret_cast<const bf16x8*>(sb + w_base + ni * 1024);
@@ -318,6 +330,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         return (full && p.C != nullptr) ? ESTORES : 0;
     };
 
+    if constexpr (VAR & 16) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[q][i] = bf16x8{};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[q][i] = bf16x8{};
+        }
+    }
     // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----
     issue(0); advance(); issue(1); advance(); issue(2); advance(); issue(3); advance();
     wait_vm<12>();
@@ -337,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         else wait_vm<8>();
         if (after_epi > 0) --after_epi;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
         issue(g & 3);                                       // stage g+4 into the buffer stage g occupied

@@ -77,13 +77,15 @@ int main(int argc, char** argv) {
     } else {
         // w<MI>[abc]: a = setprio, b = interleaved reads, c = both
         const int mi = var[0] == 'w' ? var[1] - '0' : 0;
-        const int vv = var.size() > 2 ? (var[2] == 'a' ? 1 : var[2] == 'b' ? 2 : 3) : 0;
+        // + ablations (wrong results, timing only): n = no barrier, l = no stage loads, r = no fragment reads, x = all three
+        const int vv = var.size() > 2 ? (var[2] == 'a' ? 1 : var[2] == 'b' ? 2 : var[2] == 'c' ? 3 : var[2] == 'n' ? 6 : var[2] == 'l' ? 10 :
+                                         var[2] == 'r' ? 18 : var[2] == 'x' ? 30 : 0) : 0;
         if (mi < 6 || mi > 8 || N % 256 || K % 128) { printf("bad variant / shape\n"); return 1; }
         static g8w::Dev d;
         memset(&d, 0, sizeof(d));
         d.A = dA; d.W = dW; d.C = dC; d.M = M; d.N = N; d.K = K; d.lda = K; d.ldw = K; d.ldc = N;
         d.stats = want_stats ? dStats : nullptr;
-        d.rev = getenv("LAB_REV") ? 1 : 0;
+        d.gs = 1; d.g_hw = 1; d.g_wo = 1; d.a_rows = M;
         const int BM = mi * 32;
         d.tiles_m = (M + BM - 1) / BM;
         d.ncol = N / 256;
@@ -99,8 +101,12 @@ int main(int argc, char** argv) {
         printf("  tiles_m %d ncol %d grid_m %d grid %d rounds %.2f\n", d.tiles_m, d.ncol, gm, grid, (double)d.tiles_m / gm);
 #define PICK(MI_) \
         if (mi == MI_) { if (vv == 0) run = [=]() { launch_w<MI_, 0, 0>(d, grid, st); }; else if (vv == 1) run = [=]() { launch_w<MI_, 0, 1>(d, grid, st); }; \
-                         else if (vv == 2) run = [=]() { launch_w<MI_, 0, 2>(d, grid, st); }; else run = [=]() { launch_w<MI_, 0, 3>(d, grid, st); }; }
+                         else if (vv == 2) run = [=]() { launch_w<MI_, 0, 2>(d, grid, st); }; else if (vv == 3) run = [=]() { launch_w<MI_, 0, 3>(d, grid, st); }; }
         PICK(8) PICK(7) PICK(6)
+        if (mi == 8 && vv == 6) run = [=]() { launch_w<8, 0, 6>(d, grid, st); };
+        if (mi == 8 && vv == 10) run = [=]() { launch_w<8, 0, 10>(d, grid, st); };
+        if (mi == 8 && vv == 18) run = [=]() { launch_w<8, 0, 18>(d, grid, st); };
+        if (mi == 8 && vv == 30) run = [=]() { launch_w<8, 0, 30>(d, grid, st); };
     }
     run();
     CK(hipStreamSynchronize(st));
