@@ -79,7 +79,7 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // VAR (experiment switches): bit 0 = s_setprio(1) around the MFMA halves; bit 1 = the post-barrier fragment reads and stage
 // loads are interleaved with the second half's MFMAs (sched_group_barrier) instead of being issued ahead of them.
 // Ablations for tools/gemm_lab only (WRONG results, timing of what is left): bit 2 = no per-stage barrier, bit 3 = no stage
-// loads, bit 4 = no fragment reads.  The library instantiates VAR = 2.
+// loads, bit 4 = no fragment reads, bit 5 = no epilogue (except m-tile 0).  The library instantiates VAR = 2.
 // What the ablations say (tools/gemm_lab/ablate.sh, 4096^3: 110 us = 1.25 PFLOP/s as is): without the barrier 112 us (the
 // barrier costs nothing), without the stage loads 94, without the fragment reads 93, without all three 72 us = 1.92 PFLOP/s
 // (MFMAs + epilogue alone: the clock-limited ceiling).  The loss is the LDS traffic itself (96 KB of fragment reads + 32 KB of
@@ -88,6 +88,13 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // s_waitcnt lgkmcnt(n) around inline-asm reads so that no wait ever covered a recent read) was bit-exact and SLOWER:
 // 1.09-1.13 PFLOP/s at 4096^3, equal or -3 % on the workload's shapes.  Fewer LDS bytes per flop needs a 128 x 128 tile per
 // wave (256 accumulators), which this compiler spills (round-2 notes in DESIGN.md).
+// The epilogue (all eight waves at once, MFMA pipe idle: ~1100 instructions per wave -- BN statistics 350, accumulator
+// clearing 135, the LDS transpose, 64-bit addresses, row predicates) costs 15-19 % at K = 512..768 (qkv shape 212 -> 171 us
+// without it, layer-3 conv3 63 -> 53) and 3 % at K >= 1024.  It is local to the workgroup, not a store burst: starting the
+// workgroups in four phases 3.4 us apart only added the skew to every shape, and ordinary (write-back) stores instead of
+// nontemporal ones are equal on small outputs and 18 % slower on large ones.  A leaner version (clearing folded into a
+// zero-C first stage, a predicate-free path for full tiles, pointer walking) put every MI = 8 instantiation over 256
+// registers (40-88 bytes of scratch per lane) and was not pursued: its instruction savings are worth ~4 % of such a launch.
 template <int MI, int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     constexpr int BM = MI * 32;
@@ -247,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     // -> a lower bound on the VMEM instructions this call issued (exact for a full tile with stores and no residual)
     auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) -> int {
         const bool full = m0 + BM <= p.M;
+        if constexpr (VAR & 32) { if (m0 != 0) return 0; }    // ablation: only the first m-tile is written
         float st_sum[8], st_sq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
