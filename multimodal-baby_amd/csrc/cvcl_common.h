@@ -84,6 +84,21 @@ template <> struct Chunk<bf16_t> {
     __device__ inline void set(int i, float f) { v[i] = (bf16_t)f; }
 };
 
+// two bf16 in one register <-> two floats (v_lshlrev / v_and; v_cvt_pk_bf16_f32): bandwidth-bound kernels write their VALU work on
+// register pairs so that it compiles to the packed fp32 instructions (v_pk_fma_f32, v_pk_add_f32) -- half the issue slots
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 widen2(unsigned u) {
+    return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned round2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+// relu on a rounded bf16 pair: rounding keeps the sign, and a bf16 is negative (or -0) exactly when its bits are a negative
+// int16 -> one packed integer max
+__device__ __forceinline__ unsigned relu2(unsigned pair) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, pair), s16x2{0, 0}));
+}
+
 // streamed-out results: nontemporal by default (the L2 keeps the operands); -DCVCL_PLAIN_STORES builds the same kernels with
 // ordinary stores (experiment: does the consumer find the tensor in the Infinity Cache?)
 template <typename V> __device__ __forceinline__ void stream_store(V v, V* dst) {

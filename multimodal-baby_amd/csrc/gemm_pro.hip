@@ -24,17 +24,6 @@
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-
-// two bf16 in one register <-> two floats (v_lshlrev / v_and; v_cvt_pk_bf16_f32): the VALU work of this kernel is written on
-// register pairs so that it compiles to the packed fp32 instructions (v_pk_fma_f32, v_pk_add_f32) -- half the issue slots
-__device__ __forceinline__ f32x2 widen2(unsigned u) {
-    return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
-}
-__device__ __forceinline__ unsigned round2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
-
 constexpr int PM = 64;                     // rows per tile
 constexpr int PN = 256;                    // columns per workgroup
 
@@ -115,10 +104,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
             u32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                // round(relu(y)) = relu(round(y)): rounding keeps the sign, and a bf16 is negative (or -0) exactly when its bits
-                // are a negative int16 -> the ReLU is one packed integer max on the rounded pair
+                // round(relu(y)) = relu(round(y)): the ReLU is one packed integer max on the rounded pair (relu2)
                 const unsigned y = round2(__builtin_elementwise_fma(widen2(araw[slot][i][e]), sc[e], sh[e]));
-                v[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), s16x2{0, 0}));
+                v[e] = relu2(y);
             }
             *reinterpret_cast<u32x4*>(dst + r * PITCH + ((s_c ^ (r & 15)) << 4)) = v;
         }

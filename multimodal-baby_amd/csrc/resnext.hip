@@ -418,12 +418,14 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
 
     // staging role: 8 chunks (of 8 channels) per pixel, 32 pixels per pass
     const int s_chunk = tid & 7, s_pix0 = tid >> 3;
-    float sc[8], sh[8];
+    f32x2 sc[4], sh[4];                                           // (channel pairs: the staging math runs on packed fp32)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = p.a_scale ? p.a_scale[c0 + s_chunk * 8 + e] : 1.f;
-        sh[e] = p.a_scale ? p.a_shift[c0 + s_chunk * 8 + e] : 0.f;
+    for (int e = 0; e < 4; ++e) {
+        const int ch = c0 + s_chunk * 8 + 2 * e;
+        sc[e] = p.a_scale ? f32x2{p.a_scale[ch], p.a_scale[ch + 1]} : f32x2{1.f, 1.f};
+        sh[e] = p.a_scale ? f32x2{p.a_shift[ch], p.a_shift[ch + 1]} : f32x2{0.f, 0.f};
     }
+    const bool relu_in = p.act_floor == 0.f;                      // (-inf: no activation -- the data-gradient use)
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 
     const int npix_in = p.rows_in * Wp;
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     // software pipeline over work items: the next band's pixels are loaded into registers (raw, no waiting) before
     // the current band is multiplied out of LDS; BN+ReLU and the LDS write happen one iteration later.
     // NPF = ceil(staged pixels / 32) rounded up to an even count (template parameter: every slot is loaded, see below)
-    bf16x8 pf[NPF];
+    u32x4 pf[NPF];
     bool pf_in[NPF];
     // Every slot issues its load unconditionally from a clamped (always valid) address and the predicate only decides later whether
     // the value or the zero padding is staged.  With the loads inside divergent `if`s the compiler put an s_waitcnt vmcnt(0) in
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
             const int yin = iy0 + (slot_rc[i] >> 16), xin = (slot_rc[i] & 0xffff) - 1;
             pf_in[i] = slot_rc[i] >= 0 && yin >= 0 && yin < p.H && xin >= 0 && xin < p.W;
             const int yc = min(max(yin, 0), p.H - 1), xc = min(max(xin, 0), p.W - 1);
-            pf[i] = *reinterpret_cast<const bf16x8*>(xb + (yc * p.W + xc) * p.C);
+            pf[i] = *reinterpret_cast<const u32x4*>(xb + (yc * p.W + xc) * p.C);
         }
     };
     const int n_items = p.B * p.bands;
@@ -484,17 +486,20 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         for (int i = 0; i < NPF; ++i) {
             const int pi = s_pix0 + 32 * i;
             if (pi < npix_in) {
-                bf16x8 v;
+                u32x4 v;
                 if (pf_in[i] && (p.ablate & 1)) {
                     v = pf[i];
                 } else if (pf_in[i]) {
+                    // relu(round(x * scale + shift)) on channel pairs: v_pk_fma_f32, v_cvt_pk_bf16_f32, v_pk_max_i16
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)fmaxf(fmaf((float)pf[i][e], sc[e], sh[e]), p.act_floor);
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned y = round2(__builtin_elementwise_fma(widen2(pf[i][e]), sc[e], sh[e]));
+                        v[e] = relu_in ? relu2(y) : y;
+                    }
                 } else {
-                    const u32x4 z = {0u, 0u, 0u, 0u};
-                    v = __builtin_bit_cast(bf16x8, z);           // zero padding lives in the post-activation domain
+                    v = u32x4{0u, 0u, 0u, 0u};                   // zero padding lives in the post-activation domain
                 }
-                if (!(p.ablate & 8)) *reinterpret_cast<bf16x8*>(smem + pi * GC_PIXB + s_chunk * 16) = v;
+                if (!(p.ablate & 8)) *reinterpret_cast<u32x4*>(smem + pi * GC_PIXB + s_chunk * 16) = v;
             }
         }
         __syncthreads();

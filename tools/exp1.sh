@@ -5,7 +5,5 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernel_ms_per_step']
 print('$1', d['value'], d['ms_per_step'], {a:round(b,3) for a,b in k.items() if b>0.1})
 "; }
-CVCL_PRO_DEPTH=1 run depth1
 run default
-CVCL_PRO_LATE=1 run late
-CVCL_PRO_DEPTH=2 run depth2
+run default_again
