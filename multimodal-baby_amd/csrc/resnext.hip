@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         sh[e] = p.a_scale ? f32x2{p.a_shift[ch], p.a_shift[ch + 1]} : f32x2{0.f, 0.f};
     }
     const bool relu_in = p.act_floor == 0.f;                      // (-inf: no activation -- the data-gradient use)
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 ssum[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, ssq[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};     // (channel pairs: packed fp32)
 
     const int npix_in = p.rows_in * Wp;
     const int n_out = p.TH * p.Wo, n_mt = cvcl_div_up(n_out, 16);
@@ -523,16 +523,16 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a1, acc1, 0, 0, 0);
             }
             if (ok0 && oy0 + ty0 < p.Ho) {
-                bf16x4 o = {(bf16_t)acc0[0], (bf16_t)acc0[1], (bf16_t)acc0[2], (bf16_t)acc0[3]};
-                *reinterpret_cast<bf16x4*>(s_out + q0 * GC_PIXB + wave * 32 + kb * 8) = o;
+                const u32x2 o = {round2(f32x2{acc0[0], acc0[1]}), round2(f32x2{acc0[2], acc0[3]})};
+                *reinterpret_cast<u32x2*>(s_out + q0 * GC_PIXB + wave * 32 + kb * 8) = o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float sv = (float)o[e]; ssum[e] += sv; ssq[e] = fmaf(sv, sv, ssq[e]); }
+                for (int e = 0; e < 2; ++e) { const f32x2 sv = widen2(o[e]); ssum[e] += sv; ssq[e] = __builtin_elementwise_fma(sv, sv, ssq[e]); }
             }
             if (ok1 && oy0 + ty1 < p.Ho) {
-                bf16x4 o = {(bf16_t)acc1[0], (bf16_t)acc1[1], (bf16_t)acc1[2], (bf16_t)acc1[3]};
-                *reinterpret_cast<bf16x4*>(s_out + q1 * GC_PIXB + wave * 32 + kb * 8) = o;
+                const u32x2 o = {round2(f32x2{acc1[0], acc1[1]}), round2(f32x2{acc1[2], acc1[3]})};
+                *reinterpret_cast<u32x2*>(s_out + q1 * GC_PIXB + wave * 32 + kb * 8) = o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float sv = (float)o[e]; ssum[e] += sv; ssq[e] = fmaf(sv, sv, ssq[e]); }
+                for (int e = 0; e < 2; ++e) { const f32x2 sv = widen2(o[e]); ssum[e] += sv; ssq[e] = __builtin_elementwise_fma(sv, sv, ssq[e]); }
             }
             q0 = q1 + 16; ty0 = ty1; ox0 = ox1 + 16;
             while (ox0 >= p.Wo) { ox0 -= p.Wo; ++ty0; }
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     // per-channel partial sums: reduce over the 16 pixel lanes; channel = c0 + wave*16 + kb*4 + e
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float s = ssum[e], q = ssq[e];
+        float s = ssum[e >> 1][e & 1], q = ssq[e >> 1][e & 1];
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (pix == 0 && p.stats) {

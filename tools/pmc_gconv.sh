@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_gconv
 rm -rf $OUT; mkdir -p $OUT
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" ; do
+for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum" ; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace -d $OUT/g$i -o pmc --output-format csv -- python3 $GRAFT_REPO_ROOT/tools/gconv_ablate.py > $OUT/g$i.log 2>&1
 done
