@@ -117,6 +117,24 @@ class VisionTransformer(nn.Module):
         from . import vit_hip
         return vit_hip.enable_trunk_stream(self, device, inputs, stream, n_streams)
 
+    def interpolate_pos_encoding(self, x, w, h):
+        """Position table for an input whose patch grid differs from the one the table was learned on (reference :210-230; same
+        arguments: ``x`` = the token tensor -- only its token count and width are read --, ``w`` / ``h`` = the image's dim 2 / dim 3).
+        Identity at the native square resolution; otherwise the patch part is resampled bicubically to (w // patch, h // patch) with the
+        reference's +0.1 on the target sizes (its guard against an output one short), the class-token entry kept.  A once-per-shape
+        parameter transform (cached by the caller), not hot-path arithmetic: it runs on ``F.interpolate``."""
+        n_native = self.pos_embed.shape[1] - 1
+        if x.shape[1] - 1 == n_native and w == h:
+            return self.pos_embed
+        side = int(math.sqrt(n_native))
+        gh, gw = w // self.patch_size, h // self.patch_size
+        table = self.pos_embed[:, 1:].reshape(1, side, side, -1).permute(0, 3, 1, 2)
+        table = nn.functional.interpolate(table, scale_factor=((gh + 0.1) / math.sqrt(n_native), (gw + 0.1) / math.sqrt(n_native)),
+                                          mode="bicubic")
+        if table.shape[-2] != gh or table.shape[-1] != gw:
+            raise AssertionError(f"interpolated grid {tuple(table.shape[-2:])} != {(gh, gw)}")
+        return torch.cat([self.pos_embed[:, :1], table.permute(0, 2, 3, 1).reshape(1, gh * gw, -1)], dim=1)
+
     def forward(self, x):
         """-> cls token after the final LayerNorm, [B, D] fp32 (reference :245-250)."""
         from . import vit_hip

@@ -124,16 +124,23 @@ def _vit_forward(model, x: torch.Tensor, slot) -> torch.Tensor:
     lib, s = H.lib(), H.stream_ptr()
     n_p = (Hh // p) * (Ww // p)
     T = n_p + 1
-    if T != model.pos_embed.shape[1]:
-        raise NotImplementedError("positional-embedding interpolation (non-native resolution) is not on the hot path")
     with torch.no_grad():
         w = _packed(model, dt, x.device)
+        pos = w["pos"]
+        if T != model.pos_embed.shape[1] or Hh != Ww:           # non-native resolution: resampled table (reference :210-230), cached
+            key = ("pos", Hh, Ww, model.pos_embed.data_ptr(), model.pos_embed._version)
+            hit = model._cache.get("pos_interp")
+            if hit is None or hit[0] != key:
+                probe = torch.empty(1, T, 1, device="meta")
+                hit = (key, model.interpolate_pos_encoding(probe, Hh, Ww).detach().reshape(-1, D).float().contiguous())
+                model._cache["pos_interp"] = hit
+            pos = hit[1]
         dev = x.device
         cols = torch.empty(B * n_p, w["Kpad"], dtype=dt, device=dev)
         H.check(lib.cvcl_im2col_patches(cd, H.ptr(x), H.ptr(cols), B, Hh, Ww, p, w["Kpad"], s), "cvcl_im2col_patches")
         tok = H.gemm(cols, w["pe_w"], bias=w["pe_b"])
         h = torch.empty(B * T, D, dtype=dt, device=dev)
-        H.check(lib.cvcl_vit_assemble_tokens(cd, H.ptr(tok), H.ptr(w["cls"]), H.ptr(w["pos"]), H.ptr(h), B, T, D, s),
+        H.check(lib.cvcl_vit_assemble_tokens(cd, H.ptr(tok), H.ptr(w["cls"]), H.ptr(pos), H.ptr(h), B, T, D, s),
                 "cvcl_vit_assemble_tokens")
         y = torch.empty_like(h)
         att = torch.empty_like(h)

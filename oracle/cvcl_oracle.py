@@ -474,10 +474,25 @@ def gelu_erf(x: Tensor) -> Tensor:
     return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))    # nn.GELU default, vit:88
 
 
+def vit_interpolate_pos_encoding(pos_embed: Tensor, gh: int, gw: int) -> Tensor:
+    """``VisionTransformer.interpolate_pos_encoding`` (vit:210-230): the [1, 1 + N, D] learned table resampled (bicubic,
+    scale factors (gh + 0.1) / sqrt(N), (gw + 0.1) / sqrt(N) -- the reference's guard against a floor() one short) to a gh x gw
+    patch grid; identity when the grid is the native square one."""
+    N = pos_embed.shape[1] - 1
+    if gh * gw == N and gh == gw:
+        return pos_embed
+    D = pos_embed.shape[-1]
+    s = int(math.sqrt(N))
+    grid = pos_embed[:, 1:].reshape(1, s, s, D).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, scale_factor=((gh + 0.1) / math.sqrt(N), (gw + 0.1) / math.sqrt(N)), mode="bicubic")
+    assert grid.shape[-2] == gh and grid.shape[-1] == gw
+    return torch.cat([pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], dim=1)
+
+
 def vit_forward(p: Dict[str, Tensor], x: Tensor, patch: int, num_heads: int, quant: Quant = None,
                 prefix: str = "", eps: float = 1e-6, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
     """``VisionTransformer.forward`` (vit:245-250): prepare_tokens (:232-243; pos-embed
-    interpolation is the identity at the native resolution, :213-214) -> depth x pre-LN
+    interpolation :210-230, the identity at the native resolution) -> depth x pre-LN
     ``Block`` (:133-149; attention :106-130 scale head_dim**-0.5, MLP :87-103 GELU-erf)
     -> LayerNorm -> cls token.  Returns [B, D] (the ``head`` is applied by the caller,
     multimodal.py:91-92)."""
@@ -489,7 +504,7 @@ def vit_forward(p: Dict[str, Tensor], x: Tensor, patch: int, num_heads: int, qua
     cols = x.reshape(B, C, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * patch * patch)
     wpe = pp["patch_embed.proj.weight"].reshape(D, -1)
     tok = _q(quant, cols) @ _q(quant, wpe).t() + pp["patch_embed.proj.bias"]
-    h = torch.cat([pp["cls_token"].expand(B, -1, -1), tok], dim=1) + pp["pos_embed"]   # :237-241
+    h = torch.cat([pp["cls_token"].expand(B, -1, -1), tok], dim=1) + vit_interpolate_pos_encoding(pp["pos_embed"], gh, gw)   # :237-241
     h = _q(quant, h)
     T = h.shape[1]
     hd = D // num_heads

@@ -306,6 +306,18 @@ def case_vit(vits):
     print(f"vit/tiny: oracle-vs-reference rel err {e:.2e}")
     assert e < 5e-6
     save("vit_tiny", x=x, cls=y, **{"w." + k: v for k, v in sd.items()})
+    # the same model at two non-native resolutions (interpolate_pos_encoding, vit:210-230): 6 x 5 and 3 x 7 patches
+    extra = {}
+    for tag, (hh, ww) in (("a", (48, 40)), ("b", (24, 56))):
+        xi = torch.randn(2, 3, hh, ww, generator=torch.Generator().manual_seed(40 + hh))
+        with torch.no_grad():
+            yi = m(xi)
+        e = maxrel(O.vit_forward(sd, xi, 8, 2), yi)
+        print(f"vit/tiny {hh}x{ww}: oracle-vs-reference rel err {e:.2e}")
+        assert e < 5e-6
+        extra["x_" + tag] = xi
+        extra["cls_" + tag] = yi
+    save("vit_tiny_interp", **extra)
 
     # full ViT-B/16 and ViT-B/14 (formula weights, B=1): output only
     for patch in (16, 14):

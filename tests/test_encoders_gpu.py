@@ -103,6 +103,31 @@ def test_vit_tiny_golden(dev, dt):
         assert maxrel(y, yo) < 3e-2 and maxrel(y, g["cls"]) < 6e-2
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_vit_tiny_non_native_resolution_golden(dev, dt):
+    """interpolate_pos_encoding (reference vision_transformer_dino_mugs.py:210-230): the tiny ViT of `vit_tiny` (native 32 x 32 =
+    4 x 4 patches) on 48 x 40 (6 x 5 patches) and 24 x 56 (3 x 7) inputs against the reference's own output."""
+    g, gi = load_golden("vit_tiny"), load_golden("vit_tiny_interp")
+    m = _tiny_vit()
+    m.load_state_dict(_w(g))
+    m = m.to(dev).eval()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    m.compute_dtype = torch.bfloat16 if dt == "bf16" else torch.float32
+    for tag in ("a", "b"):
+        x, want = gi["x_" + tag], gi["cls_" + tag]
+        y = m(x.to(dev))
+        y2 = m(x.to(dev))                                       # second call: the cached table
+        assert torch.equal(y, y2)
+        if dt == "f32":
+            assert maxrel(y, want) < 2e-5, (tag, maxrel(y, want))
+        else:
+            yo = O.vit_forward(_w(g), x, 8, 2, quant=O.bf16_round)
+            assert maxrel(y, yo) < 3e-2 and maxrel(y, want) < 6e-2
+    # back at the native resolution the learned table itself is used
+    assert maxrel(m(g["x"].to(dev)), g["cls"]) < (2e-5 if dt == "f32" else 6e-2)
+
+
 @pytest.mark.parametrize("patch", [16, 14])
 def test_vit_base_golden(dev, patch):
     """Full-size DINO ViT-B/16 (BASELINE configs 4-5) and ViT-B/14 (the reference's hard-coded model) at B=1 with

@@ -119,6 +119,29 @@ def test_vit_tiny():
     assert maxrel(y, g["cls"]) < TOL
 
 
+def test_vit_tiny_non_native_resolution():
+    """interpolate_pos_encoding (vit:210-230): the oracle's restatement, and the host-side mirror's method (a parameter transform
+    in plain torch), against the reference's own output on 6 x 5 and 3 x 7 patch grids (native: 4 x 4)."""
+    from functools import partial
+
+    import torch.nn as nn
+    from multimodal import vision_transformer_dino_mugs as vits
+    g, gi = load_golden("vit_tiny"), load_golden("vit_tiny_interp")
+    w = _weights(g)
+    m = vits.VisionTransformer(img_size=[32], patch_size=8, embed_dim=32, depth=2, num_heads=2, mlp_ratio=4, qkv_bias=True,
+                               norm_layer=partial(nn.LayerNorm, eps=1e-6))
+    m.load_state_dict(w)
+    for tag in ("a", "b"):
+        x = gi["x_" + tag]
+        assert maxrel(O.vit_forward(w, x, 8, 2), gi["cls_" + tag]) < TOL
+        gh, gw = x.shape[2] // 8, x.shape[3] // 8
+        with torch.no_grad():
+            got = m.interpolate_pos_encoding(torch.empty(1, gh * gw + 1, 32), x.shape[2], x.shape[3])
+        assert torch.equal(got, O.vit_interpolate_pos_encoding(w["pos_embed"], gh, gw))
+    with torch.no_grad():
+        assert m.interpolate_pos_encoding(torch.empty(1, 17, 32), 32, 32) is m.pos_embed
+
+
 def test_cvcl_step_c1():
     """Reference training_step (VisionEncoder wrapper + TextEncoder + MultiModalLitModel) on the C1 shape."""
     g = load_golden("cvcl_step_c1")
