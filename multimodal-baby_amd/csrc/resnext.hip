@@ -14,6 +14,7 @@
 //                          input band staged in LDS with BN+ReLU applied on the way in
 //   fp32 (parity mode)   : direct VALU kernels with identical semantics + a column-statistics pass
 #include <cstdlib>
+#include <type_traits>
 
 #include "cvcl_common.h"
 
@@ -393,8 +394,13 @@ struct GconvDev {
     const void* x; const float* a_scale; const float* a_shift; const void* w; void* y; float* stats;
     int B, H, W, C, cg, stride, Ho, Wo, TH, bands, rows_in;
     float act_floor; // 0 = ReLU after the affine; -inf = none (a_scale == NULL: plain convolution of x, used by the data gradient)
-    int ablate;      // debug only ($CVCL_GCONV_ABLATE): 1 skip BN math, 2 skip MFMA loop, 4 skip stores, 8 skip LDS staging writes
 };
+// Phase ablation for timing studies is a BUILD option (no run-time flag in the loop: the per-slot tests it needed cost branches in
+// every work item): -DCVCL_GCONV_ABLATE=<bits>, 1 skip the BN math, 2 skip the MFMA loop (and the stores), 4 skip the stores,
+// 8 skip the LDS staging writes -- e.g. CVCL_EXTRA_FLAGS=-DCVCL_GCONV_ABLATE=2 CVCL_LIB_SUFFIX=_abl2 python build.py.
+#ifndef CVCL_GCONV_ABLATE
+#define CVCL_GCONV_ABLATE 0
+#endif
 
 template <bool WIDE, int NPF>
 __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev p) {
@@ -406,6 +412,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     const int slab = blockIdx.y, c0 = slab * GC_CS;
     const int Wp = p.W + 2;                                       // staged row width incl. halo columns
     constexpr bool wide = WIDE;                                   // 32 channels per group (layer4) vs 4/8/16
+    constexpr int ABL = CVCL_GCONV_ABLATE;
     constexpr int KS = WIDE ? 9 : 5;
     // this wave's unit: 16 output channels [c0 + 16*wave, +16); for cg == 32 the unit's inputs are the
     // 32 channels of its group, else the same 16 channels (block-diagonal weights)
@@ -482,29 +489,29 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         const int b = item / p.bands, band = item - b * p.bands;
         const int oy0 = band * p.TH;
         __syncthreads();
+        // staging without per-slot branches: every slot is transformed (relu(round(x * scale + shift)) on channel pairs:
+        // v_pk_fma_f32, v_cvt_pk_bf16_f32, v_pk_max_i16), padding slots are then zeroed with a mask (zero padding lives in the
+        // post-activation domain), and only the write itself is predicated (the last slot may lie past the band)
+        auto stage = [&](auto RELU) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NPF; ++i) {
-            const int pi = s_pix0 + 32 * i;
-            if (pi < npix_in) {
+            for (int i = 0; i < NPF; ++i) {
+                const int pi = s_pix0 + 32 * i;
+                const unsigned keep = pf_in[i] ? 0xffffffffu : 0u;
                 u32x4 v;
-                if (pf_in[i] && (p.ablate & 1)) {
-                    v = pf[i];
-                } else if (pf_in[i]) {
-                    // relu(round(x * scale + shift)) on channel pairs: v_pk_fma_f32, v_cvt_pk_bf16_f32, v_pk_max_i16
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned y = round2(__builtin_elementwise_fma(widen2(pf[i][e]), sc[e], sh[e]));
-                        v[e] = relu_in ? relu2(y) : y;
-                    }
-                } else {
-                    v = u32x4{0u, 0u, 0u, 0u};                   // zero padding lives in the post-activation domain
+                for (int e = 0; e < 4; ++e) {
+                    unsigned y = (ABL & 1) ? pf[i][e] : round2(__builtin_elementwise_fma(widen2(pf[i][e]), sc[e], sh[e]));
+                    if constexpr (decltype(RELU)::value) y = relu2(y);
+                    v[e] = y & keep;
                 }
-                if (!(p.ablate & 8)) *reinterpret_cast<u32x4*>(smem + pi * GC_PIXB + s_chunk * 16) = v;
+                if (!(ABL & 8) && pi < npix_in) *reinterpret_cast<u32x4*>(smem + pi * GC_PIXB + s_chunk * 16) = v;
             }
-        }
+        };
+        if (relu_in) stage(std::true_type{});
+        else stage(std::false_type{});
         __syncthreads();
         if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
-        if (p.ablate & 2) continue;
+        if (ABL & 2) continue;
         // two independent m-tiles (16 output pixels each) in flight per wave: their LDS reads and MFMA chains
         // interleave.  Pixel coordinates advance incrementally (no divisions in the loop).
         int q0 = pix, ty0 = ty_init, ox0 = ox_init;
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         // (16 B per lane).  Scattered 8-byte stores straight from the MFMA layout cost more than the whole
         // load + compute phases together (ablation in DESIGN.md).
         __syncthreads();
-        if (!(p.ablate & 4)) {
+        if (!(ABL & 4)) {
             const int valid_rows = min(p.TH, p.Ho - oy0);
             const int n_chunks = valid_rows * p.Wo * 8;
             for (int i = tid; i < n_chunks; i += 256) {
@@ -910,7 +917,6 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         d.B = B; d.H = H; d.W = W; d.C = C; d.cg = cg; d.stride = stride; d.Ho = Ho; d.Wo = Wo;
         d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
         d.act_floor = act_floor;
-        { const char* e = getenv("CVCL_GCONV_ABLATE"); d.ablate = e ? atoi(e) : 0; }
         CvclProfScope prof(stream, CVCL_K_GCONV);
         int rc;
         const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);

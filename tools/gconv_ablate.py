@@ -1,5 +1,7 @@
-"""Ablation timing of the grouped-conv kernel (debug aid): time layer1-shaped and layer2.0-shaped launches with
-phases skipped via $CVCL_GCONV_ABLATE (set before the process starts)."""
+"""Timing of the grouped-conv kernel on the trunk's shapes.  Phase ablation is a build option of the library
+(-DCVCL_GCONV_ABLATE=<bits>, see csrc/resnext.hip): build a variant with
+    CVCL_EXTRA_FLAGS=-DCVCL_GCONV_ABLATE=2 CVCL_LIB_SUFFIX=_abl2 python multimodal-baby_amd/build.py
+and run this script with CVCL_HIP_LIB=multimodal-baby_amd/lib/libcvcl_hip_abl2.so."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "multimodal-baby_amd"))
 from multimodal import _hip as H
@@ -25,5 +27,5 @@ def run(B, S, C, stride):
     for _ in range(10): call()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 10 * 1000
-print("ablate=%s  layer1(56,128,s1): %.0f us   layer2.0(56,256,s2): %.0f us   layer2(28,256,s1): %.0f us   layer3(14,512): %.0f us" % (
-    os.environ.get("CVCL_GCONV_ABLATE", "0"), run(256, 56, 128, 1), run(256, 56, 256, 2), run(256, 28, 256, 1), run(256, 14, 512, 1)))
+print("lib%s  layer1(56,128,s1): %.0f us   layer2.0(56,256,s2): %.0f us   layer2(28,256,s1): %.0f us   layer3(14,512): %.0f us" % (
+    os.path.basename(os.environ.get("CVCL_HIP_LIB", "")), run(256, 56, 128, 1), run(256, 56, 256, 2), run(256, 28, 256, 1), run(256, 14, 512, 1)))
