@@ -402,7 +402,7 @@ struct GconvDev {
 #define CVCL_GCONV_ABLATE 0
 #endif
 
-template <bool WIDE, int NPF>
+template <bool WIDE, int NPF, int NMT>
 __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const bf16_t* __restrict__ x = (const bf16_t*)p.x;
@@ -447,7 +447,17 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         const int ky = tap / 3, kx = tap - ky * 3;
         tap_off[ks] = (ky * Wp + kx) * GC_PIXB + in_ch_off * 2;
     }
-    const int ty_init = pix / p.Wo, ox_init = pix - ty_init * p.Wo;
+    // the m-tiles (16 output pixels each) of a band are the same for every work item: per lane, the LDS byte offset of the tile's
+    // first tap (< 64 KiB), its band row and whether it exists, packed offset | row << 16 | exists << 24 (NMT = 4 | 8 tiles:
+    // gconv_plan keeps TH * Wo <= 128)
+    int mtab[NMT];
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt) {
+        const int q = pix + 16 * mt;
+        const bool ok = mt < n_mt && q < n_out;
+        const int ty = q / p.Wo, ox = q - ty * p.Wo;
+        mtab[mt] = ok ? ((((ty * p.stride) * Wp + ox * p.stride) * GC_PIXB) | (ty << 16) | (1 << 24)) : 0;
+    }
     char* s_out = smem + npix_in * GC_PIXB;                            // output band [TH * Wo pixels][GC_PIXB]
     // software pipeline over work items: the next band's pixels are loaded into registers (raw, no waiting) before
     // the current band is multiplied out of LDS; BN+ReLU and the LDS write happen one iteration later.
@@ -458,26 +468,29 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     // the value or the zero padding is staged.  With the loads inside divergent `if`s the compiler put an s_waitcnt vmcnt(0) in
     // front of each of them: ten serialized memory round trips per work item -- the kernel's phases simply added up (179 us for
     // layer 1, of which 86 were this chain).
-    // (row, column) of this thread's staging slots inside the band are the same for every work item: computed once (the division
-    // by the runtime row width is ~30 instructions per slot, and with the loads no longer serialized the staging phase is bound
-    // by instruction issue), packed row << 16 | column
-    int slot_rc[NPF];
+    // (row, column) of this thread's staging slots inside the band are the same for every work item, so everything about a slot
+    // that does not depend on the item is computed once (the kernel is bound by VALU issue): its band row -- or a sentinel far
+    // below zero when the slot is past the band or its column is horizontal padding, which makes the one range test on the
+    // input row fail -- and the element offset of its (clamped) input column
+    int slot_y[NPF], slot_xoff[NPF];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
         const int pi = s_pix0 + 32 * i;
-        const int ry = pi / Wp, rx = pi - ry * Wp;
-        slot_rc[i] = pi < npix_in ? ((ry << 16) | rx) : -1;
+        const int ry = pi / Wp, xin = pi - ry * Wp - 1;
+        slot_y[i] = (pi < npix_in && xin >= 0 && xin < p.W) ? ry : -(1 << 20);
+        slot_xoff[i] = min(max(xin, 0), p.W - 1) * p.C;
     }
+    const int row_elems = p.W * p.C;
     auto prefetch = [&](int item) {
         const int b = item / p.bands, band = item - b * p.bands;
         const int iy0 = band * p.TH * p.stride - 1;
         const bf16_t* xb = x + (long)b * p.H * p.W * p.C + c0 + s_chunk * 8;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
-            const int yin = iy0 + (slot_rc[i] >> 16), xin = (slot_rc[i] & 0xffff) - 1;
-            pf_in[i] = slot_rc[i] >= 0 && yin >= 0 && yin < p.H && xin >= 0 && xin < p.W;
-            const int yc = min(max(yin, 0), p.H - 1), xc = min(max(xin, 0), p.W - 1);
-            pf[i] = *reinterpret_cast<const u32x4*>(xb + (yc * p.W + xc) * p.C);
+            const int yin = iy0 + slot_y[i];
+            pf_in[i] = (unsigned)yin < (unsigned)p.H;
+            const int yc = min(max(yin, 0), p.H - 1);
+            pf[i] = *reinterpret_cast<const u32x4*>(xb + (yc * row_elems + slot_xoff[i]));
         }
     };
     const int n_items = p.B * p.bands;
@@ -512,15 +525,15 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         __syncthreads();
         if (item + (int)gridDim.x < n_items) prefetch(item + gridDim.x);
         if (ABL & 2) continue;
-        // two independent m-tiles (16 output pixels each) in flight per wave: their LDS reads and MFMA chains
-        // interleave.  Pixel coordinates advance incrementally (no divisions in the loop).
-        int q0 = pix, ty0 = ty_init, ox0 = ox_init;
-        for (int mt = 0; mt < n_mt; mt += 2) {
-            int q1 = q0 + 16, ty1 = ty0, ox1 = ox0 + 16;
-            while (ox1 >= p.Wo) { ox1 -= p.Wo; ++ty1; }
-            const bool ok0 = q0 < n_out, ok1 = (mt + 1 < n_mt) && q1 < n_out;
-            const int base0 = ok0 ? ((ty0 * p.stride) * Wp + ox0 * p.stride) * GC_PIXB : 0;
-            const int base1 = ok1 ? ((ty1 * p.stride) * Wp + ox1 * p.stride) * GC_PIXB : 0;
+        // two independent m-tiles in flight per wave: their LDS reads and MFMA chains interleave
+        const int rows_left = p.Ho - oy0;                            // (a last band may be partial)
+#pragma unroll
+        for (int mt = 0; mt < NMT; mt += 2) {
+            if (mt >= n_mt) break;
+            const int e0 = mtab[mt], e1 = mtab[mt + 1];
+            const int base0 = e0 & 0xffff, base1 = e1 & 0xffff;
+            const int q0 = pix + 16 * mt, q1 = q0 + 16;
+            const bool wr0 = (e0 >> 24) && ((e0 >> 16) & 0xff) < rows_left, wr1 = (e1 >> 24) && ((e1 >> 16) & 0xff) < rows_left;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
@@ -529,20 +542,18 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks], a1, acc1, 0, 0, 0);
             }
-            if (ok0 && oy0 + ty0 < p.Ho) {
+            if (wr0) {
                 const u32x2 o = {round2(f32x2{acc0[0], acc0[1]}), round2(f32x2{acc0[2], acc0[3]})};
                 *reinterpret_cast<u32x2*>(s_out + q0 * GC_PIXB + wave * 32 + kb * 8) = o;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { const f32x2 sv = widen2(o[e]); ssum[e] += sv; ssq[e] = __builtin_elementwise_fma(sv, sv, ssq[e]); }
             }
-            if (ok1 && oy0 + ty1 < p.Ho) {
+            if (wr1) {
                 const u32x2 o = {round2(f32x2{acc1[0], acc1[1]}), round2(f32x2{acc1[2], acc1[3]})};
                 *reinterpret_cast<u32x2*>(s_out + q1 * GC_PIXB + wave * 32 + kb * 8) = o;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { const f32x2 sv = widen2(o[e]); ssum[e] += sv; ssq[e] = __builtin_elementwise_fma(sv, sv, ssq[e]); }
             }
-            q0 = q1 + 16; ty0 = ty1; ox0 = ox1 + 16;
-            while (ox0 >= p.Wo) { ox0 -= p.Wo; ++ty0; }
         }
         // the band's output sits in LDS as [pixel][64 channels]: write it out as full 128-byte pixel rows
         // (16 B per lane).  Scattered 8-byte stores straight from the MFMA layout cost more than the whole
@@ -868,7 +879,7 @@ GconvPlan gconv_plan(int B, int H, int W, int C, int stride) {
     auto bytes = [&](int th) { return (size_t)(((th - 1) * stride + 3) * Wp + th * Wo) * GC_PIXB; };
     static const int lds_kb = [] { const char* e = getenv("CVCL_GCONV_LDS_KB"); return e ? atoi(e) : 52; }();
     int TH = Ho;
-    while (TH > 1 && (bytes(TH) > (size_t)lds_kb * 1024 || ((TH - 1) * stride + 3) * Wp > 10 * 32)) TH = (TH + 1) / 2;
+    while (TH > 1 && (bytes(TH) > (size_t)lds_kb * 1024 || ((TH - 1) * stride + 3) * Wp > 10 * 32 || TH * Wo > 128)) TH = (TH + 1) / 2;
     g.TH = TH;
     g.bands = cvcl_div_up(Ho, TH);
     g.rows_in = (TH - 1) * stride + 3;
@@ -909,7 +920,7 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         CVCL_CHECK_ARG((cg == 4 || cg == 8 || cg == 16 || cg == 32) && C % GC_CS == 0,
                        "cvcl_gconv3x3: unsupported channels-per-group %d (C=%d)", cg, C);
         const GconvPlan g = gconv_plan(B, H, W, C, stride);
-        CVCL_CHECK_ARG(g.lds <= 160 * 1024 && g.rows_in * (W + 2) <= 10 * 32,
+        CVCL_CHECK_ARG(g.lds <= 160 * 1024 && g.rows_in * (W + 2) <= 10 * 32 && g.TH * ((W - 1) / stride + 1) <= 128,
                        "cvcl_gconv3x3: feature map too wide for one staged band (%zu B, %d pixels)", g.lds, g.rows_in * (W + 2));
         CVCL_CHECK_ARG(!stats || stats_rows >= g.grid_x, "cvcl_gconv3x3: stats_rows %d < %d", stats_rows, g.grid_x);
         GconvDev d;
@@ -920,9 +931,9 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         CvclProfScope prof(stream, CVCL_K_GCONV);
         int rc;
         const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);
-        static bool attr_set[2][11] = {};                    // per instantiation (wide, slots)
+        static bool attr_set[2][2][11] = {};                 // per instantiation (wide, short m-tile table, slots)
         auto launch = [&](auto kern) -> int {
-            bool& done = attr_set[cg == 32][slots <= 4 ? 4 : slots <= 6 ? 6 : slots <= 8 ? 8 : 10];
+            bool& done = attr_set[cg == 32][g.TH * Wo <= 64][slots <= 4 ? 4 : slots <= 6 ? 6 : slots <= 8 ? 8 : 10];
             if (!done) {
                 if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
@@ -933,10 +944,14 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
             hipLaunchKernelGGL(kern, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
             return CVCL_OK;
         };
-        if (cg == 32) rc = slots <= 4 ? launch(gconv_mfma_kernel<true, 4>) : slots <= 6 ? launch(gconv_mfma_kernel<true, 6>)
-                         : slots <= 8 ? launch(gconv_mfma_kernel<true, 8>) : launch(gconv_mfma_kernel<true, 10>);
-        else rc = slots <= 4 ? launch(gconv_mfma_kernel<false, 4>) : slots <= 6 ? launch(gconv_mfma_kernel<false, 6>)
-                : slots <= 8 ? launch(gconv_mfma_kernel<false, 8>) : launch(gconv_mfma_kernel<false, 10>);
+        const bool few = g.TH * Wo <= 64;                    // <= 4 m-tiles per band: the short m-tile table
+#define CVCL_GCONV_PICK(W_) \
+        (slots <= 4 ? (few ? launch(gconv_mfma_kernel<W_, 4, 4>) : launch(gconv_mfma_kernel<W_, 4, 8>)) \
+         : slots <= 6 ? (few ? launch(gconv_mfma_kernel<W_, 6, 4>) : launch(gconv_mfma_kernel<W_, 6, 8>)) \
+         : slots <= 8 ? (few ? launch(gconv_mfma_kernel<W_, 8, 4>) : launch(gconv_mfma_kernel<W_, 8, 8>)) \
+                      : (few ? launch(gconv_mfma_kernel<W_, 10, 4>) : launch(gconv_mfma_kernel<W_, 10, 8>)))
+        rc = cg == 32 ? CVCL_GCONV_PICK(true) : CVCL_GCONV_PICK(false);
+#undef CVCL_GCONV_PICK
         if (rc) return rc;
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
