@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         }
     };
     const int n_items = p.B * p.bands;
+    const int st_off = (tid >> 3) * p.C + (tid & 7) * 8;             // store phase: this thread's chunk inside a band's output
     // the weight fragments (loaded above) are ready from here on: without this the compiler, conservative across the loop's back
     // edge, waits on vmcnt before the first MFMAs of every work item -- i.e. for the next item's prefetch just issued
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
@@ -562,10 +563,14 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         if (!(ABL & 4)) {
             const int valid_rows = min(p.TH, p.Ho - oy0);
             const int n_chunks = valid_rows * p.Wo * 8;
-            for (int i = tid; i < n_chunks; i += 256) {
-                const int px = i >> 3, ch = i & 7;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(s_out + px * GC_PIXB + ch * 16);
-                *reinterpret_cast<bf16x8*>(y + (((long)b * p.Ho + oy0) * p.Wo + px) * p.C + c0 + ch * 8) = v;
+            // chunk tid + 256 k of the band (pixel (tid >> 3) + 32 k, channels 8 (tid & 7) ..): the element offset inside the band's
+            // output rows is item-invariant up to the stride 32 C per k; only the band's base pointer changes per item
+            bf16_t* yb = y + ((long)b * p.Ho + oy0) * p.Wo * p.C + c0 + st_off;
+            const char* so = s_out + (tid >> 3) * GC_PIXB + (tid & 7) * 16;
+#pragma unroll
+            for (int k = 0; k < NMT / 2; ++k) {                   // NMT * 16 pixels * 8 chunks / 256 threads
+                if (tid + 256 * k < n_chunks)
+                    *reinterpret_cast<bf16x8*>(yb + (long)k * 32 * p.C) = *reinterpret_cast<const bf16x8*>(so + k * 32 * GC_PIXB);
             }
         }
     }
