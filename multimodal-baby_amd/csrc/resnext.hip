@@ -469,15 +469,19 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     // front of each of them: ten serialized memory round trips per work item -- the kernel's phases simply added up (179 us for
     // layer 1, of which 86 were this chain).
     // (row, column) of this thread's staging slots inside the band are the same for every work item, so everything about a slot
-    // that does not depend on the item is computed once (the kernel is bound by VALU issue): its band row -- or a sentinel far
-    // below zero when the slot is past the band or its column is horizontal padding, which makes the one range test on the
-    // input row fail -- and the element offset of its (clamped) input column
+    // that does not depend on the item is computed once (the kernel is bound by VALU issue): its band row, the element offset of
+    // its (clamped) input column, and whether it is inside the band and not horizontal padding.  A slot that stages padding
+    // still loads -- from the clamped neighbour pixel, a line the band reads anyway (a far-away dummy address showed up as +39 %
+    // HBM reads in the PMC pass)
     int slot_y[NPF], slot_xoff[NPF];
+    bool slot_ok[NPF];
 #pragma unroll
     for (int i = 0; i < NPF; ++i) {
         const int pi = s_pix0 + 32 * i;
-        const int ry = pi / Wp, xin = pi - ry * Wp - 1;
-        slot_y[i] = (pi < npix_in && xin >= 0 && xin < p.W) ? ry : -(1 << 20);
+        const int pc = min(pi, npix_in - 1);                          // (slots past the band re-read its last pixel)
+        const int ry = pc / Wp, xin = pc - ry * Wp - 1;
+        slot_y[i] = ry;
+        slot_ok[i] = pi < npix_in && xin >= 0 && xin < p.W;
         slot_xoff[i] = min(max(xin, 0), p.W - 1) * p.C;
     }
     const int row_elems = p.W * p.C;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const int yin = iy0 + slot_y[i];
-            pf_in[i] = (unsigned)yin < (unsigned)p.H;
+            pf_in[i] = slot_ok[i] && (unsigned)yin < (unsigned)p.H;
             const int yc = min(max(yin, 0), p.H - 1);
             pf[i] = *reinterpret_cast<const u32x4*>(xb + (yc * row_elems + slot_xoff[i]));
         }
