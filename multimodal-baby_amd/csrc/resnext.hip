@@ -198,6 +198,7 @@ __global__ void pack_gconv_kernel(const float* __restrict__ w, bf16_t* __restric
 constexpr int STEM_TH = 4;                 // output rows per work item
 constexpr int STEM_ROWS = 2 * STEM_TH + 5; // input rows per channel
 constexpr int STEM_PITCH = 144;            // dwords per patch row (288 bf16 >= 224 + 6 + 8 slack); 144 % 32 == 16
+constexpr int STEM_OPITCH = 144;           // bytes per pixel of a wave's output slot (128 + 16 pad)
 
 __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
                                                         bf16_t* __restrict__ y, float* __restrict__ stats,
@@ -216,85 +217,113 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
         for (int ks = 0; ks < 6; ++ks)
             wf[nt][ks] = *reinterpret_cast<const bf16x8*>(wp + ((nt * 6 + ks) * 16 + pix) * 32 + kb * 8);
 
-    float ssum[4][4], ssq[4][4];
+    f32x2 ssum[4][2], ssq[4][2];                              // (channel pairs: packed fp32)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { ssum[a][b] = 0.f; ssq[a][b] = 0.f; }
+        for (int b = 0; b < 2; ++b) { ssum[a][b] = f32x2{0.f, 0.f}; ssq[a][b] = f32x2{0.f, 0.f}; }
 
     const int mtiles_per_row = cvcl_div_up(Wo, 16);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // per-lane constants of the multiply loop: patch row (dwords) of k step ks -- k = 4 ks + kb -> (channel, ky), padded k at 20
+    int koff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int r = min(4 * ks + kb, 20);
+        const int c = r / 7, ky = r - c * 7;
+        koff[ks] = (c * STEM_ROWS + ky) * STEM_PITCH;
+    }
     for (int i = tid; i < 3 * STEM_ROWS * STEM_PITCH; i += 256) patch[i] = 0u;       // pad columns stay zero for good
+    char* wst = smem + 3 * STEM_ROWS * STEM_PITCH * 4 + wave * (16 * STEM_OPITCH);  // this wave's output slot: 16 pixels
     for (int item = blockIdx.x; item < B * bands; item += gridDim.x) {
         const int b = item / bands, band = item - b * bands;
         const int oy0 = band * STEM_TH;
         __syncthreads();
-        // stage: rows (c, iy) <- x[b][c][2*oy0 - 3 + iy][*] as bf16 at columns x + 3 (the 3 + slack pad columns on
-        // either side were zeroed once and are never written).  All of a thread's 16-byte loads are issued before
-        // the first LDS write so they overlap instead of paying one memory round trip each.
+        // stage: rows (c, iy) <- x[b][c][2*oy0 - 3 + iy][*] as bf16 at columns x + 3 (the 3 + slack pad columns on either side were
+        // zeroed once and are never written).  Slot s of a wave is patch row 4 s + wave, a lane is one 16-byte vector of that row
+        // (Win / 4 <= 64 of them): the row, its channel, input row and validity are wave-uniform scalars -- no per-thread index
+        // arithmetic (the flat index form spent two runtime divisions per slot and phase).  All of a batch's loads are issued
+        // before the first LDS write; rows outside the image are staged as zeros.
         {
-            // two batches of 5 x 16 B per thread (one batch of 10 kept 40 more registers live and the kernel at one workgroup per
-            // CU); loads are unconditional from clamped rows, rows outside the image are staged as zeros
-            const int vec_per_row = Win / 4, nvec = 3 * STEM_ROWS * vec_per_row;
-            constexpr int NV = 5;
+            constexpr int NROW = 3 * STEM_ROWS, NV = 5;          // two batches of 5 slots: 10 x 4 rows >= 39
+            const int vec_per_row = Win / 4, jl = min(lane, vec_per_row - 1);
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 f32x4 v[NV];
-                bool ok[NV];
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    const int idx = min(tid + 256 * (half * NV + i), nvec - 1);
-                    const int r = idx / vec_per_row, j = idx - r * vec_per_row;
+                    const int r = min((half * NV + i) * 4 + wave_u, NROW - 1);
                     const int c = r / STEM_ROWS, iy = r - c * STEM_ROWS;
-                    const int yin = 2 * oy0 - 3 + iy;
-                    ok[i] = yin >= 0 && yin < Hin;
-                    v[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + min(max(yin, 0), Hin - 1)) * Win + 4 * j);
+                    const int yin = min(max(2 * oy0 - 3 + iy, 0), Hin - 1);
+                    v[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + yin) * Win + 4 * jl);
                 }
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    const int idx = tid + 256 * (half * NV + i);
-                    if (idx < nvec) {
-                        const int r = idx / vec_per_row, j = idx - r * vec_per_row;
-                        bf16_t* dst = (bf16_t*)(patch + r * STEM_PITCH) + 4 * j + 3;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dst[e] = ok[i] ? (bf16_t)v[i][e] : (bf16_t)0.f;
+                    const int r = (half * NV + i) * 4 + wave_u;
+                    const int iy = r % STEM_ROWS, yin = 2 * oy0 - 3 + iy;
+                    if (r < NROW && lane < vec_per_row) {
+                        const bool ok = yin >= 0 && yin < Hin;
+                        const unsigned u01 = ok ? round2(f32x2{v[i][0], v[i][1]}) : 0u, u23 = ok ? round2(f32x2{v[i][2], v[i][3]}) : 0u;
+                        // four pixels from padded column 4 lane + 3 (odd): 2 + 4 + 2 bytes
+                        char* dst = reinterpret_cast<char*>(patch + r * STEM_PITCH) + 8 * lane + 6;
+                        *reinterpret_cast<unsigned short*>(dst) = (unsigned short)u01;
+                        *reinterpret_cast<unsigned*>(dst + 2) = (u01 >> 16) | (u23 << 16);
+                        *reinterpret_cast<unsigned short*>(dst + 6) = (unsigned short)(u23 >> 16);
                     }
                 }
             }
         }
         __syncthreads();
-        const int n_mt = STEM_TH * mtiles_per_row;
-        for (int mt = wave; mt < n_mt; mt += 4) {
-            const int ty = mt / mtiles_per_row, ox0 = (mt - ty * mtiles_per_row) * 16;
+        // m-tiles of the band in row-major order, wave w takes w, w + 4, ...: (row, tile in row) advance as scalars
+        int ty = 0, tx = wave_u;
+        while (tx >= mtiles_per_row) { tx -= mtiles_per_row; ++ty; }
+        while (ty < STEM_TH) {
+            const int ox0 = tx * 16;
             const int oy = oy0 + ty, ox = ox0 + pix;
             f32x4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned int* row0 = patch + 2 * ty * STEM_PITCH + (ox < Wo ? ox : 0);
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
-                int r = 4 * ks + kb;
-                if (r > 20) r = 20;                                // padded k: weights are zero there
-                const int c = r / 7, ky = r - c * 7;
-                const unsigned int* src = patch + (c * STEM_ROWS + 2 * ty + ky) * STEM_PITCH + (ox < Wo ? ox : 0);
+                const unsigned int* src = row0 + koff[ks];
                 u32x4 raw = {src[0], src[1], src[2], src[3]};      // 8 consecutive input pixels (kx = 0..7)
                 const bf16x8 bfrag = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], bfrag, acc[nt], 0, 0, 0);
             }
-            if (oy < Ho && ox < Wo) {
-                bf16_t* dst = y + (((long)b * Ho + oy) * Wo + ox) * 64 + kb * 4;
+            // the tile (16 pixels x 64 channels) goes through a wave-private LDS slot so that it leaves as full 128-byte pixel rows
+            // (16 B per lane) instead of 8-byte pieces in the MFMA layout
+            const bool inside = oy < Ho && ox < Wo;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    bf16x4 o = {(bf16_t)acc[nt][0], (bf16_t)acc[nt][1], (bf16_t)acc[nt][2], (bf16_t)acc[nt][3]};
-                    *reinterpret_cast<bf16x4*>(dst + nt * 16) = o;
+            for (int nt = 0; nt < 4; ++nt) {
+                const u32x2 o = {round2(f32x2{acc[nt][0], acc[nt][1]}), round2(f32x2{acc[nt][2], acc[nt][3]})};
+                *reinterpret_cast<u32x2*>(wst + pix * STEM_OPITCH + nt * 32 + kb * 8) = o;
+                if (inside) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float s = (float)o[e];
-                        ssum[nt][e] += s;
-                        ssq[nt][e] = fmaf(s, s, ssq[nt][e]);
+                    for (int e = 0; e < 2; ++e) {
+                        const f32x2 sv = widen2(o[e]);
+                        ssum[nt][e] += sv;
+                        ssq[nt][e] = __builtin_elementwise_fma(sv, sv, ssq[nt][e]);
                     }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            if (oy < Ho) {
+                bf16_t* drow = y + (((long)b * Ho + oy) * Wo + ox0) * 64 + (lane & 7) * 8;
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int px = (lane >> 3) + 8 * rd;
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(wst + px * STEM_OPITCH + (lane & 7) * 16);
+                    if (ox0 + px < Wo) *reinterpret_cast<u32x4*>(drow + (long)px * 64) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            tx += 4;
+            while (tx >= mtiles_per_row) { tx -= mtiles_per_row; ++ty; }
         }
     }
     // statistics: reduce over the 16 pixel lanes, then over the 4 waves; channel = nt*16 + kb*4 + e
@@ -304,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float s = ssum[nt][e], q = ssq[nt][e];
+            float s = ssum[nt][e >> 1][e & 1], q = ssq[nt][e >> 1][e & 1];
 #pragma unroll
             for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
             if (pix == 0) {
@@ -840,11 +869,11 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
     CVCL_CHECK_ARG(x_nchw && w_packed && y_nhwc && B > 0 && H % 2 == 0 && W % 2 == 0, "cvcl_stem_conv7x7: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16) {
-        CVCL_CHECK_ARG(W + 6 + 8 <= 2 * STEM_PITCH && W % 4 == 0 && 3 * STEM_ROWS * (W / 4) <= 10 * 256,
+        CVCL_CHECK_ARG(W + 6 + 8 <= 2 * STEM_PITCH && W % 4 == 0 && W / 4 <= 64,
                        "cvcl_stem_conv7x7: width %d not supported by the staged patch", W);
         const int g = stem_grid(B, H);
         CVCL_CHECK_ARG(!stats || stats_rows >= g, "cvcl_stem_conv7x7: stats_rows %d < %d", stats_rows, g);
-        const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4;
+        const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH;
         float* st = stats;
         CVCL_CHECK_ARG(st, "cvcl_stem_conv7x7: the bf16 kernel always emits statistics; pass a buffer");
         CvclProfScope prof(stream, CVCL_K_STEM);
