@@ -348,25 +348,44 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * ATT_KP + ks * 32 + h * 16);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], acc, 0, 0, 0);
             }
-            float mx = -INFINITY;
+            // softmax bookkeeping is the VALU half of this loop (per 32-key tile: 16 exponentials, the running-max update and the
+            // rescale of 32 accumulators against 8 MFMAs), so it is kept lean: logits stay unscaled (the scale folds into the
+            // exponent's fma), keys are masked only in the last tile (the only one with keys >= Tn), arithmetic runs on register
+            // pairs (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32), and O is rescaled only when some query of the wave moved its max
+            if (t == NT - 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-                acc[r] = key < Tn ? acc[r] * scale2 : -INFINITY;
-                mx = fmaxf(mx, acc[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                    acc[r] = key < Tn ? acc[r] : -INFINITY;
+                }
             }
+            float mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx);                   // finite: key 0 of tile 0 is always valid
+            const float m_new = fmaxf(m_run, mx * scale2);          // finite: key 0 of tile 0 is always valid (scale2 > 0)
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
-            float psum = 0.f;
+            const f32x2 sc2 = {scale2, scale2}, nm2 = {-m_new, -m_new};
+            f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = __builtin_amdgcn_exp2f(acc[r] - m_new); psum += acc[r]; }   // v_exp_f32
-            l_run = fmaf(l_run, alpha, psum);
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 a = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, sc2, nm2);
+                acc[r] = __builtin_amdgcn_exp2f(a[0]);              // v_exp_f32 (exp2(-inf) = 0 for the masked keys)
+                acc[r + 1] = __builtin_amdgcn_exp2f(a[1]);
+                ps2 += f32x2{acc[r], acc[r + 1]};
+            }
+            l_run = fmaf(l_run, alpha, ps2[0] + ps2[1]);
+            if (__any(alpha != 1.f)) {
+                const f32x2 al2 = {alpha, alpha};
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 v = f32x2{o[dt][e], o[dt][e + 1]} * al2;
+                        o[dt][e] = v[0]; o[dt][e + 1] = v[1];
+                    }
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 bf16x8 pf;
