@@ -427,15 +427,23 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
             if (q0 + l31 < Tn && h == 0)                           // d blocks 2 hh, 2 hh + 1 of tile hh / 2
                 *reinterpret_cast<unsigned short*>(out_bs + ((long)(hh >> 1) * Mtot + mrow) * 4 + 2 * (hh & 1)) =
                     (unsigned short)(sbs[0] | (sbs[1] << 8));
-        } else if (q0 + l31 < Tn) {
-            bf16_t* orow = out + ((long)b * Tn + q0 + l31) * D + hh * 64;
+        } else {
+            // a lane and its partner (lane ^ 32) hold alternating 4-element runs of the query's 64 d; one v_permlane32_swap per
+            // register gives each of them whole 8-element runs, so the row leaves in 16-byte pieces (8 stores of 8 B before)
+            const bool valid = q0 + l31 < Tn;
+            bf16_t* orow = out + ((long)b * Tn + min(q0 + l31, Tn - 1)) * D + hh * 64 + 8 * h;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    const bf16x4 v = {(bf16_t)(o[dt][4 * bb + 0] * inv), (bf16_t)(o[dt][4 * bb + 1] * inv),
-                                      (bf16_t)(o[dt][4 * bb + 2] * inv), (bf16_t)(o[dt][4 * bb + 3] * inv)};
-                    *reinterpret_cast<bf16x4*>(orow + dt * 32 + 8 * bb + 4 * h) = v;
+                for (int j = 0; j < 2; ++j) {
+                    const int e0 = 8 * j;                          // runs bb = 2 j (elements e0 .. e0+3) and 2 j + 1 (e0+4 .. e0+7)
+                    const unsigned a0 = round2(f32x2{o[dt][e0 + 0] * inv, o[dt][e0 + 1] * inv});
+                    const unsigned a1 = round2(f32x2{o[dt][e0 + 2] * inv, o[dt][e0 + 3] * inv});
+                    const unsigned b0 = round2(f32x2{o[dt][e0 + 4] * inv, o[dt][e0 + 5] * inv});
+                    const unsigned b1 = round2(f32x2{o[dt][e0 + 6] * inv, o[dt][e0 + 7] * inv});
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    if (valid) *reinterpret_cast<u32x4*>(orow + dt * 32 + 16 * j) = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
         }
     }

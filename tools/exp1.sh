@@ -1,9 +1,7 @@
-# A/B runs of bench.py under experiment switches: name, pairs/s, ms/step, single-stream kernel ms per class
-run() { python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-parity 2>/dev/null | python -c "
+run() { python bench.py --config $2 --steps 20 --warmup 5 --no-cpu-baseline --no-parity 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-k=d['kernel_ms_per_step']
-print('$1', d['value'], d['ms_per_step'], {a:round(b,3) for a,b in k.items() if b>0.1})
+print('$1', d['value'], d['ms_per_step'], {k:round(v,3) for k,v in d.get('kernel_ms_per_step',{}).items() if k in ('attention','layernorm','gemm8w','gemm')})
 "; }
-run default
-run default_again
+run c4 c4
+run c5 c5
