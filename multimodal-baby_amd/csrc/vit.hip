@@ -417,11 +417,16 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
                 amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
                 sbs[dt] = mx_scale_byte(amax);
                 const float qi = mx_inv_scale(sbs[dt]);
-                if (q0 + l31 < Tn) {
+                // (the same lane-pair exchange as the bf16 output below: 8-byte pieces instead of 4-byte ones)
+                unsigned w[4];
 #pragma unroll
-                    for (int bb = 0; bb < 4; ++bb)
-                        *reinterpret_cast<unsigned*>(out8 + mrow * D + hh * 64 + dt * 32 + 8 * bb + 4 * h) =
-                            pack4_fp8(vq[4 * bb] * qi, vq[4 * bb + 1] * qi, vq[4 * bb + 2] * qi, vq[4 * bb + 3] * qi);
+                for (int bb = 0; bb < 4; ++bb) w[bb] = pack4_fp8(vq[4 * bb] * qi, vq[4 * bb + 1] * qi, vq[4 * bb + 2] * qi, vq[4 * bb + 3] * qi);
+                const auto s01 = __builtin_amdgcn_permlane32_swap(w[0], w[1], false, false);
+                const auto s23 = __builtin_amdgcn_permlane32_swap(w[2], w[3], false, false);
+                if (q0 + l31 < Tn) {
+                    unsigned char* dst = out8 + mrow * D + hh * 64 + dt * 32 + 8 * h;
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{s01[0], s01[1]};
+                    *reinterpret_cast<u32x2*>(dst + 16) = u32x2{s23[0], s23[1]};
                 }
             }
             if (q0 + l31 < Tn && h == 0)                           // d blocks 2 hh, 2 hh + 1 of tile hh / 2
