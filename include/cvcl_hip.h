@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CVCL_ABI_VERSION 1
+#define CVCL_ABI_VERSION 2
 
 enum { CVCL_OK = 0, CVCL_EINVAL = -1, CVCL_ELAUNCH = -2, CVCL_EWORKSPACE = -3, CVCL_EUNSUPPORTED = -4 };
 enum { CVCL_F32 = 0, CVCL_BF16 = 1 };
@@ -45,6 +45,9 @@ enum { CVCL_K_GEMM = 0, CVCL_K_GCONV = 1, CVCL_K_STEM = 2, CVCL_K_BN_FINALIZE = 
        CVCL_K_WGRAD = 15, CVCL_K_GEMM8W = 16, CVCL_K_GEMM_PRO = 17, CVCL_K_NCLASSES = 18 };
 int cvcl_prof_enable(int on);
 int cvcl_prof_collect(double* ms_per_class, long* launches_per_class, int n_classes);
+/* average event-to-event time (us) of the same bracket around a kernel that does nothing, over n launches: the share of
+ * every bracket that is dispatch gap rather than kernel (a rocprofv3 kernel duration = bracket - this, to first order).  */
+int cvcl_prof_null_bracket_us(void* stream, int n, double* avg_us);
 
 /* ------------------------------------------------------------------------------------------
  * Text encoder, "embedding" branch.  Replaces nn.Embedding + sum/len
@@ -116,7 +119,7 @@ typedef struct {
     /* optional epilogue */
     const float* exp_scale; const float* bias; int act;
     const void* R; int ldr;
-    float* stats; int stats_rows;    /* stats_rows = capacity (>= cvcl_gemm_grid_m(dtype, M, N, a_scale != NULL)) */
+    float* stats; int stats_rows;    /* stats_rows = capacity (>= cvcl_gemm_stats_rows(dtype, args)); rows written = that value */
     /* Bottleneck tail (bf16): C = relu(round(A'W^T) * c_scale[N] + c_shift[N] + (R | R * r_scale[N] + r_shift[N])).
      * With C == NULL and stats != NULL the product is not stored, only its column statistics (same rounding). */
     const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;
@@ -124,12 +127,19 @@ typedef struct {
      * (C = round(gelu(u))); G != NULL multiplies the rounded product by gelu'(G) (G [M][ldg] = the saved u): the data gradient
      * through the GELU, C = round(round(A W^T) * gelu'(G)).  Both NULL for every other use. */
     void* C_pre; const void* G; int ldg;
+    /* centred storage of a raw convolution output (bf16 and fp32): with centre != NULL the product is stored (and its
+     * statistics taken, and the Bottleneck tail's c_scale / c_shift applied) as round(A'W^T - centre[n]).  Train-mode
+     * BatchNorm is invariant under a per-channel shift of its input, so consumers that apply (scale, shift) on load need no
+     * change; cvcl_bn_finalize adds the centre back into the running mean.  Only the convolution epilogues honour it (no
+     * bias / activation / residual-only epilogue).  See "Centred storage" below.                                          */
+    const float* centre;
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);
 /* exact number of statistics rows cvcl_gemm writes for these arguments when given a buffer of at least that many rows
- * (args->stats / stats_rows are ignored).  With a smaller buffer sized by cvcl_gemm_grid_m the 128-tile kernel runs and
- * writes cvcl_gemm_grid_m rows.                                                                          */
+ * (args->stats / stats_rows are ignored); ONLY those rows are defined afterwards -- reduce exactly that many.  With a smaller
+ * buffer sized by cvcl_gemm_grid_m the 128-tile kernel runs and writes cvcl_gemm_grid_m rows.  (The 8-wave and the
+ * BN-prologue kernels write fewer rows than cvcl_gemm_grid_m: always size and reduce by this function.)  */
 int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* args);
 /* The 8-wave 256 (224) x 256 bf16 kernel the dispatcher of cvcl_gemm selects for the MFMA-bound shapes (ResNeXt layers 2-4 1x1
  * convolutions, ViT linears; N % 256 == 0, K % 128 == 0), callable directly with the same argument block.
@@ -158,7 +168,15 @@ int cvcl_colsum_f32(const float* dY, float* d_bias, int M, int N, void* stream);
  * "raw" = convolution output before BatchNorm; every conv kernel emits per-channel sum / sumsq
  * partial rows stats[rows][2][C] of what it stored; cvcl_bn_finalize turns them into (scale, shift)
  * + running-stat EMA (nn.BatchNorm2d train mode: eps 1e-5, momentum 0.1, unbiased running var,
- * num_batches_tracked += 1); consumers apply scale/shift(+ReLU) on load.                          */
+ * num_batches_tracked += 1); consumers apply scale/shift(+ReLU) on load.
+ *
+ * Centred storage.  A raw conv output whose per-channel batch mean is large next to its spread loses precision when it
+ * is rounded to bf16 BEFORE BatchNorm subtracts the mean (the rounding error 2^-9 |y| becomes 2^-9 |y| / sigma of the
+ * normalised value).  Every convolution entry therefore takes an optional per-output-channel `centre` c (fp32, device):
+ * it stores round(y - c) and takes the statistics of THAT; BatchNorm(y - c) == BatchNorm(y), so (scale, shift) from
+ * cvcl_bn_finalize apply to the stored tensor unchanged and the finalize adds c back where the true mean is needed
+ * (running_mean, moments).  c only has to be within ~sigma of the batch mean: the host keeps the batch means of a
+ * calibration pass (multimodal/resnext.py).  centre == NULL is c = 0 (plain storage).                               */
 enum { CVCL_PACK_DENSE = 0, CVCL_PACK_STEM7 = 1, CVCL_PACK_GCONV3 = 2 };
 
 typedef struct {
@@ -167,11 +185,13 @@ typedef struct {
     float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* updated when training */
 } cvcl_convbn_params;
 
+/* centre (nullable): the c the producer stored its output with; running_mean receives batch mean + c.
+ * cvcl_bn_eval_affine: shift = beta - (running_mean - c) * scale, the eval-mode affine of a tensor stored as y - c.  */
 int cvcl_bn_finalize(const float* stats, int rows, long count, const float* gamma, const float* beta,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                     float eps, float* scale, float* shift, int C, void* stream);
+                     float eps, float* scale, float* shift, const float* centre, int C, void* stream);
 int cvcl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                        float eps, float* scale, float* shift, int C, void* stream);
+                        float eps, float* scale, float* shift, const float* centre, int C, void* stream);
 int cvcl_col_stats_rows(long rows);
 int cvcl_col_stats(int dtype, const void* x, long rows, int C, float* stats, int stats_rows, void* stream);
 
@@ -183,7 +203,7 @@ int cvcl_pack_conv_weight(int dtype, int kind, const float* w_oihw, void* out, i
 /* conv1 7x7/2 pad 3, 3->64: x NCHW f32 [B,3,H,W] -> y NHWC raw [B,H/2,W/2,64] (+stats) */
 int cvcl_stem_conv_stats_rows(int dtype, int B, int H, int W);
 int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void* y_nhwc, float* stats, int stats_rows,
-                      int B, int H, int W, void* stream);
+                      const float* centre /* [64] or NULL */, int B, int H, int W, void* stream);
 /* relu(bn(x)) then maxpool 3x3/2 pad 1: [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
 int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int B, int H, int W,
                          int C, void* stream);
@@ -191,7 +211,8 @@ int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const flo
  * a_scale == a_shift == NULL: plain convolution of x (no affine, no ReLU) -- the data-gradient form. */
 int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int C, int stride);
 int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed, void* y,
-                  float* stats, int stats_rows, int B, int H, int W, int C, int groups, int stride, void* stream);
+                  float* stats, int stats_rows, const float* centre /* [C] or NULL */, int B, int H, int W, int C, int groups,
+                  int stride, void* stream);
 /* out = relu(raw*scale+shift + (idn | idn*idn_scale+idn_shift)), [rows, C] */
 int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, const float* shift, const void* idn,
                      const float* idn_scale, const float* idn_shift, void* out, long rows, int C, void* stream);
@@ -204,11 +225,15 @@ int cvcl_avgpool(int dtype, const void* x, float* out, int B, int HW, int C, voi
 /* Whole trunk in one call: conv1..layer4 + avgpool.  layers[53] in torchvision state_dict order
  * (conv1; per block conv1, conv2, conv3, [downsample.0]).  training != 0: batch statistics + running
  * stat updates (what the reference does even with a frozen CNN: Lightning keeps .train()).
- * -> layer4_out_nhwc [B,H/32,W/32,2048] (dtype), pooled [B,2048] f32.                             */
+ * -> layer4_out_nhwc [B,H/32,W/32,2048] (dtype), pooled [B,2048] f32.
+ * centres (nullable): [53][2048] fp32 = cvcl_resnext50_centres_floats(), layer l's storage centre at centres + 2048 l
+ * ("Centred storage" above).  NULL = plain storage, except eval mode in bf16, where NULL selects c = running_mean (the
+ * stored tensors are then y - running_mean; $CVCL_CENTRED_STORAGE=0 turns that default off).                         */
 size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W);
+size_t cvcl_resnext50_centres_floats(void);
 int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
                        const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
-                       void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream);
+                       void* layer4_out_nhwc, float* pooled, float momentum, float eps, const float* centres, void* stream);
 /* ONE Bottleneck of that trunk (torchvision.models.resnet.Bottleneck.forward, reached from multimodal.py:101), enqueued as
  * exactly the launch sequence cvcl_resnext50_fwd uses for it -- the unit the teacher-forced parity tests drive: feed the
  * oracle's block input, compare the block output.  stage 0..3 = layer1..layer4; first != 0 for the stage's first block
@@ -217,7 +242,8 @@ int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float
 size_t cvcl_resnext50_block_workspace_bytes(int dtype, int B, int h, int w, int stage);
 int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stage, int first, int training, const void* x_nhwc,
                              const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
-                             void* out_nhwc, float momentum, float eps, void* stream);
+                             void* out_nhwc, float momentum, float eps, const float* centres /* [n_layers][2048] or NULL */,
+                             void* stream);
 /* The train-mode pass with its BatchNorm running-statistics update split off (no counterpart in the reference, which runs
  * one pass at a time; same results).  Consecutive passes of a FROZEN trunk are independent except for those 53 EMA updates
  * (torch.nn.BatchNorm2d train mode, reached from multimodal.py:88-104 because Lightning keeps .train()), so a host may enqueue
@@ -229,7 +255,8 @@ int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stage, int firs
 size_t cvcl_resnext50_moments_floats(void);
 int cvcl_resnext50_fwd_deferred_stats(int dtype, int B, int H, int W, const float* x_nchw,
                                       const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
-                                      void* layer4_out_nhwc, float* pooled, float eps, float* moments, void* stream);
+                                      void* layer4_out_nhwc, float* pooled, float eps, float* moments, const float* centres,
+                                      void* stream);
 int cvcl_resnext50_apply_moments(const cvcl_convbn_params* layers, int n_layers, const float* moments, float momentum,
                                  void* stream);
 
@@ -322,9 +349,12 @@ int cvcl_bn_bwd_partial_rows(int dtype, long rows, int C);
 int cvcl_bn_bwd(int dtype, int mode, const void* x, const void* out, const void* dy, const float* scale, const float* shift,
                 const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, void* dx, void* g_out,
                 long rows, int C, float* partial, int partial_rows, float* coef, void* stream);
-/* batch mean and 1/sqrt(var_biased + eps) from the forward statistics rows (what bn_finalize normalised with) */
-int cvcl_bn_batch_moments(const float* stats, int stats_rows, long count, float eps, float* mean, float* rstd, int C,
-                          void* stream);
+/* batch mean and 1/sqrt(var_biased + eps) from the forward statistics rows (what bn_finalize normalised with; with centred
+ * storage they are the moments of the STORED tensor y - c, which is what cvcl_bn_bwd needs next to that tensor).
+ * centre_track (nullable, [C]): the c the producer used, updated in place to c + mean = the batch mean of y -- the storage
+ * centre of the next step (a trunk that is being fine-tuned re-centres every step: its weights move).                 */
+int cvcl_bn_batch_moments(const float* stats, int stats_rows, long count, float eps, float* mean, float* rstd,
+                          float* centre_track, int C, void* stream);
 /* OIHW f32 weight of the convolution that computes the data gradient of a grouped 3x3 conv (flip + in/out swap per group) */
 int cvcl_gconv_weight_dgrad(const float* w, float* out, int C, int cin_per_group, void* stream);
 int cvcl_transpose(int dtype, const void* in, void* out, long rows, int cols, void* stream);     /* out[c][r] = in[r][c] */

@@ -55,6 +55,30 @@ extern "C" int cvcl_prof_enable(int on) {
     return CVCL_OK;
 }
 
+// the part of an event bracket that is not the kernel: the same two event records around a kernel that does nothing
+__global__ void cvcl_null_kernel() {}
+extern "C" int cvcl_prof_null_bracket_us(void* stream, int n, double* avg_us) {
+    if (!avg_us || n <= 0) { cvcl_set_error("cvcl_prof_null_bracket_us: bad args"); return CVCL_EINVAL; }
+    std::vector<Rec> recs;
+    for (int i = 0; i < n; ++i) {
+        Rec r{get_event(), get_event(), 0};
+        if (!r.a || !r.b) { cvcl_set_error("cvcl_prof_null_bracket_us: no events"); return CVCL_ELAUNCH; }
+        (void)hipEventRecord(r.a, (hipStream_t)stream);
+        hipLaunchKernelGGL(cvcl_null_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+        (void)hipEventRecord(r.b, (hipStream_t)stream);
+        recs.push_back(r);
+    }
+    double tot = 0.0;
+    int cnt = 0;
+    for (auto& r : recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { tot += ms; ++cnt; }
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    *avg_us = cnt ? tot / cnt * 1e3 : 0.0;
+    return CVCL_OK;
+}
+
 extern "C" int cvcl_prof_collect(double* ms_per_class, long* launches_per_class, int n_classes) {
     if (!ms_per_class || !launches_per_class || n_classes <= 0) { cvcl_set_error("cvcl_prof_collect: bad args"); return CVCL_EINVAL; }
     for (int i = 0; i < n_classes; ++i) { ms_per_class[i] = 0.0; launches_per_class[i] = 0; }

@@ -40,6 +40,7 @@ struct GemmDev {
     const void* R; int ldr;
     const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;   // BN-apply epilogue
     float* stats;
+    const float* centre;   // storage centre of a raw convolution output (NULL = 0): accumulators start at -centre[n]
     int vec_in;    // A/W rows are 16-byte aligned and K is a whole number of chunks
     int vec_out;   // C/R rows are 16-byte aligned
     int num_m_tiles;
@@ -181,6 +182,17 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     bool l_live = l_mt < p.num_m_tiles;
     if (l_live) { set_rows(l_mt); issue(); }
 
+    // centred storage (convolution epilogues only): the accumulators of column n start at -centre[n]; this lane's columns are
+    // n0 + wn*64 + nt*32 + 8g + 4h + e
+    float cinit[2][16];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int n = n0 + wn * 64 + nt * 32 + 8 * (e >> 2) + 4 * h + (e & 3);
+            cinit[nt][e] = (p.centre && n < p.N) ? -p.centre[n] : 0.f;
+        }
+
     for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
         const int m0 = cm * BM;
         f32x16 acc[2][2];
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = cinit[i][e];
 
         for (int kt = 0; kt < ktiles; ++kt) {
             // registers hold tile (cm, kt): BatchNorm(+ReLU) of the producer on the fly, then into LDS
@@ -481,6 +493,21 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
             }
     }
 
+    // centred storage (EPI 0 / 2): the accumulators of column n start at -centre[n] (this lane's 32 columns, fixed per workgroup)
+    f32x4 cinit[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            cinit[nt][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == 0 || EPI == 2) {
+                if (p.centre) {
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(p.centre + n0 + wn * 64 + nt * 32 + 8 * g + 4 * h);
+                    cinit[nt][g] = f32x4{-cv[0], -cv[1], -cv[2], -cv[3]};
+                }
+            }
+        }
+
     // fragment read offsets inside a buffer (rows fixed per lane, swizzle per row)
     int fw_off[2], fa_off[2], fw_sw[2], fa_sw[2];
 #pragma unroll
@@ -504,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = cinit[i][e >> 2][e & 3];
 
         // EPI 2: the residual rows this lane will need in the read-back phase are fetched now, so that their latency
         // hides behind the K loop instead of sitting between the last MFMA and the stores
@@ -904,7 +931,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.g_ho = a->gather_ho; d.g_wo = a->gather_wo; d.g_hi = a->gather_hi; d.g_wi = a->gather_wi;
     d.g_s = a->gather_stride;
     d.exp_scale = a->exp_scale; d.bias = a->bias; d.act = a->act;
-    d.R = a->R; d.ldr = a->ldr; d.stats = a->stats;
+    d.R = a->R; d.ldr = a->ldr; d.stats = a->stats; d.centre = a->centre;
     d.c_scale = a->c_scale; d.c_shift = a->c_shift; d.r_scale = a->r_scale; d.r_shift = a->r_shift;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     d.vec_in = (a->K % EPC == 0) && (a->lda % EPC == 0) && (a->ldw % EPC == 0) && al16(a->A) && al16(a->W);
@@ -1000,6 +1027,10 @@ extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {
     CVCL_CHECK_ARG(!a->c_scale || dtype == CVCL_BF16, "cvcl_gemm: the c_scale epilogue exists for bf16 only");
     CVCL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "cvcl_gemm: bad shape %d %d %d", a->M, a->N, a->K);
     CVCL_CHECK_ARG((a->a_scale == nullptr) == (a->a_shift == nullptr), "cvcl_gemm: a_scale/a_shift must come together");
+    // centred storage belongs to the convolution epilogues (plain / statistics / Bottleneck tail); nn.Linear epilogues have no BN behind them
+    CVCL_CHECK_ARG(!a->centre || (((uintptr_t)a->centre & 15) == 0 && !a->bias && !a->exp_scale && !a->C_pre && !a->G &&
+                                  (a->c_scale || (!a->R && a->act == CVCL_ACT_NONE))),
+                   "cvcl_gemm: centre goes with the convolution epilogues only (16-byte aligned, no bias / activation / residual)");
     if (dtype == CVCL_F32) return launch_gemm<float>(a, (hipStream_t)stream);
     if (dtype == CVCL_BF16) return launch_gemm<bf16_t>(a, (hipStream_t)stream);
     cvcl_set_error("cvcl_gemm: unknown dtype %d", dtype);

@@ -45,6 +45,7 @@ constexpr int MAX_BIAS_N = (LDS_BYTES - ACC_OFF) / 4;               // 4096
 struct Dev {
     const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
     const float* bias; float* stats;
+    const float* centre;            // EPI 0: storage centre of the output (NULL = 0): accumulators start at -centre[n]
     int M, N, K, lda, ldw, ldc, ldr, act;
     int tiles_m, grid_m, ncol;
     // row gather of a strided 1x1 convolution: output row m = (b, oy, ox) reads A row (b, oy * gs, ox * gs); gs <= 1 = off
@@ -242,8 +243,18 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     } else {
         lds_acc[tid] = 0.f;
         lds_acc[tid + 512] = 0.f;
+        // centred storage: -centre of the column tile's 256 columns behind the partial sums; every accumulator tile starts from it
+        if (tid < BN) lds_acc[1024 + tid] = p.centre ? -p.centre[tj * BN + tid] : 0.f;
     }
     // (ordered before the first epilogue by the prologue's barrier)
+    // this lane's four columns of accumulator tile ni are cen_of() + ni * 16.  The address is re-derived from the thread id behind
+    // an opaque copy wherever it is used: hoisted out of the K loop it is one more loop-invariant VGPR in a kernel that sits at
+    // exactly 256, and the compiler then spills to scratch -- whose loads would also sit in the counted vmcnt queue
+    auto cen_of = [&]() __attribute__((always_inline)) -> const float* {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return lds_acc + 1024 + wn * 64 + ((t >> 4) & 3) * 4;
+    };
 
     char* stg = smem + NSTAGE * STAGE_BYTES + wave * STG_BYTES;
     const int e_row = lane & 15;                             // accumulator layout: m = mi*16 + (lane & 15), n = ni*16 + (lane >> 4)*4 + e
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                 } else {
                     q = bf16x4{(bf16_t)acc[ni][mi][0], (bf16_t)acc[ni][mi][1], (bf16_t)acc[ni][mi][2], (bf16_t)acc[ni][mi][3]};
                 }
-                acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};         // ready for the next output tile
+                if constexpr (EPI != 0) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};     // ready for the next output tile
                 const int chunk = ni * 2 + e_wchunk;
                 *reinterpret_cast<bf16x4*>(stg + e_row * 128 + ((chunk ^ e_wsw) << 4) + e_wsub) = q;
             }
@@ -335,6 +346,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                 for (int e = 0; e < 8; ++e) { s0[e] += st_sum[e]; s1[e] += st_sq[e]; }
             }
         }
+        if constexpr (EPI == 0) {                            // the next output tile's accumulators start at -centre (one column
+            const float* cen = cen_of();                     // group at a time: four live registers, not sixteen)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cen + ni * 16);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = c4;
+            }
+        }
         return (full && p.C != nullptr) ? ESTORES : 0;
     };
 
@@ -349,9 +369,19 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     }
     // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----
     issue(0); advance(); issue(1); advance(); issue(2); advance(); issue(3); advance();
+    if constexpr (EPI == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this thread's LDS writes above (-centre)
     wait_vm<12>();
     __builtin_amdgcn_s_barrier();
     read_frags(0, std::integral_constant<int, 0>{});
+    if constexpr (EPI == 0) {
+        const float* cen = cen_of();
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cen + ni * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = c4;
+        }
+    }
 
     // stores issued by an epilogue sit between stage loads in the in-order vmcnt queue for the next three waits
     // (the count passed to s_waitcnt must not exceed the number of younger instructions; a smaller one only waits longer)

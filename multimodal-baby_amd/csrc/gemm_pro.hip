@@ -31,13 +31,14 @@ struct ProDev {
     const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
     const float* a_scale; const float* a_shift; const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;
     float* stats;
+    const float* centre;            // storage centre of the output (NULL = 0): accumulators start at -centre[n]
     int M, N, lda, ldw, ldc, ldr;
     int tiles;
 };
 
 enum { PRO_STATS = 0, PRO_STORE = 1, PRO_TAIL = 2 };
 
-template <int KT> constexpr int pro_lds_bytes() { return 2 * PM * KT * 64 + 8 * 4096 + 4 * PN * 4 + 2 * 256 * 4; }
+template <int KT> constexpr int pro_lds_bytes() { return 2 * PM * KT * 64 + 8 * 4096 + 5 * PN * 4 + 2 * 256 * 4; }
 
 // D = tiles of A in flight per workgroup (registers); more than one buys ~2 % (the per-tile chain stage -> barrier -> fragment
 // reads -> MFMA -> statistics is the bound, not the load latency)
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     // K = 256 holds 128 registers of W fragments: the operand affine of this thread's 8 channels is then re-read from LDS per
     // tile (4 ds_read_b128) instead of living in 16 registers
     constexpr bool AFF_LDS = KT == 8;
-    float* in_aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096 + 4 * PN * 4);      // [2][K]
+    float* in_aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096 + 5 * PN * 4);      // [2][K]
     f32x2 sc[4], sh[4];
     if constexpr (AFF_LDS) {
         if (tid < K) { in_aff[tid] = p.a_scale[tid]; in_aff[K + tid] = p.a_shift[tid]; }
@@ -120,6 +121,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     // the strip's BN3 / downsample-BN affines sit in LDS ([4][256] floats) and are fetched per tile: 32 registers that would
     // otherwise be live across the MFMA phase (K = 256 holds 128 registers of W fragments)
     float* aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096);
+    // centred storage: -centre of the strip's 256 columns at aff + 4 PN; every tile's accumulators start from it
+    if (tid < PN) aff[4 * PN + tid] = p.centre ? -p.centre[n0 + tid] : 0.f;
+    const float* cen = aff + 4 * PN + wn * 64 + (lane >> 4) * 4;        // + ni * 16: accumulator columns ni*16 + (lane >> 4)*4 + e
     if constexpr (MODE == PRO_TAIL) {
         if (tid < PN) {
             aff[tid] = p.c_scale[n0 + tid];
@@ -182,9 +186,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
         const int next = tile + G;
         if (tile + D * G < p.tiles) load_a(tile + D * G, slot);
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cen + ni * 16);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = c4;
+        }
         const char* ab = smem + buf * ABUF + (wm * 32 + f_row) * PITCH;
 #pragma unroll
         for (int ks = 0; ks < KT; ++ks) {
@@ -356,7 +362,7 @@ extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream) {
     ProDev d;
     d.A = (const bf16_t*)a->A; d.W = (const bf16_t*)a->W; d.C = (bf16_t*)a->C; d.R = (const bf16_t*)a->R;
     d.a_scale = a->a_scale; d.a_shift = a->a_shift; d.c_scale = a->c_scale; d.c_shift = a->c_shift;
-    d.r_scale = a->r_scale; d.r_shift = a->r_shift; d.stats = a->stats;
+    d.r_scale = a->r_scale; d.r_shift = a->r_shift; d.stats = a->stats; d.centre = a->centre;
     d.M = a->M; d.N = a->N; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr;
     d.tiles = cvcl_div_up(a->M, PM);
     const int gx = cvcl_gemm_pro_stats_rows(a->M, a->N);

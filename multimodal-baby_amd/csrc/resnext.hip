@@ -37,7 +37,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
                                                            int64_t* __restrict__ nbt, float momentum, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift, int C,
-                                                           float* __restrict__ moments, int moments_ld) {
+                                                           float* __restrict__ moments, int moments_ld,
+                                                           const float* __restrict__ centre) {
     // 16 channels x 64 row slices per workgroup (short dependent-load chains: the early layers have 512 partial rows and
     // only 64-256 channels); slices combined in a fixed order (deterministic)
     constexpr int NS = 64, NC = 16;
@@ -67,6 +68,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     if (sl == 0 && ch < C) {
         s = 0.0; q = 0.0;
         for (int i = 0; i < NS; ++i) { s += ps[i][c]; q += pq[i][c]; }
+        // the statistics are those of the STORED tensor y - c (centred storage): (scale, shift) apply to it as it lies in memory;
+        // the mean of y itself, for the running statistics, is mean + c
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -74,11 +77,12 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         scale[ch] = sc;
         shift[ch] = beta[ch] - (float)mean * sc;
         const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        const float true_mean = centre ? (float)(mean + (double)centre[ch]) : (float)mean;
         if (moments) {
-            moments[ch] = (float)mean;
+            moments[ch] = true_mean;
             moments[moments_ld + ch] = (float)unbiased;
         } else if (running_mean) {
-            running_mean[ch] = bn_ema(running_mean[ch], (float)mean, momentum);
+            running_mean[ch] = bn_ema(running_mean[ch], true_mean, momentum);
             running_var[ch] = bn_ema(running_var[ch], (float)unbiased, momentum);
         }
     }
@@ -102,12 +106,12 @@ __global__ __launch_bounds__(256) void bn_apply_moments_kernel(ApplyMomentsAll t
 
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
-                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+                                      float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ centre, int C) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch < C) {
         const float sc = gamma[ch] / sqrtf(rv[ch] + eps);
         scale[ch] = sc;
-        shift[ch] = beta[ch] - rm[ch] * sc;
+        shift[ch] = beta[ch] - (centre ? rm[ch] - centre[ch] : rm[ch]) * sc;      // affine of the tensor stored as y - c
     }
 }
 
@@ -117,12 +121,24 @@ struct EvalAffineAll {
     const float* gamma[53]; const float* beta[53]; const float* rm[53]; const float* rv[53];
     int C[53];
 };
-__global__ __launch_bounds__(256) void bn_eval_affine_all_kernel(EvalAffineAll t, float eps, float* __restrict__ affine) {
+// centres: the storage centres the pass will use ([53][2048], "Centred storage" in cvcl_hip.h); NULL with centres_out: the
+// running means themselves, which this kernel then writes to centres_out for the convolutions to read (shift = beta);
+// both NULL: plain storage
+__global__ __launch_bounds__(256) void bn_eval_affine_all_kernel(EvalAffineAll t, float eps, float* __restrict__ affine,
+                                                                 const float* __restrict__ centres, float* __restrict__ centres_out) {
     const int l = blockIdx.x;
     for (int ch = threadIdx.x; ch < t.C[l]; ch += 256) {
         const float sc = t.gamma[l][ch] / sqrtf(t.rv[l][ch] + eps);
+        const float rm = t.rm[l][ch];
         affine[(size_t)l * 4096 + ch] = sc;
-        affine[(size_t)l * 4096 + 2048 + ch] = t.beta[l][ch] - t.rm[l][ch] * sc;
+        if (centres) {
+            affine[(size_t)l * 4096 + 2048 + ch] = t.beta[l][ch] - (rm - centres[(size_t)l * 2048 + ch]) * sc;
+        } else if (centres_out) {
+            affine[(size_t)l * 4096 + 2048 + ch] = t.beta[l][ch];
+            centres_out[(size_t)l * 2048 + ch] = rm;
+        } else {
+            affine[(size_t)l * 4096 + 2048 + ch] = t.beta[l][ch] - rm * sc;
+        }
     }
 }
 
@@ -202,7 +218,7 @@ constexpr int STEM_OPITCH = 144;           // bytes per pixel of a wave's output
 
 __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
                                                         bf16_t* __restrict__ y, float* __restrict__ stats,
-                                                        int B, int Hin, int Win) {
+                                                        const float* __restrict__ centre, int B, int Hin, int Win) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned int* patch = (unsigned int*)smem;                 // [3*STEM_ROWS][STEM_PITCH] dwords (2 bf16 each)
     const int Ho = Hin / 2, Wo = Win / 2;
@@ -235,6 +251,10 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
     }
     for (int i = tid; i < 3 * STEM_ROWS * STEM_PITCH; i += 256) patch[i] = 0u;       // pad columns stay zero for good
     char* wst = smem + 3 * STEM_ROWS * STEM_PITCH * 4 + wave * (16 * STEM_OPITCH);  // this wave's output slot: 16 pixels
+    // centred storage: the accumulators start at -centre[channel] (64 floats in LDS behind the output slots, re-read per tile:
+    // the weights already hold 96 registers)
+    float* cen = reinterpret_cast<float*>(smem + 3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH);
+    if (tid < 64) cen[tid] = centre ? -centre[tid] : 0.f;                           // (visible after the first item's barrier)
     for (int item = blockIdx.x; item < B * bands; item += gridDim.x) {
         const int b = item / bands, band = item - b * bands;
         const int oy0 = band * STEM_TH;
@@ -282,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
             const int oy = oy0 + ty, ox = ox0 + pix;
             f32x4 acc[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(cen + nt * 16 + kb * 4);
             const unsigned int* row0 = patch + 2 * ty * STEM_PITCH + (ox < Wo ? ox : 0);
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
@@ -352,14 +372,15 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
 
 // fp32 parity path: direct convolution, one thread per (pixel, output channel); weights in OIHW
 __global__ __launch_bounds__(256) void stem_direct_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              float* __restrict__ y, int B, int Hin, int Win) {
+                                                              float* __restrict__ y, const float* __restrict__ centre,
+                                                              int B, int Hin, int Win) {
     const int Ho = Hin / 2, Wo = Win / 2;
     const long total = (long)B * Ho * Wo * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int co = (int)(i & 63);
         const long p = i >> 6;
         const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
-        float acc = 0.f;
+        float acc = centre ? -centre[co] : 0.f;
         for (int c = 0; c < 3; ++c)
             for (int ky = 0; ky < 7; ++ky) {
                 const int yin = 2 * oy - 3 + ky;
@@ -421,6 +442,7 @@ constexpr int GC_PIXB = 144;               // LDS bytes per staged pixel (128 B 
 
 struct GconvDev {
     const void* x; const float* a_scale; const float* a_shift; const void* w; void* y; float* stats;
+    const float* centre;            // storage centre of the output (NULL = 0): the accumulators start at -centre[channel]
     int B, H, W, C, cg, stride, Ho, Wo, TH, bands, rows_in;
     float act_floor; // 0 = ReLU after the affine; -inf = none (a_scale == NULL: plain convolution of x, used by the data gradient)
 };
@@ -526,6 +548,11 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
             pf[i] = *reinterpret_cast<const u32x4*>(xb + (yc * row_elems + slot_xoff[i]));
         }
     };
+    f32x4 acc_init = {0.f, 0.f, 0.f, 0.f};                             // output channel c0 + wave*16 + kb*4 + e
+    if (p.centre) {
+        const f32x4 cv = *reinterpret_cast<const f32x4*>(p.centre + c0 + wave * 16 + kb * 4);
+        acc_init = f32x4{-cv[0], -cv[1], -cv[2], -cv[3]};
+    }
     const int n_items = p.B * p.bands;
     const int st_off = (tid >> 3) * p.C + (tid & 7) * 8;             // store phase: this thread's chunk inside a band's output
     // the weight fragments (loaded above) are ready from here on: without this the compiler, conservative across the loop's back
@@ -568,7 +595,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
             const int base0 = e0 & 0xffff, base1 = e1 & 0xffff;
             const int q0 = pix + 16 * mt, q1 = q0 + 16;
             const bool wr0 = (e0 >> 24) && ((e0 >> 16) & 0xff) < rows_left, wr1 = (e1 >> 24) && ((e1 >> 16) & 0xff) < rows_left;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc0 = acc_init, acc1 = acc_init;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(smem + base0 + tap_off[ks]);
@@ -624,7 +651,8 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
 // fp32 parity path: direct grouped convolution, weights in the reference OIHW layout [C][cg][3][3]
 __global__ __launch_bounds__(256) void gconv_direct_f32_kernel(const float* __restrict__ x, const float* __restrict__ a_scale,
                                                                const float* __restrict__ a_shift, const float* __restrict__ w,
-                                                               float* __restrict__ y, int B, int H, int W, int C, int cg,
+                                                               float* __restrict__ y, const float* __restrict__ centre,
+                                                               int B, int H, int W, int C, int cg,
                                                                int stride, int Ho, int Wo, float act_floor) {
     const long total = (long)B * Ho * Wo * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(256) void gconv_direct_f32_kernel(const float* __re
         const long pp = i / C;
         const int ox = (int)(pp % Wo), oy = (int)((pp / Wo) % Ho), b = (int)(pp / ((long)Wo * Ho));
         const int g0 = (co / cg) * cg;
-        float acc = 0.f;
+        float acc = centre ? -centre[co] : 0.f;
         for (int ci = 0; ci < cg; ++ci) {
             const float sc = a_scale ? a_scale[g0 + ci] : 1.f, sh = a_scale ? a_shift[g0 + ci] : 0.f;
             for (int ky = 0; ky < 3; ++ky) {
@@ -772,29 +800,31 @@ int grid_for(long total, int per_block = 256, int cap = 4096) {
 // ================================================================================================
 static int bn_finalize_launch(const float* stats, int rows, long count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                              float eps, float* scale, float* shift, int C, float* moments, int moments_ld, void* stream) {
+                              float eps, float* scale, float* shift, int C, float* moments, int moments_ld, const float* centre,
+                              void* stream) {
     CVCL_CHECK_ARG(stats && gamma && beta && scale && shift && rows > 0 && count > 0 && C > 0, "cvcl_bn_finalize: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cvcl_div_up(C, 16)), dim3(1024), 0, (hipStream_t)stream, stats, rows,
                        (double)count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
-                       shift, C, moments, moments_ld);
+                       shift, C, moments, moments_ld, centre);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
 
 extern "C" int cvcl_bn_finalize(const float* stats, int rows, long count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
-                                float eps, float* scale, float* shift, int C, void* stream) {
+                                float eps, float* scale, float* shift, const float* centre, int C, void* stream) {
     return bn_finalize_launch(stats, rows, count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
-                              scale, shift, C, nullptr, 0, stream);
+                              scale, shift, C, nullptr, 0, centre, stream);
 }
 
 extern "C" int cvcl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
-                                   const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+                                   const float* running_var, float eps, float* scale, float* shift, const float* centre, int C,
+                                   void* stream) {
     CVCL_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "cvcl_bn_eval_affine: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
     hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cvcl_div_up(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
-                       running_mean, running_var, eps, scale, shift, C);
+                       running_mean, running_var, eps, scale, shift, centre, C);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
@@ -865,7 +895,7 @@ extern "C" int cvcl_stem_conv_stats_rows(int dtype, int B, int H, int W) {
 }
 
 extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void* y_nhwc, float* stats,
-                                 int stats_rows, int B, int H, int W, void* stream) {
+                                 int stats_rows, const float* centre, int B, int H, int W, void* stream) {
     CVCL_CHECK_ARG(x_nchw && w_packed && y_nhwc && B > 0 && H % 2 == 0 && W % 2 == 0, "cvcl_stem_conv7x7: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16) {
@@ -873,19 +903,19 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
                        "cvcl_stem_conv7x7: width %d not supported by the staged patch", W);
         const int g = stem_grid(B, H);
         CVCL_CHECK_ARG(!stats || stats_rows >= g, "cvcl_stem_conv7x7: stats_rows %d < %d", stats_rows, g);
-        const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH;
+        const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH + 64 * 4;
         float* st = stats;
         CVCL_CHECK_ARG(st, "cvcl_stem_conv7x7: the bf16 kernel always emits statistics; pass a buffer");
         CvclProfScope prof(stream, CVCL_K_STEM);
         hipLaunchKernelGGL(stem_mfma_kernel, dim3(g), dim3(256), lds, s, x_nchw, (const bf16_t*)w_packed, (bf16_t*)y_nhwc,
-                           st, B, H, W);
+                           st, centre, B, H, W);
         CVCL_LAUNCH_CHECK();
         return CVCL_OK;
     }
     const long total = (long)B * (H / 2) * (W / 2) * 64;
     { CvclProfScope prof(stream, CVCL_K_STEM);
     hipLaunchKernelGGL(stem_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, x_nchw,
-                       (const float*)w_packed, (float*)y_nhwc, B, H, W); }
+                       (const float*)w_packed, (float*)y_nhwc, centre, B, H, W); }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y_nhwc, (long)B * (H / 2) * (W / 2), 64, stats, stats_rows, stream);
     return CVCL_OK;
@@ -946,8 +976,8 @@ extern "C" int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int C, i
 }
 
 extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed,
-                             void* y, float* stats, int stats_rows, int B, int H, int W, int C, int groups, int stride,
-                             void* stream) {
+                             void* y, float* stats, int stats_rows, const float* centre, int B, int H, int W, int C, int groups,
+                             int stride, void* stream) {
     CVCL_CHECK_ARG(x && w_packed && y && (!a_scale == !a_shift), "cvcl_gconv3x3: null pointer");
     const float act_floor = a_scale ? 0.f : -INFINITY;
     CVCL_CHECK_ARG(B > 0 && (stride == 1 || stride == 2) && groups > 0 && C % groups == 0, "cvcl_gconv3x3: bad shape");
@@ -962,7 +992,7 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
                        "cvcl_gconv3x3: feature map too wide for one staged band (%zu B, %d pixels)", g.lds, g.rows_in * (W + 2));
         CVCL_CHECK_ARG(!stats || stats_rows >= g.grid_x, "cvcl_gconv3x3: stats_rows %d < %d", stats_rows, g.grid_x);
         GconvDev d;
-        d.x = x; d.a_scale = a_scale; d.a_shift = a_shift; d.w = w_packed; d.y = y; d.stats = stats;
+        d.x = x; d.a_scale = a_scale; d.a_shift = a_shift; d.w = w_packed; d.y = y; d.stats = stats; d.centre = centre;
         d.B = B; d.H = H; d.W = W; d.C = C; d.cg = cg; d.stride = stride; d.Ho = Ho; d.Wo = Wo;
         d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
         d.act_floor = act_floor;
@@ -997,7 +1027,7 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
     const long total = (long)B * Ho * Wo * C;
     { CvclProfScope prof(stream, CVCL_K_GCONV);
     hipLaunchKernelGGL(gconv_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, (const float*)x, a_scale,
-                       a_shift, (const float*)w_packed, (float*)y, B, H, W, C, cg, stride, Ho, Wo, act_floor); }
+                       a_shift, (const float*)w_packed, (float*)y, centre, B, H, W, C, cg, stride, Ho, Wo, act_floor); }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y, (long)B * Ho * Wo, C, stats, stats_rows, stream);
     return CVCL_OK;
@@ -1083,8 +1113,10 @@ inline size_t act_elems(int B, int H, int W) {
 extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W) {
     const size_t es = dtype == CVCL_BF16 ? 2 : 4;
     return 5 * al256(act_elems(B, H, W) * es) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)53 * 2 * 2048 * 4) +
-           gram_ws_bytes(B, H, W);
+           gram_ws_bytes(B, H, W) + al256((size_t)53 * 2048 * 4);
 }
+
+extern "C" size_t cvcl_resnext50_centres_floats(void) { return (size_t)53 * 2048; }
 
 // ------------------------------------------------------------------------------------------------
 // One Bottleneck (torchvision Bottleneck.forward: conv1-bn1-relu, conv2(grouped 3x3, stride)-bn2-relu, conv3-bn3,
@@ -1101,8 +1133,9 @@ struct BlockCtx {
     void* stream;
 };
 
+// cen = the block's storage centres ([n_layers][2048] floats, "Centred storage" in cvcl_hip.h) or NULL
 int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, const char* X, char* R1, char* R2, char* R3, char* RD,
-                   char* dst, const cvcl_convbn_params* L, float* aff, float* mom) {
+                   char* dst, const cvcl_convbn_params* L, float* aff, float* mom, const float* cen) {
     const int dtype = c.dtype, B = c.B, training = c.training;
     float* stats = c.stats;
     void* stream = c.stream;
@@ -1115,11 +1148,12 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     int rc;
     auto scale_of = [&](int l) { return aff + (size_t)l * 4096; };
     auto shift_of = [&](int l) { return aff + (size_t)l * 4096 + 2048; };
+    auto centre_of = [&](int l) -> const float* { return cen ? cen + (size_t)l * 2048 : nullptr; };
     auto finalize = [&](int l, int rows, long count, int C) -> int {
         if (training)
             return bn_finalize_launch(stats, rows, count, L[l].gamma, L[l].beta, L[l].running_mean, L[l].running_var,
                                       L[l].num_batches_tracked, c.momentum, c.eps, scale_of(l), shift_of(l), C,
-                                      mom ? mom + (size_t)l * 4096 : nullptr, 2048, stream);
+                                      mom ? mom + (size_t)l * 4096 : nullptr, 2048, centre_of(l), stream);
         return CVCL_OK;                                   // eval mode: every layer's affine was produced up front
     };
     // conv1 1x1: X [m_in, inplanes] -> R1 [m_in, width]
@@ -1128,12 +1162,13 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         a.A = X; a.W = L[l1].w; a.C = R1;
         a.M = (int)m_in; a.N = width; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = width;
         a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+        a.centre = centre_of(l1);
         if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
         if ((rc = finalize(l1, cvcl_gemm_stats_rows(dtype, &a), m_in, width))) return rc;
     }
     // conv2 grouped 3x3 (stride here): R1 -> R2 [m_out, width], BN1+ReLU fused into the load
     if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), L[l2].w, R2, training ? stats : nullptr,
-                            kMaxStatsRows, B, h, wd, width, 32, stride, stream))) return rc;
+                            kMaxStatsRows, centre_of(l2), B, h, wd, width, 32, stride, stream))) return rc;
     if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, width, stride), m_out, width))) return rc;
     // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  Layers 1-2 (K = width <= 256, bandwidth-bound): BN2 + ReLU rides conv3's
     // operand load (gemm_pro.hip: applied once per element, W resident in registers) -- no pass of its own over the tensor.
@@ -1158,12 +1193,13 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         a.A = R2; a.W = L[l3].w;
         a.M = (int)m_out; a.N = outc; a.K = width; a.lda = width; a.ldw = width; a.ldc = outc;
         if (pro) { a.a_scale = scale_of(l2); a.a_shift = shift_of(l2); a.a_relu = 1; }
+        a.centre = centre_of(l3);
         return a;
     };
     // opt-in ($CVCL_BN3_GRAM=1): measured SLOWER than the statistics-only GEMM pass on MI355X at B=256 (8.14 vs 7.74
     // ms/step: the Gram TN GEMM runs at ~400 TFLOP/s and needs two small follow-up kernels), kept as an experiment
     static const bool use_gram = [] { const char* e = getenv("CVCL_BN3_GRAM"); return e && e[0] == '1'; }();
-    if (fused_tail && training && use_gram && c.gram_ws) {
+    if (fused_tail && training && use_gram && c.gram_ws && !cen) {
         // BN3 statistics from the Gram matrix of conv3's (narrow) input: one read of R2 instead of a statistics-only
         // GEMM pass (the conv is linear: sum_y = W colsum(R2), sum_y2[n] = w_n^T (R2^T R2) w_n)
         if ((rc = cvcl_conv1x1_bn_stats_gram(R2, width, L[l3].w, width, m_out, outc, width, stats, c.gram_ws,
@@ -1185,6 +1221,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
         if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
         a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+        a.centre = centre_of(ld);
         if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
         if ((rc = finalize(ld, cvcl_gemm_stats_rows(dtype, &a), m_out, outc))) return rc;
     }
@@ -1219,8 +1256,9 @@ extern "C" size_t cvcl_resnext50_block_workspace_bytes(int dtype, int B, int h, 
 
 extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stage, int first, int training, const void* x_nhwc,
                                         const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
-                                        void* out_nhwc, float momentum, float eps, void* stream) {
+                                        void* out_nhwc, float momentum, float eps, const float* centres, void* stream) {
     CVCL_CHECK_ARG(x_nhwc && layers && workspace && out_nhwc, "cvcl_resnext50_block_fwd: null pointer");
+    CVCL_CHECK_ARG(((uintptr_t)centres & 15) == 0, "cvcl_resnext50_block_fwd: centres must be 16-byte aligned");
     CVCL_CHECK_ARG(stage >= 0 && stage < 4 && n_layers == (first ? 4 : 3), "cvcl_resnext50_block_fwd: stage %d with %d layers", stage, n_layers);
     CVCL_CHECK_ARG(B > 0 && h > 0 && w > 0 && (!(stage > 0 && first) || (h % 2 == 0 && w % 2 == 0)), "cvcl_resnext50_block_fwd: bad shape");
     if (workspace_bytes < cvcl_resnext50_block_workspace_bytes(dtype, B, h, w, stage)) {
@@ -1237,18 +1275,22 @@ extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stag
         const int Cs[4] = {planes * 2, planes * 2, planes * 4, planes * 4};
         for (int l = 0; l < n_layers; ++l) {
             int rc = cvcl_bn_eval_affine(layers[l].gamma, layers[l].beta, layers[l].running_mean, layers[l].running_var, eps,
-                                         aff + (size_t)l * 4096, aff + (size_t)l * 4096 + 2048, Cs[l], stream);
+                                         aff + (size_t)l * 4096, aff + (size_t)l * 4096 + 2048,
+                                         centres ? centres + (size_t)l * 2048 : nullptr, Cs[l], stream);
             if (rc) return rc;
         }
     }
     BlockCtx ctx = {dtype, B, training, momentum, eps, stats, nullptr, 0, stream};
-    return bottleneck_fwd(ctx, stage, first != 0, h, w, (const char*)x_nhwc, R1, R2, R1, RD, (char*)out_nhwc, layers, aff, nullptr);
+    return bottleneck_fwd(ctx, stage, first != 0, h, w, (const char*)x_nhwc, R1, R2, R1, RD, (char*)out_nhwc, layers, aff, nullptr,
+                          centres);
 }
 
 static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, const float* x_nchw,
                               const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
-                              void* layer4_out_nhwc, float* pooled, float momentum, float eps, float* moments, void* stream) {
+                              void* layer4_out_nhwc, float* pooled, float momentum, float eps, float* moments,
+                              const float* centres, void* stream) {
     CVCL_CHECK_ARG(x_nchw && layers && workspace && layer4_out_nhwc && pooled, "cvcl_resnext50_fwd: null pointer");
+    CVCL_CHECK_ARG(((uintptr_t)centres & 15) == 0, "cvcl_resnext50_fwd: centres must be 16-byte aligned");
     CVCL_CHECK_ARG(n_layers == 53, "cvcl_resnext50_fwd: expected 53 conv+bn layers, got %d", n_layers);
     CVCL_CHECK_ARG(B > 0 && H % 32 == 0 && W % 32 == 0, "cvcl_resnext50_fwd: H, W must be multiples of 32");
     if (workspace_bytes < cvcl_resnext50_workspace_bytes(dtype, B, H, W)) {
@@ -1261,8 +1303,9 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     for (int i = 0; i < 5; ++i) { buf[i] = w; w += al256(act_elems(B, H, W) * es); }
     float* stats = (float*)w; w += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
     float* affine = (float*)w; w += al256((size_t)53 * 2 * 2048 * 4);
-    char* gram_ws = w;
+    char* gram_ws = w; w += gram_ws_bytes(B, H, W);
     const size_t gram_bytes = gram_ws_bytes(B, H, W);
+    float* eval_centres = (float*)w;                      // eval mode without caller centres: the running means (see below)
     int rc, li = 0;
 
     // (scale, shift) of layer l live at affine + l * 4096
@@ -1273,7 +1316,7 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
         if (training)
             return bn_finalize_launch(stats, rows, count, L.gamma, L.beta, L.running_mean, L.running_var, L.num_batches_tracked,
                                       momentum, eps, scale_of(l), shift_of(l), C, moments ? moments + (size_t)l * 4096 : nullptr, 2048,
-                                      stream);
+                                      centres ? centres + (size_t)l * 2048 : nullptr, stream);
         return CVCL_OK;                                   // eval mode: every layer's affine was produced up front
     };
     if (!training) {
@@ -1293,15 +1336,20 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
         for (int i = 0; i < 53; ++i)
             CVCL_CHECK_ARG(t.gamma[i] && t.beta[i] && t.rm[i] && t.rv[i], "cvcl_resnext50_fwd: layer %d lacks BatchNorm tensors", i);
         CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
-        hipLaunchKernelGGL(bn_eval_affine_all_kernel, dim3(53), dim3(256), 0, (hipStream_t)stream, t, eps, affine);
+        // eval mode in bf16 stores every raw conv output as y - running_mean unless the caller brings its own centres
+        // ($CVCL_CENTRED_STORAGE=0: plain storage; fp32 keeps plain storage -- nothing to gain there)
+        static const bool centred = [] { const char* e = getenv("CVCL_CENTRED_STORAGE"); return !(e && e[0] == '0'); }();
+        float* own = (!centres && centred && dtype == CVCL_BF16) ? eval_centres : nullptr;
+        hipLaunchKernelGGL(bn_eval_affine_all_kernel, dim3(53), dim3(256), 0, (hipStream_t)stream, t, eps, affine, centres, own);
         CVCL_LAUNCH_CHECK();
+        if (own) centres = own;
     }
 
     // ---- stem ----
     int h = H / 2, wd = W / 2;
     char* RAW = buf[2];
     const int srows = cvcl_stem_conv_stats_rows(dtype, B, H, W);
-    if ((rc = cvcl_stem_conv7x7(dtype, x_nchw, layers[0].w, RAW, stats, kMaxStatsRows, B, H, W, stream))) return rc;
+    if ((rc = cvcl_stem_conv7x7(dtype, x_nchw, layers[0].w, RAW, stats, kMaxStatsRows, centres, B, H, W, stream))) return rc;
     if ((rc = finalize(0, srows, (long)B * h * wd, 64))) return rc;
     char* X = buf[0];
     char* OUT = buf[1];
@@ -1315,7 +1363,8 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
             const bool last = (stage == 3 && bi == kLayers[3] - 1);
             char* dst = last ? (char*)layer4_out_nhwc : OUT;
             if ((rc = bottleneck_fwd(ctx, stage, bi == 0, h, wd, X, buf[2], buf[3], buf[2], buf[4], dst, layers + li,
-                                     affine + (size_t)li * 4096, moments ? moments + (size_t)li * 4096 : nullptr))) return rc;
+                                     affine + (size_t)li * 4096, moments ? moments + (size_t)li * 4096 : nullptr,
+                                     centres ? centres + (size_t)li * 2048 : nullptr))) return rc;
             li += bi == 0 ? 4 : 3;
             char* t = X; X = dst; OUT = (t == (char*)layer4_out_nhwc) ? OUT : t;
             h /= stride; wd /= stride;
@@ -1326,9 +1375,10 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
 
 extern "C" int cvcl_resnext50_fwd(int dtype, int B, int H, int W, int training, const float* x_nchw,
                                   const cvcl_convbn_params* layers, int n_layers, void* workspace, size_t workspace_bytes,
-                                  void* layer4_out_nhwc, float* pooled, float momentum, float eps, void* stream) {
+                                  void* layer4_out_nhwc, float* pooled, float momentum, float eps, const float* centres,
+                                  void* stream) {
     return resnext50_fwd_impl(dtype, B, H, W, training, x_nchw, layers, n_layers, workspace, workspace_bytes, layer4_out_nhwc, pooled,
-                              momentum, eps, nullptr, stream);
+                              momentum, eps, nullptr, centres, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1343,10 +1393,10 @@ extern "C" size_t cvcl_resnext50_moments_floats(void) { return (size_t)53 * 2 * 
 extern "C" int cvcl_resnext50_fwd_deferred_stats(int dtype, int B, int H, int W, const float* x_nchw,
                                                  const cvcl_convbn_params* layers, int n_layers, void* workspace,
                                                  size_t workspace_bytes, void* layer4_out_nhwc, float* pooled, float eps,
-                                                 float* moments, void* stream) {
+                                                 float* moments, const float* centres, void* stream) {
     CVCL_CHECK_ARG(moments, "cvcl_resnext50_fwd_deferred_stats: moments is NULL");
     return resnext50_fwd_impl(dtype, B, H, W, 1, x_nchw, layers, n_layers, workspace, workspace_bytes, layer4_out_nhwc, pooled,
-                              0.f, eps, moments, stream);
+                              0.f, eps, moments, centres, stream);
 }
 
 extern "C" int cvcl_resnext50_apply_moments(const cvcl_convbn_params* layers, int n_layers, const float* moments, float momentum,

@@ -425,7 +425,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const void* __re
 
 // batch mean / rstd from the forward statistics rows [prow][2][C] (fp64, biased variance: what bn_finalize normalised with)
 __global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict__ stats, int prow, long count, float eps, int C,
-                                                         float* __restrict__ mean, float* __restrict__ rstd) {
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
+                                                         float* __restrict__ centre_track) {
     __shared__ double ss[8][32], sq[8][32];
     const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, ch = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
@@ -444,6 +445,8 @@ __global__ __launch_bounds__(256) void bn_moments_kernel(const float* __restrict
         if (var < 0.0) var = 0.0;
         mean[ch] = (float)m;
         rstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+        // the statistics are those of the tensor stored as y - c: c + m is the batch mean of y, the next step's storage centre
+        if (centre_track) centre_track[ch] = (float)((double)centre_track[ch] + m);
     }
 }
 
@@ -540,12 +543,12 @@ extern "C" int cvcl_bn_bwd(int dtype, int mode, const void* x, const void* out, 
     return CVCL_OK;
 }
 
-extern "C" int cvcl_bn_batch_moments(const float* stats, int stats_rows, long count, float eps, float* mean, float* rstd, int C,
-                                     void* stream) {
+extern "C" int cvcl_bn_batch_moments(const float* stats, int stats_rows, long count, float eps, float* mean, float* rstd,
+                                     float* centre_track, int C, void* stream) {
     CVCL_CHECK_ARG(stats && mean && rstd && stats_rows > 0 && count > 0 && C > 0, "cvcl_bn_batch_moments: bad args");
     CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
     hipLaunchKernelGGL(bn_moments_kernel, dim3(cvcl_div_up(C, 32)), dim3(256), 0, (hipStream_t)stream, stats, stats_rows, count, eps, C,
-                       mean, rstd);
+                       mean, rstd, centre_track);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvcl_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
                   "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply", "bn_bwd", "wgrad", "gemm8w", "gemm_pro")
@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("stats", C.c_void_p), ("stats_rows", C.c_int),
         ("c_scale", C.c_void_p), ("c_shift", C.c_void_p), ("r_scale", C.c_void_p), ("r_shift", C.c_void_p),
         ("C_pre", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_int),
+        ("centre", C.c_void_p),
     ]
 
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "cvcl_last_error": (C.c_char_p, []),
     "cvcl_prof_enable": (_I, [_I]),
     "cvcl_prof_collect": (_I, [_P, _P, _I]),
+    "cvcl_prof_null_bracket_us": (_I, [_P, _I, _P]),
     "cvcl_embed_meanpool_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_embed_meanpool_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_l2norm_fwd": (_I, [_P, _P, _P, _I, _I, _F, _P]),
@@ -70,17 +72,17 @@ SIGNATURES = {
     "cvcl_gemm": (_I, [_I, C.POINTER(GemmArgs), _P]),
     "cvcl_transpose_f32": (_I, [_P, _P, _I, _I, _P]),
     "cvcl_colsum_f32": (_I, [_P, _P, _I, _I, _P]),
-    "cvcl_bn_finalize": (_I, [_P, _I, C.c_long, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _P]),
-    "cvcl_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "cvcl_bn_finalize": (_I, [_P, _I, C.c_long, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P]),
+    "cvcl_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _P, _P, _P, _I, _P]),
     "cvcl_col_stats_rows": (_I, [C.c_long]),
     "cvcl_col_stats": (_I, [_I, _P, C.c_long, _I, _P, _I, _P]),
     "cvcl_packed_weight_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "cvcl_pack_conv_weight": (_I, [_I, _I, _P, _P, _I, _I, _I, _P]),
     "cvcl_stem_conv_stats_rows": (_I, [_I, _I, _I, _I]),
-    "cvcl_stem_conv7x7": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "cvcl_stem_conv7x7": (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "cvcl_bn_relu_maxpool": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_gconv3x3_stats_rows": (_I, [_I, _I, _I, _I, _I, _I]),
-    "cvcl_gconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "cvcl_gconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "cvcl_bn_add_relu": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_bn_relu_apply": (_I, [_I, _P, _P, _P, _P, C.c_long, _I, _P]),
     "cvcl_avgpool": (_I, [_I, _P, _P, _I, _I, _I, _P]),
@@ -102,7 +104,7 @@ SIGNATURES = {
     "cvcl_bn_apply": (_I, [_I, _P, _P, _P, _P, C.c_long, _I, _I, _P]),
     "cvcl_bn_bwd_partial_rows": (_I, [_I, C.c_long, _I]),
     "cvcl_bn_bwd": (_I, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_long, _I, _P, _I, _P, _P]),
-    "cvcl_bn_batch_moments": (_I, [_P, _I, C.c_long, C.c_float, _P, _P, _I, _P]),
+    "cvcl_bn_batch_moments": (_I, [_P, _I, C.c_long, C.c_float, _P, _P, _P, _I, _P]),
     "cvcl_gconv_weight_dgrad": (_I, [_P, _P, _I, _I, _P]),
     "cvcl_transpose": (_I, [_I, _P, _P, C.c_long, _I, _P]),
     "cvcl_add": (_I, [_I, _P, _P, _P, C.c_long, _I, _P]),
@@ -151,11 +153,12 @@ SIGNATURES = {
     "cvcl_gemm_fp8_mx": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "cvcl_gemm_fp8": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P]),
+    "cvcl_resnext50_centres_floats": (_SZ, []),
+    "cvcl_resnext50_fwd": (_I, [_I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _F, _P, _P]),
     "cvcl_resnext50_block_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
-    "cvcl_resnext50_block_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _F, _F, _P]),
+    "cvcl_resnext50_block_fwd": (_I, [_I, _I, _I, _I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _F, _F, _P, _P]),
     "cvcl_resnext50_moments_floats": (_SZ, []),
-    "cvcl_resnext50_fwd_deferred_stats": (_I, [_I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _P, _P]),
+    "cvcl_resnext50_fwd_deferred_stats": (_I, [_I, _I, _I, _I, _P, C.POINTER(ConvBnParams), _I, _P, _SZ, _P, _P, _F, _P, _P, _P]),
     "cvcl_resnext50_apply_moments": (_I, [C.POINTER(ConvBnParams), _I, _P, _F, _P]),
 }
 
@@ -318,8 +321,9 @@ def cvcl_dtype(t: torch.dtype) -> int:
 
 
 def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None, a_shift=None, a_relu=False,
-         exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None):
-    """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype."""
+         exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None, centre=None):
+    """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype.
+    ``centre`` [N] f32 (convolution epilogues): C = round(A' W^T - centre), statistics of that (cvcl_hip.h "Centred storage")."""
     dt = cvcl_dtype(A.dtype)
     if W.dtype != A.dtype:
         raise CvclError("gemm operands must share a dtype")
@@ -347,6 +351,7 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
         a.C_pre = ptr(pre_out, A.dtype)
     if gelu_grad_of is not None:                          # C = (A W^T) * gelu'(gelu_grad_of)
         a.G, a.ldg = ptr(gelu_grad_of, A.dtype), N
+    a.centre = ptr(centre, torch.float32)
     check(lib().cvcl_gemm(dt, C.byref(a), stream_ptr()), "cvcl_gemm")
     return out
 
@@ -367,6 +372,13 @@ def gemm_stats_rows(dtype: int, M: int, N: int, K: int, gather=None) -> int:
 
 def prof_enable(on: bool):
     check(lib().cvcl_prof_enable(int(on)), "cvcl_prof_enable")
+
+
+def prof_null_bracket_us(n: int = 256) -> float:
+    """Event bracket of a kernel that does nothing (us): what every event-timed launch carries on top of its kernel."""
+    v = C.c_double(0.0)
+    check(lib().cvcl_prof_null_bracket_us(stream_ptr(), n, C.byref(v)), "cvcl_prof_null_bracket_us")
+    return float(v.value)
 
 
 def prof_collect():

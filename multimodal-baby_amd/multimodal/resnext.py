@@ -83,6 +83,7 @@ class ResNet(nn.Module):
         self._pack_cache = {}
         self._ws_cache = {}
         self._pre_head_callback = None                  # parallel.OverlappedUpdate: runs between the trunk and fc
+        self._centres = None                            # storage centres of the 53 raw conv outputs (see storage_centres)
 
     # ---- (conv, bn) pairs in torchvision state_dict order -----------------------------------
     def conv_bn_pairs(self):
@@ -124,6 +125,57 @@ class ResNet(nn.Module):
             torch.cuda.current_stream(device).synchronize()   # packed once, then read by every stream that runs the trunk
         self._pack_cache["k"] = (key, (arr, keep))
         return arr, keep
+
+    # ---- centred storage of the raw convolution outputs (include/cvcl_hip.h "Centred storage") ------------------------
+    # A raw conv output y whose per-channel batch mean is large next to its spread loses precision when it is rounded to bf16
+    # before BatchNorm subtracts the mean.  BatchNorm(y - c) == BatchNorm(y), so the kernels store round(y - c) with c close to
+    # the batch mean.  The frozen trunk takes c from ONE calibration pass -- the batch means of the first train-mode batch it
+    # sees after its weights (re)appeared -- and keeps it: a forward pass stays a pure function of (input, weights, BatchNorm
+    # buffers, centres), whatever the stream schedule.  c only has to be within ~sigma of the batch mean, which a stationary
+    # input distribution guarantees; ``recalibrate_centres()`` drops it (e.g. after a change of data distribution).
+    # Eval mode centres on the running means (the library's default for centres == NULL).  The fine-tuning twin
+    # (trunk_train) tracks instead: its weights move every step, so each layer's c follows the previous step's batch mean.
+    # $CVCL_CENTRED_STORAGE=0 switches the whole mechanism off (plain storage, the round-2 numerics).
+    def recalibrate_centres(self):
+        """Forget the calibrated (frozen path) and the tracked (fine-tuning path) centres: the next train-mode pass starts over."""
+        self.__dict__["_centres"] = None
+        self.__dict__["_track_centres"] = None
+
+    def centred_storage(self) -> bool:
+        return os.environ.get("CVCL_CENTRED_STORAGE", "1") != "0" and self.compute_dtype == torch.bfloat16
+
+    def tracking_centres(self, device):
+        """[53, 2048] f32 centres of the fine-tuning path, updated in place by every BatchNorm forward (trunk_train)."""
+        if not self.centred_storage():
+            return None
+        t = self.__dict__.get("_track_centres")
+        if t is None or t.device != device:
+            t = torch.zeros(53, 2048, dtype=torch.float32, device=device)
+            self.__dict__["_track_centres"] = t
+        return t
+
+    def _calibrated_centres(self, x, dt, arr, ws, nb, key):
+        """-> [53, 2048] f32 centres for a train-mode pass over ``x``'s distribution (calibrating first if need be), or None."""
+        if not self.centred_storage():
+            return None
+        hit = self.__dict__.get("_centres")
+        if hit is not None and hit[0] == key:
+            if hit[2] is not None:
+                torch.cuda.current_stream(x.device).wait_event(hit[2])     # (calibrated on another trunk stream)
+            return hit[1]
+        lib = H.lib()
+        B, _, Hh, Ww = x.shape
+        moments = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=x.device)
+        fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
+        pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
+        # a plain-storage train-mode pass that leaves every layer's batch mean behind and touches no BatchNorm buffer
+        H.check(lib.cvcl_resnext50_fwd_deferred_stats(dt, B, Hh, Ww, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap), H.ptr(pooled),
+                                                      BN_EPS, H.ptr(moments), None, H.stream_ptr()), "cvcl_resnext50_fwd_deferred_stats")
+        centres = moments.view(53, 2, 2048)[:, 0, :].contiguous()
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(x.device))
+        self.__dict__["_centres"] = (key, centres, ready)
+        return centres
 
     def trunk(self, x: torch.Tensor, defer_wait: bool = False):
         """conv1 .. layer4 + avgpool.  -> (pooled [B,2048] f32, layer4 map as a logical NCHW view).  With a trunk stream and
@@ -179,6 +231,7 @@ class ResNet(nn.Module):
                     self._ws_cache[key] = (torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device),
                                            torch.empty(B, 2048, dtype=torch.float32, device=x.device))
                 fmap, pooled = self._ws_cache[key]
+            centres = self._calibrated_centres(x, dt, arr, ws, nb, self._pack_cache["k"][0]) if self.training else None
             if piped and self.training:
                 # the pass leaves its batch moments behind; the 53 running-statistics updates run as one launch behind the
                 # previous pass's (other stream), so they are applied in pass order with the one-stream arithmetic
@@ -187,7 +240,7 @@ class ResNet(nn.Module):
                     self._ws_cache[mkey] = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=x.device)
                 moments = self._ws_cache[mkey]
                 H.check(lib.cvcl_resnext50_fwd_deferred_stats(dt, B, Hh, Ww, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap),
-                                                              H.ptr(pooled), BN_EPS, H.ptr(moments), H.stream_ptr()),
+                                                              H.ptr(pooled), BN_EPS, H.ptr(moments), H.ptr(centres), H.stream_ptr()),
                         "cvcl_resnext50_fwd_deferred_stats")
                 cur = torch.cuda.current_stream(x.device)
                 prev = self.__dict__.get("_ema_done")
@@ -202,8 +255,9 @@ class ResNet(nn.Module):
                 prev = self.__dict__.get("_ema_done")
                 if prev is not None and x.is_cuda:           # this pass reads / updates the running statistics in place: behind
                     torch.cuda.current_stream(x.device).wait_event(prev)     # the last deferred update, whatever stream ran it
+                # (eval mode: centres None = the library centres every stored tensor on its running mean)
                 H.check(lib.cvcl_resnext50_fwd(dt, B, Hh, Ww, int(self.training), H.ptr(x), arr, len(arr), H.ptr(ws), nb,
-                                               H.ptr(fmap), H.ptr(pooled), BN_MOMENTUM, BN_EPS, H.stream_ptr()),
+                                               H.ptr(fmap), H.ptr(pooled), BN_MOMENTUM, BN_EPS, H.ptr(centres), H.stream_ptr()),
                         "cvcl_resnext50_fwd")
         return pooled, fmap.permute(0, 3, 1, 2)
 
@@ -214,6 +268,8 @@ class ResNet(nn.Module):
         d["_pre_head_callback"] = None
         d["_trunk_stream"] = None
         d["_ema_done"] = None
+        d["_centres"] = None
+        d["_track_centres"] = None
         return d
 
     def __setstate__(self, d):
@@ -223,6 +279,7 @@ class ResNet(nn.Module):
         self.__dict__.setdefault("_ws_cache", {})
         self.__dict__.setdefault("_pre_head_callback", None)
         self.__dict__.setdefault("_trunk_stream", None)
+        self.__dict__.setdefault("_centres", None)
 
     def forward(self, x):
         ts = self.__dict__.get("_trunk_stream")

@@ -142,7 +142,7 @@ class Conv1x1(torch.autograd.Function):
     """nn.Conv2d(cin, cout, 1, stride, bias=False) on NHWC: x [B,H,W,K] -> raw [B,Ho,Wo,N]."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False):
+    def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False, centre=None):
         ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, Hh, Ww, K = x.shape
         N = weight.shape[0]
@@ -153,7 +153,7 @@ class Conv1x1(torch.autograd.Function):
         gather = (Ho, Wo, Hh, Ww, stride) if stride > 1 else None
         M = B * Ho * Wo
         st = torch.empty(H.gemm_stats_rows(_cd(x), M, N, K, gather), 2, N, dtype=_F, device=x.device)   # BN statistics from the epilogue
-        H.gemm(x, wq, out=out, gather=gather, M=M, lda=K, stats=st)
+        H.gemm(x, wq, out=out, gather=gather, M=M, lda=K, stats=st, centre=centre)
         ctx.save_for_backward(x, wq)
         ctx.stride = stride
         ctx.mark_non_differentiable(st)
@@ -177,7 +177,7 @@ class Conv1x1(torch.autograd.Function):
                 _defer_wgrad(ctx.param, lambda: _gemm_tn(dy2, x2), dy2, x2)
             else:
                 dw = _gemm_tn(dy2, x2).view(N, K, 1, 1)
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class Conv1x1Skip(torch.autograd.Function):
@@ -188,7 +188,7 @@ class Conv1x1Skip(torch.autograd.Function):
     dX = round(round(dY W) + d_skip) -- the same two roundings as GEMM + add, one pass less."""
 
     @staticmethod
-    def forward(ctx, x, weight, defer_wgrad: bool = False):
+    def forward(ctx, x, weight, defer_wgrad: bool = False, centre=None):
         ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, Hh, Ww, K = x.shape
         N = weight.shape[0]
@@ -197,7 +197,7 @@ class Conv1x1Skip(torch.autograd.Function):
         out = torch.empty(B, Hh, Ww, N, dtype=x.dtype, device=x.device)
         M = B * Hh * Ww
         st = torch.empty(H.gemm_stats_rows(_cd(x), M, N, K), 2, N, dtype=_F, device=x.device)   # BN statistics from the epilogue
-        H.gemm(x, wq, out=out, M=M, lda=K, stats=st)
+        H.gemm(x, wq, out=out, M=M, lda=K, stats=st, centre=centre)
         ctx.save_for_backward(x, wq)
         ctx.mark_non_differentiable(st)
         return out, st, x.view_as(x)
@@ -218,14 +218,14 @@ class Conv1x1Skip(torch.autograd.Function):
                 _defer_wgrad(ctx.param, lambda: _gemm_tn(dy2, x2), dy2, x2)
             else:
                 dw = _gemm_tn(dy2, x2).view(N, K, 1, 1)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class GroupedConv3x3(torch.autograd.Function):
     """nn.Conv2d(C, C, 3, stride, 1, groups=32, bias=False) on NHWC."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False):
+    def forward(ctx, x, weight, stride: int, defer_wgrad: bool = False, centre=None):
         ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, Hh, Ww, Cn = x.shape
         ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
@@ -234,8 +234,8 @@ class GroupedConv3x3(torch.autograd.Function):
         out = torch.empty(B, Ho, Wo, Cn, dtype=x.dtype, device=x.device)
         srows = H.lib().cvcl_gconv3x3_stats_rows(_cd(x), B, Hh, Ww, Cn, stride)
         st = torch.empty(srows, 2, Cn, dtype=_F, device=x.device)
-        H.check(H.lib().cvcl_gconv3x3(_cd(x), H.ptr(x), None, None, H.ptr(wp), H.ptr(out), H.ptr(st), srows, B, Hh, Ww, Cn, 32,
-                                      stride, H.stream_ptr()), "cvcl_gconv3x3")
+        H.check(H.lib().cvcl_gconv3x3(_cd(x), H.ptr(x), None, None, H.ptr(wp), H.ptr(out), H.ptr(st), srows, H.ptr(centre), B, Hh, Ww,
+                                      Cn, 32, stride, H.stream_ptr()), "cvcl_gconv3x3")
         ctx.save_for_backward(x, weight)
         ctx.stride = stride
         ctx.mark_non_differentiable(st)
@@ -272,16 +272,16 @@ class GroupedConv3x3(torch.autograd.Function):
             wp = _pack(wf, H.PACK_GCONV3, x.dtype)
             z = _zero_stuff(dy) if ctx.stride > 1 else dy
             dx = torch.empty_like(x)
-            H.check(lib.cvcl_gconv3x3(_cd(x), H.ptr(z), None, None, H.ptr(wp), H.ptr(dx), None, 0, B, Hh, Ww, Cn, 32, 1, s),
+            H.check(lib.cvcl_gconv3x3(_cd(x), H.ptr(z), None, None, H.ptr(wp), H.ptr(dx), None, 0, None, B, Hh, Ww, Cn, 32, 1, s),
                     "cvcl_gconv3x3")
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class StemConv(torch.autograd.Function):
     """conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False) on the NCHW fp32 images -> raw NHWC."""
 
     @staticmethod
-    def forward(ctx, x, weight, dtype, defer_wgrad: bool = False):
+    def forward(ctx, x, weight, dtype, defer_wgrad: bool = False, centre=None):
         ctx.set_materialize_grads(False)         # the statistics output gets no gradient: None, not a zero tensor filled on the device
         B, _, Hh, Ww = x.shape
         ctx.param = weight if defer_wgrad and _wgrad_deferrable(weight) else None
@@ -290,8 +290,8 @@ class StemConv(torch.autograd.Function):
         out = torch.empty(B, Hh // 2, Ww // 2, 64, dtype=dtype, device=x.device)
         rows = H.lib().cvcl_stem_conv_stats_rows(dt, B, Hh, Ww)
         st = torch.empty(rows, 2, 64, dtype=_F, device=x.device)
-        H.check(H.lib().cvcl_stem_conv7x7(dt, H.ptr(x, _F), H.ptr(wp), H.ptr(out), H.ptr(st), rows, B, Hh, Ww, H.stream_ptr()),
-                "cvcl_stem_conv7x7")
+        H.check(H.lib().cvcl_stem_conv7x7(dt, H.ptr(x, _F), H.ptr(wp), H.ptr(out), H.ptr(st), rows, H.ptr(centre), B, Hh, Ww,
+                                          H.stream_ptr()), "cvcl_stem_conv7x7")
         ctx.save_for_backward(x)
         ctx.mark_non_differentiable(st)
         return out, st
@@ -313,13 +313,14 @@ class StemConv(torch.autograd.Function):
             return dw_
         if ctx.param is not None:
             _defer_wgrad(ctx.param, wgrad, x, dy)
-            return None, None, None, None
-        return None, wgrad(), None, None
+            return None, None, None, None, None
+        return None, wgrad(), None, None, None
 
 
-def _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked):
+def _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, centre=None):
     """statistics rows (from the producing conv's epilogue, or a cvcl_col_stats pass) -> scale/shift (+ running-stat EMA),
-    batch mean and rstd."""
+    batch mean and rstd -- all of the tensor AS STORED (raw = y - centre: include/cvcl_hip.h "Centred storage"); the running
+    mean gets the centre added back, and ``centre`` is then moved to this batch's mean of y for the next step."""
     Cn = raw.shape[-1]
     rows = raw.numel() // Cn
     lib, s, dev = H.lib(), H.stream_ptr(), raw.device
@@ -332,8 +333,9 @@ def _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_ba
     scale, shift, mean, rstd = vec[0], vec[1], vec[2], vec[3]
     H.check(lib.cvcl_bn_finalize(H.ptr(stats), srows, rows, H.ptr(gamma.detach(), _F), H.ptr(beta.detach(), _F),
                                  H.ptr(running_mean, _F), H.ptr(running_var, _F), H.ptr(num_batches_tracked, torch.int64),
-                                 BN_MOMENTUM, BN_EPS, H.ptr(scale), H.ptr(shift), Cn, s), "cvcl_bn_finalize")
-    H.check(lib.cvcl_bn_batch_moments(H.ptr(stats), srows, rows, BN_EPS, H.ptr(mean), H.ptr(rstd), Cn, s), "cvcl_bn_batch_moments")
+                                 BN_MOMENTUM, BN_EPS, H.ptr(scale), H.ptr(shift), H.ptr(centre), Cn, s), "cvcl_bn_finalize")
+    H.check(lib.cvcl_bn_batch_moments(H.ptr(stats), srows, rows, BN_EPS, H.ptr(mean), H.ptr(rstd), H.ptr(centre), Cn, s),
+            "cvcl_bn_batch_moments")
     return scale, shift, mean, rstd
 
 
@@ -359,10 +361,10 @@ class BatchNormTrain(torch.autograd.Function):
     ``stats``: the per-channel (sum, sumsq) rows the producing convolution emitted, or None (computed here)."""
 
     @staticmethod
-    def forward(ctx, raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, relu: bool):
+    def forward(ctx, raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, relu: bool, centre=None):
         Cn = raw.shape[-1]
         rows = raw.numel() // Cn
-        scale, shift, mean, rstd = _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked)
+        scale, shift, mean, rstd = _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, centre)
         y = torch.empty_like(raw)
         H.check(H.lib().cvcl_bn_apply(_cd(raw), H.ptr(raw), H.ptr(scale), H.ptr(shift), H.ptr(y), rows, Cn, int(relu),
                                       H.stream_ptr()), "cvcl_bn_apply")
@@ -374,7 +376,7 @@ class BatchNormTrain(torch.autograd.Function):
     def backward(ctx, dy):
         raw, scale, shift, mean, rstd, gamma = ctx.saved_tensors
         dx, dgamma, dbeta, _ = _bn_backward(1 if ctx.relu else 0, raw, None, dy.contiguous(), scale, shift, mean, rstd, gamma, False)
-        return dx, None, dgamma, dbeta, None, None, None, None
+        return dx, None, dgamma, dbeta, None, None, None, None, None
 
 
 class BnAddRelu(torch.autograd.Function):
@@ -382,10 +384,10 @@ class BnAddRelu(torch.autograd.Function):
     hands g = dy * mask to the identity branch and runs the BatchNorm backward on g."""
 
     @staticmethod
-    def forward(ctx, raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, identity):
+    def forward(ctx, raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, identity, centre=None):
         Cn = raw.shape[-1]
         rows = raw.numel() // Cn
-        scale, shift, mean, rstd = _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked)
+        scale, shift, mean, rstd = _bn_forward_stats(raw, stats, gamma, beta, running_mean, running_var, num_batches_tracked, centre)
         out = torch.empty_like(raw)
         H.check(H.lib().cvcl_bn_add_relu(_cd(raw), H.ptr(raw), H.ptr(scale), H.ptr(shift), H.ptr(identity.contiguous(), raw.dtype),
                                          None, None, H.ptr(out), rows, Cn, H.stream_ptr()), "cvcl_bn_add_relu")
@@ -396,7 +398,7 @@ class BnAddRelu(torch.autograd.Function):
     def backward(ctx, dy):
         raw, out, mean, rstd, gamma = ctx.saved_tensors
         dx, dgamma, dbeta, g = _bn_backward(2, raw, out, dy.contiguous(), None, None, mean, rstd, gamma, True)
-        return dx, None, dgamma, dbeta, None, None, None, g
+        return dx, None, dgamma, dbeta, None, None, None, g, None
 
 
 class MaxPool3x3s2(torch.autograd.Function):
@@ -465,9 +467,9 @@ class AvgPool(torch.autograd.Function):
         return dx
 
 
-def _bn(raw_and_stats, bn, relu):
+def _bn(raw_and_stats, bn, relu, centre=None):
     raw, st = raw_and_stats
-    return BatchNormTrain.apply(raw, st, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, relu)
+    return BatchNormTrain.apply(raw, st, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, relu, centre)
 
 
 def trunk_train(model, x: torch.Tensor):
@@ -481,18 +483,35 @@ def trunk_train(model, x: torch.Tensor):
     x = x.contiguous()
     cdt = model.compute_dtype
     _WGRAD_PENDING.clear()                  # leftovers of a backward pass that died half way must not reach the next one
-    h = StemConv.apply(x, model.conv1.weight, cdt, True)
-    h = _bn(h, model.bn1, True)
+    # centred storage (resnext.ResNet "centred storage"): layer l (torchvision state_dict order) stores round(y - cen[l]) and its
+    # BatchNorm moves cen[l] to this batch's mean of y; the weights move every step, so the centres track instead of staying
+    # calibrated.  The first step runs with whatever is there (zeros = plain storage).
+    cen = model.tracking_centres(x.device)
+    li_ = [0]
+
+    def nxt():
+        c = None if cen is None else cen[li_[0]]
+        li_[0] += 1
+        return c
+    c0 = nxt()
+    h = StemConv.apply(x, model.conv1.weight, cdt, True, None if c0 is None else c0[:64])
+    h = _bn(h, model.bn1, True, None if c0 is None else c0[:64])
     h = MaxPool3x3s2.apply(h)
     for li in (1, 2, 3, 4):
         for blk in getattr(model, f"layer{li}"):
-            raw1, st1, idn = Conv1x1Skip.apply(h, blk.conv1.weight, True)      # idn = h, its gradient folded into conv1's dX GEMM
-            o = _bn((raw1, st1), blk.bn1, True)
-            o = _bn(GroupedConv3x3.apply(o, blk.conv2.weight, blk.conv2.stride[0], True), blk.bn2, True)
+            width, outc = blk.conv1.weight.shape[0], blk.conv3.weight.shape[0]
+            c1, c2, c3 = nxt(), nxt(), nxt()
+            cd_ = nxt() if blk.downsample is not None else None
+            cut = (lambda c, n: None if c is None else c[:n])
+            raw1, st1, idn = Conv1x1Skip.apply(h, blk.conv1.weight, True, cut(c1, width))      # idn = h, its gradient folded into conv1's dX GEMM
+            o = _bn((raw1, st1), blk.bn1, True, cut(c1, width))
+            o = _bn(GroupedConv3x3.apply(o, blk.conv2.weight, blk.conv2.stride[0], True, cut(c2, width)), blk.bn2, True, cut(c2, width))
             if blk.downsample is not None:
-                idn = _bn(Conv1x1.apply(idn, blk.downsample[0].weight, blk.downsample[0].stride[0], True), blk.downsample[1], False)
-            raw3, st3 = Conv1x1.apply(o, blk.conv3.weight, 1, True)
+                idn = _bn(Conv1x1.apply(idn, blk.downsample[0].weight, blk.downsample[0].stride[0], True, cut(cd_, outc)),
+                          blk.downsample[1], False, cut(cd_, outc))
+            raw3, st3 = Conv1x1.apply(o, blk.conv3.weight, 1, True, cut(c3, outc))
             b3 = blk.bn3
-            h = BnAddRelu.apply(raw3, st3, b3.weight, b3.bias, b3.running_mean, b3.running_var, b3.num_batches_tracked, idn)
+            h = BnAddRelu.apply(raw3, st3, b3.weight, b3.bias, b3.running_mean, b3.running_var, b3.num_batches_tracked, idn,
+                                cut(c3, outc))
     pooled = AvgPool.apply(h)
     return pooled, h.permute(0, 3, 1, 2)

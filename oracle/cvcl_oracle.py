@@ -349,17 +349,21 @@ def bn_name_of(conv_name: str) -> str:
 
 
 def batch_norm(x: Tensor, p: Dict[str, Tensor], name: str, training: bool,
-               stats_out: Optional[Dict[str, Tensor]] = None, impl: str = "explicit") -> Tensor:
+               stats_out: Optional[Dict[str, Tensor]] = None, impl: str = "explicit", centre: Optional[Tensor] = None) -> Tensor:
     """``nn.BatchNorm2d`` (eps 1e-5, momentum 0.1): batch statistics + running-stat EMA with
     the unbiased variance in training mode, running statistics in eval mode.  ``stats_out``
     receives the *updated* running buffers (the reference mutates them in place, also when the
     CNN is frozen: SURVEY 0.4).  ``impl="torch"`` runs the same layer through ``F.batch_norm`` on
     copies of the running buffers -- exactly what ``nn.BatchNorm2d.forward`` executes on the host;
     the CPU baseline uses it so that it times what the reference would run (tests/test_oracle_golden.py
-    checks the two forms against each other)."""
+    checks the two forms against each other).
+    ``centre`` (the HIP path's centred storage, include/cvcl_hip.h): ``x`` is the tensor stored as y - centre; BatchNorm is
+    invariant under that shift, only the running mean (train) / the mean that is subtracted (eval) need the centre back."""
     w, b = p[name + ".weight"], p[name + ".bias"]
     rm, rv = p[name + ".running_mean"], p[name + ".running_var"]
+    c = 0.0 if centre is None else centre
     if impl == "torch":
+        assert centre is None
         rm2, rv2 = rm.detach().clone(), rv.detach().clone()
         y = F.batch_norm(x, rm2, rv2, w, b, training, BN_MOMENTUM, BN_EPS)
         if training and stats_out is not None:
@@ -371,28 +375,44 @@ def batch_norm(x: Tensor, p: Dict[str, Tensor], name: str, training: bool,
         mean = x.mean(dim=(0, 2, 3))
         var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
         if stats_out is not None:
-            stats_out[name + ".running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean.detach()
+            stats_out[name + ".running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * (mean.detach() + c)
             stats_out[name + ".running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var.detach() * n / max(n - 1, 1)
             stats_out[name + ".num_batches_tracked"] = p[name + ".num_batches_tracked"] + 1
     else:
-        mean, var = rm, rv
+        mean, var = rm - c, rv
     scale = w / torch.sqrt(var + BN_EPS)
     shift = b - mean * scale
     return x * scale[None, :, None, None] + shift[None, :, None, None]
 
 
-def _conv_bn(pp, inp, name, stride, pad, groups, relu, training, quant, stats_out, taps, bn_impl="explicit", conv_fn=None):
+def _centre_of(centres, pp, name):
+    """Storage centre of conv ``name``'s raw output: None (plain), the string "running_mean" (the HIP library's eval-mode
+    default: every stored tensor is y - running_mean) or a dict conv name -> [C] tensor (calibrated / tracked centres)."""
+    if centres is None:
+        return None
+    if isinstance(centres, str):
+        assert centres == "running_mean"
+        return pp[bn_name_of(name) + ".running_mean"]
+    return centres.get(name)
+
+
+def _conv_bn(pp, inp, name, stride, pad, groups, relu, training, quant, stats_out, taps, bn_impl="explicit", conv_fn=None,
+             centres=None):
     y = (conv_fn or F.conv2d)(_q(quant, inp), _q(quant, pp[name + ".weight"]), None, stride, pad, 1, groups)
-    y = _q(quant, y)                                        # raw conv output as stored
+    c = _centre_of(centres, pp, name)
+    if c is not None:
+        y = y - c[None, :, None, None]
+    y = _q(quant, y)                                        # raw conv output as stored (centred storage: y - c)
     if taps is not None:
         taps[name + ".raw"] = y
-    y = batch_norm(y, pp, bn_name_of(name), training, stats_out, bn_impl)
+    y = batch_norm(y, pp, bn_name_of(name), training, stats_out, bn_impl, c)
     return torch.relu(y) if relu else y
 
 
-def resnext50_stem(pp, x, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit") -> Tensor:
+def resnext50_stem(pp, x, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit", centres=None,
+                  conv_fn=None) -> Tensor:
     """conv1 7x7/2 -> bn1 -> relu -> maxpool 3x3/2 pad 1."""
-    h = _conv_bn(pp, x, "conv1", 2, 3, 1, True, training, quant, stats_out, taps, bn_impl)
+    h = _conv_bn(pp, x, "conv1", 2, 3, 1, True, training, quant, stats_out, taps, bn_impl, conv_fn, centres)
     h = _q(quant, F.max_pool2d(h, 3, 2, 1))
     if taps is not None:
         taps["maxpool"] = h
@@ -400,14 +420,14 @@ def resnext50_stem(pp, x, training, quant: Quant = None, stats_out=None, taps=No
 
 
 def resnext50_block(pp, h, li: int, bi: int, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit",
-                   conv_fn=None) -> Tensor:
+                   conv_fn=None, centres=None) -> Tensor:
     """One torchvision ``Bottleneck`` of ``layer{li}``: 1x1 -> grouped 3x3 (stride here, v1.5) -> 1x1, + identity /
     1x1-stride-s downsample on the first block, ReLU after the add.  ``conv_fn`` (tests only) replaces ``F.conv2d`` -- e.g.
     by the same convolution with its input channels visited in another order, to measure what fp32 summation order alone
     does to a block's output."""
     pre = f"layer{li}.{bi}."
     stride = 2 if (li > 1 and bi == 0) else 1
-    a = (training, quant, stats_out, taps, bn_impl, conv_fn)
+    a = (training, quant, stats_out, taps, bn_impl, conv_fn, centres)
     o = _q(quant, _conv_bn(pp, h, pre + "conv1", 1, 0, 1, True, *a))
     o = _q(quant, _conv_bn(pp, o, pre + "conv2", stride, 1, RESNEXT_GROUPS, True, *a))
     o = _conv_bn(pp, o, pre + "conv3", 1, 0, 1, False, *a)
@@ -418,16 +438,17 @@ def resnext50_block(pp, h, li: int, bi: int, training, quant: Quant = None, stat
     return h
 
 
-def resnext50_stage(pp, h, li: int, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit") -> Tensor:
+def resnext50_stage(pp, h, li: int, training, quant: Quant = None, stats_out=None, taps=None, bn_impl="explicit",
+                   centres=None, conv_fn=None) -> Tensor:
     """``layer{li}``: Bottleneck x RESNEXT_LAYERS[li-1]."""
     for bi in range(RESNEXT_LAYERS[li - 1]):
-        h = resnext50_block(pp, h, li, bi, training, quant, stats_out, taps, bn_impl)
+        h = resnext50_block(pp, h, li, bi, training, quant, stats_out, taps, bn_impl, conv_fn, centres)
     return h
 
 
 def resnext50_forward(p: Dict[str, Tensor], x: Tensor, training: bool, quant: Quant = None,
                       prefix: str = "", stats_out: Optional[Dict[str, Tensor]] = None,
-                      taps: Optional[Dict[str, Tensor]] = None, bn_impl: str = "explicit"):
+                      taps: Optional[Dict[str, Tensor]] = None, bn_impl: str = "explicit", centres=None, conv_fn=None):
     """torchvision ``ResNet.forward`` for resnext50_32x4d up to and including avgpool+flatten.
 
     Returns (pooled [B,2048] fp32, layer4 feature map [B,2048,7,7]).  The ``fc`` is applied
@@ -436,13 +457,31 @@ def resnext50_forward(p: Dict[str, Tensor], x: Tensor, training: bool, quant: Qu
     (BN statistics are taken from the stored tensor), normalised activations, block outputs.
     ``taps`` (optional) collects intermediate tensors by name for layer-wise kernel tests.
     ``stats_out`` keys carry no prefix.
+    ``centres`` models the HIP path's centred storage of the raw conv outputs (``_centre_of``): stored = quant(y - c).
+    ``conv_fn`` (tests only) replaces ``F.conv2d``, e.g. by ``reordered_conv2d``: same mathematics, other fp32 summation
+    order -- the yardstick of what bf16 storage does to a chaotic network.
     """
     pp = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)} if prefix else p
-    h = resnext50_stem(pp, x, training, quant, stats_out, taps, bn_impl)
+    h = resnext50_stem(pp, x, training, quant, stats_out, taps, bn_impl, centres, conv_fn)
     for li in (1, 2, 3, 4):
-        h = resnext50_stage(pp, h, li, training, quant, stats_out, taps, bn_impl)
+        h = resnext50_stage(pp, h, li, training, quant, stats_out, taps, bn_impl, centres, conv_fn)
     pooled = h.mean(dim=(2, 3))
     return pooled, h
+
+
+def reordered_conv2d(x, w, bias, stride, pad, dil, groups):
+    """``F.conv2d`` with the input channels of every group visited in reverse order: same mathematics, other fp32 summation order."""
+    cg = w.shape[1]
+    idx = torch.arange(x.shape[1]).view(groups, cg).flip(1).reshape(-1)
+    return F.conv2d(x[:, idx].contiguous(), w.flip(1).contiguous(), bias, stride, pad, dil, groups)
+
+
+def resnext50_batch_means(p: Dict[str, Tensor], x: Tensor, quant: Quant = None) -> Dict[str, Tensor]:
+    """conv name -> per-channel batch mean of its raw output in a plain-storage train-mode pass: what the HIP trunk's
+    calibration pass leaves behind as storage centres (multimodal/resnext.py ``_calibrated_centres``)."""
+    taps: Dict[str, Tensor] = {}
+    resnext50_forward(p, x, True, quant, taps=taps)
+    return {k[:-4]: v.mean(dim=(0, 2, 3)) for k, v in taps.items() if k.endswith(".raw")}
 
 
 def resnext50_random_params(seed: int = 0, dtype=torch.float32) -> Dict[str, Tensor]:

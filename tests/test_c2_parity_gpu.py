@@ -20,14 +20,23 @@ pytestmark = pytest.mark.gpu
 
 # Thresholds (the measured values are printed by the tests and tabulated in DESIGN.md section 3).
 # The bench batch is iid uniform-noise frames (as reference tests/test_cvcl.py:14 / demo.py:11 draw them) through a
-# RANDOM-INIT trunk: every frame has the same statistics, so a conv output's per-channel spread over the batch is small next to
-# its mean, and train-mode BatchNorm (x - mean) / sigma turns one bf16 rounding of the stored conv output (2^-8 |x|) into
-# 2^-8 |x| / sigma of the normalised value -- the amplification the teacher-forced test below measures per block.  Measured on
-# MI355X at B = 256: logits max-rel 0.138, cosine 0.9915, |loss difference| 0.006 (loss 5.607); the gate below is that with
-# margin.  The 1e-3 logits gate of BASELINE.json is met in the fp32 parity mode (tests/test_head_gpu.py, test_train_entry_gpu.py).
-LOGITS_REL_BF16 = 0.25       # max |logit_bf16 - logit_fp32| / max |logit_fp32| at B = 256
-LOGITS_COS_BF16 = 0.98
-LOSS_ABS_BF16 = 2e-2
+# RANDOM-INIT trunk with train-mode BatchNorm.  That network amplifies ANY relative perturbation ~100x on the way to the
+# logits (fp32 rounding, 6e-8, arrives as 3e-5; rounding only the input frames to bf16 moves the pooled features by 0.2:
+# measured with the oracle), so a bf16 figure only means something next to what another correct bf16
+# implementation does on the same weights and batch.  The yardstick is therefore MEASURED IN THE TEST: torch's own
+# autocast(bfloat16) against torch's own fp32, both running the oracle's restatement of the reference forward on the GPU
+# (bench.torch_yardstick).  Measured on MI355X at B = 256: torch autocast 0.146 / cosine 0.9911 / |d loss| 0.005; HIP bf16
+# (centred storage, calibrated on another batch) 0.127 / 0.9922 / 0.004; plain storage (round 2) 0.134 / 0.9917.
+# The 1e-3 logits gate of BASELINE.json belongs to the fp32 parity mode and is checked here at the full size against torch fp32.
+LOGITS_REL_BF16_VS_TORCH_AUTOCAST = 1.1     # HIP bf16 deviation <= 1.1 x torch autocast's own deviation ...
+LOGITS_REL_BF16_CAP = 0.2                   # ... and below this in absolute terms
+LOGITS_COS_BF16 = 0.99
+LOSS_ABS_BF16 = 1e-2
+LOGITS_REL_FP32_VS_TORCH = 2e-4             # fp32 parity mode vs torch fp32 at B = 256 (north_star: 1e-3; measured 3.3e-5)
+# C4 (ViT-B/16, no BatchNorm) bf16 vs fp32: measured 0.016; C5 (e4m3 linears, per-token / MX block scales) vs fp32: measured
+# 0.14, cosine 0.993 -- e4m3 carries 3 mantissa bits (2^-4 relative rounding per operand element against 2^-9 for bf16)
+LOGITS_REL_C4, LOGITS_COS_C4 = 0.03, 0.9995
+LOGITS_REL_C5, LOGITS_COS_C5 = 0.2, 0.99
 # Teacher-forced block output, in bf16 ulps (2^-8) of the magnitudes that were rounded (see _ulp_error).  A block is three
 # convolutions with a train-mode BatchNorm behind each: a stored conv output whose bf16 rounding flips (fp32 summation order
 # differs between the MFMA tiles and the oracle's conv2d) is amplified by |x| / sigma in the BatchNorm that follows and spreads
@@ -49,14 +58,43 @@ def test_c2_bf16_logits_vs_fp32_at_benchmark_batch(dev):
     lit, ve, _opt = bench.build_model("c2", dev, "bf16")
     batch = bench.synthetic_batch_on_device(bench.PER_GPU_BATCH, seed=0, device=dev)
     before = {k: v.clone() for k, v in lit.state_dict().items() if "running_" in k}
+    # the trunk calibrates its storage centres on the first train-mode batch it sees: ANOTHER batch, as in a training run
+    other = bench.synthetic_batch_on_device(bench.PER_GPU_BATCH, seed=977, device=dev)
+    with torch.no_grad():
+        lit.model(other[0], other[1], other[2])
+    lit.load_state_dict(before, strict=False)
     r = bench.logits_vs_fp32(lit, batch, "bf16")
-    print("C2 B=256 bf16 vs fp32:", {k: float(f"{v:.4g}") for k, v in r.items()})
-    assert r["logits_rel_vs_fp32"] < LOGITS_REL_BF16
-    assert r["logits_cosine_vs_fp32"] > LOGITS_COS_BF16
+    ty, torch_logits = bench.torch_yardstick(lit, batch)
+    print("C2 B=256 bf16 vs fp32:", {k: float(f"{v:.4g}") for k, v in r.items()}, "| torch autocast(bf16) vs torch fp32:",
+          {k: float(f"{v:.4g}") for k, v in ty.items()})
+    assert r["logits_rel_vs_fp32"] < min(LOGITS_REL_BF16_VS_TORCH_AUTOCAST * ty["logits_rel"], LOGITS_REL_BF16_CAP)
+    assert r["logits_cosine_vs_fp32"] > max(LOGITS_COS_BF16, ty["logits_cosine"] - 1e-3)
     assert r["loss_abs_vs_fp32"] < LOSS_ABS_BF16
     after = lit.state_dict()
     assert all(torch.equal(v, after[k]) for k, v in before.items())          # the check leaves the BatchNorm buffers alone
     assert ve.model.compute_dtype == torch.bfloat16 and lit.training
+    # the fp32 parity mode against torch's own fp32 ops (the oracle's forward on the GPU) at the full benchmark size
+    lit.set_precision("32")
+    lit.model.text_embed.eval()
+    gn, lit.model.global_negatives = lit.model.global_negatives, False
+    with torch.no_grad():
+        li, _ = lit.model(batch[0], batch[1], batch[2])
+    lit.model.global_negatives = gn
+    e = float((li.double() - torch_logits.double()).abs().max() / torch_logits.double().abs().max())
+    print(f"C2 B=256 HIP fp32 vs torch fp32: logits max-rel {e:.3g}")
+    assert e < LOGITS_REL_FP32_VS_TORCH
+
+
+@pytest.mark.parametrize("cfg,rel,cos", [("c4", LOGITS_REL_C4, LOGITS_COS_C4), ("c5", LOGITS_REL_C5, LOGITS_COS_C5)])
+def test_vit_configs_logits_vs_fp32_at_benchmark_batch(dev, cfg, rel, cos):
+    """BASELINE configs[3] / [4] (saycam_contrastive_transformer: ViT-B/16 + transformer text encoder; reference
+    runner_config/saycam_contrastive_transformer.py) at their stated 256 pairs per GPU: bf16 / e4m3 linears vs the fp32 mode."""
+    import bench
+    lit, _ve, _opt = bench.build_model(cfg, dev)
+    batch = bench.synthetic_batch_on_device(bench.PER_GPU_BATCH, seed=0, device=dev)
+    r = bench.logits_vs_fp32(lit, batch, "fp8" if cfg == "c5" else "bf16")
+    print(f"{cfg.upper()} B=256 vs fp32:", {k: float(f"{v:.4g}") for k, v in r.items()})
+    assert r["logits_rel_vs_fp32"] < rel and r["logits_cosine_vs_fp32"] > cos and r["loss_abs_vs_fp32"] < 1e-2
 
 
 def _nhwc(t):
@@ -102,15 +140,14 @@ def _ulp_error(got, want, mag):
     return float(e.max()), float((e > 1.0).double().mean())
 
 
-def _reordered_conv(x, w, bias, stride, pad, dil, groups):
-    """F.conv2d with the input channels of every group visited in reverse order: same mathematics, other fp32 summation order."""
-    import torch.nn.functional as F
-    cg = w.shape[1]
-    idx = torch.arange(x.shape[1]).view(groups, cg).flip(1).reshape(-1)
-    return F.conv2d(x[:, idx].contiguous(), w.flip(1).contiguous(), bias, stride, pad, dil, groups)
+_reordered_conv = O.reordered_conv2d
 
 
-def test_bf16_blocks_teacher_forced_vs_oracle_b32(H, dev):
+@pytest.mark.parametrize("centred", [False, True])
+def test_bf16_blocks_teacher_forced_vs_oracle_b32(H, dev, centred):
+    """centred: every raw conv output stored as round(y - c) (include/cvcl_hip.h "Centred storage") with c = the batch means
+    of a plain-storage pass over ANOTHER batch (what the trunk's calibration leaves behind); the oracle's storage-point model
+    stores the same way with the same c."""
     B = 32
     p = O.resnext50_random_params(seed=1)
     g = torch.Generator().manual_seed(7)
@@ -121,7 +158,8 @@ def test_bf16_blocks_teacher_forced_vs_oracle_b32(H, dev):
             p[k] = torch.randn(p[k].shape, generator=g) * 0.1
     x, _tok, _ln = O.synthetic_batch(B, seed=3)
     taps, stats_o = {}, {}
-    O.resnext50_forward(p, x, True, O.bf16_round, stats_out=stats_o, taps=taps)
+    centres = O.resnext50_batch_means(p, O.synthetic_batch(B, seed=4)[0], O.bf16_round) if centred else None
+    O.resnext50_forward(p, x, True, O.bf16_round, stats_out=stats_o, taps=taps, centres=centres)
     lib = H.lib()
     worst, failures = (0.0, ""), []
     prev = "maxpool"
@@ -137,8 +175,15 @@ def test_bf16_blocks_teacher_forced_vs_oracle_b32(H, dev):
             out = torch.empty(B, h // stride, w // stride, 256 << (li - 1), dtype=torch.bfloat16, device=dev)
             nb = lib.cvcl_resnext50_block_workspace_bytes(H.BF16, B, h, w, li - 1)
             ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            cen = None
+            if centred:
+                cen = torch.zeros(len(arr), 2048)
+                for i, n in enumerate(["conv1", "conv2", "conv3"] + (["downsample.0"] if first else [])):
+                    c = centres[pre + n]
+                    cen[i, :c.numel()] = c
+                cen = cen.to(dev)
             H.check(lib.cvcl_resnext50_block_fwd(H.BF16, B, h, w, li - 1, int(first), 1, H.ptr(xin), arr, len(arr), H.ptr(ws), nb,
-                                                 H.ptr(out), 0.1, 1e-5, H.stream_ptr()), "cvcl_resnext50_block_fwd")
+                                                 H.ptr(out), 0.1, 1e-5, H.ptr(cen), H.stream_ptr()), "cvcl_resnext50_block_fwd")
             torch.cuda.synchronize()
             want = _nhwc(taps[pre + "out"])
             raw3 = _nhwc(taps[pre + "conv3.raw"])
@@ -148,7 +193,7 @@ def test_bf16_blocks_teacher_forced_vs_oracle_b32(H, dev):
                 mag = mag + rawd.abs() * _bn_scale(rawd, p[pre + "downsample.1.weight"])
             e_max, frac_gt1 = _ulp_error(out.float().cpu(), want, mag)
             # yardstick: the oracle's own block on the same input with the other summation order
-            alt = _nhwc(O.resnext50_block(p, taps[prev], li, bi, True, O.bf16_round, conv_fn=_reordered_conv))
+            alt = _nhwc(O.resnext50_block(p, taps[prev], li, bi, True, O.bf16_round, conv_fn=_reordered_conv, centres=centres))
             y_max, y_frac = _ulp_error(alt, want, mag)
             print(f"{pre}out: HIP vs oracle max {e_max:.1f} ulp, {frac_gt1 * 100:.4f} % > 1 ulp (max-rel {maxrel(out.float(), want):.2e}); "
                   f"oracle vs reordered oracle max {y_max:.1f} ulp, {y_frac * 100:.4f} % > 1 ulp")
@@ -208,5 +253,5 @@ def test_loss_trajectory_bf16_vs_fp32(dev, finetune, B, lr):
         # the first AdamW steps (lr / sqrt(v) normalised) move 25 M weights at once and the loss falls 100x within ~7 steps, so
         # the curves are compared by pace (above) and end point, not pointwise
         # (through the steep part of the descent -- lr 2e-3, the loss halves every few steps -- the curves differ by their local
-        # noise: measured |gap| <= 0.09 at loss ~1, 0.002 on the plateau before and 0.004 at the end)
-        assert all(abs(a - b) <= 0.1 * max(a, b) + 0.02 for a, b in zip(f32, b16)), gap
+        # noise: measured |gap| <= 0.12 at loss ~1 (round 3: 1.049 vs 0.932 at step 32), 0.002 on the plateau before and 0.005 at the end)
+        assert all(abs(a - b) <= 0.15 * max(a, b) + 0.03 for a, b in zip(f32, b16)), gap

@@ -57,21 +57,26 @@ def check_stats(stats, rows, y):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("centred", [False, True])
 @pytest.mark.parametrize("B,S", [(2, 64), (1, 224)])
-def test_stem(H, dev, dt, B, S):
+def test_stem(H, dev, dt, B, S, centred):
     g = torch.Generator().manual_seed(S)
-    x = torch.randn(B, 3, S, S, generator=g)
+    x = torch.randn(B, 3, S, S, generator=g) + (1.5 if centred else 0.0)      # (a DC component: channel means far from zero)
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
     q = _q(dt)
     ref = F.conv2d(q(x), q(w), None, 2, 3)
+    cen = ref.mean(dim=(0, 2, 3)) + 0.01 * torch.randn(64, generator=g) if centred else None   # centred storage: round(y - c)
+    if centred:
+        ref = ref - cen[None, :, None, None]
+    cend = cen.to(dev) if centred else None
     cd = H.BF16 if dt == "bf16" else H.F32
     wp = pack(H, dt, H.PACK_STEM7, w, dev)
     y = torch.empty(B, S // 2, S // 2, 64, dtype=_t(dt), device=dev)
     rows = H.lib().cvcl_stem_conv_stats_rows(cd, B, S, S)
     st = stats_tensor(rows, 64, dev)
     xd = x.to(dev)
-    H.check(H.lib().cvcl_stem_conv7x7(cd, H.ptr(xd), H.ptr(wp), H.ptr(y), H.ptr(st), rows, B, S, S, H.stream_ptr()), "stem")
-    assert maxrel(y.float(), nhwc(ref)) < (6e-3 if dt == "bf16" else 2e-5)
+    H.check(H.lib().cvcl_stem_conv7x7(cd, H.ptr(xd), H.ptr(wp), H.ptr(y), H.ptr(st), rows, H.ptr(cend), B, S, S, H.stream_ptr()), "stem")
+    assert maxrel(y.float(), nhwc(ref)) < (6e-3 if dt == "bf16" else (1e-4 if centred else 2e-5))
     check_stats(st, rows, y)
 
 
@@ -97,7 +102,7 @@ def test_bn_finalize_and_maxpool(H, dev, dt):
     scale, shift = torch.empty(Cn, device=dev), torch.empty(Cn, device=dev)
     H.check(H.lib().cvcl_bn_finalize(H.ptr(st), rows, B * S * S, H.ptr(d["bn.weight"]), H.ptr(d["bn.bias"]),
                                      H.ptr(d["bn.running_mean"]), H.ptr(d["bn.running_var"]),
-                                     H.ptr(d["bn.num_batches_tracked"]), 0.1, 1e-5, H.ptr(scale), H.ptr(shift), Cn,
+                                     H.ptr(d["bn.num_batches_tracked"]), 0.1, 1e-5, H.ptr(scale), H.ptr(shift), None, Cn,
                                      H.stream_ptr()), "bn_finalize")
     assert maxrel(d["bn.running_mean"], so["bn.running_mean"]) < 1e-5
     assert maxrel(d["bn.running_var"], so["bn.running_var"]) < 1e-5
@@ -107,15 +112,35 @@ def test_bn_finalize_and_maxpool(H, dev, dt):
     assert maxrel(y.float(), nhwc(_q(dt)(pool_o))) < (5e-3 if dt == "bf16" else 1e-5)
     # eval-mode affine
     H.check(H.lib().cvcl_bn_eval_affine(H.ptr(d["bn.weight"]), H.ptr(d["bn.bias"]), H.ptr(d["bn.running_mean"]),
-                                        H.ptr(d["bn.running_var"]), 1e-5, H.ptr(scale), H.ptr(shift), Cn, H.stream_ptr()), "affine")
+                                        H.ptr(d["bn.running_var"]), 1e-5, H.ptr(scale), H.ptr(shift), None, Cn, H.stream_ptr()), "affine")
     ref_scale = d["bn.weight"].cpu() / torch.sqrt(d["bn.running_var"].cpu() + 1e-5)
     assert maxrel(scale, ref_scale) < 1e-6
+    # centred storage: the same statistics of a tensor stored as y - c give the same scale, a shift that applies to the stored
+    # tensor, and running statistics of y itself (include/cvcl_hip.h "Centred storage")
+    cen = (raw.mean(dim=(0, 2, 3)) + 0.05 * torch.randn(Cn, generator=g))
+    xc = nhwc(_q(dt)(raw - cen[None, :, None, None])).to(_t(dt)).to(dev)
+    H.check(H.lib().cvcl_col_stats(cd, H.ptr(xc), B * S * S, Cn, H.ptr(st), rows, H.stream_ptr()), "col_stats")
+    d2 = {k: v.clone().to(dev) for k, v in p.items()}
+    scale2, shift2, cend = torch.empty(Cn, device=dev), torch.empty(Cn, device=dev), cen.to(dev)
+    H.check(H.lib().cvcl_bn_finalize(H.ptr(st), rows, B * S * S, H.ptr(d2["bn.weight"]), H.ptr(d2["bn.bias"]),
+                                     H.ptr(d2["bn.running_mean"]), H.ptr(d2["bn.running_var"]),
+                                     H.ptr(d2["bn.num_batches_tracked"]), 0.1, 1e-5, H.ptr(scale2), H.ptr(shift2), H.ptr(cend), Cn,
+                                     H.stream_ptr()), "bn_finalize")
+    tol = 1e-2 if dt == "bf16" else 1e-4
+    assert maxrel(d2["bn.running_mean"], so["bn.running_mean"]) < tol and maxrel(d2["bn.running_var"], so["bn.running_var"]) < tol
+    y_c = xc.float() * scale2 + shift2                                    # the affine applies to the stored (centred) tensor
+    assert maxrel(torch.relu(y_c), nhwc(yo)) < (2e-2 if dt == "bf16" else 1e-4)
+    H.check(H.lib().cvcl_bn_eval_affine(H.ptr(d["bn.weight"]), H.ptr(d["bn.bias"]), H.ptr(d["bn.running_mean"]),
+                                        H.ptr(d["bn.running_var"]), 1e-5, H.ptr(scale2), H.ptr(shift2), H.ptr(cend), Cn, H.stream_ptr()), "affine")
+    want = d["bn.bias"].cpu() - (d["bn.running_mean"].cpu() - cen) * ref_scale
+    assert maxrel(shift2, want) < 1e-5
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("C_,S,stride,B", [(128, 16, 1, 2), (256, 16, 2, 2), (256, 28, 1, 1), (512, 14, 2, 3),
                                            (512, 14, 1, 2), (1024, 14, 2, 2), (1024, 7, 1, 5), (128, 56, 1, 1)])
-def test_gconv(H, dev, dt, C_, S, stride, B):
+@pytest.mark.parametrize("centred", [False, True])
+def test_gconv(H, dev, dt, C_, S, stride, B, centred):
     """grouped 3x3, 32 groups, all channels-per-group the network uses (4, 8, 16, 32), both strides,
     with the producer's BN+ReLU fused into the operand load and zero padding applied after it."""
     g = torch.Generator().manual_seed(C_ + S + stride)
@@ -126,7 +151,10 @@ def test_gconv(H, dev, dt, C_, S, stride, B):
     q = _q(dt)
     xq = q(x)
     act = q(torch.relu(xq * sc[None, :, None, None] + sh[None, :, None, None]))
-    ref = q(F.conv2d(act, q(w), None, stride, 1, 1, 32))
+    ref = F.conv2d(act, q(w), None, stride, 1, 1, 32)
+    cen = ref.mean(dim=(0, 2, 3)) + 0.05 * torch.randn(C_, generator=g) if centred else None      # centred storage: round(y - c)
+    ref = q(ref - cen[None, :, None, None]) if centred else q(ref)
+    cend = cen.to(dev) if centred else None
     cd = H.BF16 if dt == "bf16" else H.F32
     wp = pack(H, dt, H.PACK_GCONV3, w, dev)
     So = (S - 1) // stride + 1
@@ -135,7 +163,7 @@ def test_gconv(H, dev, dt, C_, S, stride, B):
     st = stats_tensor(rows, C_, dev)
     xd, scd, shd = nhwc(xq).to(_t(dt)).to(dev), sc.to(dev), sh.to(dev)      # keep device operands alive
     H.check(H.lib().cvcl_gconv3x3(cd, H.ptr(xd), H.ptr(scd), H.ptr(shd), H.ptr(wp),
-                                  H.ptr(y), H.ptr(st), rows, B, S, S, C_, 32, stride, H.stream_ptr()), "gconv")
+                                  H.ptr(y), H.ptr(st), rows, H.ptr(cend), B, S, S, C_, 32, stride, H.stream_ptr()), "gconv")
     torch.cuda.synchronize()
     assert maxrel(y.float(), nhwc(ref)) < (8e-3 if dt == "bf16" else 2e-5)
     check_stats(st, rows, y)
@@ -194,7 +222,12 @@ def test_trunk_vs_oracle(H, dev, dt, training, B, S):
             p[k] = torch.randn(p[k].shape, generator=g) * 0.1
     x = torch.randn(B, 3, S, S, generator=g)
     stats_o = {}
-    pooled_o, fmap_o = O.resnext50_forward(p, x, training, _q(dt) if dt == "bf16" else None, stats_out=stats_o)
+    # bf16 stores every raw conv output centred (include/cvcl_hip.h "Centred storage"): on the batch means of a plain-storage
+    # calibration pass in train mode, on the running means in eval mode; the oracle's storage-point emulation does the same
+    centres = None
+    if dt == "bf16":
+        centres = O.resnext50_batch_means(p, x, _q(dt)) if training else "running_mean"
+    pooled_o, fmap_o = O.resnext50_forward(p, x, training, _q(dt) if dt == "bf16" else None, stats_out=stats_o, centres=centres)
     model = ResNet()
     _load_oracle_params_into(model, p)
     model = model.to(dev)
@@ -209,12 +242,17 @@ def test_trunk_vs_oracle(H, dev, dt, training, B, S):
     assert fmap.shape == fmap_o.shape
     sd = model.state_dict()
     if dt == "bf16" and training:
-        # A random-init ResNeXt with batch-statistic BN over a handful of samples is chaotic in bf16: the
-        # oracle's own bf16 emulation moves by 0.1 (pooled) / 0.3 (map) max-rel when its inputs are perturbed by
-        # 2e-7 (measured in the build container, DESIGN.md "bf16 train-mode sensitivity").  So the end-to-end
-        # check is directional, and exactness is carried by the per-kernel tests above plus the statistics of
-        # the early layers, which the amplification has not reached yet.
-        assert cos > 0.97 and e_p < 0.6
+        # A random-init ResNeXt with batch-statistic BN over a handful of samples is chaotic in bf16: one flipped bf16
+        # rounding of a stored value spreads through every later BatchNorm.  The tolerance is therefore MEASURED, not assumed:
+        # the oracle's own storage-point emulation with every convolution's input channels visited in reverse order (same
+        # mathematics, other fp32 summation order) against itself.  The HIP trunk must be as close to the oracle as that
+        # (x 3: a max over 2048 x B values of a heavy-tailed error), and the early layers' statistics, which the amplification
+        # has not reached yet, must agree to bf16 precision.
+        pooled_y, fmap_y = O.resnext50_forward(p, x, True, _q(dt), centres=centres, conv_fn=O.reordered_conv2d)
+        y_p, y_f = maxrel(pooled_y, pooled_o), maxrel(fmap_y, fmap_o)
+        y_cos = float(torch.nn.functional.cosine_similarity(pooled_y.flatten().double(), pooled_o.flatten().double(), dim=0))
+        print(f"   yardstick (oracle vs reordered oracle): pooled {y_p:.2e}, map {y_f:.2e}, cos {y_cos:.5f}")
+        assert e_p < 3 * y_p + 0.02 and e_f < 3 * y_f + 0.02 and 1 - cos < 3 * (1 - y_cos) + 1e-3
         for k, tol_k in (("bn1.running_mean", 2e-3), ("bn1.running_var", 2e-3), ("layer1.0.bn1.running_mean", 1e-2),
                          ("layer1.0.bn2.running_var", 2e-2), ("layer1.0.downsample.1.running_var", 2e-2)):
             assert maxrel(sd[k], stats_o[k]) < tol_k, k
@@ -257,8 +295,10 @@ def test_deferred_statistics_pass_is_the_in_place_pass(H, dev, dt):
         before = {k: v.clone() for k, v in alt.state_dict().items() if "running" in k or "tracked" in k}
         fmap = torch.empty(B, S // 32, S // 32, 2048, dtype=_t(dt), device=dev)
         pooled = torch.empty(B, 2048, dtype=torch.float32, device=dev)
+        cen = ref.__dict__["_centres"][1] if ref.__dict__.get("_centres") else None      # bf16: the storage centres ref calibrated
+        assert (cen is not None) == (dt == "bf16")
         H.check(lib.cvcl_resnext50_fwd_deferred_stats(cd, B, S, S, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap), H.ptr(pooled),
-                                                      BN_EPS, H.ptr(moments), H.stream_ptr()), "deferred")
+                                                      BN_EPS, H.ptr(moments), H.ptr(cen), H.stream_ptr()), "deferred")
         after = alt.state_dict()
         assert all(torch.equal(v, after[k]) for k, v in before.items())          # the pass wrote no BatchNorm buffer
         H.check(lib.cvcl_resnext50_apply_moments(arr, len(arr), H.ptr(moments), BN_MOMENTUM, H.stream_ptr()), "apply")
@@ -272,7 +312,7 @@ def test_deferred_statistics_pass_is_the_in_place_pass(H, dev, dt):
     assert n == 53 * 3 and int(sd_a["layer4.2.bn3.num_batches_tracked"]) == 3
     with pytest.raises(H.CvclError):
         H.check(lib.cvcl_resnext50_fwd_deferred_stats(cd, B, S, S, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap), H.ptr(pooled),
-                                                      BN_EPS, None, H.stream_ptr()), "deferred")
+                                                      BN_EPS, None, None, H.stream_ptr()), "deferred")
 
 
 def test_trunk_properties_full_batch(H, dev):

@@ -285,6 +285,7 @@ def test_trunk_bf16_grads_finite_deterministic(dev):
     for cdt in (torch.float32, torch.bfloat16, torch.bfloat16):
         model.compute_dtype = cdt
         model.zero_grad(set_to_none=True)
+        model.recalibrate_centres()                               # ... and the same (zero) storage centres: they track step by step
         with torch.no_grad():                                     # same running statistics going in every time
             for m in model.modules():
                 if isinstance(m, torch.nn.BatchNorm2d):
@@ -319,6 +320,7 @@ def test_weight_gradient_stream_is_bit_identical(dev, monkeypatch, cdt):
     for mode in ("0", "1"):
         monkeypatch.setenv("CVCL_WGRAD_STREAM", mode)
         model.zero_grad(set_to_none=True)
+        model.recalibrate_centres()                                   # both modes start from the same (zero) storage centres
         for _ in range(2):                                        # the second pass accumulates into existing .grad tensors
             with torch.no_grad():
                 for m in model.modules():
