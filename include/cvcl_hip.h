@@ -11,6 +11,9 @@
  *    only enqueues work on the passed hipStream_t (passed as void*; NULL = default stream).
  *  - return 0 on success, negative CVCL_E* otherwise; cvcl_last_error() gives the thread-local text.
  *  - scratch comes from the caller: cvcl_*_workspace_bytes() sizes it.
+ *  - ONE DEVICE PER PROCESS (the launch model of the path: one rank per GPU).  Occupancy queries, CU counts and the raised
+ *    dynamic-LDS attributes are cached per process on first use, for the device that is current then; a process that
+ *    switches devices afterwards gets the first device's grid and statistics-row counts and unraised LDS limits there.
  *  - dtype: CVCL_F32 = fp32 storage + exact-fp32 MFMA (parity mode, the reference numerics);
  *           CVCL_BF16 = bf16 storage + bf16 MFMA with fp32 accumulation/statistics (perf mode).
  *  - image activations inside the library are NHWC ("channels last"); the API takes the

@@ -223,7 +223,12 @@ class Trainer:
         if parallel.is_distributed():
             # replicas were initialised from the same seed (identical weights); from here on every rank draws its own dropout
             # masks / augmentation parameters, and the data module hands it its own shard of every global batch
-            seed_everything(int(os.environ.get("PL_GLOBAL_SEED", torch.initial_seed() % (2 ** 31))) + parallel.rank())
+            # (seeded directly: seed_everything would overwrite $PL_GLOBAL_SEED with base + rank, and a second fit() in the same
+            # process -- resume, fit after fit -- would add the rank again)
+            base = int(os.environ.get("PL_GLOBAL_SEED", torch.initial_seed() % (2 ** 31)))
+            random.seed(base + parallel.rank())
+            np.random.seed((base + parallel.rank()) % (2 ** 32))
+            torch.manual_seed(base + parallel.rank())
         model.trainer = self
         datamodule.prepare_data()
         datamodule.setup()

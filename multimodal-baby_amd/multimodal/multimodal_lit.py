@@ -182,11 +182,15 @@ class MultiModalLitModel(LightningModule):
         else:
             lm_ce_loss = 0.
         # data-parallel, global negatives: InfoNCE is the replicated full-batch loss and per-rank gradients are SUMMED; the LM
-        # cross entropy is a mean over this rank's tokens only, so it enters with 1 / world (sum over ranks = global mean).
-        # The logged / returned ce_loss values stay the rank's own means.
+        # cross entropy is a mean over this rank's tokens only, so it enters with 1 / world: the sum over ranks is then the mean
+        # of the rank means -- the token-weighted global mean a single process computes whenever the ranks hold the same number
+        # of tokens (equal-length shards), an approximation of it otherwise (like the mean of per-rank means under Lightning
+        # DDP).  The optimised loss carries the scale; the logged / returned values are the unscaled joint loss and the rank's
+        # own ce means.
         lm_scale = parallel.local_term_scale(self.model.global_negatives) if (self.training and self.lambda_lm) else 1.0
         loss = self.lambda_mm * infonce_loss + (self.lambda_lm * lm_scale) * lm_ce_loss
-        log(f"{stage}_loss", loss)
+        logged = loss if lm_scale == 1.0 else (self.lambda_mm * infonce_loss + self.lambda_lm * lm_ce_loss).detach()
+        log(f"{stage}_loss", logged)
         ret.update({"loss": loss})
         return ret
 

@@ -36,7 +36,13 @@ import torch.distributed as dist
 
 
 def is_distributed() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group with more than one rank -- or, with $CVCL_FORCE_DIST=1, any initialised process group: a world-size-1
+    ``nccl`` (= RCCL) group then drives the whole multi-GPU path (feature all-gather, bucket all-reduce from the hooks,
+    ``OverlappedUpdate``, the trunk streams) on a single GPU, with results that must equal the plain single-process step bit
+    for bit (tests/test_parallel_gpu.py::test_rccl_world1_*)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CVCL_FORCE_DIST", "0") == "1"
 
 
 def world_size() -> int:
@@ -145,7 +151,7 @@ class DataParallelEngine:
             offs[id(p)] = off
             off += p.numel()
         b = {"params": list(params), "buf": torch.zeros(total, dtype=params[0].dtype, device=params[0].device),
-             "pending": len(params), "handle": None, "seen": set(), "offs": offs}
+             "pending": len(params), "handle": None, "seen": set(), "offs": offs, "events": []}
         self.buckets.append(b)
         for p in params:
             self._bucket_of[id(p)] = b
@@ -158,6 +164,14 @@ class DataParallelEngine:
         b["seen"].add(id(p))
         off = b["offs"][id(p)]
         b["buf"][off:off + p.numel()].copy_(grad.reshape(-1))
+        # Gradients reach a bucket from more than one stream: autograd's hooks run on the backward (main) stream, trunk_train's
+        # weight gradients on its side stream.  The collective is enqueued behind whichever stream makes the LAST arrival, so
+        # every arrival leaves an event behind its copy and ``_launch`` makes the launching stream wait for all of them
+        # (without this a bucket that closes on a BatchNorm hook reduced conv gradients still being written on the side stream).
+        if b["buf"].is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(b["buf"].device))
+            b["events"].append(ev)
         b["pending"] -= 1
         if b["pending"] == 0:
             self._launch(b)
@@ -180,6 +194,11 @@ class DataParallelEngine:
 
     def _launch(self, b):
         b["had_grad"] = [id(p) in b["seen"] or p.grad is not None for p in b["params"]]
+        if b["events"]:                                      # behind every stream that wrote into the bucket
+            cur = torch.cuda.current_stream(b["buf"].device)
+            for ev in b["events"]:
+                cur.wait_event(ev)
+            b["events"] = []
         for p in b["params"]:                                # parameters without a gradient this step contribute zeros
             if id(p) not in b["seen"] or id(p) in b.get("late", ()):
                 off = b["offs"][id(p)]
@@ -205,6 +224,7 @@ class DataParallelEngine:
                     averaged = (not self.global_negatives) or getattr(p, "_cvcl_replicated_grad", False)
                     p.grad.copy_(g / world if averaged else g)
             b["pending"], b["handle"] = len(b["params"]), None
+            b["events"] = []
             b["seen"].clear()
             b.pop("late", None)
 

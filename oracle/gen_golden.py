@@ -514,6 +514,67 @@ def case_reference_checkpoint(mm, lit_mod, vits):
     save("ref_lit_vit_io", x=x, tokens=tok, lengths=ln, logits_per_image=lpi, logits_per_text=lpt, image_features=fi,
          text_features=ft, keys=np.array(sorted(sd.keys())), temperature=sd["model.logit_neg_log_temperature"].reshape(1),
          n_params=np.array([sum(p_.numel() for p_ in lit.parameters())]))
+    case_eval_trials(lit)
+
+
+def case_eval_trials(lit):
+    """f2: the evaluation callers, driven on the REFERENCE with the checkpoint model above (eval mode).
+    * ``MultiModalLitModel.validation_step(batch, i, dataloader_idx=1)`` (multimodal_lit.py:456-511): one 4-image trial per
+      batch, x [1, 4, C, H, W] reshaped to the batch dim, ``logits_per_text[0]``, accuracy / entropy / per-category accuracy
+      as the reference logs them (the stub LightningModule.log records every call);
+    * ``validation_step(batch, i, dataloader_idx=0)``: the val pairs through calculate_joint_loss (:266-309) in eval mode;
+    * the per-trial record of eval.py:196-232 for --eval_type image (one label, four frames: softmax(logits_per_text)[0],
+      argmax) and --eval_type text (one frame, four labels: softmax(logits_per_image)[0], argmax) -- the reference model is
+      called exactly as eval.py calls it (``model(img, label, label_len)``), the three post-processing expressions are
+      eval.py's own."""
+    cats = ["ball", "car", "kitty", "dog", "chair", "bottle"]
+    n_tr = len(cats)
+    g = torch.Generator().manual_seed(21)
+    x_tr = torch.randn(n_tr, 4, 3, 32, 32, generator=g)
+    calls = []
+    lit.log = lambda name, value, *a, **k: calls.append((name, float(value)))
+    acc, ent, logit_rows, keys = [], [], [], []
+    toks, lens = [], []
+    for i, c in enumerate(cats):
+        y, y_len = lit.tokenize([c])                                  # <sos> c <eos>, padded to 25 (multimodal_lit.py:163-183)
+        toks.append(y[0]); lens.append(y_len[0])
+        calls.clear()
+        with torch.no_grad():
+            ret = lit.validation_step((x_tr[i:i + 1], y, y_len, [[c]]), i, dataloader_idx=1)
+            _lpi, lpt = lit.model(x_tr[i], y, y_len)
+        d = dict(calls)
+        assert set(d) == {"val_accuracy", "val_entropy", f"val_accuracy_{c}"}, d
+        assert d["val_accuracy"] == ret["accuracy"] == d[f"val_accuracy_{c}"]
+        acc.append(ret["accuracy"]); ent.append(d["val_entropy"]); logit_rows.append(lpt[0]); keys.append(sorted(d))
+    # eval.py:196-232, --eval_type image
+    img_soft = [torch.softmax(r[None], dim=-1).detach().cpu().numpy().tolist()[0] for r in logit_rows]
+    img_pred = [int(torch.argmax(r[None], dim=-1).item()) for r in logit_rows]
+    # --eval_type text: frame 0 of every trial against four labels (target first)
+    txt_soft, txt_pred, txt_tok, txt_len = [], [], [], []
+    for i in range(n_tr):
+        labels = [cats[i]] + [cats[(i + k) % n_tr] for k in (1, 2, 3)]
+        y, y_len = lit.tokenize(labels)
+        with torch.no_grad():
+            lpi, _ = lit.model(x_tr[i, :1], y, y_len)
+        txt_soft.append(torch.softmax(lpi, dim=-1).detach().cpu().numpy().tolist()[0])
+        txt_pred.append(int(torch.argmax(lpi, dim=-1).item()))
+        txt_tok.append(y); txt_len.append(y_len)
+    # dataloader_idx 0: the val pairs (batch of 5 image / utterance pairs)
+    xv = torch.randn(5, 3, 32, 32, generator=g)
+    yv, lv = lit.tokenize(["look at the ball", "car", "a kitty here", "the dog", "bottle on the chair"])
+    calls.clear()
+    with torch.no_grad():
+        rv = lit.validation_step((xv, yv, lv, [["x"]] * 5), 0, dataloader_idx=0)
+    assert not calls                                                  # validation logs at epoch end only (empty_log, :461-463)
+    val = {k: float(v) for k, v in rv.items() if torch.is_tensor(v) and v.numel() == 1 or isinstance(v, (int, float))}
+    print("eval trials: accuracy", acc, "val step keys", sorted(rv.keys()))
+    save("eval_trials", x_trials=x_tr, tokens=torch.stack(toks), lengths=torch.stack(lens), categories=np.array(cats),
+         logits_per_text_row=torch.stack(logit_rows), accuracy=np.array(acc), entropy=np.array(ent),
+         logged_keys=np.array(keys), image_softmax=np.array(img_soft), image_pred=np.array(img_pred),
+         text_tokens=torch.stack(txt_tok), text_lengths=torch.stack(txt_len), text_softmax=np.array(txt_soft),
+         text_pred=np.array(txt_pred), x_val=xv, val_tokens=yv, val_lengths=lv,
+         val_keys=np.array(sorted(val.keys())), val_values=np.array([val[k] for k in sorted(val.keys())]),
+         val_all_keys=np.array(sorted(rv.keys())))
 
 
 def case_tokenizer(lit_mod):

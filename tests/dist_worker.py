@@ -3,6 +3,7 @@ share the box's one GPU over the gloo backend (CVCL_DIST_BACKEND=gloo; RCCL refu
 
     dist_worker.py bench_step OUT            one C2 step at 256 pairs per rank through DataParallelEngine + OverlappedUpdate
     dist_worker.py train OUT -- <train.py args>   Trainer.fit through train.py; dumps the trainable parameters
+    dist_worker.py rccl_w1 OUT               ONE rank, backend nccl (= RCCL), $CVCL_FORCE_DIST=1: the whole multi-GPU path on one GPU
 
 Not a test module itself (no test_ prefix)."""
 import os
@@ -69,8 +70,74 @@ def train(out_dir, argv):
         dist.destroy_process_group()
 
 
+def rccl_w1(out_dir):
+    """World-size-1 RCCL process group driving _AllGatherRows, DataParallelEngine (hooks, bucket launch behind the producing
+    streams, handle.wait()), OverlappedUpdate and the two trunk streams; each schedule is run twice -- through the process group
+    ($CVCL_FORCE_DIST=1) and as the plain single-process step -- from identical initial states, for the frozen C2 step and for
+    --finetune_cnn (weight gradients arriving from trunk_train's side stream).  The caller compares bit for bit."""
+    import bench
+    from multimodal import parallel
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl"
+    res = {}
+
+    def run(tag, forced, finetune, B, steps):
+        os.environ["CVCL_FORCE_DIST"] = "1" if forced else "0"
+        assert parallel.is_distributed() == forced
+        lit, ve, _ = bench.build_model("c2", device, "bf16", seed=5)
+        if finetune:
+            for prm in ve.model.parameters():
+                prm.requires_grad_(True)
+        opt = lit.configure_optimizers()
+        engine = parallel.DataParallelEngine(device, bucket_bytes=8 << 20, global_negatives=True).attach(lit)
+        assert bool(engine.buckets) == forced
+        batch = bench.synthetic_batch_on_device(B, seed=1, device=device) + (None,)
+        if not finetune:
+            ve.model.enable_trunk_stream(device, inputs="ready", n_streams=2)
+        upd = parallel.OverlappedUpdate(engine, opt, ve) if forced else None
+        assert upd is None or upd.can_defer == (not finetune)
+        losses = []
+        for _ in range(steps):
+            if upd is None:
+                opt.zero_grad(set_to_none=True)
+                out = lit.training_step(batch, 0)
+                out["loss"].backward()
+                engine.reduce_gradients()
+                opt.step()
+            else:
+                out = lit.training_step(batch, 0)
+                upd.zero_grad()
+                out["loss"].backward()
+                upd.step_done()
+            losses.append(out["loss"].detach().clone())
+        if upd is not None:
+            upd.flush()
+        torch.cuda.synchronize()
+        if not finetune:
+            ve.model.enable_trunk_stream(device, inputs=None)
+        res[tag] = {"losses": [float(v) for v in losses],
+                    "state": {k: v.detach().cpu().clone() for k, v in lit.state_dict().items()}}
+        del lit, ve, opt, engine, upd
+
+    run("frozen_dist", True, False, 256, 4)
+    run("frozen_plain", False, False, 256, 4)
+    run("finetune_dist", True, True, 16, 3)
+    run("finetune_plain", False, True, 16, 3)
+    with open("/proc/self/maps") as f:
+        res["librccl_mapped"] = any("librccl" in line for line in f)
+    torch.save(res, os.path.join(out_dir, "w1.pt"))
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
     mode, out = sys.argv[1], sys.argv[2]
+    if mode == "rccl_w1":
+        rccl_w1(out)
+        raise SystemExit(0)
     if mode == "bench_step":
         bench_step(out)
     elif mode == "train":

@@ -62,3 +62,59 @@ def test_reference_written_checkpoint_reproduces_reference_logits(ckpt_path, dev
     with torch.no_grad():
         lpi16, _ = lit(x, tok, ln)
     assert maxrel(lpi16, g["logits_per_image"]) < 3e-2
+
+
+@pytest.mark.gpu
+def test_eval_callers_reproduce_the_reference(ckpt_path, dev):
+    """f2 -- the evaluation callers against the REFERENCE's own outputs (tests/golden/eval_trials.npz, written by
+    oracle/gen_golden.py::case_eval_trials with the reference's MultiModalLitModel.validation_step, multimodal_lit.py:456-511,
+    and the per-trial record of the reference's eval.py:196-232), on the checkpoint the reference wrote:
+    validation_step idx 1 (one 4-image trial per batch: accuracy, entropy, logged keys incl. the per-category accuracy),
+    validation_step idx 0 (the val pairs through calculate_joint_loss in eval mode), and eval.py's batched trial evaluation
+    for --eval_type image / text (softmax list, pred)."""
+    import eval as eval_entry
+    from multimodal.multimodal_lit import MultiModalLitModel
+    g = load_golden("eval_trials")
+    lit, _pre = MultiModalLitModel.load_model("cvcl", checkpoint_path=ckpt_path)
+    lit.to(dev).eval()
+    lit.set_precision("32")
+    calls = []
+    lit.log = lambda name, value, *a, **k: calls.append((name, float(value)))
+    cats = [str(c) for c in g["categories"]]
+    x_tr = g["x_trials"]
+    for i, c in enumerate(cats):
+        y, y_len = g["tokens"][i:i + 1].to(dev), g["lengths"][i:i + 1].to(dev)
+        calls.clear()
+        with torch.no_grad():
+            ret = lit.validation_step((x_tr[i:i + 1].to(dev), y, y_len, [[c]]), i, dataloader_idx=1)
+        d = dict(calls)
+        assert sorted(d) == [str(k) for k in g["logged_keys"][i]], (c, sorted(d))
+        row = g["logits_per_text_row"][i]
+        clear = float(torch.sort(row, descending=True).values[:2].diff().abs()) > 1e-3 * float(row.abs().max())
+        if clear:                                                          # (a near-tie may fall either way within 1e-4 rel)
+            assert ret["accuracy"] == int(g["accuracy"][i]) == d["val_accuracy"] == d[f"val_accuracy_{c}"], c
+        assert abs(d["val_entropy"] - float(g["entropy"][i])) < 1e-4, (c, d["val_entropy"], float(g["entropy"][i]))
+    # eval.py: --eval_type image (all six trials in ONE device pass: trial t = the t-th diagonal block) and the batch-1 loop
+    trials = [(x_tr[i:i + 1], g["tokens"][i:i + 1], g["lengths"][i:i + 1], [[cats[i]]]) for i in range(len(cats))]
+    for group in (trials, None):
+        outs = (eval_entry.evaluate_trials(lit, trials, "image", dev) if group is not None
+                else [eval_entry.evaluate_trials(lit, [t], "image", dev)[0] for t in trials])
+        for i, (soft, pred) in enumerate(outs):
+            want = g["image_softmax"][i]
+            assert float((torch.tensor(soft) - want).abs().max()) < 2e-5, i
+            if float(torch.sort(want, descending=True).values[:2].diff().abs()) > 1e-4:
+                assert pred == int(g["image_pred"][i]), i
+    # --eval_type text: one frame, four labels
+    ttr = [(x_tr[i:i + 1, :1], g["text_tokens"][i:i + 1], g["text_lengths"][i:i + 1], [[cats[i]]]) for i in range(len(cats))]
+    for i, (soft, pred) in enumerate(eval_entry.evaluate_trials(lit, ttr, "text", dev)):
+        want = g["text_softmax"][i]
+        assert float((torch.tensor(soft) - want).abs().max()) < 2e-5, i
+        if float(torch.sort(want, descending=True).values[:2].diff().abs()) > 1e-4:
+            assert pred == int(g["text_pred"][i]), i
+    # validation_step idx 0: the val pairs
+    calls.clear()
+    with torch.no_grad():
+        rv = lit.validation_step((g["x_val"].to(dev), g["val_tokens"].to(dev), g["val_lengths"].to(dev), [["x"]] * 5), 0, dataloader_idx=0)
+    assert not calls and sorted(rv.keys()) == [str(k) for k in g["val_all_keys"]]
+    for k, v in zip(g["val_keys"], g["val_values"]):
+        assert abs(float(rv[str(k)]) - float(v)) < 1e-4 * max(1.0, abs(float(v))), (k, float(rv[str(k)]), float(v))

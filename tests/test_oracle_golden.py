@@ -205,3 +205,17 @@ def test_batch_norm_forms_agree():
     a = O.cvcl_contrastive_loss(pr, img, tok, ln, normalize_features=True, training=True)
     b = O.cvcl_contrastive_loss(pr, img, tok, ln, normalize_features=True, training=True, bn_impl="torch")
     assert abs(float(a[0]) - float(b[0])) < 1e-4
+
+
+def test_eval_trials_fixture_is_self_consistent_with_the_oracle():
+    """tests/golden/eval_trials.npz (reference validation_step idx 1 + eval.py record): accuracy = [argmax == 0], entropy =
+    get_entropy(logits row) (oracle restatement of multimodal/utils.py:106-108), eval.py's softmax list / pred of the same row."""
+    g = load_golden("eval_trials")
+    rows = g["logits_per_text_row"]
+    for i in range(rows.shape[0]):
+        assert int(g["accuracy"][i]) == int(int(torch.argmax(rows[i])) == 0)
+        assert abs(float(O.get_entropy(rows[i])) - float(g["entropy"][i])) < 1e-5
+        assert float((torch.softmax(rows[i].double(), -1) - g["image_softmax"][i]).abs().max()) < 1e-6
+        assert int(g["image_pred"][i]) == int(torch.argmax(rows[i]))
+        c = str(g["categories"][i])
+        assert [str(k) for k in g["logged_keys"][i]] == sorted(["val_accuracy", "val_entropy", f"val_accuracy_{c}"])

@@ -71,6 +71,28 @@ def test_two_ranks_global_negatives_n512_vs_oracle(tmp_path):
     assert r[0]["losses"] == r[1]["losses"] and r[0]["losses"][1] < r[0]["losses"][0] + 0.5
 
 
+def test_rccl_world1_drives_the_whole_multi_gpu_path_bit_identically(tmp_path):
+    """The RCCL branch on the one GPU there is: a world-size-1 ``nccl`` process group with $CVCL_FORCE_DIST=1 runs the feature
+    all-gather (all_gather_into_tensor), the bucketed all-reduce launched from the gradient hooks / from trunk_train's side
+    stream, OverlappedUpdate and the two trunk streams.  With one rank every collective is the identity, so losses, parameters
+    and BatchNorm buffers must equal the plain single-process schedule bit for bit -- any missing stream edge (a collective
+    reading a bucket before its producer stream has written it, an update applied before the wait) breaks that."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CVCL_DIST_BACKEND"):
+        env.pop(k, None)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, WORKER, "rccl_w1", str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = torch.load(tmp_path / "w1.pt", weights_only=False)
+    assert res["librccl_mapped"]
+    for mode in ("frozen", "finetune"):
+        a, b = res[mode + "_dist"], res[mode + "_plain"]
+        assert a["losses"] == b["losses"], (mode, a["losses"], b["losses"])
+        assert a["losses"][-1] < a["losses"][0]
+        for k, v in a["state"].items():
+            assert torch.equal(v, b["state"][k]), (mode, k)
+
+
 COMMON = ("--dataset synthetic --text_encoder embedding --embedding_dim 64 --vit_dino --normalize_features --fix_temperature "
           "--optimize_unused --checkpoint_callback False --logger False --max_epochs 1 --limit_train_batches 2 "
           "--check_val_every_n_epoch 100 --lr 1e-3 --weight_decay 0.1 --precision 32 --seed 3")
