@@ -19,7 +19,7 @@ def run(B, S, C, stride):
     rows = H.lib().cvcl_gconv3x3_stats_rows(H.BF16, B, S, S, C, stride)
     st = torch.empty(rows, 2, C, device=dev)
     def call():
-        H.check(H.lib().cvcl_gconv3x3(H.BF16, H.ptr(x), H.ptr(sc), H.ptr(sh), H.ptr(wp), H.ptr(y), H.ptr(st), rows, B, S, S, C, 32, stride, H.stream_ptr()), "gconv")
+        H.check(H.lib().cvcl_gconv3x3(H.BF16, H.ptr(x), H.ptr(sc), H.ptr(sh), H.ptr(wp), H.ptr(y), H.ptr(st), rows, None, B, S, S, C, 32, stride, H.stream_ptr()), "gconv")
     for _ in range(3): call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

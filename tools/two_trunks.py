@@ -22,7 +22,7 @@ def run(nstreams):
         s = i % nstreams
         with torch.cuda.stream(streams[s]):
             H.check(lib.cvcl_resnext50_fwd(dt, B, 224, 224, 1, H.ptr(x), arr, len(arr), H.ptr(ws[s]), nb, H.ptr(fmap[s]), H.ptr(pooled[s]),
-                                           BN_MOMENTUM, BN_EPS, H.stream_ptr()), "fwd")
+                                           BN_MOMENTUM, BN_EPS, None, H.stream_ptr()), "fwd")
     for i in range(6): step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
