@@ -372,8 +372,10 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
             if cfg == "c2" and hasattr(ve.model, "recalibrate_centres"):
                 keep = {k: v.clone() for k, v in lit.state_dict().items() if "running_" in k or "num_batches_tracked" in k}
                 other = synthetic_batch_on_device(batch_size, seed=977 + rank, device=device)
+                gn, lit.model.global_negatives = lit.model.global_negatives, False      # (rank-local: no collective in this check)
                 with torch.no_grad():
                     lit.model(other[0], other[1], other[2])
+                lit.model.global_negatives = gn
                 lit.load_state_dict(keep, strict=False)
             par.update(logits_vs_fp32(lit, batch, precision))
         if yardstick and cfg == "c2":

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../multimodal-baby_amd/csrc/gemm8w_kernel.h"
+#include "gemm4w_kernel.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -39,6 +40,13 @@ static void launch_w(const g8w::Dev& d, int grid, hipStream_t st) {
     static bool attr = false;
     if (!attr) { CK(hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES)); attr = true; }
     hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, VAR>), dim3(grid), dim3(512), g8w::LDS_BYTES, st, d);
+}
+
+template <int MI, int EPI, int VAR>
+static void launch_q(const g4w::Dev& d, int grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)g4w::gemm4w_kernel<MI, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, g4w::LDS_BYTES)); attr = true; }
+    hipLaunchKernelGGL((g4w::gemm4w_kernel<MI, EPI, VAR>), dim3(grid), dim3(256), g4w::LDS_BYTES, st, d);
 }
 
 typedef int (*gemm_fn)(int, const cvcl_gemm_args*, void*);
@@ -74,6 +82,34 @@ int main(int argc, char** argv) {
         a.A = dA; a.W = dW; a.C = dC; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N;
         if (want_stats) { a.stats = dStats; a.stats_rows = 2048; stats_rows = rf(CVCL_BF16, &a); }
         run = [=]() { int rc = g(CVCL_BF16, &a, st); if (rc) { printf("cvcl_gemm rc %d\n", rc); exit(3); } };
+    } else if (var[0] == 'q') {
+        // q<MI>[b|n|l|r|x|e] (4-wave, 128 | 112 x 128 per wave, one wave per SIMD): q7 / q8 = plain, b = interleaved reads / loads;
+        // ablations n l r x e as for w8
+        const int mi = var.size() > 1 ? var[1] - '0' : 0;
+        if ((mi != 7 && mi != 8) || N % 256 || K % 128) { printf("bad variant / shape\n"); return 1; }
+        static g4w::Dev d;
+        memset(&d, 0, sizeof(d));
+        d.A = dA; d.W = dW; d.C = dC; d.M = M; d.N = N; d.K = K; d.lda = K; d.ldw = K; d.ldc = N;
+        d.stats = want_stats ? dStats : nullptr;
+        d.gs = 1; d.g_hw = 1; d.g_wo = 1; d.a_rows = M;
+        const int BMq = mi * 32;
+        d.tiles_m = (M + BMq - 1) / BMq;
+        d.ncol = N / 256;
+        int dev = 0, cus = 256;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int gm = (cus / d.ncol) & ~7;
+        if (gm < 8) gm = 8;
+        const int need = (d.tiles_m + 7) & ~7;
+        if (gm > need) gm = need;
+        d.grid_m = gm;
+        stats_rows = gm;
+        const int grid = gm * d.ncol;
+        const char c = var.size() > 2 ? var[2] : '0';
+        const int vv = c == '0' ? 0 : c == 'b' ? 2 : c == 'n' ? 6 : c == 'l' ? 10 : c == 'r' ? 18 : c == 'x' ? 30 : c == 'e' ? 34 : -1;
+        if (vv < 0) { printf("bad variant\n"); return 1; }
+#define PICKQ(MI_, V_) if (mi == MI_ && vv == V_) run = [=]() { launch_q<MI_, 0, V_>(d, grid, st); };
+        PICKQ(7, 0) PICKQ(7, 2) PICKQ(7, 6) PICKQ(7, 10) PICKQ(7, 18) PICKQ(7, 30) PICKQ(7, 34)
+        PICKQ(8, 0) PICKQ(8, 2)
     } else {
         // w<MI>[abc]: a = setprio, b = interleaved reads, c = both
         const int mi = var[0] == 'w' ? var[1] - '0' : 0;
