@@ -451,12 +451,17 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
         prof = instrumented(nprof)
         # An event bracket (previous launch's end -> this launch's end on the stream) also holds the dispatch gap ahead of the
         # kernel.  The gap is calibrated per run with a kernel that does nothing (cvcl_prof_null_bracket_us: two event packets +
-        # one dispatch) and taken as HALF of that bracket per launch -- the first event packet overlaps the previous kernel --
-        # which reproduces the rocprofv3 --kernel-trace durations of the 5 us bn_finalize launches and of the 70 us GEMMs alike
-        # (profiles/<round>_bench_c2_kernel_stats.csv).  event_ms = bracket sums, kernel_ms = event_ms - gap_ms.
+        # one dispatch + ~3.6 us of empty kernel) and taken per launch as HALF of that bracket for launch-bound classes (average
+        # bracket < 4 null brackets: bn_finalize, head) and a QUARTER of it for long kernels (the command processor has the
+        # packets decoded while the previous kernel still runs) -- a two-point calibration against rocprofv3 --kernel-trace of
+        # this command: bn_finalize 4.8 vs 5.1 us, gemm8w 76.7 vs 77.1, gemm_pro 107.5 vs 109.0, gconv 57.6 vs 56.5
+        # (profiles/r03_bench_c2_1stream_kernel_stats.csv).  event_ms = bracket sums, kernel_ms = event_ms - gap_ms.
         null_us = H.prof_null_bracket_us()
-        gap_us = 0.5 * null_us
-        gap = {k: v[1] / nprof * gap_us * 1e-3 for k, v in prof.items() if v[1] > 0}
+
+        def gap_us_of(c):
+            avg_bracket = prof[c][0] / max(prof[c][1], 1) * 1e3
+            return null_us * (0.25 if avg_bracket > 4 * null_us else 0.5)
+        gap = {k: v[1] / nprof * gap_us_of(k) * 1e-3 for k, v in prof.items() if v[1] > 0}
         res["event_ms_per_step"] = {k: round(v[0] / nprof, 4) for k, v in prof.items() if v[1] > 0}
         res["kernel_ms_per_step"] = {k: round(max(v[0] / nprof - gap[k], 0.0), 4) for k, v in prof.items() if v[1] > 0}
         res["gap_ms_per_step"] = {k: round(g, 4) for k, g in gap.items()}
@@ -464,7 +469,7 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
         res["event_bracket_of_a_null_kernel_us"] = round(null_us, 2)
 
         def kern_ms(c):                                         # per step, gap removed
-            return max(prof[c][0] / nprof - prof[c][1] / nprof * gap_us * 1e-3, 1e-9)
+            return max(prof[c][0] / nprof - gap.get(c, 0.0), 1e-9)
         dom = max((c for c in prof if prof[c][1] > 0), key=kern_ms)
         per_kernel = None
         if cfg == "c2":

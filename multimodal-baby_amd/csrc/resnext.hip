@@ -438,7 +438,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
 // grouped 3x3 convolution, pad 1, stride 1|2, NHWC raw in (BN+ReLU applied on load) -> NHWC raw out
 // ------------------------------------------------------------------------------------------------
 constexpr int GC_CS = 64;                  // channels per workgroup slab
-constexpr int GC_PIXB = 144;               // LDS bytes per staged pixel (128 B of channels + 16 B pad)
+#ifndef CVCL_GC_PIXB
+#define CVCL_GC_PIXB 144
+#endif
+constexpr int GC_PIXB = CVCL_GC_PIXB;      // LDS bytes per staged pixel (128 B of channels + pad; an odd number of 16-byte slots)
 
 struct GconvDev {
     const void* x; const float* a_scale; const float* a_shift; const void* w; void* y; float* stats;
