@@ -360,13 +360,24 @@ def gemm_grid_m(dtype: int, M: int, N: int, has_prologue: bool = False) -> int:
     return lib().cvcl_gemm_grid_m(dtype, M, N, int(has_prologue))
 
 
-def gemm_stats_rows(dtype: int, M: int, N: int, K: int, gather=None) -> int:
-    """BN-statistics rows ``gemm(..., stats=...)`` writes for a plain [M, K] x [N, K]^T product of this dtype (depends on
-    which kernel the dispatcher picks: cvcl_gemm_stats_rows)."""
+def gemm_stats_rows(dtype: int, M: int, N: int, K: int, gather=None, *, prologue=False, a_relu=False, bias=False, residual=False,
+                    act=ACT_NONE) -> int:
+    """BN-statistics rows ``gemm(..., stats=...)`` writes for an [M, K] x [N, K]^T product of this dtype with these options
+    (which kernel the dispatcher picks decides: cvcl_gemm_stats_rows).  Size the statistics buffer by this, reduce exactly
+    this many rows."""
     a = GemmArgs()
     a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, K, K, N
     if gather is not None:
         a.gather_ho, a.gather_wo, a.gather_hi, a.gather_wi, a.gather_stride = gather
+    dummy = 16                                             # a non-null, 16-byte aligned stand-in: only null-ness / alignment is inspected
+    if prologue:
+        a.a_scale, a.a_shift, a.a_relu = dummy, dummy, int(a_relu)
+    if bias:
+        a.bias = dummy
+    if residual:
+        a.R, a.ldr = dummy, N
+    a.act = act
+    a.A, a.W, a.C = dummy, dummy, dummy
     return lib().cvcl_gemm_stats_rows(dtype, C.byref(a))
 
 

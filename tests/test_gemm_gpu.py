@@ -70,7 +70,7 @@ def test_gemm_fused_everything(H, dev, dt):
     bias = torch.randn(N, generator=g)
     R = torch.randn(M, N, generator=g).to(tdt)
     for act in (0, 1, 2):
-        rows = H.gemm_grid_m(H.BF16 if bf else H.F32, M, N, True)
+        rows = H.gemm_stats_rows(H.BF16 if bf else H.F32, M, N, K, prologue=True, a_relu=True, bias=True, residual=True, act=act)
         stats = torch.full((rows, 2, N), float("nan"), device=dev)
         y = H.gemm(A.to(dev), W.to(dev), bias=bias.to(dev), act=act, residual=R.to(dev), a_scale=sc.to(dev),
                    a_shift=sh.to(dev), a_relu=True, stats=stats)
@@ -516,3 +516,63 @@ def test_gemm_pro_exact_on_small_integers(dev):
     assert all(torch.equal(outs[0][0], c) and torch.equal(outs[0][1], s) for c, s in outs[1:])
     assert torch.equal(outs[0][0].cpu(), ref)
     assert torch.equal(outs[0][1][:, 0].double().sum(0).cpu(), ref.double().sum(0))
+
+
+@pytest.mark.parametrize("kernel,M,N,K", [("gemm_glds", 6272, 128, 64), ("gemm8w", 50176, 512, 512), ("gemm8w", 12544, 2048, 512),
+                                          ("gemm_pro", 12544, 256, 128), ("gemm_pro", 5000, 512, 256), ("generic_f32", 300, 130, 72)])
+def test_gemm_centred_storage(dev, kernel, M, N, K):
+    """Centred storage of a raw convolution output (include/cvcl_hip.h "Centred storage"): with args.centre the convolution
+    epilogues store round(A'W^T - centre[n]), take the statistics of that, and the Bottleneck tail applies its affine to that --
+    in every kernel the dispatcher can pick for a conv (128 x 128 direct-to-LDS, 8-wave, BN-prologue in its three modes, and
+    the generic fp32 kernel).  Integer operands and integer centres: every product and partial sum is exact -> bit-exact."""
+    import ctypes as Cc
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(M + N)
+    f32 = kernel == "generic_f32"
+    tdt = torch.float32 if f32 else torch.bfloat16
+    dt = H.F32 if f32 else H.BF16
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    cen = torch.randint(-40, 41, (N,), generator=g).float()
+    pro = kernel == "gemm_pro"
+    act = torch.relu(a) if pro else a
+    y = (act.double() @ w.double().t() - cen.double()).float()
+    ref = y.to(tdt)
+    assert torch.equal(ref.float(), y) or not f32
+    ad, wd, cd_ = a.to(tdt).to(dev), w.to(tdt).to(dev), cen.to(dev)
+    one, zero = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+
+    def args(C, stats, tail=None):
+        t = _gemm_args(H, ad, wd, C, stats, one if pro else None, zero if pro else None, *(tail or ()))
+        t.centre = H.ptr(cd_)
+        return t
+    probe = args(torch.empty(1, dtype=tdt, device=dev), torch.empty(1, device=dev))
+    rows = H.lib().cvcl_gemm_stats_rows(dt, Cc.byref(probe))
+    if kernel == "gemm_pro":
+        assert H.lib().cvcl_gemm_pro_supported(Cc.byref(probe)) == 1 and rows == H.lib().cvcl_gemm_pro_stats_rows(M, N)
+    elif kernel == "gemm8w":
+        assert rows == H.lib().cvcl_gemm8w_stats_rows(M, N)
+    C = torch.full((M, N), float("nan"), dtype=tdt, device=dev)
+    st = torch.full((rows, 2, N), float("nan"), device=dev)
+    H.check(H.lib().cvcl_gemm(dt, Cc.byref(args(C, st)), H.stream_ptr()), "cvcl_gemm")
+    assert torch.equal(C.cpu(), ref)
+    s = st.double().sum(0).cpu()
+    assert torch.equal(s[0], ref.double().sum(0)) and maxrel(s[1], (ref.double() ** 2).sum(0)) < 1e-6
+    if f32:
+        return
+    if kernel in ("gemm_pro", "gemm8w"):                                       # statistics only (nothing stored)
+        st2 = torch.full((rows, 2, N), float("nan"), device=dev)
+        H.check(H.lib().cvcl_gemm(dt, Cc.byref(args(None, st2)), H.stream_ptr()), "cvcl_gemm")
+        assert torch.equal(st2.double().sum(0).cpu()[0], ref.double().sum(0))
+    if kernel in ("gemm_pro", "gemm_glds"):                                    # Bottleneck tail on the centred product
+        cs, cb = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g).bfloat16()
+        want = torch.relu(torch.addcmul(cb, ref.float(), cs) + r.float()).bfloat16()      # fmaf(round(acc - c), cs, cb) + idn
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        t = args(out, None, (cs.to(dev), cb.to(dev), r.to(dev)))
+        keep = (t,)
+        H.check(H.lib().cvcl_gemm(dt, Cc.byref(t), H.stream_ptr()), "cvcl_gemm")
+        e = (out.double().cpu() - want.double()).abs() / (want.double().abs() + float(want.abs().max()) * 5e-2)
+        assert float(e.max()) < 8e-3
+    with pytest.raises(H.CvclError):                                           # centre belongs to the convolution epilogues
+        H.gemm(ad, wd, bias=torch.zeros(N, device=dev), centre=cd_)
