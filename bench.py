@@ -424,6 +424,17 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
     if cfg in STEP_BYTES_PER_PAIR and precision == "bf16":
         res["whole_step"].update({"hbm_frac": round(pairs_s_gpu * STEP_BYTES_PER_PAIR[cfg] / 1e9 / HBM_PEAK_GBS, 4),
                                   "bytes_per_pair": STEP_BYTES_PER_PAIR[cfg]})
+        if batch_size == PER_GPU_BATCH:
+            # the bytes the step ACTUALLY moves (PMC, static summary of the same command at this batch) against the same clock:
+            # what fraction of the HBM peak the whole step sustains on its real traffic
+            try:
+                with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_hbm_traffic.json")) as f:
+                    gb = json.load(f)["trunk_total"]["total_GB"]
+                res["whole_step"].update({"pmc_traffic_gb_per_step": round(gb, 2),
+                                          "pmc_traffic_frac_of_hbm_peak": round(gb / (elapsed / steps) / HBM_PEAK_GBS, 4),
+                                          "pmc_traffic_source": f"profiles/{PROFILE_ROUND}_pmc_hbm_traffic.json (static)"})
+            except Exception:
+                pass
 
     if roofline and precision != "32":
         # further passes of the same steps with HIP events around every launch (on the launch stream).  The roofline figures come
