@@ -404,6 +404,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                                                               int B, int H, int W, int C) {
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, CC = C / 8;
     const long total = (long)B * Ho * Wo * CC;
+    // (measured in round 3: an XCD-major block order -- consecutive 32-pixel blocks on one XCD so that the input row two output
+    // rows share is fetched by one L2 instead of two -- made this kernel 7 % SLOWER (0.132 -> 0.142 ms); plain order kept)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(i % CC);
         const long p = i / CC;
@@ -561,8 +563,13 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     // the weight fragments (loaded above) are ready from here on: without this the compiler, conservative across the loop's back
     // edge, waits on vmcnt before the first MFMAs of every work item -- i.e. for the next item's prefetch just issued
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0) only
-    if ((int)blockIdx.x < n_items) prefetch(blockIdx.x);
-    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // Work items in XCD-major order: block (x, y) has linear id x + y * gridDim.x and runs on XCD (linear id) % 8, every XCD with
+    // an L2 of its own; consecutive items are adjacent bands of one image and share their halo rows.  With gridDim.x a multiple
+    // of 8 the XCD is x % 8, and XCD j takes the contiguous item range [j * gridDim.x / 8, (j + 1) * gridDim.x / 8) of every round
+    // (plain order: a band's neighbours sat on other XCDs and the halo rows were fetched twice: 2.12 GB read for 1.95 in the PMC pass)
+    const int bx = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    if (bx < n_items) prefetch(bx);
+    for (int item = bx; item < n_items; item += gridDim.x) {
         const int b = item / p.bands, band = item - b * p.bands;
         const int oy0 = band * p.TH;
         __syncthreads();
@@ -930,11 +937,12 @@ extern "C" int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale
     CvclProfScope prof(stream, CVCL_K_MAXPOOL);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long total = (long)B * Ho * Wo * (C / 8);
+    const int grid = grid_for(total, 256, 8192);
     if (dtype == CVCL_F32)
-        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const float*)x, scale, shift, (float*)y, B, H, W, C);
     else
-        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, scale, shift, (bf16_t*)y, B, H, W, C);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
