@@ -156,6 +156,10 @@ def resnext_gemm_work(B):
     -> {kernel: [bytes, flops, launches]} and the totals."""
     fused_stages = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "2"))
     pro_stages = int(os.environ.get("CVCL_CONV3_PRO_STAGES", "2"))
+    # layer1.0: the downsample launch is a statistics-only pass (A + W) and the tail pass recomputes the branch from the block
+    # input (reads X [M, 64] + W2 instead of the stored [M, 256] branch) -- csrc/resnext.hip, $CVCL_DS_RECOMPUTE
+    ds_recompute = (os.environ.get("CVCL_DS_RECOMPUTE", "1") != "0" and os.environ.get("CVCL_GEMM_PRO", "1") != "0"
+                    and fused_stages >= 1 and pro_stages >= 1)
     per = {"gemm": [0, 0, 0], "gemm8w": [0, 0, 0], "gemm_pro": [0, 0, 0]}
 
     def add(kernel, nbytes, flops):
@@ -175,15 +179,19 @@ def resnext_gemm_work(B):
             m_in, m_out = B * h * h, B * ho * ho
             m, n, k = m_in, width, inplanes                          # conv1
             add(plain_kernel(m, n, k, False), 2 * (m * k + n * k + m * n), 2 * m * n * k)
+            recompute = ds_recompute and stage == 0 and bi == 0
             if bi == 0:                                              # downsample
                 m, n, k = m_out, outc, inplanes
-                add(plain_kernel(m, n, k, stride > 1), 2 * (m * k + n * k + m * n), 2 * m * n * k)
+                add(plain_kernel(m, n, k, stride > 1), 2 * (m * k + n * k + (0 if recompute else m * n)), 2 * m * n * k)
             m, n, k = m_out, outc, width                             # conv3
             pro = stage < pro_stages and width in (128, 256)
             kern = "gemm_pro" if pro else plain_kernel(m, n, k, False)
             if stage < fused_stages:                                 # statistics pass + fused tail pass
                 add(kern if pro else "gemm", 2 * (m * k + n * k), 2 * m * n * k)
-                add(kern if pro else "gemm", 2 * (m * k + n * k + 2 * m * n), 2 * m * n * k)
+                if recompute:                                        # + X and W2 read, + the K2 = 64 product; no residual read
+                    add(kern, 2 * (m * k + n * k + m * n + m * inplanes + n * inplanes), 2 * m * n * (k + inplanes))
+                else:
+                    add(kern if pro else "gemm", 2 * (m * k + n * k + 2 * m * n), 2 * m * n * k)
             else:
                 add(kern, 2 * (m * k + n * k + m * n), 2 * m * n * k)
             h, inplanes = ho, outc

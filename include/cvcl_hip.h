@@ -136,6 +136,11 @@ typedef struct {
      * change; cvcl_bn_finalize adds the centre back into the running mean.  Only the convolution epilogues honour it (no
      * bias / activation / residual-only epilogue).  See "Centred storage" below.                                          */
     const float* centre;
+    /* Bottleneck tail with the downsample branch RECOMPUTED (bf16, the BN-prologue kernel, K = 128): instead of reading the
+     * stored branch through R, identity = round(A2[M,K2] . W2[N,K2]^T - centre2[n]) * r_scale[n] + r_shift[n] with A2 = the block
+     * input and W2 = the 1x1 downsample weight, K2 = 64 (torchvision Bottleneck.downsample of layer1.0: nn.Conv2d(64, 256, 1) +
+     * BatchNorm).  R must be NULL; the statistics behind r_scale / r_shift come from a statistics-only cvcl_gemm(A2, W2, C = NULL). */
+    const void* A2; const void* W2; int K2, lda2, ldw2; const float* centre2;
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);

@@ -17,7 +17,11 @@
 //     multiplied (32 / 64 MFMAs per wave -- a fraction of the tile's HBM time);
 //   * three epilogues: statistics only (BN partial sums of the rounded output straight from the accumulators, nothing
 //     stored), store + statistics, and the Bottleneck tail relu(bn3(.) + identity | bn_d(downsample)) with the block output
-//     written as full 128-byte row segments through wave-private LDS.
+//     written as full 128-byte row segments through wave-private LDS;
+//   * round 3, PRO_TAIL_DS: the tail of a stage's FIRST block with the downsample branch RECOMPUTED in the kernel -- the 1x1
+//     downsample of layer1.0 is a K = 64 product of the block input X, cheaper to redo here (16 MFMAs per wave and tile next
+//     to conv3's 32) than to write its [M, 256] output to HBM and read it back: the separate downsample launch shrinks to a
+//     statistics-only pass (reads X, stores nothing) and this kernel reads X (103 MB) instead of the stored branch (411 MB).
 #include <cstdlib>
 
 #include "cvcl_common.h"
@@ -34,16 +38,22 @@ struct ProDev {
     const float* centre;            // storage centre of the output (NULL = 0): accumulators start at -centre[n]
     int M, N, lda, ldw, ldc, ldr;
     int tiles;
+    // PRO_TAIL_DS: identity = round(X . W2^T - centre2) * r_scale + r_shift with X [M, 64] (the block input), W2 [N, 64]
+    const bf16_t* A2; const bf16_t* W2; const float* centre2;
+    int lda2, ldw2;
 };
 
-enum { PRO_STATS = 0, PRO_STORE = 1, PRO_TAIL = 2 };
+enum { PRO_STATS = 0, PRO_STORE = 1, PRO_TAIL = 2, PRO_TAIL_DS = 3 };
+constexpr int K2 = 64, KT2 = 2;            // PRO_TAIL_DS: depth of the recomputed downsample product
+constexpr int X2BUF = PM * K2 * 2;         // one staged X tile: 64 rows x 128 B
 
-template <int KT> constexpr int pro_lds_bytes() { return 2 * PM * KT * 64 + 8 * 4096 + 5 * PN * 4 + 2 * 256 * 4; }
+template <int KT> constexpr int pro_lds_bytes() { return 2 * PM * KT * 64 + 8 * 4096 + 6 * PN * 4 + 2 * 256 * 4 + 2 * X2BUF; }
 
 // D = tiles of A in flight per workgroup (registers); more than one buys ~2 % (the per-tile chain stage -> barrier -> fragment
 // reads -> MFMA -> statistics is the bound, not the load latency)
 template <int KT, int MODE, int D>
 __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
+    constexpr bool TAIL = MODE == PRO_TAIL || MODE == PRO_TAIL_DS, DS = MODE == PRO_TAIL_DS;
     constexpr int K = KT * 32;
     constexpr int PITCH = K * 2;                        // LDS row pitch of the A tile in bytes (256 | 512)
     constexpr int CPR = K / 8;                          // 16-byte chunks per row (16 | 32)
@@ -69,7 +79,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     // K = 256 holds 128 registers of W fragments: the operand affine of this thread's 8 channels is then re-read from LDS per
     // tile (4 ds_read_b128) instead of living in 16 registers
     constexpr bool AFF_LDS = KT == 8;
-    float* in_aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096 + 5 * PN * 4);      // [2][K]
+    float* in_aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096 + 6 * PN * 4);      // [2][K]
+    char* x2buf = smem + 2 * ABUF + 8 * 4096 + 6 * PN * 4 + 2 * 256 * 4;                     // DS: [2][64 rows][128 B] staged X tiles
     f32x2 sc[4], sh[4];
     if constexpr (AFF_LDS) {
         if (tid < K) { in_aff[tid] = p.a_scale[tid]; in_aff[K + tid] = p.a_shift[tid]; }
@@ -123,8 +134,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     float* aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096);
     // centred storage: -centre of the strip's 256 columns at aff + 4 PN; every tile's accumulators start from it
     if (tid < PN) aff[4 * PN + tid] = p.centre ? -p.centre[n0 + tid] : 0.f;
+    if constexpr (DS) { if (tid < PN) aff[5 * PN + tid] = p.centre2 ? -p.centre2[n0 + tid] : 0.f; }
     const float* cen = aff + 4 * PN + wn * 64 + (lane >> 4) * 4;        // + ni * 16: accumulator columns ni*16 + (lane >> 4)*4 + e
-    if constexpr (MODE == PRO_TAIL) {
+    // DS: the downsample weights' strip as fragments (8 more, K2 = 64) and the X tile's staging role: one 16-byte chunk per thread
+    bf16x8 fw2[DS ? 4 : 1][DS ? KT2 : 1];
+    u32x4 x2raw[DS ? D : 1];
+    const int x_r = tid >> 3, x_c = tid & 7;
+    if constexpr (DS) {
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < KT2; ++ks)
+                fw2[ni][ks] = *reinterpret_cast<const bf16x8*>(p.W2 + (long)(n0 + wn * 64 + ni * 16 + (lane & 15)) * p.ldw2 + ks * 32 + (lane >> 4) * 8);
+    }
+    auto load_x2 = [&](int tile, int slot) __attribute__((always_inline)) {
+        int m = tile * PM + x_r;
+        if (m >= p.M) m = p.M - 1;
+        x2raw[slot] = *reinterpret_cast<const u32x4*>(p.A2 + (long)m * p.lda2 + x_c * 8);
+    };
+    auto stage_x2 = [&](int buf, int slot) __attribute__((always_inline)) {
+        *reinterpret_cast<u32x4*>(x2buf + buf * X2BUF + x_r * 128 + ((x_c ^ (x_r & 7)) << 4)) = x2raw[slot];
+    };
+    if constexpr (TAIL) {
         if (tid < PN) {
             aff[tid] = p.c_scale[n0 + tid];
             aff[PN + tid] = p.c_shift[n0 + tid];
@@ -132,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
             aff[3 * PN + tid] = p.r_scale ? p.r_shift[n0 + tid] : 0.f;
         }
     }                                                    // (visible after the first tile's barrier)
-    bf16x8 rres[4];                                      // residual rows of the current tile (TAIL)
+    bf16x8 rres[4];                                      // residual rows of the current tile (PRO_TAIL)
     auto load_r = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -154,7 +185,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     const int G = gridDim.x;
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (first + d * G < p.tiles) load_a(first + d * G, d);
+        if (first + d * G < p.tiles) {
+            load_a(first + d * G, d);
+            if constexpr (DS) load_x2(first + d * G, d);
+        }
     if constexpr (MODE == PRO_TAIL) {
         if (first < p.tiles) load_r(first);
     }
@@ -184,9 +218,46 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
       for (int slot = 0; slot < D; ++slot) {             // (static register slot of the tile being staged)
         if (tile >= p.tiles) break;
         stage_a(buf, slot);
+        if constexpr (DS) stage_x2(buf, slot);
         __syncthreads();                                 // tile staged by everyone; the other buffer's readers (tile - 2) are long done
         const int next = tile + G;
-        if (tile + D * G < p.tiles) load_a(tile + D * G, slot);
+        if (tile + D * G < p.tiles) {
+            load_a(tile + D * G, slot);
+            if constexpr (DS) load_x2(tile + D * G, slot);
+        }
+        // DS: the downsample product of the same 32 x 64 wave tile first -- X tile (raw bf16, no prologue) x the W2 fragments --
+        // kept as ROUNDED bf16 pairs (what the separate pass would have stored: 16 registers) while conv3's K loop runs
+        unsigned r2[DS ? 4 : 1][2][2];
+        if constexpr (DS) {
+            f32x4 acc2[4][2];
+            const float* cen2 = aff + 5 * PN + wn * 64 + (lane >> 4) * 4;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cen2 + ni * 16);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) acc2[ni][mi] = c4;
+            }
+            const char* xb = x2buf + buf * X2BUF + (wm * 32 + f_row) * 128;
+#pragma unroll
+            for (int ks = 0; ks < KT2; ++ks) {
+                bf16x8 fx[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    fx[mi] = *reinterpret_cast<const bf16x8*>(xb + mi * 16 * 128 + (((ks * 4 + f_kc) ^ (f_row & 7)) << 4));
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+                        acc2[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[ni][ks], fx[mi], acc2[ni][mi], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    r2[ni][mi][0] = round2(f32x2{acc2[ni][mi][0], acc2[ni][mi][1]});
+                    r2[ni][mi][1] = round2(f32x2{acc2[ni][mi][2], acc2[ni][mi][3]});
+                }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const f32x4 c4 = *reinterpret_cast<const f32x4*>(cen + ni * 16);
@@ -209,6 +280,34 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
         const int m0 = tile * PM + wm * 32;
         if constexpr (MODE == PRO_STATS) {
             tile_stats(m0);
+        } else if constexpr (DS) {
+            // combine in the accumulator layout with the arithmetic of the separate passes -- relu(fmaf(round(acc), cs, cb) +
+            // fmaf(round(acc2), rs, rb)), rounded -- then out through the wave's staging as full 128-byte row segments
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const float* t = aff + wn * 64 + ni * 16 + (lane >> 4) * 4;
+                const f32x4 cs = *reinterpret_cast<const f32x4*>(t), cb = *reinterpret_cast<const f32x4*>(t + PN);
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(t + 2 * PN), rb = *reinterpret_cast<const f32x4*>(t + 3 * PN);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    bf16x4 q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = fmaf((float)(bf16_t)acc[ni][mi][e], cs[e], cb[e]);
+                        const float idv = fmaf(widen2(r2[ni][mi][e >> 1])[e & 1], rs[e], rb[e]);
+                        q[e] = (bf16_t)fmaxf(y + idv, 0.f);
+                    }
+                    const int row = mi * 16 + e_row, chunk = ni * 2 + e_wchunk;
+                    *reinterpret_cast<bf16x4*>(stg + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + e_wsub) = q;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = j * 8 + r_row0;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((r_chunk ^ ((row >> 1) & 7)) << 4));
+                const int m = m0 + row, n = n0 + wn * 64 + r_chunk * 8;
+                if (m < p.M) stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+            }
         } else {
             // accumulator layout (m = mi*16 + (lane & 15), n = ni*16 + (lane >> 4)*4 + e) -> rows of 128 B in the wave's staging
 #pragma unroll
@@ -260,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
       }
     }
 
-    if (MODE != PRO_TAIL && p.stats) {
+    if (!TAIL && p.stats) {
         __syncthreads();
         float* red = (float*)smem;                       // [8 waves][2][64]
         if constexpr (MODE == PRO_STATS) {
@@ -346,6 +445,10 @@ extern "C" int cvcl_gemm_pro_supported(const cvcl_gemm_args* a) {
     if (a->lda % 8 || a->ldw % 8 || (a->C && a->ldc % 8) || a->gather_stride > 1 || a->exp_scale || a->bias || a->C_pre || a->G) return 0;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!al16(a->A) || !al16(a->W) || !al16(a->C) || !al16(a->R)) return 0;
+    if (a->c_scale && a->A2)                              // tail with the downsample branch recomputed from the block input
+        return a->c_shift && !a->R && a->C && !a->stats && a->act == CVCL_ACT_RELU && a->W2 && a->K2 == K2 && a->K == 128 && a->r_scale &&
+               a->r_shift && a->lda2 % 8 == 0 && a->ldw2 % 8 == 0 && al16(a->A2) && al16(a->W2);
+    if (a->A2 || a->W2) return 0;
     if (a->c_scale) return a->c_shift && a->R && a->C && !a->stats && a->ldr % 8 == 0 && a->act == CVCL_ACT_RELU &&
                            (a->r_scale == nullptr) == (a->r_shift == nullptr);
     return !a->R && a->act == CVCL_ACT_NONE && (a->C || a->stats);
@@ -366,16 +469,20 @@ extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream) {
     d.a_scale = a->a_scale; d.a_shift = a->a_shift; d.c_scale = a->c_scale; d.c_shift = a->c_shift;
     d.r_scale = a->r_scale; d.r_shift = a->r_shift; d.stats = a->stats; d.centre = a->centre;
     d.M = a->M; d.N = a->N; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr;
+    d.A2 = (const bf16_t*)a->A2; d.W2 = (const bf16_t*)a->W2; d.centre2 = a->centre2; d.lda2 = a->lda2; d.ldw2 = a->ldw2;
     d.tiles = cvcl_div_up(a->M, PM);
     const int gx = cvcl_gemm_pro_stats_rows(a->M, a->N);
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gx, "cvcl_gemm_pro: stats_rows %d < %d", a->stats_rows, gx);
     dim3 grid(gx, a->N / PN);
-    const int mode = a->c_scale ? PRO_TAIL : (a->C ? PRO_STORE : PRO_STATS);
+    const int mode = a->c_scale ? (a->A2 ? PRO_TAIL_DS : PRO_TAIL) : (a->C ? PRO_STORE : PRO_STATS);
     CvclProfScope prof(stream, CVCL_K_GEMM_PRO);
     hipStream_t st = (hipStream_t)stream;
     // tiles of A in flight: 3 (K = 128) / 2 (K = 256: the register budget); $CVCL_PRO_DEPTH overrides (measured on C2: depth 1
     // 1.502 ms per step over the 14 launches, default 1.471)
     static const int depth = [] { const char* e = getenv("CVCL_PRO_DEPTH"); return e ? atoi(e) : 0; }();
+    if (mode == PRO_TAIL_DS) {                               // K = 128 only; two tiles of A and X in flight (the register budget)
+        return pro_launch<4, PRO_TAIL_DS, 2>(d, grid, st);
+    }
     if (a->K == 128) {
         const int dd = depth ? depth : 3;
         if (mode == PRO_TAIL) return dd >= 3 ? pro_launch<4, PRO_TAIL, 3>(d, grid, st) : dd == 2 ? pro_launch<4, PRO_TAIL, 2>(d, grid, st) : pro_launch<4, PRO_TAIL, 1>(d, grid, st);

@@ -1228,22 +1228,35 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     } else {
         if ((rc = finalize(l3, 0, m_out, outc))) return rc;              // eval mode: affine from the running stats
     }
+    // layer1.0 (bf16, fused tail, BN-prologue kernel): the downsample branch is a K = 64 product of the block input, recomputed
+    // inside the tail pass (gemm_pro.hip PRO_TAIL_DS) instead of being written to HBM (411 MB at B = 256) and read back; its own
+    // launch shrinks to a statistics-only pass (train mode) or disappears (eval mode).  $CVCL_DS_RECOMPUTE=0: the stored form.
+    static const bool ds_recompute_on = [] {
+        const char* e = getenv("CVCL_DS_RECOMPUTE");
+        const char* g = getenv("CVCL_GEMM_PRO");
+        return !(e && e[0] == '0') && !(g && g[0] == '0');
+    }();
+    const bool ds_recompute = ds_recompute_on && first && stride == 1 && inplanes == 64 && fused_tail && pro && width == 128;
     if (first) {
         // downsample 1x1 stride s: X -> RD [m_out, outc]
         cvcl_gemm_args a = {};
-        a.A = X; a.W = L[ld].w; a.C = RD;
+        a.A = X; a.W = L[ld].w; a.C = ds_recompute ? nullptr : RD;
         a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
         if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
         a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
         a.centre = centre_of(ld);
-        if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-        if ((rc = finalize(ld, cvcl_gemm_stats_rows(dtype, &a), m_out, outc))) return rc;
+        if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
+        if ((rc = finalize(ld, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
     }
     if (fused_tail) {
         cvcl_gemm_args a = conv3_args();
         a.C = dst; a.act = CVCL_ACT_RELU;
         a.c_scale = scale_of(l3); a.c_shift = shift_of(l3);
-        a.R = first ? RD : X; a.ldr = outc;
+        if (ds_recompute) {
+            a.A2 = X; a.W2 = L[ld].w; a.K2 = inplanes; a.lda2 = inplanes; a.ldw2 = inplanes; a.centre2 = centre_of(ld);
+        } else {
+            a.R = first ? RD : X; a.ldr = outc;
+        }
         if (first) { a.r_scale = scale_of(ld); a.r_shift = shift_of(ld); }
         if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
     } else if (first) {

@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("c_scale", C.c_void_p), ("c_shift", C.c_void_p), ("r_scale", C.c_void_p), ("r_shift", C.c_void_p),
         ("C_pre", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_int),
         ("centre", C.c_void_p),
+        ("A2", C.c_void_p), ("W2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldw2", C.c_int), ("centre2", C.c_void_p),
     ]
 
 

@@ -576,3 +576,63 @@ def test_gemm_centred_storage(dev, kernel, M, N, K):
         assert float(e.max()) < 8e-3
     with pytest.raises(H.CvclError):                                           # centre belongs to the convolution epilogues
         H.gemm(ad, wd, bias=torch.zeros(N, device=dev), centre=cd_)
+
+
+@pytest.mark.parametrize("M", [12544, 5000, 63])
+def test_gemm_pro_tail_with_recomputed_downsample(dev, M):
+    """Bottleneck tail of a stage's first block with the downsample branch recomputed in the kernel (cvcl_gemm_args.A2 / W2,
+    gemm_pro.hip PRO_TAIL_DS; torchvision Bottleneck.forward: out = relu(bn3(conv3(.)) + downsample(x)) of layer1.0):
+    out = relu(round(relu(bn2(A)) W^T - c) cs + cb + round(X W2^T - c2) rs + rb) against (a) the SAME call with the branch stored
+    by a separate cvcl_gemm and read through R -- bit for bit on integer operands -- and (b) float64 of the storage-point model
+    on random operands."""
+    import ctypes as Cc
+    from multimodal import _hip as H
+    N, K, K2 = 256, 128, 64
+    g = torch.Generator().manual_seed(M)
+    for exact in (True, False):
+        if exact:
+            a = torch.randint(-3, 4, (M, K), generator=g).float()
+            w = torch.randint(-2, 3, (N, K), generator=g).float()
+            x = torch.randint(-3, 4, (M, K2), generator=g).float()
+            w2 = torch.randint(-2, 3, (N, K2), generator=g).float()
+            sc, sh = torch.ones(K), torch.zeros(K)
+            cen, cen2 = torch.randint(-8, 9, (N,), generator=g).float(), torch.randint(-8, 9, (N,), generator=g).float()
+        else:
+            a = torch.randn(M, K, generator=g) * 2 + 0.5
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            x = torch.randn(M, K2, generator=g)
+            w2 = torch.randn(N, K2, generator=g) / K2 ** 0.5
+            sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+            cen, cen2 = torch.randn(N, generator=g), torch.randn(N, generator=g)
+        cs, cb = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+        rs, rb = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+        ab, wb, xb, w2b = a.bfloat16(), w.bfloat16(), x.bfloat16(), w2.bfloat16()
+        act = torch.relu(ab.float() * sc + sh).bfloat16()
+        y3 = (act.double() @ wb.double().t() - cen.double()).float().bfloat16()
+        yd = (xb.double() @ w2b.double().t() - cen2.double()).float().bfloat16()
+        want = torch.relu(torch.addcmul(cb, y3.float(), cs) + torch.addcmul(rb, yd.float(), rs)).bfloat16()
+        d = {k: v.to(dev) for k, v in dict(a=ab, w=wb, x=xb, w2=w2b, sc=sc, sh=sh, cen=cen, cen2=cen2, cs=cs, cb=cb, rs=rs, rb=rb).items()}
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        t = _gemm_args(H, d["a"], d["w"], out, None, d["sc"], d["sh"], d["cs"], d["cb"], None, d["rs"], d["rb"])
+        t.R = None
+        t.centre = H.ptr(d["cen"])
+        t.A2, t.W2, t.K2, t.lda2, t.ldw2, t.centre2 = H.ptr(d["x"]), H.ptr(d["w2"]), K2, K2, K2, H.ptr(d["cen2"])
+        assert H.lib().cvcl_gemm_pro_supported(Cc.byref(t)) == 1
+        H.check(H.lib().cvcl_gemm(H.BF16, Cc.byref(t), H.stream_ptr()), "cvcl_gemm")
+        # the stored form: downsample through a separate cvcl_gemm, then the tail reading it through R
+        rd = H.gemm(d["x"], d["w2"], centre=d["cen2"])
+        out2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev)
+        t2 = _gemm_args(H, d["a"], d["w"], out2, None, d["sc"], d["sh"], d["cs"], d["cb"], rd, d["rs"], d["rb"])
+        t2.centre = H.ptr(d["cen"])
+        H.check(H.lib().cvcl_gemm(H.BF16, Cc.byref(t2), H.stream_ptr()), "cvcl_gemm")
+        torch.cuda.synchronize()
+        if exact:
+            assert torch.equal(rd.cpu(), yd) and torch.equal(out.cpu(), out2.cpu())
+        # random operands: a product whose bf16 rounding falls the other way (fp32 vs float64 accumulation) moves a term by one
+        # ulp of ITS magnitude, which the sum of two large terms of opposite sign does not bound -- so: all but a few elements
+        # within one bf16 ulp of the result, and every element within one ulp of the larger term
+        mag = (y3.float().abs() * cs + yd.float().abs() * rs + want.float().abs()).double()       # the magnitudes that were rounded
+        for got, ref in ((out.cpu(), want), (out.cpu(), out2.cpu())):
+            err = (got.double() - ref.double()).abs()
+            assert float((err / (ref.double().abs() + float(ref.abs().max()) * 5e-2) > 8e-3).double().mean()) < 2e-3, exact
+            assert float((err / (mag * 2.0 ** -7 + 1e-3)).max()) < 1.5, exact
