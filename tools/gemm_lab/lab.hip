@@ -52,6 +52,24 @@ static void launch_q(const g4w::Dev& d, int grid, hipStream_t st) {
 typedef int (*gemm_fn)(int, const cvcl_gemm_args*, void*);
 typedef int (*rows_fn)(int, const cvcl_gemm_args*);
 
+__global__ __launch_bounds__(256) void lab_read_kernel(const f32x4* p, size_t n, float* out) {
+    f32x4 a = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a += p[i];
+    if (a.x + a.y + a.z + a.w == 123.4567f) out[0] = 1.f;
+}
+__global__ __launch_bounds__(256) void lab_touch_kernel(f32x4* p, size_t n) {       // rewrites the same values (reads + writes every line)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { f32x4 v = p[i]; asm volatile("" : "+v"(v)); p[i] = v; }
+}
+// A = 0 * (b1 + b2) + A's own values would need a read of A; instead keep A's VALUES by adding zeros: b1 = b2 = 0 and A = A_old is not
+// needed for timing -- the check ran before.  walk 0: grid-stride; 1: contiguous 1024-chunk blocks front to back; 2: back to front
+__global__ __launch_bounds__(256) void lab_add_kernel(const f32x4* b1, const f32x4* b2, f32x4* a, size_t n, int walk) {
+    if (walk == 0) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a[i] = b1[i] + b2[i];
+    } else {
+        const size_t blk = walk == 2 ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+        for (size_t i = blk * 1024 + threadIdx.x; i < n && i < blk * 1024 + 1024; i += 256) a[i] = b1[i] + b2[i];
+    }
+}
 int main(int argc, char** argv) {
     if (argc < 5) { printf("usage: lab variant M N K [iters] [fill] [stats]\n"); return 1; }
     std::string var = argv[1];
@@ -193,11 +211,27 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 3; ++i) run();
     float ms = 0;
     const char* cold = getenv("LAB_COLD");
-    if (cold && cold[0] == '1') {
+    if (cold && cold[0] >= '1' && cold[0] <= '7') {
+        // 1: 1 GiB memset (caches full of DIRTY foreign lines, operands evicted); 2: 1 GiB read (CLEAN foreign lines, operands
+        // evicted); 3: A rewritten in place by an elementwise pass (A cached and DIRTY: what a producer leaves behind);
+        // 4: 1 GiB memset, then A read once (A cached clean, the rest dirty)
         void* scratch; const size_t sb = (size_t)1 << 30;
         CK(hipMalloc(&scratch, sb));
+        CK(hipMemsetAsync(scratch, 0, sb, st));
+        const int mode = cold[0] - '0';
+        const size_t a_bytes = (size_t)M * K * 2;
+        // 5: A = B1 + B2 (two other tensors of A's size read, A written: the bn_add_relu that precedes a conv1), grid-stride like the
+        // library's kernel; 6: the same in contiguous 16 KiB blocks front to back; 7: the same back to front
+        f32x4 *b1 = nullptr, *b2 = nullptr;
+        if (mode >= 5) { CK(hipMalloc(&b1, a_bytes)); CK(hipMalloc(&b2, a_bytes)); CK(hipMemsetAsync(b1, 0, a_bytes, st)); CK(hipMemsetAsync(b2, 0, a_bytes, st)); }
         for (int i = 0; i < iters; ++i) {
-            CK(hipMemsetAsync(scratch, i, sb, st));
+            if (mode == 1 || mode == 4) CK(hipMemsetAsync(scratch, i, sb, st));
+            if (mode == 2) hipLaunchKernelGGL(lab_read_kernel, dim3(8192), dim3(256), 0, st, (const f32x4*)scratch, sb / 16, (float*)dStats);
+            if (mode == 3) hipLaunchKernelGGL(lab_touch_kernel, dim3(8192), dim3(256), 0, st, (f32x4*)dA, a_bytes / 16);
+            if (mode == 5) hipLaunchKernelGGL(lab_add_kernel, dim3(6272), dim3(256), 0, st, (const f32x4*)b1, (const f32x4*)b2, (f32x4*)dA, a_bytes / 16, 0);
+            if (mode == 6) hipLaunchKernelGGL(lab_add_kernel, dim3((a_bytes / 16 + 1023) / 1024), dim3(256), 0, st, (const f32x4*)b1, (const f32x4*)b2, (f32x4*)dA, a_bytes / 16, 1);
+            if (mode == 7) hipLaunchKernelGGL(lab_add_kernel, dim3((a_bytes / 16 + 1023) / 1024), dim3(256), 0, st, (const f32x4*)b1, (const f32x4*)b2, (f32x4*)dA, a_bytes / 16, 2);
+            if (mode == 4) hipLaunchKernelGGL(lab_read_kernel, dim3(8192), dim3(256), 0, st, (const f32x4*)dA, a_bytes / 16, (float*)dStats);
             CK(hipEventRecord(e0, st));
             run();
             CK(hipEventRecord(e1, st));
