@@ -398,6 +398,73 @@ __global__ __launch_bounds__(256) void stem_direct_f32_kernel(const float* __res
     }
 }
 
+// fp32 parity path, LDS-tiled (the direct kernel above stays as the fallback for shapes whose band does not fit): one workgroup =
+// one band of TH output rows of one image.  The band's input rows (zero padding included) are staged per channel in LDS, the
+// weights transposed to [tap][co]; a wave then takes (16-channel chunk, 64 output pixels) units: lane = pixel, 16 accumulators,
+// per tap one LDS read of the input value and 16 FMAs against wave-uniform weights (broadcast 16-byte LDS reads).
+__global__ __launch_bounds__(256) void stem_tiled_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             float* __restrict__ y, const float* __restrict__ centre,
+                                                             int B, int Hin, int Win, int TH, int bands) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int Ho = Hin / 2, Wo = Win / 2;
+    const int Wp = Win + 6, rows_in = 2 * TH + 5, plane = rows_in * Wp;
+    float* ws = smf;                                  // [147][64]
+    float* cs = ws + 147 * 64;                        // [64]  -centre
+    float* xs = cs + 64;                              // [3][plane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 147 * 64; e += 256) {
+        const int co = e / 147, tap = e - co * 147;   // (contiguous reads of the OIHW weights)
+        ws[tap * 64 + co] = w[e];
+    }
+    if (tid < 64) cs[tid] = centre ? -centre[tid] : 0.f;
+    for (int item = blockIdx.x; item < B * bands; item += gridDim.x) {
+        const int b = item / bands, band = item - b * bands;
+        const int oy0 = band * TH, iy0 = 2 * oy0 - 3;
+        __syncthreads();                              // the previous item's readers are done (first item: weights visible)
+        for (int e = tid; e < 3 * plane; e += 256) {
+            const int c = e / plane, r = e - c * plane, ry = r / Wp, rx = r - ry * Wp;
+            const int yin = iy0 + ry, xin = rx - 3;
+            float v = 0.f;
+            if ((unsigned)yin < (unsigned)Hin && (unsigned)xin < (unsigned)Win) v = x[(((long)b * 3 + c) * Hin + yin) * Win + xin];
+            xs[e] = v;
+        }
+        __syncthreads();
+        const int n_out = min(TH, Ho - oy0) * Wo, nblk = (n_out + 63) / 64;
+        for (int u = wave; u < 4 * nblk; u += 4) {
+            const int chunk = u / nblk, blk = u - chunk * nblk;
+            const int q = blk * 64 + lane;
+            const bool ok = q < n_out;
+            const int qq = ok ? q : 0, ty = qq / Wo, ox = qq - ty * Wo;
+            float acc[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) acc[o] = cs[chunk * 16 + o];
+            const float* xb = xs + (2 * ty) * Wp + 2 * ox;
+            const float* wb = ws + chunk * 16;
+            for (int c = 0; c < 3; ++c)
+                for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx) {
+                        const float xv = xb[c * plane + ky * Wp + kx];
+                        const float* wt = wb + ((c * 7 + ky) * 7 + kx) * 64;
+#pragma unroll
+                        for (int o4 = 0; o4 < 4; ++o4) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wt + o4 * 4);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[o4 * 4 + k] = fmaf(xv, w4[k], acc[o4 * 4 + k]);
+                        }
+                    }
+                }
+            if (ok) {
+                float* dst = y + (((long)b * Ho + oy0 + ty) * Wo + ox) * 64 + chunk * 16;
+#pragma unroll
+                for (int o4 = 0; o4 < 4; ++o4)
+                    *reinterpret_cast<f32x4*>(dst + o4 * 4) = f32x4{acc[o4 * 4], acc[o4 * 4 + 1], acc[o4 * 4 + 2], acc[o4 * 4 + 3]};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // BN + ReLU + maxpool 3x3 stride 2 pad 1 (NHWC), 8 channels per thread
 // ------------------------------------------------------------------------------------------------
@@ -691,6 +758,93 @@ __global__ __launch_bounds__(256) void gconv_direct_f32_kernel(const float* __re
     }
 }
 
+// fp32 parity path, LDS-tiled, for the trunk's shapes (C % 64 == 0, 4 | 8 | 16 | 32 channels per group; anything else and bands that
+// do not fit take the direct kernel above): one workgroup = one band of TH output rows of one image x one 64-channel slab.  The
+// band's input (producer BN + ReLU applied, zero padding after it) is staged channel-major in LDS, the slab's weights transposed to
+// [group][tap][ci][co]; a wave takes (group, 64 output pixels) units: lane = pixel, CG accumulators, per (tap, ci) one LDS read of
+// the input value and CG FMAs against wave-uniform weights (broadcast 16-byte LDS reads).  ~60x the direct kernel at B = 256.
+template <int CG>
+__global__ __launch_bounds__(256) void gconv_tiled_f32_kernel(const float* __restrict__ x, const float* __restrict__ a_scale,
+                                                              const float* __restrict__ a_shift, const float* __restrict__ w,
+                                                              float* __restrict__ y, const float* __restrict__ centre,
+                                                              int B, int H, int W, int C, int stride, int Ho, int Wo, int TH,
+                                                              int bands, int plane_p, float act_floor) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    constexpr int NG = 64 / CG;
+    const int Wp = W + 2, rows_in = (TH - 1) * stride + 3, plane = rows_in * Wp;
+    float* ws = smf;                                  // [NG][9][CG ci][CG co]
+    float* cs = ws + 64 * 9 * CG;                     // [64]  -centre
+    float* xs = cs + 64;                              // [64][plane_p]  (plane_p = plane padded to 1 mod 8: staging writes spread over banks)
+    const int c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 64 * CG * 9; e += 256) {    // OIHW [C][CG][3][3], read contiguously
+        const int co = e / (CG * 9), r = e - co * (CG * 9), ci = r / 9, tap = r - ci * 9;
+        const int g = co / CG, o = co - g * CG;
+        ws[((g * 9 + tap) * CG + ci) * CG + o] = w[(long)c0 * CG * 9 + e];
+    }
+    if (tid < 64) cs[tid] = centre ? -centre[c0 + tid] : 0.f;
+    const int ch4 = tid & 15;                         // staging role: 4 channels of a pixel
+    f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+    if (a_scale) {
+        sc4 = *reinterpret_cast<const f32x4*>(a_scale + c0 + ch4 * 4);
+        sh4 = *reinterpret_cast<const f32x4*>(a_shift + c0 + ch4 * 4);
+    }
+    for (int item = blockIdx.x; item < B * bands; item += gridDim.x) {
+        const int b = item / bands, band = item - b * bands;
+        const int oy0 = band * TH, iy0 = oy0 * stride - 1;
+        __syncthreads();                              // the previous item's readers are done (first item: weights visible)
+        for (int pix = tid >> 4; pix < plane; pix += 16) {
+            const int ry = pix / Wp, rx = pix - ry * Wp;
+            const int yin = iy0 + ry, xin = rx - 1;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};           // zero padding lives in the post-activation domain
+            if ((unsigned)yin < (unsigned)H && (unsigned)xin < (unsigned)W) {
+                v = *reinterpret_cast<const f32x4*>(x + (((long)b * H + yin) * W + xin) * C + c0 + ch4 * 4);
+                if (a_scale) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(v[k], sc4[k], sh4[k]), act_floor);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xs[(ch4 * 4 + k) * plane_p + pix] = v[k];
+        }
+        __syncthreads();
+        const int n_out = min(TH, Ho - oy0) * Wo, nblk = (n_out + 63) / 64;
+        for (int u = wave; u < NG * nblk; u += 4) {
+            const int g = u / nblk, blk = u - g * nblk;
+            const int q = blk * 64 + lane;
+            const bool ok = q < n_out;
+            const int qq = ok ? q : 0, ty = qq / Wo, ox = qq - ty * Wo;
+            float acc[CG];
+#pragma unroll
+            for (int o = 0; o < CG; ++o) acc[o] = cs[g * CG + o];
+            const float* xb = xs + (g * CG) * plane_p + (ty * stride) * Wp + ox * stride;
+            const float* wb = ws + g * 9 * CG * CG;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll 4
+                for (int ci = 0; ci < CG; ++ci) {
+                    const float xv = xb[ci * plane_p + ky * Wp + kx];
+                    const float* wt = wb + (tap * CG + ci) * CG;
+#pragma unroll
+                    for (int o4 = 0; o4 < CG / 4; ++o4) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wt + o4 * 4);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[o4 * 4 + k] = fmaf(xv, w4[k], acc[o4 * 4 + k]);
+                    }
+                }
+            }
+            if (ok) {
+                float* dst = y + (((long)b * Ho + oy0 + ty) * Wo + ox) * C + c0 + g * CG;
+#pragma unroll
+                for (int o4 = 0; o4 < CG / 4; ++o4)
+                    *reinterpret_cast<f32x4*>(dst + o4 * 4) = f32x4{acc[o4 * 4], acc[o4 * 4 + 1], acc[o4 * 4 + 2], acc[o4 * 4 + 3]};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // out = relu(raw * scale + shift + identity),  identity = idn  or  idn * idn_scale + idn_shift
 // ------------------------------------------------------------------------------------------------
@@ -926,9 +1080,32 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
         return CVCL_OK;
     }
     const long total = (long)B * (H / 2) * (W / 2) * 64;
-    { CvclProfScope prof(stream, CVCL_K_STEM);
-    hipLaunchKernelGGL(stem_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, x_nchw,
-                       (const float*)w_packed, (float*)y_nhwc, centre, B, H, W); }
+    {
+        CvclProfScope prof(stream, CVCL_K_STEM);
+        // LDS-tiled kernel when a band of >= 1 output row fits (weights 37 KB + 3 x (2 TH + 5) x (W + 6) floats)
+        const int Ho = H / 2;
+        auto lds_of = [&](int th) { return (size_t)(147 * 64 + 64 + 3 * (2 * th + 5) * (W + 6)) * 4; };
+        int TH = Ho < 8 ? Ho : 8;
+        while (TH > 1 && lds_of(TH) > 150 * 1024) --TH;
+        static const bool tiled_on = [] { const char* e = getenv("CVCL_F32_TILED"); return !(e && e[0] == '0'); }();
+        if (tiled_on && lds_of(TH) <= 150 * 1024) {
+            static bool attr = false;
+            if (!attr) {
+                if (hipFuncSetAttribute((const void*)stem_tiled_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    cvcl_set_error("cvcl_stem_conv7x7: cannot raise the dynamic LDS limit");
+                    return CVCL_ELAUNCH;
+                }
+                attr = true;
+            }
+            const int bands = cvcl_div_up(Ho, TH);
+            const long items = (long)B * bands;
+            hipLaunchKernelGGL(stem_tiled_f32_kernel, dim3((unsigned)(items < 1024 ? items : 1024)), dim3(256), lds_of(TH), s, x_nchw,
+                               (const float*)w_packed, (float*)y_nhwc, centre, B, H, W, TH, bands);
+        } else {
+            hipLaunchKernelGGL(stem_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, x_nchw,
+                               (const float*)w_packed, (float*)y_nhwc, centre, B, H, W);
+        }
+    }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y_nhwc, (long)B * (H / 2) * (W / 2), 64, stats, stats_rows, stream);
     return CVCL_OK;
@@ -1039,9 +1216,44 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         return CVCL_OK;
     }
     const long total = (long)B * Ho * Wo * C;
-    { CvclProfScope prof(stream, CVCL_K_GCONV);
-    hipLaunchKernelGGL(gconv_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, (const float*)x, a_scale,
-                       a_shift, (const float*)w_packed, (float*)y, centre, B, H, W, C, cg, stride, Ho, Wo, act_floor); }
+    {
+        CvclProfScope prof(stream, CVCL_K_GCONV);
+        // LDS-tiled kernel for the trunk's shapes when a band fits: weights 64 x 9 x cg floats + 64 channel planes of the band
+        auto plane_p_of = [&](int th) { const int pl = ((th - 1) * stride + 3) * (W + 2); return pl + ((9 - (pl & 7)) & 7); };   // = 1 mod 8
+        auto lds_of = [&](int th) { return (size_t)(64 * 9 * cg + 64 + 64 * plane_p_of(th)) * 4; };
+        int TH = Ho;
+        while (TH > 1 && lds_of(TH) > 150 * 1024) --TH;
+        static const bool tiled_on = [] { const char* e = getenv("CVCL_F32_TILED"); return !(e && e[0] == '0'); }();
+        const bool tiled = tiled_on && C % 64 == 0 && (cg == 4 || cg == 8 || cg == 16 || cg == 32) && lds_of(TH) <= 150 * 1024 &&
+                           ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)a_scale & 15) == 0 && ((uintptr_t)a_shift & 15) == 0;
+        if (tiled) {
+            const int bands = cvcl_div_up(Ho, TH);
+            const long items = (long)B * bands;
+            const int slabs = C / 64;
+            long gx = 1024 / slabs;                          // ~4 workgroups per CU in total; each stages its weights once
+            if (gx < 1) gx = 1;
+            if (gx > items) gx = items;
+            static bool attr[4] = {};
+            auto launch = [&](auto kern, int slot) -> int {
+                if (!attr[slot]) {
+                    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                        cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
+                        return CVCL_ELAUNCH;
+                    }
+                    attr[slot] = true;
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)gx, slabs), dim3(256), lds_of(TH), s, (const float*)x, a_scale, a_shift,
+                                   (const float*)w_packed, (float*)y, centre, B, H, W, C, stride, Ho, Wo, TH, bands, plane_p_of(TH), act_floor);
+                return CVCL_OK;
+            };
+            const int rc = cg == 4 ? launch(gconv_tiled_f32_kernel<4>, 0) : cg == 8 ? launch(gconv_tiled_f32_kernel<8>, 1)
+                         : cg == 16 ? launch(gconv_tiled_f32_kernel<16>, 2) : launch(gconv_tiled_f32_kernel<32>, 3);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(gconv_direct_f32_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, s, (const float*)x, a_scale,
+                               a_shift, (const float*)w_packed, (float*)y, centre, B, H, W, C, cg, stride, Ho, Wo, act_floor);
+        }
+    }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y, (long)B * Ho * Wo, C, stats, stats_rows, stream);
     return CVCL_OK;
