@@ -123,6 +123,8 @@ def main(args):
     model = MultiModalLitModel.load_from_checkpoint(checkpoint, map_location=device)
     model.to(device)
     model.eval()
+    if args.hip_graph:                                     # replay the image encoder's launches as a HIP graph per batch shape
+        model.vision_encoder.enable_hip_graphs(True)
 
     data_args = _setup_parser().parse_args("")
     for key, value in model.args.items():
@@ -199,6 +201,8 @@ def _parser():
     parser.add_argument("--save_predictions", action="store_true", help="save model predictions to JSON")
     # additions of this implementation
     parser.add_argument("--trial_batch", type=int, default=64, help="trials encoded per device pass (1 = the reference's loop)")
+    parser.add_argument("--hip_graph", action="store_true", help="capture the eval-mode image encoder into a HIP graph per batch "
+                                                                  "shape and replay it (removes the host's launch lead; same results)")
     parser.add_argument("--checkpoints_root", type=str, default="checkpoints", help="where run names resolve to checkpoints")
     parser.add_argument("--n_trials", type=int, default=32, help="number of synthetic trials")
     return parser

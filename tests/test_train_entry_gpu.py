@@ -197,6 +197,12 @@ def test_eval_entry_batched_trials_match_reference_loop(dev, tmp_path, monkeypat
                 runs[tb] = ev.main(a)
             assert "Total accuracy:" in out.getvalue()
         assert len(runs[1]) == len(runs[64]) == 10
+        ag = ev._parser().parse_args(["--checkpoint", exp, "--eval_dataset", "synthetic", "--eval_type", eval_type, "--n_trials", "10",
+                                      "--trial_batch", "4", "--hip_graph"])        # batches of 4, 4, 2 trials: two graph shapes
+        with contextlib.redirect_stdout(io.StringIO()):
+            graphed = ev.main(ag)
+        for r1, rg in zip(runs[1], graphed):
+            assert r1["pred"] == rg["pred"] and torch.allclose(torch.tensor(r1["logits"]), torch.tensor(rg["logits"]), rtol=1e-4, atol=1e-6)
         for r1, r64 in zip(runs[1], runs[64]):
             assert r1["pred"] == r64["pred"] and r1["correct"] == r64["correct"] and r1["categories"] == r64["categories"]
             assert torch.allclose(torch.tensor(r1["logits"]), torch.tensor(r64["logits"]), rtol=1e-4, atol=1e-6)
@@ -387,3 +393,47 @@ def test_three_adamw_steps_match_the_oracle_step_fp32(dev):
         assert float((a - b).abs().max()) < 2e-4 * max(1e-3, float(b.abs().max())), k
         assert not torch.equal(b, sd[k])
     assert int(now["image_embed.model.layer4.2.bn3.num_batches_tracked"]) == 3
+
+
+@pytest.mark.parametrize("config", ["c2", "c4"])
+def test_eval_hip_graph_replay_is_bit_identical_to_eager_launches(dev, config):
+    """Opt-in HIP-graph replay of the eval-mode image encoder (VisionEncoder.enable_hip_graphs; eval.py --hip_graph): one graph per
+    input shape over a static input buffer, results bit-identical to the eager launches for new inputs, dropped by train() so that
+    updated weights are seen, never pickled, and bypassed whenever gradients or train-mode BatchNorm are involved."""
+    import pickle
+    import bench
+    lit, ve, _ = bench.build_model(config, dev, precision="bf16")
+    lit.eval()
+    g = torch.Generator(device=dev).manual_seed(5)
+    xs = {B: [torch.randn(B, 3, 224, 224, generator=g, device=dev) for _ in range(3)] for B in (1, 4)}
+    with torch.no_grad():
+        eager = {B: [tuple(None if t is None else t.clone() for t in ve(x)) for x in v] for B, v in xs.items()}
+        ve.enable_hip_graphs(True)
+        for B, v in xs.items():
+            for i, x in enumerate(v):
+                f, m = ve(x)
+                assert torch.equal(f, eager[B][i][0])
+                assert (m is None and eager[B][i][1] is None) or torch.equal(m, eager[B][i][1])
+        assert set(k[0][0] for k in ve._graphs) == {1, 4}
+        f_keep, _ = ve(xs[1][0])
+        ve(xs[1][1])                                          # a later replay must not overwrite results handed out earlier
+        assert torch.equal(f_keep, eager[1][0][0])
+        logits_graph = lit(xs[4][0], torch.tensor([[2, 9, 3]], device=dev), torch.tensor([3], device=dev))[1]
+    pickle.dumps(ve)                                          # graphs are not part of a pickled encoder
+    # weights change in train mode: the graphs go, the next eval call captures the new weights
+    lit.train()
+    assert ve._graphs == {}
+    with torch.no_grad():
+        (ve.model.head if config == "c4" else ve.model.fc).weight.mul_(2.0)
+    lit.eval()
+    with torch.no_grad():
+        f2, _ = ve(xs[1][0])
+        ve.enable_hip_graphs(False)
+        f2_eager, _ = ve(xs[1][0])
+        logits_eager = lit(xs[4][0], torch.tensor([[2, 9, 3]], device=dev), torch.tensor([3], device=dev))[1]
+    assert torch.equal(f2, f2_eager) and not torch.equal(f2, eager[1][0][0])
+    assert logits_graph.shape == logits_eager.shape == (1, 4)
+    # gradients enabled or train mode: never a graph
+    ve.enable_hip_graphs(True)
+    ve(xs[1][0])
+    assert ve._graphs == {}
