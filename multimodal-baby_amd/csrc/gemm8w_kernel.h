@@ -69,6 +69,8 @@ __device__ __forceinline__ int swz(int g) { return (0x78 >> (2 * g)) & 3; }
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -80,7 +82,8 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // VAR (experiment switches): bit 0 = s_setprio(1) around the MFMA halves; bit 1 = the post-barrier fragment reads and stage
 // loads are interleaved with the second half's MFMAs (sched_group_barrier) instead of being issued ahead of them.
 // Ablations for tools/gemm_lab only (WRONG results, timing of what is left): bit 2 = no per-stage barrier, bit 3 = no stage
-// loads, bit 4 = no fragment reads, bit 5 = no epilogue (except m-tile 0).  The library instantiates VAR = 2.
+// loads, bit 4 = no fragment reads, bit 5 = no epilogue (except m-tile 0).  Bit 6 = stagger experiment
+// (round 3, see the K loop: 3-8 % slower, profiles/r03_gemm_lab.txt).  The library instantiates VAR = 2.
 // What the ablations say (tools/gemm_lab/ablate.sh, 4096^3: 110 us = 1.25 PFLOP/s as is): without the barrier 112 us (the
 // barrier costs nothing), without the stage loads 94, without the fragment reads 93, without all three 72 us = 1.92 PFLOP/s
 // (MFMAs + epilogue alone: the clock-limited ceiling).  The loss is the LDS traffic itself (96 KB of fragment reads + 32 KB of
@@ -370,7 +373,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----
     issue(0); advance(); issue(1); advance(); issue(2); advance(); issue(3); advance();
     if constexpr (EPI == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this thread's LDS writes above (-centre)
-    wait_vm<12>();
+    if constexpr (VAR & 64) wait_vm<8>();                    // (stagger experiment: stages 0 and 1 landed)
+    else wait_vm<12>();
     __builtin_amdgcn_s_barrier();
     read_frags(0, std::integral_constant<int, 0>{});
     if constexpr (EPI == 0) {
@@ -390,10 +394,17 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     int c_ks = 0, c_i = ti, c_j = tj;                        // k stage / (m-tile, column tile) of the tile being multiplied
     auto step = [&](int g, auto P) __attribute__((always_inline)) {
         constexpr int q = decltype(P)::value;
+        if constexpr (VAR & 64) __builtin_amdgcn_s_setprio(1);
         mma_half(P, std::integral_constant<int, 0>{});
+        if constexpr (VAR & 64) __builtin_amdgcn_s_setprio(0);
         // stage g+1 has landed (this wave's part); the fragment reads of stage g are complete
-        if (after_epi > 0 && epi_ops == ESTORES) wait_vm<8 + ESTORES>();
-        else wait_vm<8>();
+        if constexpr (VAR & 64) {                            // stagger experiment: the other wave group is half a stage away, so
+            if (after_epi > 0 && epi_ops == ESTORES) wait_vm<4 + ESTORES>();     // a stage is awaited one stage earlier
+            else wait_vm<4>();
+        } else {
+            if (after_epi > 0 && epi_ops == ESTORES) wait_vm<8 + ESTORES>();
+            else wait_vm<8>();
+        }
         if (after_epi > 0) --after_epi;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr (!(VAR & 4)) __builtin_amdgcn_s_barrier();
@@ -414,6 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             }
         }
         advance();
+        if constexpr (VAR & 64) __builtin_amdgcn_s_barrier();      // second barrier of the stage: the groups sit half a stage apart
         if (++c_ks == KS) {
             c_ks = 0;
             epi_ops = epilogue(c_i * BM, c_j * BN);
@@ -425,10 +437,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             }
         }
     };
+    // VAR bit 6 (lab experiment): waves 4-7 (the second wave of every SIMD) run half a stage behind waves 0-3 -- one wave of a SIMD in
+    // its pure-MFMA half while its partner reads fragments / issues stage loads (the "ping-pong" of the guide's 8-phase template)
+    if constexpr (VAR & 64) { if (wm == 1) __builtin_amdgcn_s_barrier(); }
     for (int g = 0; g < S; g += 2) {
         step(g, std::integral_constant<int, 0>{});
         step(g + 1, std::integral_constant<int, 1>{});
     }
+    if constexpr (VAR & 64) { if (wm == 0) __builtin_amdgcn_s_barrier(); }
     wait_vm<0>();                                            // the re-loads past the end must not outlive the workgroup
 
     if (EPI == 0 && p.stats) {

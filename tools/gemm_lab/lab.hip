@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
         const int mi = var[0] == 'w' ? var[1] - '0' : 0;
         // + ablations (wrong results, timing only): n = no barrier, l = no stage loads, r = no fragment reads, x = all three, e = no epilogue
         const int vv = var.size() > 2 ? (var[2] == 'a' ? 1 : var[2] == 'b' ? 2 : var[2] == 'c' ? 3 : var[2] == 'n' ? 6 : var[2] == 'l' ? 10 :
-                                         var[2] == 'r' ? 18 : var[2] == 'x' ? 30 : var[2] == 'e' ? 34 : 0) : 0;
+                                         var[2] == 'r' ? 18 : var[2] == 'x' ? 30 : var[2] == 'e' ? 34 : var[2] == 's' ? 66 : 0) : 0;
         if (mi < 6 || mi > 8 || N % 256 || K % 128) { printf("bad variant / shape\n"); return 1; }
         static g8w::Dev d;
         memset(&d, 0, sizeof(d));
@@ -162,6 +162,8 @@ int main(int argc, char** argv) {
         if (mi == 8 && vv == 18) run = [=]() { launch_w<8, 0, 18>(d, grid, st); };
         if (mi == 8 && vv == 30) run = [=]() { launch_w<8, 0, 30>(d, grid, st); };
         if (mi == 8 && vv == 34) run = [=]() { launch_w<8, 0, 34>(d, grid, st); };
+        if (mi == 8 && vv == 66) run = [=]() { launch_w<8, 0, 66>(d, grid, st); };
+        if (mi == 7 && vv == 66) run = [=]() { launch_w<7, 0, 66>(d, grid, st); };
     }
     run();
     CK(hipStreamSynchronize(st));
