@@ -169,6 +169,26 @@ def test_gconv(H, dev, dt, C_, S, stride, B, centred):
     check_stats(st, rows, y)
 
 
+def test_gconv_fp32_direct_fallback(H, dev):
+    """Shapes outside the LDS-tiled fp32 kernel's set (here 3 channels per group, C not a multiple of 64) take the direct kernel."""
+    g = torch.Generator().manual_seed(11)
+    B, C_, S, groups, stride = 2, 96, 12, 32, 2
+    cg = C_ // groups
+    x = torch.randn(B, C_, S, S, generator=g)
+    w = torch.randn(C_, cg, 3, 3, generator=g) / (3 * cg ** 0.5)
+    sc, sh = torch.rand(C_, generator=g) + 0.5, torch.randn(C_, generator=g) * 0.5
+    ref = F.conv2d(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), w, None, stride, 1, 1, groups)
+    So = (S - 1) // stride + 1
+    y = torch.empty(B, So, So, C_, device=dev)
+    rows = H.lib().cvcl_gconv3x3_stats_rows(H.F32, B, S, S, C_, stride)
+    st = stats_tensor(rows, C_, dev)
+    xd, scd, shd, wd = nhwc(x).to(dev), sc.to(dev), sh.to(dev), w.contiguous().to(dev)
+    H.check(H.lib().cvcl_gconv3x3(H.F32, H.ptr(xd), H.ptr(scd), H.ptr(shd), H.ptr(wd), H.ptr(y), H.ptr(st), rows, None, B, S, S, C_,
+                                  groups, stride, H.stream_ptr()), "gconv")
+    assert maxrel(y, nhwc(ref)) < 2e-5
+    check_stats(st, rows, y)
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_bn_add_relu_and_avgpool(H, dev, dt):
     g = torch.Generator().manual_seed(9)
