@@ -59,25 +59,46 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     const int cc = blockIdx.y * ccb + threadIdx.x % ccb, rl = threadIdx.x / ccb;
     const int c = cc * EPC;
     float sc[EPC], sh[EPC], mu[EPC], rs[EPC], s[EPC], q[EPC];
+    const float* scp = mode == 1 ? scale : mean;          // (unconditional 16-byte loads: see bn_bwd_apply_kernel)
+    const float* shp = mode == 1 ? shift : mean;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        sc[e] = mode == 1 ? scale[c + e] : 0.f; sh[e] = mode == 1 ? shift[c + e] : 0.f;
-        mu[e] = mean[c + e]; rs[e] = rstd[c + e]; s[e] = 0.f; q[e] = 0.f;
+    for (int v4 = 0; v4 < EPC / 4; ++v4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(scp + c + 4 * v4), b = *reinterpret_cast<const f32x4*>(shp + c + 4 * v4);
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(mean + c + 4 * v4), r4 = *reinterpret_cast<const f32x4*>(rstd + c + 4 * v4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[4 * v4 + e] = mode == 1 ? a[e] : 0.f; sh[4 * v4 + e] = mode == 1 ? b[e] : 0.f;
+            mu[4 * v4 + e] = m4[e]; rs[4 * v4 + e] = r4[e]; s[4 * v4 + e] = 0.f; q[4 * v4 + e] = 0.f;
+        }
     }
-    for (long r = (long)blockIdx.x * RL + rl; r < rows; r += (long)gridDim.x * RL) {
-        const long off = r * C + c;
-        Chunk<T> xv, gv, ov;
-        xv.load(x + off);
-        gv.load(dy + off);
-        if (mode == 2) ov.load(out + off);
+    // four rows' loads (clamped addresses: always valid, no branch around a load) are in flight before the first is used; the rows
+    // are then accumulated in the order of the one-row-at-a-time loop (same sums, bit for bit).  One row per iteration kept ~6 MB in
+    // flight on the whole chip: the pass ran at half the streaming rate
+    constexpr int UN = 4;
+    const long rstep = (long)gridDim.x * RL;
+    for (long r = (long)blockIdx.x * RL + rl; r < rows; r += UN * rstep) {
+        Chunk<T> xv[UN], gv[UN], ov[UN];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float xe = xv.get(e);
-            float g = gv.get(e);
-            if (mode == 1 && !(fmaf(xe, sc[e], sh[e]) > 0.f)) g = 0.f;
-            if (mode == 2 && !(ov.get(e) > 0.f)) g = 0.f;
-            s[e] += g;
-            q[e] = fmaf(g, (xe - mu[e]) * rs[e], q[e]);
+        for (int u = 0; u < UN; ++u) {
+            const long rr = r + u * rstep;
+            const long off = (rr < rows ? rr : rows - 1) * C + c;
+            xv[u].load(x + off);
+            gv[u].load(dy + off);
+            if (mode == 2) ov[u].load(out + off);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            if (r + u * rstep < rows) {
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) {
+                    const float xe = xv[u].get(e);
+                    float g = gv[u].get(e);
+                    if (mode == 1 && !(fmaf(xe, sc[e], sh[e]) > 0.f)) g = 0.f;
+                    if (mode == 2 && !(ov[u].get(e) > 0.f)) g = 0.f;
+                    s[e] += g;
+                    q[e] = fmaf(g, (xe - mu[e]) * rs[e], q[e]);
+                }
+            }
         }
     }
 #pragma unroll
@@ -141,29 +162,51 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const long total = rows * CC;
     const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(i0 % CC) * EPC;
+    // per-channel coefficients as 16-byte loads from unconditional addresses (a `mode == 1 ? scale[c + e] : 0.f` per element made the
+    // compiler wait for every channel's load in turn: 40 dependent L2 round trips in front of four chunks of work -- the pass ran at
+    // 2.7 TB/s on the 128-channel layers)
     float sc[EPC], sh[EPC], k1[EPC], k2[EPC], k3[EPC];
+    const float* scp = mode == 1 ? scale : coef;
+    const float* shp = mode == 1 ? shift : coef;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-        sc[e] = mode == 1 ? scale[c + e] : 0.f; sh[e] = mode == 1 ? shift[c + e] : 0.f;
-        k1[e] = coef[c + e]; k2[e] = coef[C + c + e]; k3[e] = coef[2 * C + c + e];
+    for (int v4 = 0; v4 < EPC / 4; ++v4) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(scp + c + 4 * v4), b = *reinterpret_cast<const f32x4*>(shp + c + 4 * v4);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + c + 4 * v4), c2 = *reinterpret_cast<const f32x4*>(coef + C + c + 4 * v4);
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c + 4 * v4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sc[4 * v4 + e] = mode == 1 ? a[e] : 0.f; sh[4 * v4 + e] = mode == 1 ? b[e] : 0.f;
+            k1[4 * v4 + e] = c1[e]; k2[4 * v4 + e] = c2[e]; k3[4 * v4 + e] = c3[e];
+        }
     }
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = i0; i < total; i += stride) {
-        Chunk<T> xv, gv, ov, o, go;
-        xv.load(x + i * EPC);
-        gv.load(dy + i * EPC);
-        if (mode == 2) ov.load(out + i * EPC);
+    for (long i = i0; i < total; i += 2 * stride) {          // two independent chunk sets in flight per thread (as in bn_add_relu)
+        const long j = i + stride;
+        const bool has_j = j < total;
+        const long jj = has_j ? j : i;                        // (clamped: the loads are unconditional)
+        Chunk<T> xv[2], gv[2], ov[2], o, go;
+        xv[0].load(x + i * EPC);
+        gv[0].load(dy + i * EPC);
+        if (mode == 2) ov[0].load(out + i * EPC);
+        xv[1].load(x + jj * EPC);
+        gv[1].load(dy + jj * EPC);
+        if (mode == 2) ov[1].load(out + jj * EPC);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {
-            const float xe = xv.get(e);
-            float g = gv.get(e);
-            if (mode == 1 && !(fmaf(xe, sc[e], sh[e]) > 0.f)) g = 0.f;
-            if (mode == 2 && !(ov.get(e) > 0.f)) g = 0.f;
-            go.set(e, g);
-            o.set(e, fmaf(k1[e], g, fmaf(k2[e], xe, k3[e])));
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !has_j) break;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const float xe = xv[u].get(e);
+                float g = gv[u].get(e);
+                if (mode == 1 && !(fmaf(xe, sc[e], sh[e]) > 0.f)) g = 0.f;
+                if (mode == 2 && !(ov[u].get(e) > 0.f)) g = 0.f;
+                go.set(e, g);
+                o.set(e, fmaf(k1[e], g, fmaf(k2[e], xe, k3[e])));
+            }
+            const long k = u ? j : i;
+            o.store(dx + k * EPC);
+            if (g_out) go.store(g_out + k * EPC);
         }
-        o.store(dx + i * EPC);
-        if (g_out) go.store(g_out + i * EPC);
     }
 }
 
@@ -519,6 +562,8 @@ extern "C" int cvcl_bn_bwd(int dtype, int mode, const void* x, const void* out, 
     CVCL_CHECK_ARG(C % epc == 0 && (cc & (cc - 1)) == 0, "cvcl_bn_bwd: channel count %d must be a power of two >= %d", C, epc);
     const int g = bn_bwd_rows(dtype, rows, C);
     CVCL_CHECK_ARG(partial_rows >= g, "cvcl_bn_bwd: partial_rows %d < %d", partial_rows, g);
+    CVCL_CHECK_ARG((((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)coef) & 15) == 0,
+                   "cvcl_bn_bwd: scale / shift / mean / rstd / coef must be 16-byte aligned");
     CvclProfScope prof(stream, CVCL_K_BN_BWD);
     hipStream_t s = (hipStream_t)stream;
     const int ccb = cc < 256 ? cc : 256;
