@@ -573,6 +573,49 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
     return res
 
 
+def measure_finetune(device, batch_size, steps=5, warmup=3):
+    """C2 with --finetune_cnn (SURVEY 8d "finetune" mode; the reference's *_finetune_cnn runner configs): the whole ResNeXt-50 trains --
+    forward with saved activations, BatchNorm / conv data and weight gradients (multimodal/trunk_train.py), AdamW over all 161 trunk
+    parameters.  Single stream, bf16 storage.  -> sub-record."""
+    import multimodal.multimodal as mm
+    from multimodal.multimodal import TextEncoder, VisionEncoder
+    from multimodal.multimodal_data_module import read_vocab
+    from multimodal.multimodal_lit import MultiModalLitModel
+    torch.manual_seed(0)
+    args = c2_args()
+    args.finetune_cnn = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        ve = VisionEncoder(args)
+        te = TextEncoder(read_vocab(), ve.last_cnn_out_dim, args)
+        lit = MultiModalLitModel(ve, te, args)
+    lit.to(device)
+    lit.set_precision("bf16")
+    lit.train()
+    opt = lit.configure_optimizers()
+    opt = opt["optimizer"] if isinstance(opt, dict) else opt
+    batch = synthetic_batch_on_device(batch_size, 0, device) + (None,)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = lit.training_step(batch, 0)
+        out["loss"].backward()
+        opt.step()
+        return out
+    for _ in range(warmup):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    n_train = sum(p.numel() for p in lit.parameters() if p.requires_grad)
+    return {"value": round(batch_size / dt, 1), "unit": "pairs/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup,
+            "dtype": "bf16", "per_gpu_batch": batch_size, "trainable_parameters": n_train, "final_loss": round(float(out["loss"]), 5),
+            "note": "C2 with --finetune_cnn: forward + backward through the whole ResNeXt-50 (BatchNorm train mode) + AdamW; the frozen "
+                    "default is the headline above"}
+
+
 def sub_record(r):
     """The bounded side measurements of the default line (other precisions / configurations of BASELINE.json)."""
     out = {"value": round(r["value"], 1), "unit": "pairs/s", "ms_per_step": round(r["ms_per_step"], 3), "steps": r["steps"],
@@ -653,6 +696,7 @@ def main(argv=None):
         for c in ("c4", "c5"):
             extras[c] = sub_record(measure(c, "fp8" if c == "c5" else "bf16", PER_GPU_BATCH, sub_steps, 5, device, world, rank,
                                            roofline=not a.no_roofline, parity=not a.no_parity))
+        extras["finetune_cnn"] = measure_finetune(device, PER_GPU_BATCH)
 
     if rank == 0:
         line = {"metric": METRIC if cfg == "c2" else f"image-text pairs/sec, CVCL ViT-B/16+transformer text 224², {cfg.upper()}, MI355X",
