@@ -16,6 +16,8 @@
 // (b, oy*stride + ky - 1, ox*stride + kx - 1) (zeros outside the image) and only the diagonal tiles (same 128-channel
 // slab of A and B) are computed: every group of <= 32 channels lies inside one slab; the reduction kernel picks the
 // block-diagonal out.  The dense 128 x 128 products waste MFMA work (x4 .. x32), which is cheap; HBM traffic is what counts.
+#include <cstdlib>
+
 #include "cvcl_common.h"
 
 namespace {
@@ -456,10 +458,268 @@ extern "C" int cvcl_gemm_tn_colsum(const void* A, int lda, const void* B, int ld
     return CVCL_OK;
 }
 
+namespace {
+// ---- grouped 3x3 weight gradient, all nine taps in ONE pass over the operands (round 3) ------------------------------------------
+// The tap-at-a-time form above reads dY and X nine times (layer 1 at B = 256: 3.7 GB per launch, 562 us).  Here a workgroup owns a
+// 128-channel slab and walks bands of TH output rows of an image: the band of X (with its halo rows / columns, zeros outside the
+// image) and the band of dY (rows padded to a multiple of 16 pixels with zeros) are staged once into LDS as pixel-major rows
+// (pitch 320 B, the TN kernel's layout); wave w owns the diagonal 32 x 32 block w of the slab (every group of <= 32 channels lies
+// inside one) for ALL nine taps -- 9 accumulator tiles = 144 registers, kept across the workgroup's bands.  Per 16 pixels of a row:
+// one dY fragment (two ds_read_b64_tr_b16) and nine X fragments whose rows are the same pixels shifted by the tap: in the staged
+// band a tap is a constant row offset (ky * Wp + kx) and the stride a row multiplier, so every tap is two transposing reads at
+// another address.  Partial blocks [workgroup][tap][wave][32][32] fp32, reduced in a fixed order (deterministic).
+constexpr int GW_PITCH = TN_PITCH;
+constexpr int GW_UN = 6;                // staging loads in flight per thread (in-place staging of an image's first band)
+constexpr int GW_XN = 4, GW_DN = 4;     // register image of an incremental band: <= 64 pixels of X and of dY (16 per thread row lane and slot)
+
+struct GwDev {
+    const bf16_t* x; const bf16_t* dy; float* P;
+    int B, H, W, C, stride, Ho, Wo, Wo_pad, TH, bands, rows_in, x_rows, dy_rows;
+    int pipe;        // the incremental band fits the register image: the next band is fetched behind the current one's MFMAs
+};
+
+__global__ __launch_bounds__(256, 2) void gconv_wgrad_band_kernel(GwDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Wp = p.W + 2, R = p.rows_in;
+    char* sX = smem;                                         // [x_rows][GW_PITCH]: a RING of R input rows x Wp pixels + zero slack rows
+    char* sD = smem + (size_t)p.x_rows * GW_PITCH;           // [TH * Wo_pad][GW_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.y * 128;
+    const int s_chunk = tid & 15, s_row0 = tid >> 4;
+    const int n_d = p.TH * p.Wo_pad;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    // slack rows behind the ring (read by the padded pixels of the last slot's row, multiplied by dY = 0: must be finite) -- zeroed once
+    for (int r = R * Wp + s_row0; r < p.x_rows; r += 16) *reinterpret_cast<u32x4*>(sX + r * GW_PITCH + s_chunk * 16) = z;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const int g4 = lane >> 4, q = lane & 15;
+    const int frag_row = (g4 >> 1) * 8 + (q >> 2);                 // + kk*16 + {0, 4}
+    const int frag_col = (g4 & 1) * 16 + (q & 3) * 4;
+    const char* fa = sD + frag_row * GW_PITCH + (wave * 32 + frag_col) * 2;
+    const char* fb = sX + (frag_row * p.stride) * GW_PITCH + (wave * 32 + frag_col) * 2;
+    const int KK = p.Wo_pad / 16;
+    const int step4 = 4 * p.stride * GW_PITCH;
+
+    // A workgroup takes a CONTIGUOUS range of bands.  Input row iy of the image lives in ring slot (iy + 1) % R: consecutive bands of an
+    // image share 3 - stride input rows, which stay where they are -- only the TH * stride new rows of a band are staged (every byte
+    // of X is read once; the tap-at-a-time form read it nine times).  The new rows and the dY band of the NEXT band are fetched into
+    // registers before the current band is multiplied and written to LDS behind it (the global round trip hides behind the MFMAs);
+    // the first band of an image (all R rows) is staged in place.
+    const int n_items = p.B * p.bands, per_wg = (n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int item_begin = blockIdx.x * per_wg, item_end = min(n_items, item_begin + per_wg);
+    const int inc_rows = p.TH * p.stride, n_xi = inc_rows * Wp;            // incremental band: new input rows / their pixels
+
+    // X rows iy_first .. iy_first + rows - 1 of image b -> ring, in place (batches of GW_UN loads per thread)
+    auto stage_x_now = [&](int b, int iy_first, int rows) {
+        const int n_x = rows * Wp;
+        for (int r0 = s_row0; r0 < n_x; r0 += 16 * GW_UN) {
+            u32x4 v[GW_UN];
+            bool ok[GW_UN];
+            int dst[GW_UN];
+#pragma unroll
+            for (int i = 0; i < GW_UN; ++i) {
+                const int r = min(r0 + 16 * i, n_x - 1);
+                const int j = r / Wp, rx = r - j * Wp;
+                const int yi = iy_first + j, xi = rx - 1;
+                ok[i] = yi >= 0 && yi < p.H && xi >= 0 && xi < p.W;
+                const int yc = min(max(yi, 0), p.H - 1), xc = min(max(xi, 0), p.W - 1);
+                v[i] = *reinterpret_cast<const u32x4*>(p.x + (((long)b * p.H + yc) * p.W + xc) * p.C + c0 + s_chunk * 8);
+                dst[i] = (((yi + 1) % R) * Wp + rx) * GW_PITCH + s_chunk * 16;
+            }
+#pragma unroll
+            for (int i = 0; i < GW_UN; ++i)
+                if (r0 + 16 * i < n_x) *reinterpret_cast<u32x4*>(sX + dst[i]) = ok[i] ? v[i] : z;
+        }
+    };
+    auto stage_d_now = [&](int b, int oy0) {
+        for (int r0 = s_row0; r0 < n_d; r0 += 16 * GW_UN) {
+            u32x4 v[GW_UN];
+            bool ok[GW_UN];
+#pragma unroll
+            for (int i = 0; i < GW_UN; ++i) {
+                const int r = min(r0 + 16 * i, n_d - 1);
+                const int ty = r / p.Wo_pad, ox = r - ty * p.Wo_pad;
+                const int oy = oy0 + ty;
+                ok[i] = oy < p.Ho && ox < p.Wo;
+                const int yc = min(oy, p.Ho - 1), xc = min(ox, p.Wo - 1);
+                v[i] = *reinterpret_cast<const u32x4*>(p.dy + (((long)b * p.Ho + yc) * p.Wo + xc) * p.C + c0 + s_chunk * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < GW_UN; ++i) {
+                const int r = r0 + 16 * i;
+                if (r < n_d) *reinterpret_cast<u32x4*>(sD + r * GW_PITCH + s_chunk * 16) = ok[i] ? v[i] : z;
+            }
+        }
+    };
+    // register image of one incremental band: GW_XN x 16 pixels of X, GW_DN x 16 pixels of dY per thread row lane
+    u32x4 px[GW_XN], pd[GW_DN];
+    unsigned px_ok = 0, pd_ok = 0;
+    auto fetch = [&](int b, int oy0, int iy_first) {
+        px_ok = 0; pd_ok = 0;
+#pragma unroll
+        for (int i = 0; i < GW_XN; ++i) {
+            const int r = min(s_row0 + 16 * i, n_xi - 1);
+            const int j = r / Wp, rx = r - j * Wp;
+            const int yi = iy_first + j, xi = rx - 1;
+            if (yi >= 0 && yi < p.H && xi >= 0 && xi < p.W) px_ok |= 1u << i;
+            const int yc = min(max(yi, 0), p.H - 1), xc = min(max(xi, 0), p.W - 1);
+            px[i] = *reinterpret_cast<const u32x4*>(p.x + (((long)b * p.H + yc) * p.W + xc) * p.C + c0 + s_chunk * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < GW_DN; ++i) {
+            const int r = min(s_row0 + 16 * i, n_d - 1);
+            const int ty = r / p.Wo_pad, ox = r - ty * p.Wo_pad;
+            const int oy = oy0 + ty;
+            if (oy < p.Ho && ox < p.Wo) pd_ok |= 1u << i;
+            const int yc = min(oy, p.Ho - 1), xc = min(ox, p.Wo - 1);
+            pd[i] = *reinterpret_cast<const u32x4*>(p.dy + (((long)b * p.Ho + yc) * p.Wo + xc) * p.C + c0 + s_chunk * 8);
+        }
+    };
+    auto commit = [&](int iy_first) {
+#pragma unroll
+        for (int i = 0; i < GW_XN; ++i) {
+            const int r = s_row0 + 16 * i;
+            if (r < n_xi) {
+                const int j = r / Wp, rx = r - j * Wp;
+                *reinterpret_cast<u32x4*>(sX + ((((iy_first + j + 1) % R) * Wp + rx) * GW_PITCH + s_chunk * 16)) = ((px_ok >> i) & 1) ? px[i] : z;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < GW_DN; ++i) {
+            const int r = s_row0 + 16 * i;
+            if (r < n_d) *reinterpret_cast<u32x4*>(sD + r * GW_PITCH + s_chunk * 16) = ((pd_ok >> i) & 1) ? pd[i] : z;
+        }
+    };
+
+    bool staged = false;                                     // this band's operands are already in LDS (committed behind the previous band)
+    for (int item = item_begin; item < item_end; ++item) {
+        const int b = item / p.bands, band = item - b * p.bands;
+        const int oy0 = band * p.TH, iy0 = oy0 * p.stride - 1;
+        if (!staged) {
+            __syncthreads();                                 // the previous band's readers are done
+            const bool full = item == item_begin || band == 0;
+            const int n_new = full ? R : inc_rows;
+            stage_x_now(b, iy0 + R - n_new, n_new);
+            stage_d_now(b, oy0);
+        }
+        __syncthreads();
+        const bool pipe = p.pipe && item + 1 < item_end && band + 1 < p.bands;          // the next band continues this image
+        if (pipe) fetch(b, oy0 + p.TH, iy0 + inc_rows + R - inc_rows);
+        const int th = min(p.TH, p.Ho - oy0);
+        for (int ty = 0; ty < th; ++ty) {
+            const char* fa_r = fa + (ty * p.Wo_pad) * GW_PITCH;
+            int slot_off[3];                                 // byte offset of the ring slot of input row iy0 + ty * stride + ky
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) slot_off[ky] = (((iy0 + ty * p.stride + ky + 1) % R) * Wp) * GW_PITCH;
+            for (int kk = 0; kk < KK; ++kk) {
+                const bf16x4 a0 = lds_tr_read(fa_r + (kk * 16) * GW_PITCH);
+                const bf16x4 a1 = lds_tr_read(fa_r + (kk * 16 + 4) * GW_PITCH);
+                const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const char* fb_k = fb + (kk * 16 * p.stride) * GW_PITCH;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {             // one input row's three taps at a time: six reads, then three MFMAs
+                    bf16x4 b0[3], b1[3];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const char* pt = fb_k + slot_off[ky] + kx * GW_PITCH;
+                        b0[kx] = lds_tr_read(pt);
+                        b1[kx] = lds_tr_read(pt + step4);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bf16x8 bfr = __builtin_shufflevector(b0[kx], b1[kx], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[ky * 3 + kx], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        staged = false;
+        if (pipe) {
+            __syncthreads();                                 // this band's readers are done: the next band's rows may land
+            commit(iy0 + inc_rows + R - inc_rows);
+            staged = true;
+        }
+    }
+    // partial blocks: P[((slab * G + wg) * 9 + tap) * 4 + wave][co 32][ci 32]
+    float* out = p.P + ((((long)blockIdx.y * gridDim.x + blockIdx.x) * 9) * 4 + wave) * 1024;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* o = out + (long)t * 4 * 1024;
+        const int col = lane & 31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
+            o[row * 32 + col] = acc[t][r];
+        }
+    }
+}
+
+// dW[co][ci][tap] = sum over the slab's workgroups (fixed order) of the (co, group-local ci) element of the diagonal block.
+// One thread per element of the [tap][wave][32][32] partial blocks (consecutive threads = consecutive columns: the G partial
+// images are read as full lines; a thread per OUTPUT element gathered one float per 4 KB and took longer than the band kernel);
+// the elements outside the block diagonal are dropped.
+__global__ __launch_bounds__(256) void gconv_wgrad_band_reduce_kernel(const float* __restrict__ P, float* __restrict__ dw, int G, int C,
+                                                                      int cg) {
+    const long per_slab = 9L * 4 * 1024;
+    const long total = (long)(C / 128) * per_slab;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int slab = (int)(e / per_slab);
+        const int rem = (int)(e - (long)slab * per_slab);
+        const int tap = rem >> 12, w = (rem >> 10) & 3, row = (rem >> 5) & 31, col = rem & 31;
+        if (row / cg != col / cg) continue;                  // (wave-divergent skip of whole 16-byte groups for cg >= 4)
+        const float* src = P + (long)slab * G * per_slab + rem;
+        const float v = ordered_sum<8, float>(G, [&](int g) { return src[(long)g * per_slab]; });
+        const int co = slab * 128 + w * 32 + row;
+        dw[((long)co * cg + col % cg) * 9 + tap] = v;
+    }
+}
+
+struct GwPlan { int TH, bands, rows_in, Wo_pad, x_rows, dy_rows, G, slabs, pipe; size_t lds, ws; bool ok; };
+GwPlan gw_plan(int B, int H, int W, int C, int stride) {
+    GwPlan g = {};
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1, Wp = W + 2;
+    g.Wo_pad = (Wo + 15) & ~15;
+    g.slabs = C / 128;
+    auto x_rows_of = [&](int th) {
+        const int rows_in = (th - 1) * stride + 3;
+        // ring of rows_in input rows + the slack the padded pixels of the LAST slot's row read (finite zeros)
+        return rows_in * Wp + g.Wo_pad * stride + 2;
+    };
+    auto lds_of = [&](int th) { return (size_t)(x_rows_of(th) + th * g.Wo_pad) * GW_PITCH; };
+    // two workgroups per CU (one stages while the other multiplies): bands of <= 80 KB when one output row fits that
+    auto fits_regs = [&](int th) { return th * stride * Wp <= 16 * GW_XN && th * g.Wo_pad <= 16 * GW_DN; };
+    int TH = Ho;
+    while (TH > 1 && (lds_of(TH) > 80 * 1024 || !fits_regs(TH))) --TH;
+    if (!fits_regs(TH)) {                                    // (stride-2 layers at 56 x 56: a band's new rows exceed the register image:
+        TH = Ho;                                             //  staged in place, one workgroup per CU with as tall a band as fits)
+        while (TH > 1 && lds_of(TH) > 160 * 1024) --TH;
+    }
+    g.pipe = fits_regs(TH);
+    g.ok = lds_of(TH) <= 160 * 1024 && C % 128 == 0;
+    g.TH = TH; g.bands = cvcl_div_up(Ho, TH); g.rows_in = (TH - 1) * stride + 3;
+    g.x_rows = x_rows_of(TH); g.dy_rows = TH * g.Wo_pad; g.lds = lds_of(TH);
+    const long items = (long)B * g.bands;
+    long G = 512 / (g.slabs > 0 ? g.slabs : 1);
+    if (G < 1) G = 1;
+    if (G > items) G = items;
+    g.G = (int)G;
+    g.ws = (size_t)g.slabs * g.G * 9 * 4 * 1024 * sizeof(float);
+    return g;
+}
+}  // namespace
+
 extern "C" size_t cvcl_gconv3x3_wgrad_workspace_bytes(int B, int H, int W, int C, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const TnPlan pl = tn_plan((long)B * Ho * Wo, C, C, 9, true, TN_T);
-    return tn_ws_bytes(pl, C, C, 9, true);
+    const size_t tap_form = tn_ws_bytes(pl, C, C, 9, true);
+    const GwPlan g = gw_plan(B, H, W, C, stride);
+    return g.ok && g.ws > tap_form ? g.ws : tap_form;       // (either form may run: see cvcl_gconv3x3_wgrad)
 }
 
 // bf16 only (the fp32 parity mode uses cvcl_conv_wgrad_direct)
@@ -472,12 +732,38 @@ extern "C" int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long M = (long)B * Ho * Wo;
     CVCL_CHECK_ARG(M < (1L << 31), "cvcl_gconv3x3_wgrad: B * Ho * Wo must be below 2^31");
+    hipStream_t st = (hipStream_t)stream;
+    // one pass over the operands with all nine taps (band kernel) when a band fits the LDS; $CVCL_GCONV_WGRAD_BAND=0: the tap-at-a-time form
+    static const bool band_on = [] { const char* e = getenv("CVCL_GCONV_WGRAD_BAND"); return !(e && e[0] == '0'); }();
+    const GwPlan gw = gw_plan(B, H, W, C, stride);
+    if (band_on && gw.ok && cg <= 32 && 32 % cg == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0) {
+        if (workspace_bytes < gw.ws) {
+            cvcl_set_error("cvcl_gconv3x3_wgrad: workspace too small");
+            return CVCL_EWORKSPACE;
+        }
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)gconv_wgrad_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                cvcl_set_error("cvcl_gconv3x3_wgrad: cannot raise the dynamic LDS limit");
+                return CVCL_ELAUNCH;
+            }
+            attr = true;
+        }
+        CvclProfScope prof(stream, CVCL_K_WGRAD);
+        GwDev d = {(const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, B, H, W, C, stride, Ho, Wo, gw.Wo_pad, gw.TH, gw.bands,
+                   gw.rows_in, gw.x_rows, gw.dy_rows, gw.pipe};
+        hipLaunchKernelGGL(gconv_wgrad_band_kernel, dim3(gw.G, gw.slabs), dim3(256), gw.lds, st, d);
+        CVCL_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gconv_wgrad_band_reduce_kernel, dim3(reduce_grid((long)gw.slabs * 9 * 4 * 1024)), dim3(256), 0, st,
+                           (const float*)workspace, dw, gw.G, C, cg);
+        CVCL_LAUNCH_CHECK();
+        return CVCL_OK;
+    }
     const TnPlan pl = tn_plan(M, C, C, 9, true, TN_T);
     if (workspace_bytes < tn_ws_bytes(pl, C, C, 9, true)) {
         cvcl_set_error("cvcl_gconv3x3_wgrad: workspace too small");
         return CVCL_EWORKSPACE;
     }
-    hipStream_t st = (hipStream_t)stream;
     CvclProfScope prof(stream, CVCL_K_WGRAD);
     TnDev d = {};
     d.A = (const bf16_t*)dy; d.B = (const bf16_t*)x; d.P = (float*)workspace;
