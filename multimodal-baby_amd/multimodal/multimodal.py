@@ -101,8 +101,9 @@ class VisionEncoder(nn.Module):
         on = self.__dict__.get("_hip_graphs")
         if on is None:
             on = os.environ.get("CVCL_EVAL_GRAPH") == "1"
+        trunk = getattr(self.model, "_resnet", self.model)          # (spatial embeddings: the Sequential wraps the ResNet that owns the caches)
         return bool(on and not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32
-                    and self.model.__dict__.get("_trunk_stream") is None and not torch.cuda.is_current_stream_capturing())
+                    and trunk.__dict__.get("_trunk_stream") is None and not torch.cuda.is_current_stream_capturing())
 
     def _graph_forward(self, x):
         graphs = self.__dict__.setdefault("_graphs", {})
@@ -121,7 +122,8 @@ class VisionEncoder(nn.Module):
             with torch.cuda.graph(graph):
                 feats, fmap = self._eager_forward(static_x)
             # (the trunk's cached workspaces are referenced by the graph: keep them alive whatever other shapes run later)
-            keep = list(getattr(self.model, "_ws_cache", {}).values()) + [getattr(self.model, "_pack_cache", None), getattr(self.model, "_cache", None)]
+            trunk = getattr(self.model, "_resnet", self.model)
+            keep = list(getattr(trunk, "_ws_cache", {}).values()) + [dict(getattr(trunk, "_pack_cache", None) or {}), dict(getattr(trunk, "_cache", None) or {})]
             entry = graphs[key] = (graph, static_x, feats, fmap, keep)
         graph, static_x, feats, fmap, _keep = entry
         static_x.copy_(x, non_blocking=True)

@@ -130,3 +130,17 @@ def test_spatial_end_to_end_vs_oracle(dev, sim):
     gw = lit.vision_encoder.model[8].weight.grad
     assert gw is not None and torch.isfinite(gw).all() and float(gw.abs().sum()) > 0
     assert lit.text_encoder.embedding.weight.grad is not None
+    # eval-mode HIP-graph replay of this Sequential-wrapped trunk (the caches live on the wrapped ResNet): identical to eager, and a
+    # pass at another batch shape in between does not disturb the captured workspaces
+    if sim == "max":
+        lit.eval()
+        ve = lit.vision_encoder
+        xd = x.to(dev)
+        with torch.no_grad():
+            f0, m0 = ve(xd)
+            ve.enable_hip_graphs(True)
+            f1, m1 = ve(xd)
+            ve(xd[:2])
+            f2, m2 = ve(xd)
+        assert torch.equal(f0, f1) and torch.equal(m0, m1) and torch.equal(f0, f2) and torch.equal(m0, m2)
+        ve.enable_hip_graphs(False)
