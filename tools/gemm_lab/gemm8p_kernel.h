@@ -1,0 +1,507 @@
+// 256 (224 / 192) x 256 bf16 GEMM tile for the MFMA-bound shapes: one 8-wave workgroup per CU, (16 MI) x 64 per wave.
+//
+//      C[M,N] = A[M,K] . W[N,K]^T          (A, W row-major, K contiguous; N % 256 == 0, K % 128 == 0)
+//
+// Why: the 128 x 128 x 64 two-buffer kernel of gemm.hip reads 1 LDS fragment per MFMA, pulls 64 B/clk/CU through the L1 fill
+// path and meets a workgroup barrier every 16 MFMAs (512 cycles) with one K tile of prefetch -- it sits at ~0.3 of the bf16
+// peak on K >= 512 shapes (profiles/r01_pmc_gemm_sq.json).  Here a wave owns a (16 MI) x 64 block of the output on
+// v_mfma_f32_16x16x32_bf16 (MI x 4 accumulator tiles = 128 registers at MI = 8, two waves per SIMD): 0.375 fragment reads per
+// MFMA, 32 B/clk/CU of operand traffic, one barrier per 32 MFMAs of a wave (1024 cycles of a SIMD's matrix pipe).
+//
+// Pipeline (per workgroup, persistent over its output tiles; "stage" = 32 k = 64 bytes per operand row):
+//   * 4-stage LDS ring, 32 KiB per stage (A: 256 rows x 64 B, W: 256 rows x 64 B), filled by global_load_lds_dwordx4.
+//     A wave instruction lands 16 rows x 64 B; the 16-byte chunk c of row r sits at chunk position c ^ swz((r >> 2) & 3)
+//     (swizzle applied on the SOURCE address, the LDS image stays lane-linear), which makes the ds_read_b128 fragment reads
+//     of a 16-row block (lane -> row lane & 15, chunk lane >> 4) conflict-free.
+//   * fragments are double-buffered in registers.  Iteration g multiplies stage g out of registers; in its middle it waits
+//     (counted vmcnt) for stage g+1, passes the one barrier of the iteration, issues the fragment reads of stage g+1 and the
+//     loads of stage g+4 (into the buffer stage g occupied: every wave finished reading it before the barrier), and the second
+//     half of the MFMAs covers those latencies.  3.5 stages of loads are in flight.
+//   * vmcnt retires in issue order for loads and stores alike: the wait for stage g+1 allows exactly the 8 younger load
+//     instructions (+ the epilogue's stores when one was issued in between).  Stages past the end of the workgroup's work are
+//     issued as harmless re-loads so that the count stays constant.
+//   * epilogue per 16-row block through 2 KiB of wave-private LDS: rounded to bf16, written as full 128-byte row segments,
+//     BN partial sums of the stored values accumulated per lane (8 fixed columns) across all tiles of the workgroup.
+#pragma once
+#include <type_traits>
+
+#include "cvcl_common.h"
+
+namespace g8p {
+
+constexpr int BN = 256;
+constexpr int BK = 32;
+constexpr int NSTAGE = 4;
+constexpr int A_BYTES = 16384;                    // 256 rows x 64 B
+constexpr int STAGE_BYTES = 2 * A_BYTES;          // + W: 256 rows x 64 B
+constexpr int STG_BYTES = 2048;                   // per-wave epilogue staging: 16 rows x 128 B
+constexpr int ACC_OFF = NSTAGE * STAGE_BYTES + 8 * STG_BYTES;       // [8 waves][2][64] f32 BN partial sums / [N] f32 bias
+constexpr int LDS_BYTES = 160 * 1024;                               // everything: 128 KiB ring + 16 KiB staging + 16 KiB
+constexpr int MAX_BIAS_N = (LDS_BYTES - ACC_OFF) / 4;               // 4096
+
+// EPI 0: C = round(acc) (+ BN partial sums when stats != nullptr; C may be nullptr: statistics only)
+// EPI 1: C = round(act(acc + bias))                 (nn.Linear: bias / ReLU / GELU)
+// EPI 2: C = round(round(acc + bias) + R)            (nn.Linear + residual: the residual rows are fetched two 16-row blocks ahead)
+struct Dev {
+    const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
+    const float* bias; float* stats;
+    const float* centre;            // EPI 0: storage centre of the output (NULL = 0): accumulators start at -centre[n]
+    int M, N, K, lda, ldw, ldc, ldr, act;
+    int tiles_m, grid_m, ncol;
+    // row gather of a strided 1x1 convolution: output row m = (b, oy, ox) reads A row (b, oy * gs, ox * gs); gs <= 1 = off
+    int gs, g_hw, g_wo, g_hi, g_wi;
+    int a_rows;                     // rows of A (= M without the gather)
+};
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                     (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+// LDS swizzle: the 16-byte chunk c of row r sits at chunk position c ^ swz((r >> 2) & 3), swz = {0, 2, 3, 1}.  A fragment read
+// (ds_read_b128: lane -> row lane & 15, chunk lane >> 4) is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+// and the same + 32: each group holds the four 4-row sets g = 0..3 with chunks (c, c, c+1, c+1) in the order (0, 3, 1, 2) or
+// (c+1 for 0, 3; c for 1, 2); with this permutation the four sets land on four different chunk positions, i.e. the 16 lanes hit
+// the 16 different 16-byte slots of a 256-byte bank row.  (The plain c ^ g -- right for the 32-row fragments of the 32x32 MFMA --
+// is 2-way conflicted here: SQ_LDS_BANK_CONFLICT was 50 % of SQ_LDS_IDX_ACTIVE.)
+__device__ __forceinline__ int swz(int g) { return (0x78 >> (2 * g)) & 3; }
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "add the literal");
+}
+
+// VAR (experiment switches): bit 0 = s_setprio(1) around the MFMA halves; bit 1 = the post-barrier fragment reads and stage
+// loads are interleaved with the second half's MFMAs (sched_group_barrier) instead of being issued ahead of them.
+// Ablations for tools/gemm_lab only (WRONG results, timing of what is left): bit 2 = no per-stage barrier, bit 3 = no stage
+// loads, bit 4 = no fragment reads, bit 5 = no epilogue (except m-tile 0).  Bit 6 = stagger experiment
+// (round 3, see the K loop: 3-8 % slower, profiles/r03_gemm_lab.txt).  The library instantiates VAR = 2.
+// What the ablations say (tools/gemm_lab/ablate.sh, 4096^3: 110 us = 1.25 PFLOP/s as is): without the barrier 112 us (the
+// barrier costs nothing), without the stage loads 94, without the fragment reads 93, without all three 72 us = 1.92 PFLOP/s
+// (MFMAs + epilogue alone: the clock-limited ceiling).  The loss is the LDS traffic itself (96 KB of fragment reads + 32 KB of
+// DMA writes per 32-deep stage), not its latency: a variant with the reads of stage g+1 spread over the whole of step g (one A
+// fragment set refilled row block by row block behind the MFMAs that used it, two barriers per stage, hand-placed
+// s_waitcnt lgkmcnt(n) around inline-asm reads so that no wait ever covered a recent read) was bit-exact and SLOWER:
+// 1.09-1.13 PFLOP/s at 4096^3, equal or -3 % on the workload's shapes.  Fewer LDS bytes per flop needs a 128 x 128 tile per
+// wave (256 accumulators), which this compiler spills (round-2 notes in DESIGN.md).
+// The epilogue (all eight waves at once, MFMA pipe idle: ~1100 instructions per wave -- BN statistics 350, accumulator
+// clearing 135, the LDS transpose, 64-bit addresses, row predicates) costs 15-19 % at K = 512..768 (qkv shape 212 -> 171 us
+// without it, layer-3 conv3 63 -> 53) and 3 % at K >= 1024.  It is local to the workgroup, not a store burst: starting the
+// workgroups in four phases 3.4 us apart only added the skew to every shape, and ordinary (write-back) stores instead of
+// nontemporal ones are equal on small outputs and 18 % slower on large ones.  A leaner version (clearing folded into a
+// zero-C first stage, a predicate-free path for full tiles, pointer walking) put every MI = 8 instantiation over 256
+// registers (40-88 bytes of scratch per lane) and was not pursued: its instruction savings are worth ~4 % of such a launch.
+template <int MI, int EPI, int VAR>
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(Dev p) {
+    constexpr int BM = MI * 32;
+    constexpr int ESTORES = MI * 2;                        // global stores per lane per full tile epilogue
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                 // waves w and w + 4 (one SIMD) own the two row halves of a column strip
+
+    // ---- this workgroup's output tiles ----
+    // EPI 0 (BN statistics per column): fixed column tile j, m-tiles i, i + grid_m, ...; blocks of one XCD (blockIdx % 8) hold
+    //   the column tiles of the same m-tiles, so an m-tile's A rows are fetched into one L2 once.
+    // EPI 1 (linear epilogue): the tiles in column-fastest order, q, q + G, ... with q = this block's rank in XCD-major order
+    //   (consecutive q = consecutive tiles = same A rows = same XCD); every CU busy whatever N / 256 is.
+    constexpr bool LIN = EPI >= 1, RES = EPI == 2;
+    constexpr bool FLAT = LIN;
+    const int b = blockIdx.x;
+    const int G = gridDim.x;
+    int ti, tj, nt;
+    if constexpr (FLAT) {
+        const int q = (b & 7) * (G >> 3) + (b >> 3);
+        const int total = p.tiles_m * p.ncol;
+        nt = q < total ? (total - q + G - 1) / G : 0;
+        ti = q / p.ncol;
+        tj = q - ti * p.ncol;
+    } else {
+        const int xcd = b & 7, s = b >> 3;
+        tj = s % p.ncol;
+        ti = (s / p.ncol) * 8 + xcd;
+        nt = ti < p.tiles_m ? (p.tiles_m - ti + p.grid_m - 1) / p.grid_m : 0;
+    }
+    const int KS = p.K / BK;
+    const int S = nt * KS;
+    if (S == 0) {                                            // more workgroup rows than m-tiles: an all-zero statistics row
+        if (EPI == 0 && p.stats && ti < p.grid_m && tid < BN) {
+            p.stats[((long)ti * 2 + 0) * p.N + tj * BN + tid] = 0.f;
+            p.stats[((long)ti * 2 + 1) * p.N + tj * BN + tid] = 0.f;
+        }
+        return;
+    }
+    // tile k of this workgroup -> the step to tile k + 1 in (m-tile, column tile); FLAT: G tiles further in column-fastest order
+    const int step_i = FLAT ? G / p.ncol : p.grid_m;         // (FLAT: + 1 more m-tile when the column index wraps)
+    const int step_j = FLAT ? G - step_i * p.ncol : 0;
+
+    const bf16_t* __restrict__ A = p.A;
+    const bf16_t* __restrict__ W = p.W;
+
+    // ---- staging: wave w lands row blocks 2w, 2w+1 (16 rows x 64 B each) of both operands per stage ----
+    const int srow = lane >> 2;
+    const int slog = (lane & 3) ^ swz((lane >> 4) & 3);     // logical chunk fetched by this lane (it lands at chunk lane & 3)
+    unsigned w_off[2], a_raw[2];                            // element offsets of this lane's two rows of W / of A (current load tile)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        w_off[j] = (unsigned)(tj * BN + (wave * 2 + j) * 16 + srow) * (unsigned)p.ldw + slog * 8;
+        int r = (wave * 2 + j) * 16 + srow;
+        if (r >= BM) r = BM - 1;                            // BM < 256: rows of the unused part of the A region
+        a_raw[j] = (unsigned)(ti * BM + r) * (unsigned)p.lda + slog * 8;
+    }
+    // gathered rows: no uniform step from tile to tile -- the two offsets are recomputed per tile (two integer divisions per
+    // row, once per K / 32 stages)
+    auto gathered = [&](int i_tile, int j) __attribute__((always_inline)) -> unsigned {
+        int r = (wave * 2 + j) * 16 + srow;
+        if (r >= BM) r = BM - 1;
+        const unsigned m = (unsigned)min(i_tile * BM + r, p.M - 1);
+        const unsigned bi = m / (unsigned)p.g_hw, rem = m - bi * (unsigned)p.g_hw;
+        const unsigned oy = rem / (unsigned)p.g_wo, ox = rem - oy * (unsigned)p.g_wo;
+        return ((bi * p.g_hi + oy * p.gs) * p.g_wi + ox * p.gs) * (unsigned)p.lda + slog * 8;
+    };
+    if (p.gs > 1) { a_raw[0] = gathered(ti, 0); a_raw[1] = gathered(ti, 1); }
+    // the next tile is a uniform step further; rows past M (ragged last tile) are clamped to an address inside the last row
+    // (any valid address will do: those rows are masked at the store) -- no per-lane state beyond the offsets
+    const unsigned a_unit = (unsigned)BM * (unsigned)p.lda, w_unit = (unsigned)BN * (unsigned)p.ldw;
+    const unsigned a_lim = (unsigned)(p.a_rows - 1) * (unsigned)p.lda + 24;
+    int l_t = 0, l_ks = 0, l_j = tj, l_i = ti;                         // (tile, k stage) of the next stage to load; its column tile
+    int l_stage = 0;                                         // stage number of the load cursor (its ring buffer = l_stage & 3)
+    auto issue_half = [&](int j) __attribute__((always_inline)) {       // one row block of A and one of W of the cursor's stage: 2 loads
+        char* base = smem + (l_stage & 3) * STAGE_BYTES + wave * 2048;
+        const int k0 = l_ks * BK;
+        glds16(A + min(a_raw[j], a_lim) + k0, base + j * 1024);
+        glds16(W + w_off[j] + k0, base + A_BYTES + j * 1024);
+    };
+    // next stage to load; kept apart from issue() so that its branch does not split the loads from the MFMAs around them.
+    // Past the end of the workgroup's work the last tile is re-loaded (never read)
+    auto advance = [&]() __attribute__((always_inline)) {
+        ++l_stage;
+        if (++l_ks == KS) {
+            l_ks = 0;
+            if (l_t + 1 < nt) {
+                ++l_t;
+                int di = step_i, dj = step_j;
+                if constexpr (FLAT) {
+                    if (l_j + dj >= p.ncol) { dj -= p.ncol; ++di; }
+                    l_j += dj;
+                }
+                const unsigned da = (unsigned)di * a_unit, dw = (unsigned)dj * w_unit;   // (negative steps wrap modulo 2^32: fine)
+                l_i += di;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (p.gs > 1) a_raw[j] = gathered(l_i, j);
+                    else a_raw[j] += da;
+                    w_off[j] += dw;
+                }
+            }
+        }
+    };
+
+    // ---- fragment addressing: lane -> row lane & 15 of a 16-row block, logical chunk lane >> 4 ----
+    const int f_off = (lane & 15) * 64 + (((lane >> 4) ^ swz((lane >> 2) & 3)) << 4);
+    const int a_base = wm * (BM / 2) * 64 + f_off;
+    const int w_base = A_BYTES + wn * 64 * 64 + f_off;
+
+    // fragments are single-buffered: a wave reads a phase's fragments in its LOAD slot and multiplies them in the next slot, while
+    // its partner on the SIMD (the other wave group, one slot away) does the opposite
+    bf16x8 fa[4], fw[4];
+    constexpr bool M32 = (VAR & 8) != 0;                    // lab: 32x32x16 MFMAs (one wave alone paces the matrix pipe); epilogue mapping NOT adapted
+    f32x4 acc[M32 ? 1 : 4][M32 ? 1 : MI];
+    f32x16 acc32[M32 ? 4 : 1][M32 ? 2 : 1];
+    auto accv = [&](int ni, int mi, int e) __attribute__((always_inline)) -> float {
+        if constexpr (M32) return acc32[mi >> 1][ni >> 1][((ni & 1) * 2 + (mi & 1)) * 4 + e];
+        else return acc[ni][mi][e];
+    };
+    auto set_acc = [&](int ni, int mi, f32x4 v) __attribute__((always_inline)) {
+        if constexpr (M32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc32[mi >> 1][ni >> 1][((ni & 1) * 2 + (mi & 1)) * 4 + e] = v[e];
+        } else acc[ni][mi] = v;
+    };
+    const int l32 = lane & 31, r32 = l32 & 15;
+    const int lane32_off = (l32 >> 4) * 1024 + r32 * 64;
+    const int sw32 = swz((r32 >> 2) & 3);
+    auto read_w = [&](int buf) __attribute__((always_inline)) {
+        const char* sb = smem + buf * STAGE_BYTES;
+        if constexpr (M32) return;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fw[ni] = *reinterpret_cast<const bf16x8*>(sb + w_base + ni * 1024);
+    };
+    auto read_a = [&](int buf, auto HALF) __attribute__((always_inline)) {
+        constexpr int h = decltype(HALF)::value;
+        const char* sb = smem + buf * STAGE_BYTES;
+        if constexpr (M32) {                                 // phase h = k step h of the stage: 2 W fragments + 4 A fragments of 32 rows x 16 k
+            const int ch = ((h * 2 + (lane >> 5)) ^ sw32) << 4;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) fw[tn] = *reinterpret_cast<const bf16x8*>(sb + A_BYTES + wn * 4096 + tn * 2048 + lane32_off + ch);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) fa[tm] = *reinterpret_cast<const bf16x8*>(sb + wm * (BM / 2) * 64 + tm * 2048 + lane32_off + ch);
+            return;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+            if (4 * h + mi < MI) fa[mi] = *reinterpret_cast<const bf16x8*>(sb + a_base + (4 * h + mi) * 1024);
+    };
+    auto mma_phase = [&](auto HALF) __attribute__((always_inline)) {
+        constexpr int h = decltype(HALF)::value;
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (M32) {
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+                    acc32[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[tn], fa[tm], acc32[tm][tn], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            return;
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                if constexpr (!M32) { if (4 * h + mi < MI) acc[ni][4 * h + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ni], fa[mi], acc[ni][4 * h + mi], 0, 0, 0); }
+        __builtin_amdgcn_s_setprio(0);
+    };
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) set_acc(ni, mi, f32x4{0.f, 0.f, 0.f, 0.f});
+
+    // Per-wave LDS slots next to the ring (registers are all spoken for: 128 accumulators + 96 fragment registers per lane):
+    // EPI 0: BN partial sums [wave][2][64], added to once per tile in a fixed order (deterministic);
+    // EPI 1: the column tile's 256 bias values, read back in the accumulator layout by the epilogue.
+    float* lds_acc = reinterpret_cast<float*>(smem + ACC_OFF);
+    if constexpr (LIN) {                                     // the whole bias vector (N <= 4096 floats fit beside the ring)
+        for (int i = tid; i < p.N; i += 512) lds_acc[i] = p.bias ? p.bias[i] : 0.f;
+    } else {
+        lds_acc[tid] = 0.f;
+        lds_acc[tid + 512] = 0.f;
+        // centred storage: -centre of the column tile's 256 columns behind the partial sums; every accumulator tile starts from it
+        if (tid < BN) lds_acc[1024 + tid] = p.centre ? -p.centre[tj * BN + tid] : 0.f;
+    }
+    // (ordered before the first epilogue by the prologue's barrier)
+    // this lane's four columns of accumulator tile ni are cen_of() + ni * 16.  The address is re-derived from the thread id behind
+    // an opaque copy wherever it is used: hoisted out of the K loop it is one more loop-invariant VGPR in a kernel that sits at
+    // exactly 256, and the compiler then spills to scratch -- whose loads would also sit in the counted vmcnt queue
+    auto cen_of = [&]() __attribute__((always_inline)) -> const float* {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        return lds_acc + 1024 + wn * 64 + ((t >> 4) & 3) * 4;
+    };
+
+    char* stg = smem + NSTAGE * STAGE_BYTES + wave * STG_BYTES;
+    const int e_row = lane & 15;                             // accumulator layout: m = mi*16 + (lane & 15), n = ni*16 + (lane >> 4)*4 + e
+    const int e_wchunk = lane >> 5, e_wsub = ((lane >> 4) & 1) * 8;
+    const int e_wsw = (e_row >> 1) & 7;
+    const int r_chunk = lane & 7, r_row0 = lane >> 3;        // read-back: row 8j + (lane >> 3), 16-byte chunk lane & 7
+
+    // -> a lower bound on the VMEM instructions this call issued (exact for a full tile with stores and no residual)
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) -> int {
+        const bool full = m0 + BM <= p.M;
+        if constexpr (VAR & 32) { if (m0 != 0) return 0; }    // ablation: only the first m-tile is written
+        float st_sum[8], st_sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
+        // EPI 2: the residual rows of block mi are in flight from block mi - 2 on (an exposed load per block cost ~0.7 us x MI per
+        // tile: the proj linear of ViT-B ran 104 us against 72 us of K loop)
+        bf16x8 rr[MI][2];
+        auto load_res = [&](int mi) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int m = m0 + wm * (BM / 2) + mi * 16 + j * 8 + r_row0;
+                if (m >= p.M) m = p.M - 1;
+                rr[mi][j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + r_chunk * 8);
+            }
+        };
+        if constexpr (RES) { load_res(0); if (MI > 1) load_res(1); }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if constexpr (RES) { if (mi + 2 < MI) load_res(mi + 2); }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                bf16x4 q;
+                if constexpr (LIN) {
+                    const f32x4 bias_r = *reinterpret_cast<const f32x4*>(lds_acc + n0 + wn * 64 + ni * 16 + (lane >> 4) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = accv(ni, mi, e) + bias_r[e];
+                        if constexpr (!RES) {
+                            if (p.act == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
+                            else if (p.act == CVCL_ACT_GELU) v = gelu_erf_fast(v);
+                        }
+                        q[e] = (bf16_t)v;
+                    }
+                } else {
+                    q = bf16x4{(bf16_t)accv(ni, mi, 0), (bf16_t)accv(ni, mi, 1), (bf16_t)accv(ni, mi, 2), (bf16_t)accv(ni, mi, 3)};
+                }
+                if constexpr (EPI != 0) set_acc(ni, mi, f32x4{0.f, 0.f, 0.f, 0.f});     // ready for the next output tile
+                const int chunk = ni * 2 + e_wchunk;
+                *reinterpret_cast<bf16x4*>(stg + e_row * 128 + ((chunk ^ e_wsw) << 4) + e_wsub) = q;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = j * 8 + r_row0;
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((r_chunk ^ ((row >> 1) & 7)) << 4));
+                const int m = m0 + wm * (BM / 2) + mi * 16 + row, n = n0 + wn * 64 + r_chunk * 8;
+                if (full || m < p.M) {
+                    if constexpr (LIN) {
+                        if constexpr (RES) {
+                            const bf16x8 r = rr[mi][j];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
+                        }
+                        stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[e];
+                            st_sum[e] += f;
+                            st_sq[e] = fmaf(f, f, st_sq[e]);
+                        }
+                        if (p.C) stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                    }
+                }
+            }
+        }
+        if (EPI == 0 && p.stats) {                           // this tile's column sums into the wave's slot, fixed order
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+#pragma unroll
+                for (int o = 8; o <= 32; o <<= 1) {
+                    st_sum[e] += __shfl_xor(st_sum[e], o, 64);
+                    st_sq[e] += __shfl_xor(st_sq[e], o, 64);
+                }
+            }
+            if (lane < 8) {
+                float* s0 = lds_acc + (wave * 2 + 0) * 64 + lane * 8;
+                float* s1 = lds_acc + (wave * 2 + 1) * 64 + lane * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s0[e] += st_sum[e]; s1[e] += st_sq[e]; }
+            }
+        }
+        if constexpr (EPI == 0) {                            // the next output tile's accumulators start at -centre (one column
+            const float* cen = cen_of();                     // group at a time: four live registers, not sixteen)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cen + ni * 16);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) set_acc(ni, mi, c4);
+            }
+        }
+        return (full && p.C != nullptr) ? ESTORES : 0;
+    };
+
+    // ---- prologue: stages 0..2 in flight, stage 0 landed ----
+    for (int i = 0; i < 3; ++i) { issue_half(0); issue_half(1); advance(); }
+    if constexpr (EPI == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this thread's LDS writes above (-centre)
+    wait_vm<8>();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (EPI == 0) {
+        const float* cen = cen_of();
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(cen + ni * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) set_acc(ni, mi, c4);
+        }
+    }
+
+    // ---- K loop: four slots per 32-deep stage and wave -- load A (W + rows 0-63 fragments), multiply A (16 MFMAs), load B (rows 64-127),
+    // multiply B -- a barrier between any two slots; wave group 1 (waves 4-7, the second wave of every SIMD) runs ONE SLOT behind group
+    // 0, so that on every SIMD one wave issues its MFMA cluster while the other reads fragments and issues stage loads.
+    // Stage loads (4 per wave and stage, into the buffer of stage s + 3 = the buffer stage s - 1 occupied):
+    //   group 1: two in load-A(s), two in load-B(s);   group 0: two in load-B(s), two in load-A(s + 1)
+    //   (group 0's load-A(s) is too early: group 1 finishes reading stage s - 1 during that slot).
+    // Stage s + 1 is awaited at the end of slot 4 s + 3 (group 0: behind its multiply-B; group 1: behind its load-B), one barrier
+    // before anyone reads it: vmcnt(6) / vmcnt(8) = the loads each group has issued behind that stage's.
+    const int grp = (VAR & 1) ? (wave & 1) : (VAR & 2) ? ((wave >> 1) & 1) : wm;     // lab: which waves form the trailing group
+    int after_epi = 0, epi_ops = 0;
+    int c_ks = 0, c_i = ti, c_j = tj;
+    if (grp == 1) __builtin_amdgcn_s_barrier();               // group 1: one slot behind
+    // lab instrumentation (VAR bit 2): shader-clock time spent in load slots / at the barrier behind them / in multiply slots / at the
+    // barrier behind those, summed over the workgroup's stages; waves 0 and 4 of workgroup 0 write them to p.bias (as long long[8])
+    long long tL = 0, tB1 = 0, tC = 0, tB2 = 0, t0 = 0, t1 = 0;
+    auto tick = [&]() __attribute__((always_inline)) -> long long { return (VAR & 4) ? (long long)__builtin_readcyclecounter() : 0; };
+    for (int g = 0; g < S; ++g) {
+        const int buf = g & 3;
+        // ---------------- phase A
+        t0 = tick();
+        read_w(buf);
+        read_a(buf, std::integral_constant<int, 0>{});
+        if (grp == 1) issue_half(0);                          // (stage g + 3, first half)
+        else if (g > 0) { issue_half(1); advance(); }        // (stage g + 2, second half)
+        t1 = tick(); tL += t1 - t0;
+        __builtin_amdgcn_s_barrier();
+        t0 = tick(); tB1 += t0 - t1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_phase(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        t1 = tick(); tC += t1 - t0;
+        __builtin_amdgcn_s_barrier();
+        t0 = tick(); tB2 += t0 - t1;
+        // ---------------- phase B
+        read_a(buf, std::integral_constant<int, 1>{});
+        if (grp == 1) {
+            issue_half(1); advance();                        // (stage g + 3, second half)
+            if (after_epi > 0 && epi_ops == ESTORES) wait_vm<8 + ESTORES>(); else wait_vm<8>();      // stage g + 1 landed (this wave's part)
+        } else {
+            issue_half(0);                                   // (stage g + 3, first half)
+        }
+        t1 = tick(); tL += t1 - t0;
+        __builtin_amdgcn_s_barrier();
+        t0 = tick(); tB1 += t0 - t1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_phase(std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0) {
+            if (after_epi > 0 && epi_ops == ESTORES) wait_vm<6 + ESTORES>(); else wait_vm<6>();      // stage g + 1 landed (this wave's part)
+        }
+        t1 = tick(); tC += t1 - t0;
+        if (after_epi > 0) --after_epi;
+        if (++c_ks == KS) {
+            c_ks = 0;
+            epi_ops = epilogue(c_i * BM, c_j * BN);
+            after_epi = grp == 1 ? 2 : 1;                    // group 1's next two waits / group 0's next one await loads OLDER than these stores
+            c_i += step_i;
+            if constexpr (FLAT) {
+                c_j += step_j;
+                if (c_j >= p.ncol) { c_j -= p.ncol; ++c_i; }
+            }
+        }
+        t0 = tick();
+        __builtin_amdgcn_s_barrier();
+        t1 = tick(); tB2 += t1 - t0;
+    }
+    if constexpr (VAR & 4) {
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && p.bias) {
+            long long* o = (long long*)p.bias + (wave == 4 ? 4 : 0);
+            o[0] = tL; o[1] = tB1; o[2] = tC; o[3] = tB2;
+        }
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();               // group 0: the slot group 1 is behind
+    wait_vm<0>();                                            // the re-loads past the end must not outlive the workgroup
+
+    if (EPI == 0 && p.stats) {
+        __syncthreads();
+        if (tid < BN) {
+            const int wn_ = tid >> 6, c = tid & 63, n = tj * BN + tid;   // column strip wn_: waves wn_ (upper rows) and wn_ + 4
+            const float sv = lds_acc[((wn_) * 2 + 0) * 64 + c] + lds_acc[((wn_ + 4) * 2 + 0) * 64 + c];
+            const float qv = lds_acc[((wn_) * 2 + 1) * 64 + c] + lds_acc[((wn_ + 4) * 2 + 1) * 64 + c];
+            p.stats[((long)ti * 2 + 0) * p.N + n] = sv;
+            p.stats[((long)ti * 2 + 1) * p.N + n] = qv;
+        }
+    }
+}
+
+}  // namespace g8p

@@ -15,6 +15,7 @@
 
 #include "../../multimodal-baby_amd/csrc/gemm8w_kernel.h"
 #include "gemm4w_kernel.h"
+#include "gemm8p_kernel.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -42,6 +43,15 @@ static void launch_w(const g8w::Dev& d, int grid, hipStream_t st) {
     hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, VAR>), dim3(grid), dim3(512), g8w::LDS_BYTES, st, d);
 }
 
+template <int MI, int EPI, int VAR = 0>
+static void launch_p(const g8w::Dev& d8, int grid, hipStream_t st) {
+    static bool attr = false;
+    g8p::Dev d;
+    static_assert(sizeof(g8p::Dev) == sizeof(g8w::Dev), "same argument block");
+    memcpy(&d, &d8, sizeof(d));
+    if (!attr) { CK(hipFuncSetAttribute((const void*)g8p::gemm8p_kernel<MI, EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, g8p::LDS_BYTES)); attr = true; }
+    hipLaunchKernelGGL((g8p::gemm8p_kernel<MI, EPI, VAR>), dim3(grid), dim3(512), g8p::LDS_BYTES, st, d);
+}
 template <int MI, int EPI, int VAR>
 static void launch_q(const g4w::Dev& d, int grid, hipStream_t st) {
     static bool attr = false;
@@ -162,6 +172,21 @@ int main(int argc, char** argv) {
         if (mi == 8 && vv == 18) run = [=]() { launch_w<8, 0, 18>(d, grid, st); };
         if (mi == 8 && vv == 30) run = [=]() { launch_w<8, 0, 30>(d, grid, st); };
         if (mi == 8 && vv == 34) run = [=]() { launch_w<8, 0, 34>(d, grid, st); };
+        if (var[0] == 'w' && var.size() > 2 && var[2] == 'T' && mi == 8) {          // timed slots: prints the per-slot shader clocks of waves 0 and 4
+            static long long* dbg = nullptr;
+            if (!dbg) { CK(hipMalloc(&dbg, 64)); CK(hipMemset(dbg, 0, 64)); }
+            g8w::Dev dd = d; dd.bias = (const float*)dbg;
+            run = [=]() { launch_p<8, 0, 4>(dd, grid, st); };
+            run(); CK(hipStreamSynchronize(st));
+            long long h[8]; CK(hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost));
+            const double stages = (double)((M + 255) / 256) * (N / 256) / grid * (K / 32);
+            printf("  slots per stage (shader clocks; ~%.0f stages in workgroup 0): wave 0: load %.0f barrier %.0f multiply %.0f barrier %.0f | wave 4: load %.0f barrier %.0f multiply %.0f barrier %.0f\n",
+                   stages, h[0] / stages / 2, h[1] / stages / 2, h[2] / stages / 2, h[3] / stages / 2, h[4] / stages / 2, h[5] / stages / 2, h[6] / stages / 2, h[7] / stages / 2);
+        }
+        if (var[0] == 'w' && var.size() > 2 && var[2] == 'M' && mi == 8) run = [=]() { launch_p<8, 0, 8>(d, grid, st); };     // 32x32x16 MFMAs (timing only: wrong epilogue mapping)
+        if (var[0] == 'w' && var.size() > 2 && var[2] == 'P' && mi == 8) run = [=]() { launch_p<8, 0, 1>(d, grid, st); };     // trailing group = odd waves
+        if (var[0] == 'w' && var.size() > 2 && var[2] == 'Q' && mi == 8) run = [=]() { launch_p<8, 0, 2>(d, grid, st); };     // trailing group = waves 2,3,6,7
+        if (var[0] == 'w' && var.size() > 2 && var[2] == 'p') { if (mi == 8) run = [=]() { launch_p<8, 0>(d, grid, st); }; else if (mi == 7) run = [=]() { launch_p<7, 0>(d, grid, st); }; }
         if (mi == 8 && vv == 66) run = [=]() { launch_w<8, 0, 66>(d, grid, st); };
         if (mi == 7 && vv == 66) run = [=]() { launch_w<7, 0, 66>(d, grid, st); };
     }
