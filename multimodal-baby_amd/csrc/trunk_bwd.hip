@@ -123,23 +123,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 // reduce the partial rows (fp64, fixed order): dbeta = sum g, dgamma = sum g*xhat, and the apply-pass coefficients
 //   dx = gamma*rstd*(g - dbeta/n - xhat*dgamma/n) = k1*g + k2*x + k3
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int prow, int C, long n,
-                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                              const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, float* __restrict__ coef) {
-    __shared__ double ss[8][32], sq[8][32];
-    const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, ch = blockIdx.x * 32 + cl;
+// 16 channels x 64 row slices per workgroup (as bn_finalize_kernel: the kernel is nothing but dependent-load latency -- with 32
+// channels x 8 slices a 512-row partial image took eight round trips per thread and a 64-channel layer ran on two workgroups: 15 us)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int prow, int C, long n,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, float* __restrict__ coef) {
+    constexpr int NS = 64, NC = 16;
+    __shared__ double ss[NS][NC], sq[NS][NC];
+    const int cl = threadIdx.x & (NC - 1), sl = threadIdx.x / NC, ch = blockIdx.x * NC + cl;
     double s = 0.0, q = 0.0;
     if (ch < C && sl < prow) {
-        const int cnt = (prow - sl + 7) / 8;
-        s = ordered_sum<8, double>(cnt, [&](int j) { return partial[((long)(sl + 8 * j) * 2 + 0) * C + ch]; });
-        q = ordered_sum<8, double>(cnt, [&](int j) { return partial[((long)(sl + 8 * j) * 2 + 1) * C + ch]; });
+        const int cnt = (prow - sl + NS - 1) / NS;
+        s = ordered_sum<8, double>(cnt, [&](int j) { return partial[((long)(sl + NS * j) * 2 + 0) * C + ch]; });
+        q = ordered_sum<8, double>(cnt, [&](int j) { return partial[((long)(sl + NS * j) * 2 + 1) * C + ch]; });
     }
     ss[sl][cl] = s;
     sq[sl][cl] = q;
     __syncthreads();
     if (sl == 0 && ch < C) {
-        for (int l = 1; l < 8; ++l) { s += ss[l][cl]; q += sq[l][cl]; }
+        for (int l = 1; l < NS; ++l) { s += ss[l][cl]; q += sq[l][cl]; }
         const float db = (float)s, dg = (float)q;
         dbeta[ch] = db;
         dgamma[ch] = dg;
@@ -572,14 +575,14 @@ extern "C" int cvcl_bn_bwd(int dtype, int mode, const void* x, const void* out, 
     if (dtype == CVCL_F32) {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, s, (const float*)x, (const float*)out, (const float*)dy,
                            scale, shift, mean, rstd, rows, C, mode, partial);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 32)), dim3(256), 0, s, partial, g, C, rows, mean, rstd, gamma,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 16)), dim3(1024), 0, s, partial, g, C, rows, mean, rstd, gamma,
                            dgamma, dbeta, coef);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(agrid), dim3(256), 0, s, (const float*)x, (const float*)out,
                            (const float*)dy, scale, shift, coef, (float*)dx, (float*)g_out, rows, C, mode);
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)out,
                            (const bf16_t*)dy, scale, shift, mean, rstd, rows, C, mode, partial);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 32)), dim3(256), 0, s, partial, g, C, rows, mean, rstd, gamma,
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cvcl_div_up(C, 16)), dim3(1024), 0, s, partial, g, C, rows, mean, rstd, gamma,
                            dgamma, dbeta, coef);
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(agrid), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)out,
                            (const bf16_t*)dy, scale, shift, coef, (bf16_t*)dx, (bf16_t*)g_out, rows, C, mode);
