@@ -84,7 +84,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(TnDev p) {
 
     u32x4 ra[4], rb[4];
     const int a_col = min(n0 + s_chunk * 8, p.N - 8), b_col = min(k0 + s_chunk * 8, p.K - 8);     // clamped: always a valid 16-byte chunk
+    // full 64-row steps of interior tiles (all but a split's last step and the ragged edge tiles): one address product per operand
+    // and no value-or-zero selects -- the general form below spent 7.4 VALU instructions per MFMA on them (profiles/r03_pmc_sq_finetune.txt)
+    const bool cols_full = n0 + TN_T <= p.N && k0 + TN_T <= p.K;
+    const long a16 = 16L * p.lda, b16 = 16L * p.ldb;
     auto load_step = [&](long m0) {
+        if constexpr (!CONV) {
+            if (cols_full && m0 + TN_BM <= m_end) {
+                const bf16_t* a = p.A + (m0 + s_row0) * (long)p.lda + a_col;
+                const bf16_t* b = p.B + (m0 + s_row0) * (long)p.ldb + b_col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ra[i] = *reinterpret_cast<const u32x4*>(a + i * a16);
+                    rb[i] = *reinterpret_cast<const u32x4*>(b + i * b16);
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long m = m0 + s_row0 + 16 * i;
