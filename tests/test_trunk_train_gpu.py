@@ -47,9 +47,12 @@ def test_gemm_tn_exact_on_small_integers(dev, dt, M, N, K, k_keep):
     assert out.shape == (N, k_keep) and torch.equal(out.cpu(), ref) and torch.equal(out, out2)
 
 
-@pytest.mark.parametrize("B,S,C_,stride", [(2, 8, 128, 1), (2, 16, 256, 2), (3, 14, 1024, 2), (4, 28, 512, 1)])
+@pytest.mark.parametrize("B,S,C_,stride", [(2, 8, 128, 1), (2, 16, 256, 2), (3, 14, 1024, 2), (4, 28, 512, 1), (3, 56, 128, 1), (2, 56, 256, 2),
+                                           (5, 7, 1024, 1)])
 def test_gconv_wgrad_exact_on_small_integers(dev, B, S, C_, stride):
-    """bf16 grouped-conv weight gradient (tap-shifted TN GEMMs on diagonal slabs) is exact on small integers."""
+    """bf16 grouped-conv weight gradient is exact on small integers: the one-pass band kernel (ring of input rows; bands pipelined through
+    registers at 56 / 28 / 14 / 7 pixels with stride 1, staged in place for the 56-pixel stride-2 layer; several bands and images per
+    workgroup) on the trunk's own feature-map sizes."""
     from multimodal import _hip as H
     g = torch.Generator().manual_seed(C_ + S)
     cg = C_ // 32
