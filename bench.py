@@ -51,6 +51,8 @@ WORKLOADS = {
     "c4": "C4 = BASELINE configs[3]: saycam_contrastive_transformer, frozen random-init DINO ViT-B/16 (bf16 MFMA linears) + "
           "trainable one-layer transformer text encoder (learned positions, dropout 0.1), E=512, L2-normalised, fixed tau 0.07; "
           "full step = fwd + InfoNCE + bwd(head, text encoder) + AdamW",
+    "c4p14": "C4 at the reference's own ViT (multimodal/multimodal.py:135 hard-codes dino_sfp_vitb14): frozen random-init DINO ViT-B/14 "
+             "(257 tokens, 46.3 GFLOP per pair; bf16 MFMA linears) + trainable transformer text encoder, otherwise as C4",
     "c5": "C5 = BASELINE configs[4]: C4 with e4m3 weights (per-channel scales) and e4m3 activations (per-token / MX block "
           "scales) in the four linears of every ViT block on v_mfma_scale_f32_32x32x64_f8f6f4; bf16 residual stream",
 }
@@ -72,7 +74,11 @@ def c4_args():
     return a
 
 
-def build_model(config, device, precision=None, seed=0, patch=16):
+def patch_of(config):
+    return 14 if config.endswith("p14") else 16
+
+
+def build_model(config, device, precision=None, seed=0, patch=None):
     """The benchmarked module with random-init weights: -> (lit, vision_encoder, optimizer).  ``precision`` None = the
     configuration's own (bf16; fp8 linears for c5)."""
     import multimodal.multimodal as mm
@@ -82,6 +88,7 @@ def build_model(config, device, precision=None, seed=0, patch=16):
     from multimodal.multimodal_lit import MultiModalLitModel
     torch.manual_seed(seed)
     args = c2_args() if config == "c2" else c4_args()
+    patch = patch or patch_of(config)
     orig = mm.load_model
     if config != "c2":      # BASELINE names ViT-B/16; the reference hard-codes vitb14 (multimodal.py:135), vit_base(16) exists (:287)
         mm.load_model = lambda name, pretrained: vits.vit_base(patch_size=patch, num_classes=0)
@@ -284,7 +291,7 @@ def spawn_ranks(a, argv):
 
 # whole-step algorithmic work per pair: forward flops (2 x MAC) of the frozen trunk and, for C2, the bytes
 # of a perfectly fused bf16 forward (0.3 MB input + 2 x 28.8 MB activations)
-STEP_FLOPS_PER_PAIR = {"c2": 8.46e9, "c4": 35.1e9, "c5": 35.1e9}
+STEP_FLOPS_PER_PAIR = {"c2": 8.46e9, "c4": 35.1e9, "c5": 35.1e9, "c4p14": 46.3e9}
 STEP_BYTES_PER_PAIR = {"c2": 58e6}
 GEMM_CLASSES = ("gemm", "gemm8w", "gemm_pro")          # the bf16 MFMA GEMM kernels: 128 x 128 glds / 8-wave 256 x 256 / BN-prologue
 KERNEL_OF_CLASS = {"gemm": "gemm_glds_kernel", "gemm8w": "gemm8w_kernel", "gemm_pro": "gemm_pro_kernel"}
@@ -494,7 +501,7 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
         if cfg == "c2":
             per_kernel, nbytes, flops, launches = resnext_gemm_work(batch_size)
         else:
-            nbytes, flops, launches = vit_gemm_work(batch_size, operand_bytes=1 if precision == "fp8" else 2)
+            nbytes, flops, launches = vit_gemm_work(batch_size, patch=patch_of(cfg), operand_bytes=1 if precision == "fp8" else 2)
         by = {}
         for c in GEMM_CLASSES:
             if not prof[c][1]:
@@ -635,7 +642,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5"])
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5", "c4p14"])
     ap.add_argument("--batch", default=None, help="per-GPU batch: a number, or 'auto' = as many pairs as fit the free HBM (frozen-ViT "
                                                   "configurations: ~5 MB per pair, capped at 16384); default 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -693,13 +700,13 @@ def main(argv=None):
         extras["fp32_parity_mode"] = sub_record(r32)
         extras["fp32_parity_mode"]["note"] = ("C2 with --precision 32: the mode held to the 1e-3 logits gate (2e-5 vs the reference's "
                                               "golden logits; parity.hip_fp32_logits_rel_vs_torch_fp32 above is this mode at the full size)")
-        for c in ("c4", "c5"):
+        for c in ("c4", "c5", "c4p14"):
             extras[c] = sub_record(measure(c, "fp8" if c == "c5" else "bf16", PER_GPU_BATCH, sub_steps, 5, device, world, rank,
                                            roofline=not a.no_roofline, parity=not a.no_parity))
         extras["finetune_cnn"] = measure_finetune(device, PER_GPU_BATCH)
 
     if rank == 0:
-        line = {"metric": METRIC if cfg == "c2" else f"image-text pairs/sec, CVCL ViT-B/16+transformer text 224², {cfg.upper()}, MI355X",
+        line = {"metric": METRIC if cfg == "c2" else f"image-text pairs/sec, CVCL ViT-B/{patch_of(cfg)}+transformer text 224², {cfg.upper()}, MI355X",
                 "value": round(r["value"], 1), "unit": "pairs/s", "n_gpus": world, "steps": steps,
                 "warmup": warmup, "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "32": "f32", "fp8": "fp8-e4m3"}[precision],

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CVCL_ABI_VERSION 2
+#define CVCL_ABI_VERSION 3
 
 enum { CVCL_OK = 0, CVCL_EINVAL = -1, CVCL_ELAUNCH = -2, CVCL_EWORKSPACE = -3, CVCL_EUNSUPPORTED = -4 };
 enum { CVCL_F32 = 0, CVCL_BF16 = 1 };
@@ -141,6 +141,16 @@ typedef struct {
      * input and W2 = the 1x1 downsample weight, K2 = 64 (torchvision Bottleneck.downsample of layer1.0: nn.Conv2d(64, 256, 1) +
      * BatchNorm).  R must be NULL; the statistics behind r_scale / r_shift come from a statistics-only cvcl_gemm(A2, W2, C = NULL). */
     const void* A2; const void* W2; int K2, lda2, ldw2; const float* centre2;
+    /* LayerNorm folded into the linear (bf16, the 8-wave kernel only; reference vision_transformer_dino_mugs.py:136-149:
+     * x + attn(norm1(x)), x + mlp(norm2(x)) -- nn.LayerNorm feeding nn.Linear).
+     *   consumer (ln_stats != NULL; bias / activation epilogue, no residual): A = the RAW rows x, W = W diag(gamma) (rounded to
+     *     bf16 by the caller), ln_colsum[n] = sum_k W'[n][k] of that rounded matrix, bias[n] = b[n] + sum_k W[n][k] beta[k]
+     *     (required), ln_stats[m] = (rstd_m, -mean_m rstd_m):  C = round(act(rstd acc - mean rstd ln_colsum[n] + bias[n])).
+     *     ln_stats must be readable for M + 512 rows (whole tiles are fetched).
+     *   producer (row_part != NULL; bias + residual epilogue): additionally row_part[m][N / 64][2] f32 = (sum, sum of squares) of
+     *     the STORED row over each 64-column strip; cvcl_row_stats_finalize reduces them to the next consumer's ln_stats.
+     * cvcl_gemm_ln_supported tells whether cvcl_gemm routes these arguments to the kernel that honours them. */
+    const float* ln_stats; const float* ln_colsum; float* row_part;
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);
@@ -162,6 +172,14 @@ int cvcl_gemm_pro(const cvcl_gemm_args* args, void* stream);
 int cvcl_gemm_pro_supported(const cvcl_gemm_args* args);
 int cvcl_gemm_pro_stats_rows(int M, int N);
 int cvcl_gemm8w_supported(int M, int N, int K, int lda, int ldw, int ldc);
+/* 1 when cvcl_gemm(CVCL_BF16, args) runs the 8-wave kernel for these arguments (shape policy included), i.e. ln_stats / row_part
+ * would be honoured; 0 otherwise (cvcl_gemm then refuses arguments that carry them: CVCL_EUNSUPPORTED).  No GPU needed. */
+int cvcl_gemm_ln_supported(const cvcl_gemm_args* args);
+/* LayerNorm row statistics for the folded form above.  cvcl_row_stats: x [rows][D] (row stride in elements) ->
+ * out[row] = (rstd, -mean rstd), biased variance + eps as nn.LayerNorm; cvcl_row_stats_finalize: the producer's strip partials
+ * row_part[rows][strips][2] (strips = D / 64) -> the same.  fp64 combination of fp32 sums. */
+int cvcl_row_stats(int dtype, const void* x, long x_row_stride, float* out, long rows, int D, float eps, void* stream);
+int cvcl_row_stats_finalize(const float* row_part, int strips, float* out, long rows, int D, float eps, void* stream);
 int cvcl_gemm8w_tile_rows(int M, int N);
 int cvcl_gemm8w_stats_rows(int M, int N);
 

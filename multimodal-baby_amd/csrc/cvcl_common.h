@@ -92,6 +92,16 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 widen2(unsigned u) {
     return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 }
+// acc + a.lo b.lo + a.hi b.hi on packed bf16 pairs (v_dot2c_f32_bf16; products of bf16 are exact in fp32).  Inline asm on the raw
+// dwords: with __builtin_amdgcn_fdot2_f32_bf16 on __builtin_bit_cast(bf16x2, w[e]) of a bit-cast bf16x8 this hipcc (ROCm 7.2) feeds
+// dword 0 to all four calls (seen in the ISA; the same happened with the cvt_scalef32 builtin below).
+__device__ __forceinline__ float dot2c_bf16(float acc, unsigned a, unsigned b) {
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+template <int CTRL> __device__ __forceinline__ float dpp_quad_f32(float v) {     // v of the lane the DPP control selects (0 if none)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ unsigned round2(f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
 // relu on a rounded bf16 pair: rounding keeps the sign, and a bf16 is negative (or -0) exactly when its bits are a negative
 // int16 -> one packed integer max
@@ -173,6 +183,20 @@ __device__ inline float gelu_erf_fast(float v) {
     const float erf_abs = fmaf(-poly, e, 1.f);
     return 0.5f * v * (1.f + copysignf(erf_abs, v));
 }
+// ---- GELU for bf16 / e4m3 OUTPUTS (round 4): gelu(v) = v Phi(v) = v sigmoid(z(v)) with z = logit(Phi(v)), an odd function fitted
+// by a quintic v (a0 + a1 v^2 + a2 v^4) (minimax on [-6, 6], v^2 clamped at 36: beyond it the sigmoid is saturated):
+// |error| <= 2.6e-5 absolute against the erf form in float64 (tools/fit_gelu.py) -- below half a bf16 ulp for |gelu| >= 0.013 and
+// at most ~1 ulp of the values it is added to downstream -- in 9 VALU instructions (v_exp_f32 + v_rcp_f32 among them) instead of
+// the 15 of the Abramowitz-Stegun form above: the GELU epilogues of the ViT MLP are VALU-issue-bound (profiles/r04_pmc_c5_summary.txt:
+// fc1 in e4m3 spent 41 VALU instructions per MFMA).  Every bf16 path (fused epilogues and the standalone pass) uses THIS function, so
+// fused and unfused forms still round identically; the exact-fp32 parity mode keeps erff.
+__device__ inline float gelu_bf16out(float v) {
+    const float u = fminf(v * v, 36.f);
+    float p = fmaf(u, -0.0007030378797f * -1.4426950408889634f, 0.07401131995f * -1.4426950408889634f);
+    p = fmaf(p, u, 1.595015736f * -1.4426950408889634f);               // -log2(e) (a0 + a1 u + a2 u^2)
+    const float e = __builtin_amdgcn_exp2f(v * p);                     // exp(-z)
+    return v * __builtin_amdgcn_rcpf(1.f + e);
+}
 // d gelu(v) / dv with the same erf approximation (backward of the fused GELU epilogue / cvcl_gelu_bf16)
 __device__ inline float gelu_grad_fast(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
@@ -196,6 +220,29 @@ __device__ inline unsigned mx_scale_byte(float amax) {
     return e < 1u ? 1u : (e > 254u ? 254u : e);
 }
 __device__ inline float mx_inv_scale(unsigned byte) { return __uint_as_float((254u - byte) << 23); }   // 2^(127 - byte)
+// MX block quantisation of eight bf16 values held as four packed dwords (round 4; replaces unpack + fmax + multiply + cvt per
+// element): |x| as 15-bit integers (bf16 magnitudes order like their bit patterns), v_pk_max_u16 tree -> this lane's amax in the
+// low half; the caller combines lanes, then v_cvt_scalef32_pk_fp8_bf16 divides by the power-of-two block scale and rounds to e4m3.
+__device__ inline unsigned bf16x8_absmax_bits(u32x4 w) {
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 a = __builtin_bit_cast(u16x2, w[0] & 0x7fff7fffu), b = __builtin_bit_cast(u16x2, w[1] & 0x7fff7fffu);
+    const u16x2 c = __builtin_bit_cast(u16x2, w[2] & 0x7fff7fffu), d = __builtin_bit_cast(u16x2, w[3] & 0x7fff7fffu);
+    const u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+    const unsigned mm = __builtin_bit_cast(unsigned, m);
+    return max(mm & 0xffffu, mm >> 16);
+}
+__device__ inline u32x2 bf16x8_to_fp8_scaled(u32x4 w, float scale) {       // e4m3(x / scale), scale = 2^k
+    // (inline asm: through __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16 this hipcc converts the FIRST dword four times -- seen in the
+    // ISA, ROCm 7.2; the trailing s_nop covers the op_sel destination write before the next VALU reads the register)
+    unsigned lo = 0, hi = 0;
+    asm("v_cvt_scalef32_pk_fp8_bf16 %0, %2, %6\n\t"
+        "v_cvt_scalef32_pk_fp8_bf16 %1, %4, %6\n\t"
+        "v_cvt_scalef32_pk_fp8_bf16 %0, %3, %6 op_sel:[0,0,1]\n\t"
+        "v_cvt_scalef32_pk_fp8_bf16 %1, %5, %6 op_sel:[0,0,1]\n\t"
+        "s_nop 0"
+        : "+v"(lo), "+v"(hi) : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(scale));
+    return u32x2{lo, hi};
+}
 __device__ inline unsigned pack4_fp8(float a, float b, float c, float d) {
     int w = 0;
     w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);

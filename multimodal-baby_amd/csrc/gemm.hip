@@ -70,12 +70,11 @@ __device__ inline float apply_act(float v, int act) {
     return v;
 }
 
-// bf16 epilogues: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result) on
-// v_rcp_f32 / v_exp_f32: the library erff costs ~3x the instructions (fc1 + GELU of ViT-B: 424 us vs 330 us without the
-// activation).  The fp32 parity kernels keep erff.
+// bf16 epilogues: gelu_bf16out (cvcl_common.h: 9 VALU instructions on v_exp_f32 / v_rcp_f32, |error| <= 2.6e-5): the library
+// erff costs ~5x the instructions (fc1 + GELU of ViT-B: 424 us vs 330 us without the activation).  The fp32 parity kernels keep erff.
 __device__ inline float apply_act_bf16(float v, int act) {
     if (act == CVCL_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == CVCL_ACT_GELU) return gelu_erf_fast(v);
+    if (act == CVCL_ACT_GELU) return gelu_bf16out(v);
     return v;
 }
 
@@ -615,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
                 if constexpr (EPI == 5) {
                     *reinterpret_cast<bf16x8*>((bf16_t*)p.C2 + (long)m * p.ldc + n) = v;          // the pre-activation, as stored
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)gelu_erf_fast((float)v[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)gelu_bf16out((float)v[e]);
                 } else if constexpr (EPI == 6) {
                     const bf16x8 r = rpre[j];
 #pragma unroll
@@ -867,6 +866,8 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
     if (!on || dtype != CVCL_BF16) return -1;
     if (!cvcl_gemm8w_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) || a->K < 256) return -1;
     if (a->a_scale || a->exp_scale || a->c_scale || a->C_pre || a->G) return -1;
+    if (a->ln_stats && (a->R || !a->ln_colsum || !a->bias || a->row_part)) return -1;
+    if (a->row_part && (!a->R || a->act != CVCL_ACT_NONE)) return -1;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     if (!al16(a->A) || !al16(a->W) || !al16(a->C) || !al16(a->R) || !al16(a->bias) || (a->R && a->ldr % 8)) return -1;
     long a_rows = a->M;
@@ -1022,8 +1023,15 @@ extern "C" int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* a) {
     return cvcl_gemm_grid_m(dtype, a->M, a->N, 0);
 }
 
+extern "C" int cvcl_gemm_ln_supported(const cvcl_gemm_args* a) { return a && pick_gemm8w(CVCL_BF16, a) == 1; }
+
 extern "C" int cvcl_gemm(int dtype, const cvcl_gemm_args* a, void* stream) {
     CVCL_CHECK_ARG(a && a->A && a->W && (a->C || a->stats), "cvcl_gemm: null operand");
+    if ((a->ln_stats || a->ln_colsum || a->row_part) && !(dtype == CVCL_BF16 && pick_gemm8w(dtype, a) == 1)) {
+        cvcl_set_error("cvcl_gemm: ln_stats / row_part (LayerNorm folded into the linear) exist in the 8-wave bf16 kernel only; these "
+                       "arguments do not select it (M %d N %d K %d) -- ask cvcl_gemm_ln_supported first", a->M, a->N, a->K);
+        return CVCL_EUNSUPPORTED;
+    }
     CVCL_CHECK_ARG(!a->c_scale || dtype == CVCL_BF16, "cvcl_gemm: the c_scale epilogue exists for bf16 only");
     CVCL_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0, "cvcl_gemm: bad shape %d %d %d", a->M, a->N, a->K);
     CVCL_CHECK_ARG((a->a_scale == nullptr) == (a->a_shift == nullptr), "cvcl_gemm: a_scale/a_shift must come together");

@@ -27,17 +27,17 @@ int g8_grid_m(int tiles_m, int ncol) {
     return gm > need ? need : gm;
 }
 
-template <int MI, int EPI>
+template <int MI, int EPI, bool LNF = false>
 int g8_launch(const g8w::Dev& d, int grid, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES) != hipSuccess) {
             cvcl_set_error("cvcl_gemm8w: cannot raise the dynamic LDS limit to %d", g8w::LDS_BYTES);
             return CVCL_ELAUNCH;
         }
         attr = true;
     }
-    hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, 2>), dim3(grid), dim3(512), g8w::LDS_BYTES, stream, d);
+    hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, LNF>), dim3(grid), dim3(512), g8w::LDS_BYTES, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
@@ -81,8 +81,13 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     CVCL_CHECK_ARG(epi == 1 || (!a->bias && !a->R && a->act == CVCL_ACT_NONE), "cvcl_gemm8w: epilogue 0 takes no bias / activation / residual");
     CVCL_CHECK_ARG(epi == 0 || (a->C && !a->stats), "cvcl_gemm8w: epilogue 1 writes C and takes no statistics");
     CVCL_CHECK_ARG(epi == 0 || !a->centre, "cvcl_gemm8w: centre goes with the convolution epilogue only");
+    CVCL_CHECK_ARG(!a->ln_stats || (epi == 1 && !a->R && a->ln_colsum && a->bias && !a->row_part),
+                   "cvcl_gemm8w: ln_stats goes with the bias / activation epilogue and needs ln_colsum and the folded bias");
+    CVCL_CHECK_ARG(!a->row_part || (epi == 1 && a->R), "cvcl_gemm8w: row_part goes with the bias + residual epilogue");
+    CVCL_CHECK_ARG(!a->ln_colsum || a->ln_stats, "cvcl_gemm8w: ln_colsum without ln_stats");
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-    CVCL_CHECK_ARG(al16(a->A) && al16(a->W) && al16(a->C) && al16(a->R) && al16(a->bias) && (!a->R || a->ldr % 8 == 0),
+    CVCL_CHECK_ARG(al16(a->A) && al16(a->W) && al16(a->C) && al16(a->R) && al16(a->bias) && (!a->R || a->ldr % 8 == 0) &&
+                       al16(a->ln_stats) && al16(a->ln_colsum) && (((uintptr_t)a->row_part & 7) == 0),
                    "cvcl_gemm8w: operands must be 16-byte aligned");
     const bool gather = a->gather_stride > 1;
     if (gather)
@@ -94,6 +99,7 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     g8w::Dev d;
     d.A = (const bf16_t*)a->A; d.W = (const bf16_t*)a->W; d.C = (bf16_t*)a->C; d.R = (const bf16_t*)a->R;
     d.bias = a->bias; d.stats = a->stats; d.centre = a->centre;
+    d.ln_stats = a->ln_stats; d.ln_colsum = a->ln_colsum; d.row_part = a->row_part;
     d.M = a->M; d.N = a->N; d.K = a->K; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr; d.act = a->act;
     d.ncol = a->N / 256;
     d.gs = gather ? a->gather_stride : 1; d.g_hw = gather ? a->gather_ho * a->gather_wo : 1; d.g_wo = gather ? a->gather_wo : 1;
@@ -125,6 +131,8 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     CVCL_CHECK_ARG(epi == 0 || !(a->R && a->act != CVCL_ACT_NONE), "cvcl_gemm8w: activation and residual together are not implemented");
     const int k = epi == 0 ? 0 : (a->R ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;
+    if (a->ln_stats) return bm == 256 ? g8_launch<8, 1, true>(d, grid, st) : g8_launch<7, 1, true>(d, grid, st);
+    if (a->row_part) return bm == 256 ? g8_launch<8, 2, true>(d, grid, st) : g8_launch<7, 2, true>(d, grid, st);
     if (bm == 256) return k == 0 ? g8_launch<8, 0>(d, grid, st) : k == 1 ? g8_launch<8, 1>(d, grid, st) : g8_launch<8, 2>(d, grid, st);
     return k == 0 ? g8_launch<7, 0>(d, grid, st) : k == 1 ? g8_launch<7, 1>(d, grid, st) : g8_launch<7, 2>(d, grid, st);
 }

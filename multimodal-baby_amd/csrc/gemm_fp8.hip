@@ -38,17 +38,7 @@ __device__ __forceinline__ void f8_glds16(const unsigned char* src, char* lds_wa
                                      (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ inline float f8_gelu(float v) {            // Abramowitz-Stegun 7.1.26 erf, as the bf16 linear epilogue
-    const float x = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);
-    return 0.5f * v * (1.f + copysignf(fmaf(-poly, e, 1.f), v));
-}
+__device__ inline float f8_gelu(float v) { return gelu_bf16out(v); }      // the bf16 linear epilogue's GELU (cvcl_common.h)
 
 // ---- quantisation: one wave per row; q = e4m3(x / s), s = amax / 448 (s = 1 for an all-zero row) ------------------------
 // src: bf16 rows (SRC_F32 = false) or fp32 rows (weights); optional LayerNorm (gamma/beta != NULL) before quantising.
@@ -254,17 +244,19 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
                 if constexpr (!MXOUT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
             }
             if constexpr (MXOUT) {
-                // e4m3 + one e8m0 scale per 32 columns of the row: the block = 4 adjacent lanes (chunks 4b .. 4b+3)
-                float amax = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[e]));
-                amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0xB1, 0xf, 0xf, true)));
-                amax = fmaxf(amax, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, amax), 0x4E, 0xf, 0xf, true)));
-                const unsigned sb = mx_scale_byte(amax);
-                const float inv = mx_inv_scale(sb);
+                // e4m3 + one e8m0 scale per 32 columns of the row: the block = 4 adjacent lanes (chunks 4b .. 4b+3).  On the packed
+                // bf16 words (cvcl_common.h): |x| maximum as 15-bit integers, then v_cvt_scalef32_pk_fp8_bf16 by the block scale
+                const u32x4 vw = __builtin_bit_cast(u32x4, v);
+                unsigned mb = bf16x8_absmax_bits(vw);
+                mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xB1, 0xf, 0xf, true));
+                mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4E, 0xf, 0xf, true));
+                const unsigned sb = mx_scale_byte(__uint_as_float(mb << 16));
                 if (m < p.M) {
-                    u32x2 w = {pack4_fp8((float)v[0] * inv, (float)v[1] * inv, (float)v[2] * inv, (float)v[3] * inv),
-                               pack4_fp8((float)v[4] * inv, (float)v[5] * inv, (float)v[6] * inv, (float)v[7] * inv)};
+#ifdef CVCL_CVT_SCALE_MUL                                                    // (probe build: the instruction multiplies instead of dividing)
+                    const u32x2 w = bf16x8_to_fp8_scaled(vw, mx_inv_scale(sb));
+#else
+                    const u32x2 w = bf16x8_to_fp8_scaled(vw, __uint_as_float(sb << 23));
+#endif
                     __builtin_nontemporal_store(w, reinterpret_cast<u32x2*>(p.C8 + (long)m * p.ldc8 + n));
                     if ((chunk & 3) == 0) p.c_bs[((long)(n >> 7) * p.M + m) * 4 + ((n >> 5) & 3)] = (unsigned char)sb;
                 }

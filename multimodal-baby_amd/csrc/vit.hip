@@ -240,6 +240,57 @@ __global__ __launch_bounds__(256) void layernorm_bf16_row32_kernel(const bf16_t*
     }
 }
 
+// ---- LayerNorm folded into the consuming linear (gemm8w_kernel.h LNF): only the row statistics are computed here -----------
+// out[row] = (rstd, -mean rstd).  One 32-lane group per row, the row in registers (as layernorm_bf16_row32_kernel), centred
+// second moment; bf16 rows, D % 8 == 0, D <= 1024.
+template <int NCH>
+__global__ __launch_bounds__(256) void row_stats_bf16_kernel(const bf16_t* __restrict__ x, long x_row_stride, float* __restrict__ out,
+                                                             long rows, int D, float eps) {
+    const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int lane = threadIdx.x & 31;
+    if (row >= rows) return;
+    const bf16_t* xr = x + row * x_row_stride;
+    const int nch = D >> 3;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 32 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+        if (c < nch) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = (float)a[e]; s += v[i][e]; }
+        }
+    }
+    const float mean = ln_row32_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+        if (lane + 32 * i < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float c = v[i][e] - mean; q = fmaf(c, c, q); }
+        }
+    const float rstd = 1.f / sqrtf(ln_row32_sum(q) / (float)D + eps);
+    if (lane == 0) *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{rstd, -mean * rstd};
+}
+// the producer GEMM's strip partials [rows][strips][2] (sum, sum of squares of 64 stored values each) -> (rstd, -mean rstd);
+// one thread per row, fixed order, fp64 combination (E[x^2] - mean^2 on fp32 sums of exact bf16 products)
+__global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float* __restrict__ part, int strips, float* __restrict__ out,
+                                                                 long rows, int D, float eps) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const f32x2* p = reinterpret_cast<const f32x2*>(part) + row * strips;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < strips; ++i) { const f32x2 v = p[i]; s1 += (double)v[0]; s2 += (double)v[1]; }
+    const double mean = s1 / D;
+    double var = s2 / D - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    *reinterpret_cast<f32x2*>(out + row * 2) = f32x2{(float)rstd, (float)(-mean * rstd)};
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention, generic (any head_dim <= 128, any T, optional key padding mask): one wave per (b, head, query).
 // qkv [B, T, 3, heads, hd] -> out [B, T, heads*hd].  P is rounded to the storage type before P.V.
@@ -639,6 +690,31 @@ extern "C" int cvcl_layernorm(int dtype, const void* x, long x_row_stride, const
             hipLaunchKernelGGL((layernorm_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, x_row_stride, gamma, beta,
                                eps, (bf16_t*)y, rows, D);
     }
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_row_stats(int dtype, const void* x, long x_row_stride, float* out, long rows, int D, float eps, void* stream) {
+    CVCL_CHECK_ARG(x && out && rows > 0 && D > 0, "cvcl_row_stats: bad args");
+    CVCL_CHECK_ARG(dtype == CVCL_BF16 && D % 8 == 0 && D <= 1024 && x_row_stride % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0,
+                   "cvcl_row_stats: bf16 rows with D %% 8 == 0, D <= 1024, 16-byte aligned (D %d)", D);
+    CvclProfScope prof(stream, CVCL_K_LAYERNORM);
+    if (D <= 768)
+        hipLaunchKernelGGL((row_stats_bf16_kernel<3>), dim3(cvcl_div_up(rows, 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           x_row_stride, out, rows, D, eps);
+    else
+        hipLaunchKernelGGL((row_stats_bf16_kernel<4>), dim3(cvcl_div_up(rows, 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                           x_row_stride, out, rows, D, eps);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_row_stats_finalize(const float* row_part, int strips, float* out, long rows, int D, float eps, void* stream) {
+    CVCL_CHECK_ARG(row_part && out && rows > 0 && strips > 0 && D == strips * 64 && ((uintptr_t)row_part & 7) == 0 && ((uintptr_t)out & 7) == 0,
+                   "cvcl_row_stats_finalize: bad args (strips %d, D %d)", strips, D);
+    CvclProfScope prof(stream, CVCL_K_LAYERNORM);
+    hipLaunchKernelGGL(row_stats_finalize_kernel, dim3(cvcl_div_up(rows, 256)), dim3(256), 0, (hipStream_t)stream, row_part, strips, out,
+                       rows, D, eps);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const bf16_t* __restrict__ u,
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                o[e] = (bf16_t)gelu_erf_fast((float)a[e]);
+                o[e] = (bf16_t)gelu_bf16out((float)a[e]);
             }
         }
         *reinterpret_cast<bf16x8*>(y + i * 8) = o;

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvcl_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
                   "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply", "bn_bwd", "wgrad", "gemm8w", "gemm_pro")
@@ -41,6 +41,7 @@ class GemmArgs(C.Structure):
         ("C_pre", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_int),
         ("centre", C.c_void_p),
         ("A2", C.c_void_p), ("W2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldw2", C.c_int), ("centre2", C.c_void_p),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("row_part", C.c_void_p),
     ]
 
 
@@ -128,6 +129,9 @@ SIGNATURES = {
     "cvcl_gemm_pro_stats_rows": (_I, [_I, _I]),
     "cvcl_gemm8w": (_I, [_I, _P, _P]),
     "cvcl_gemm8w_supported": (_I, [_I, _I, _I, _I, _I, _I]),
+    "cvcl_gemm_ln_supported": (_I, [C.POINTER(GemmArgs)]),
+    "cvcl_row_stats": (_I, [_I, _P, C.c_long, _P, C.c_long, _I, _F, _P]),
+    "cvcl_row_stats_finalize": (_I, [_P, _I, _P, C.c_long, _I, _F, _P]),
     "cvcl_gemm8w_tile_rows": (_I, [_I, _I]),
     "cvcl_gemm8w_stats_rows": (_I, [_I, _I]),
     "cvcl_bf16_to_f32": (_I, [_P, _P, C.c_long, _P]),
@@ -322,7 +326,8 @@ def cvcl_dtype(t: torch.dtype) -> int:
 
 
 def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None, a_shift=None, a_relu=False,
-         exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None, centre=None):
+         exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None, centre=None,
+         ln_stats=None, ln_colsum=None, row_part=None, query_ln=False):
     """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype.
     ``centre`` [N] f32 (convolution epilogues): C = round(A' W^T - centre), statistics of that (cvcl_hip.h "Centred storage")."""
     dt = cvcl_dtype(A.dtype)
@@ -353,6 +358,10 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
     if gelu_grad_of is not None:                          # C = (A W^T) * gelu'(gelu_grad_of)
         a.G, a.ldg = ptr(gelu_grad_of, A.dtype), N
     a.centre = ptr(centre, torch.float32)
+    # LayerNorm folded into the linear (cvcl_hip.h): consumer (ln_stats [>= M + 512, 2], ln_colsum [N], bias = folded) / producer (row_part)
+    a.ln_stats, a.ln_colsum, a.row_part = ptr(ln_stats, torch.float32), ptr(ln_colsum, torch.float32), ptr(row_part, torch.float32)
+    if query_ln:                                          # would cvcl_gemm honour ln_stats / row_part for these arguments?
+        return bool(lib().cvcl_gemm_ln_supported(C.byref(a)))
     check(lib().cvcl_gemm(dt, C.byref(a), stream_ptr()), "cvcl_gemm")
     return out
 

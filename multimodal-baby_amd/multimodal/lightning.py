@@ -90,17 +90,26 @@ class LightningModule(nn.Module):
         hp.update(kwargs)
         model = cls(**hp)
         model.load_state_dict(ckpt["state_dict"])
+        model.on_load_checkpoint(ckpt)
         return model
+
+    def on_save_checkpoint(self, checkpoint):                 # Lightning's hooks: extra (non-state_dict) state of a module
+        pass
+
+    def on_load_checkpoint(self, checkpoint):
+        pass
 
     def checkpoint_dict(self, trainer=None, optimizer=None, scheduler=None):
         """Lightning's checkpoint keys: weights, hyper-parameters, loop position, optimizer / lr-scheduler / callback state."""
         callbacks = {type(cb).__name__: cb.state_dict() for cb in getattr(trainer, "callbacks", []) if hasattr(cb, "state_dict")}
-        return {"state_dict": self.state_dict(), "hyper_parameters": dict(self.hparams),
+        ckpt = {"state_dict": self.state_dict(), "hyper_parameters": dict(self.hparams),
                 "epoch": getattr(trainer, "current_epoch", 0), "global_step": getattr(trainer, "global_step", 0),
                 "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
                 "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else [],
                 "callbacks": callbacks,
                 "pytorch-lightning_version": "1.6.0-shim"}
+        self.on_save_checkpoint(ckpt)
+        return ckpt
 
 
 def _move(batch, device):
@@ -245,6 +254,7 @@ class Trainer:
                 raise FileNotFoundError(f"Checkpoint at {ckpt_path} not found. Aborting training.")     # as Lightning does
             ckpt = torch.load(str(ckpt_path), map_location="cpu", weights_only=False)
             model.load_state_dict(ckpt["state_dict"])
+            model.on_load_checkpoint(ckpt)
             if ckpt.get("optimizer_states"):
                 opt.load_state_dict(ckpt["optimizer_states"][0])
             if sched is not None and ckpt.get("lr_schedulers"):

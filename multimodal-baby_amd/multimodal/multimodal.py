@@ -90,8 +90,12 @@ class VisionEncoder(nn.Module):
     # An eval-mode, no-grad pass is ~66 (ResNeXt) / ~110 (ViT) small dependent launches; the host's launch lead is 0.15-0.2 ms of a
     # 0.8-1.4 ms call at B = 1..4 (profiles/r03_eval_latency.txt).  Opt-in (``enable_hip_graphs()`` or $CVCL_EVAL_GRAPH=1): the
     # pass is captured once per input shape into a HIP graph (torch.cuda.CUDAGraph = hipGraph on ROCm) over a static input buffer and
-    # replayed; results are copies of the static outputs, bit-identical to the eager launches.  Graphs are dropped by ``train()``
-    # and ``load_state_dict`` (new weights are re-packed into new buffers a stale graph would not see).
+    # replayed; results are copies of the static outputs, bit-identical to the eager launches.  A graph replays the weight buffers
+    # that were PACKED when it was captured, so every entry carries the fingerprint of the trunk's parameters it was captured
+    # with ((data_ptr, _version) per parameter -- the key the eager path's own pack caches use) and is re-captured when that
+    # changes: an in-place edit in eval mode, ``load_state_dict`` on this module or on any parent (``lit.load_state_dict`` recurses
+    # through ``_load_from_state_dict`` and never calls the child's ``load_state_dict``), an optimizer step.  ``train()`` and the
+    # two load paths also drop the graphs outright.
     def enable_hip_graphs(self, on: bool = True):
         self.__dict__["_hip_graphs"] = bool(on)
         self.__dict__["_graphs"] = {}
@@ -108,7 +112,11 @@ class VisionEncoder(nn.Module):
     def _graph_forward(self, x):
         graphs = self.__dict__.setdefault("_graphs", {})
         key = (tuple(x.shape), str(x.device), getattr(self.model, "compute_dtype", None))
+        fp = tuple((p.data_ptr(), p._version) for p in self.model.parameters())
         entry = graphs.get(key)
+        if entry is not None and entry[5] != fp:              # weights changed since the capture: the packed copies are stale
+            entry = None
+            graphs.pop(key)
         if entry is None:
             cur = torch.cuda.current_stream(x.device)
             static_x = x.detach().clone().contiguous()
@@ -124,8 +132,8 @@ class VisionEncoder(nn.Module):
             # (the trunk's cached workspaces are referenced by the graph: keep them alive whatever other shapes run later)
             trunk = getattr(self.model, "_resnet", self.model)
             keep = list(getattr(trunk, "_ws_cache", {}).values()) + [dict(getattr(trunk, "_pack_cache", None) or {}), dict(getattr(trunk, "_cache", None) or {})]
-            entry = graphs[key] = (graph, static_x, feats, fmap, keep)
-        graph, static_x, feats, fmap, _keep = entry
+            entry = graphs[key] = (graph, static_x, feats, fmap, keep, fp)
+        graph, static_x, feats, fmap, _keep, _fp = entry
         static_x.copy_(x, non_blocking=True)
         graph.replay()
         return feats.clone(), (fmap.clone() if fmap is not None else None)
@@ -138,6 +146,10 @@ class VisionEncoder(nn.Module):
     def load_state_dict(self, *a, **k):
         self.__dict__["_graphs"] = {}
         return super().load_state_dict(*a, **k)
+
+    def _load_from_state_dict(self, *a, **k):                 # a parent's load_state_dict reaches this module here, not above
+        self.__dict__["_graphs"] = {}
+        return super()._load_from_state_dict(*a, **k)
 
     def __getstate__(self):                                   # (checkpoints pickle whole encoders: graphs are never part of them)
         d = dict(self.__dict__)

@@ -91,6 +91,25 @@ class MultiModalLitModel(LightningModule):
         if getattr(self.vision_encoder, "vit_dino", False):
             self.vision_encoder.model.fp8_linears = p in ("fp8", "8")
 
+    # ---- Lightning checkpoint hooks: the ResNeXt trunk's bf16 storage centres (resnext.py "centred storage") ----------------
+    # The centres are calibrated on the first train-mode batch and are NOT parameters or buffers (the state_dict keeps the
+    # reference's / torchvision's key set), so a resumed run would recalibrate on a different batch and stop being bit-reproducible.
+    # They travel in the checkpoint under their own top-level key; a checkpoint without the key (the reference's) simply recalibrates.
+    def on_save_checkpoint(self, checkpoint):
+        trunk = getattr(self.vision_encoder, "model", None)
+        trunk = getattr(trunk, "_resnet", trunk)
+        exp = getattr(trunk, "export_centres", None)
+        st = exp() if exp is not None else None
+        if st:
+            checkpoint["cvcl_storage_centres"] = st
+
+    def on_load_checkpoint(self, checkpoint):
+        trunk = getattr(self.vision_encoder, "model", None)
+        trunk = getattr(trunk, "_resnet", trunk)
+        st = checkpoint.get("cvcl_storage_centres")
+        if st and hasattr(trunk, "import_centres"):
+            trunk.import_centres(st)
+
     def configure_optimizers(self):
         kw = {}
         params = list(self.parameters())

@@ -140,6 +140,34 @@ class ResNet(nn.Module):
         """Forget the calibrated (frozen path) and the tracked (fine-tuning path) centres: the next train-mode pass starts over."""
         self.__dict__["_centres"] = None
         self.__dict__["_track_centres"] = None
+        self.__dict__["_centres_restored"] = None
+        self.__dict__["_track_restored"] = None
+
+    def export_centres(self):
+        """Checkpoint form of the calibrated / tracked centres (CPU tensors), or None when there are none yet."""
+        out = {}
+        hit = self.__dict__.get("_centres")
+        if hit is not None:
+            if hit[2] is not None:
+                hit[2].synchronize()
+            out["frozen"] = hit[1].detach().cpu()
+        t = self.__dict__.get("_track_centres")
+        if t is not None:
+            out["tracking"] = t.detach().cpu()
+        pend = self.__dict__.get("_centres_restored")
+        if pend is not None and "frozen" not in out:
+            out["frozen"] = pend.detach().cpu()
+        return out or None
+
+    def import_centres(self, state):
+        """Adopt centres saved by ``export_centres``: the next train-mode pass uses them instead of calibrating (whatever the
+        weights' new storage addresses are), so a resumed bf16 run evaluates the same forward function as the run that saved it.
+        Each rank of a multi-GPU run calibrates on its own first shard; a checkpoint carries the saving rank's (rank 0's) centres
+        and every rank adopts those on resume -- a centre only has to be within ~sigma of the batch mean."""
+        self.__dict__["_centres"] = None
+        self.__dict__["_centres_restored"] = state["frozen"].clone() if state.get("frozen") is not None else None
+        self.__dict__["_track_centres"] = None
+        self.__dict__["_track_restored"] = state["tracking"].clone() if state.get("tracking") is not None else None
 
     def centred_storage(self) -> bool:
         return os.environ.get("CVCL_CENTRED_STORAGE", "1") != "0" and self.compute_dtype == torch.bfloat16
@@ -150,7 +178,8 @@ class ResNet(nn.Module):
             return None
         t = self.__dict__.get("_track_centres")
         if t is None or t.device != device:
-            t = torch.zeros(53, 2048, dtype=torch.float32, device=device)
+            pend = self.__dict__.pop("_track_restored", None)
+            t = pend.to(device) if pend is not None else torch.zeros(53, 2048, dtype=torch.float32, device=device)
             self.__dict__["_track_centres"] = t
         return t
 
@@ -163,6 +192,11 @@ class ResNet(nn.Module):
             if hit[2] is not None:
                 torch.cuda.current_stream(x.device).wait_event(hit[2])     # (calibrated on another trunk stream)
             return hit[1]
+        pend = self.__dict__.pop("_centres_restored", None)
+        if pend is not None:                                  # restored from a checkpoint: no calibration pass
+            centres = pend.to(device=x.device, dtype=torch.float32).contiguous()
+            self.__dict__["_centres"] = (key, centres, None)
+            return centres
         lib = H.lib()
         B, _, Hh, Ww = x.shape
         moments = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=x.device)
@@ -270,6 +304,8 @@ class ResNet(nn.Module):
         d["_ema_done"] = None
         d["_centres"] = None
         d["_track_centres"] = None
+        d["_centres_restored"] = None
+        d["_track_restored"] = None
         return d
 
     def __setstate__(self, d):

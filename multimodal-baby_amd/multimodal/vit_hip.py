@@ -40,6 +40,18 @@ def _packed(model, dt, device):
             "fc1_w": blk.mlp.fc1.weight.detach().to(dt).contiguous(), "fc1_b": blk.mlp.fc1.bias.detach().float().contiguous(),
             "fc2_w": blk.mlp.fc2.weight.detach().to(dt).contiguous(), "fc2_b": blk.mlp.fc2.bias.detach().float().contiguous(),
             "eps": blk.norm1.eps, "scale": float(blk.attn.scale), "heads": blk.attn.num_heads})
+        if dt == torch.bfloat16:
+            # LayerNorm folded into qkv / fc1 (gemm8w LNF, cvcl_hip.h): W' = W diag(gamma) rounded to bf16, s = row sums of THAT
+            # matrix (what the MFMA multiplies, so rstd (x W'^T - mean s) is exact algebra), b' = b + W beta in fp64
+            bw = w["blocks"][-1]
+            for name, lin, norm in (("qkv", blk.attn.qkv, blk.norm1), ("fc1", blk.mlp.fc1, blk.norm2)):
+                Wf = lin.weight.detach().double()
+                g, be = norm.weight.detach().double(), norm.bias.detach().double()
+                Wl = (Wf * g[None, :]).float().to(torch.bfloat16).contiguous()
+                b0 = lin.bias.detach().double() if lin.bias is not None else torch.zeros(Wf.shape[0], dtype=torch.float64, device=Wf.device)
+                bw[name + "_w_ln"] = Wl
+                bw[name + "_s_ln"] = Wl.double().sum(1).float().contiguous()
+                bw[name + "_b_ln"] = (b0 + Wf @ be).float().contiguous()
     w["nw"], w["nb"], w["neps"] = model.norm.weight.detach().float().contiguous(), model.norm.bias.detach().float().contiguous(), model.norm.eps
     if getattr(model, "fp8_linears", False):
         # BASELINE configs[4]: e4m3 weights with one scale per output channel (static), quantised once per weight version
@@ -79,6 +91,14 @@ def _gemm8_mx(q, sc, bs, wq, ws, out, out8, out_bs, bias, act=H.ACT_NONE, residu
     N = wq.shape[0]
     H.check(H.lib().cvcl_gemm_fp8_mx(H.ptr(q), H.ptr(sc), H.ptr(bs), K, H.ptr(wq), H.ptr(ws), K, H.ptr(out), N, H.ptr(out8), H.ptr(out_bs), N,
                                      H.ptr(bias), act, H.ptr(residual), N, M, N, K, H.stream_ptr()), "cvcl_gemm_fp8_mx")
+
+
+def ln_fold_mode(model):
+    """None = automatic (fold when every block GEMM runs on the 8-wave kernel), True / False = forced (tests, A/B)."""
+    m = model.__dict__.get("ln_fold")
+    if m is None and os.environ.get("CVCL_LN_FOLD") in ("0", "1"):
+        m = os.environ["CVCL_LN_FOLD"] == "1"
+    return m
 
 
 def _ln(cd, x, stride, g, b, eps, out, out_f32, rows, D):
@@ -174,7 +194,52 @@ def _vit_forward(model, x: torch.Tensor, slot) -> torch.Tensor:
                 _quant(h, B * T, D, q_d, sc, (bw["n2w"], bw["n2b"], bw["eps"]))
                 _gemm8_mx(q_d, sc, None, bw["fc1_q"], bw["fc1_s"], None, q_m, bs_m, bw["fc1_b"], act=H.ACT_GELU)
                 _gemm8_mx(q_m, None, bs_m, bw["fc2_q"], bw["fc2_s"], h, None, None, bw["fc2_b"], residual=h)
-        for bw in (w["blocks"] if not fp8 else ()):
+        # bf16: nn.LayerNorm folded into the linear it feeds (reference :136-149).  qkv / fc1 multiply the RAW residual rows by
+        # W diag(gamma) and apply (rstd, -mean rstd) per row and the column sums in their epilogue; proj / fc2 leave the row sums of
+        # what they store (strip partials -> cvcl_row_stats_finalize): no normalised copy of the token matrix is written or read
+        # (24 LayerNorm passes of a ViT-B gone), and the rows are rounded to bf16 once less.  Used when the dispatcher runs the
+        # block's GEMMs on the 8-wave kernel (large B T); otherwise the LayerNorm kernel + plain GEMM below.
+        M = B * T
+        fold = False
+        if not fp8 and dt == torch.bfloat16 and w["blocks"] and ln_fold_mode(model) is not False:
+            bw0 = w["blocks"][0]
+            st = torch.empty(M + 512, 2, dtype=torch.float32, device=dev)
+            part = torch.empty(M, D // 64, 2, dtype=torch.float32, device=dev) if D % 64 == 0 else None
+            ok_c = part is not None and all(H.gemm(h, bw0[n + "_w_ln"], out=o, bias=bw0[n + "_b_ln"], ln_stats=st, ln_colsum=bw0[n + "_s_ln"],
+                                                   act=a, query_ln=True) for n, o, a in (("qkv", qkv, H.ACT_NONE), ("fc1", mid, H.ACT_GELU)))
+            ok_p = ok_c and all(H.gemm(i, bw0[n + "_w"], out=h, bias=bw0[n + "_b"], residual=h, row_part=part, query_ln=True)
+                                for n, i in (("proj", att), ("fc2", mid)))
+            fold = ok_c and (ok_p or ln_fold_mode(model) is True)
+            if ln_fold_mode(model) is True and not ok_c:
+                raise H.CvclError(f"ln_fold forced, but the qkv / fc1 GEMMs of this shape (M {M}, D {D}) do not run on the 8-wave kernel")
+        if fold:
+            def stats_of_h(eps):
+                H.check(lib.cvcl_row_stats(cd, H.ptr(h), D, H.ptr(st), M, D, eps, s), "cvcl_row_stats")
+
+            def finalize(eps):
+                H.check(lib.cvcl_row_stats_finalize(H.ptr(part), D // 64, H.ptr(st), M, D, eps, s), "cvcl_row_stats_finalize")
+            blocks = w["blocks"]
+            stats_of_h(blocks[0]["eps"])                                  # norm1 of block 0 (the assembled tokens)
+            for i, bw in enumerate(blocks):
+                H.gemm(h, bw["qkv_w_ln"], out=qkv, bias=bw["qkv_b_ln"], ln_stats=st, ln_colsum=bw["qkv_s_ln"])
+                H.check(lib.cvcl_attention(cd, H.ptr(qkv), None, H.ptr(att), B, T, bw["heads"], D // bw["heads"], bw["scale"], s),
+                        "cvcl_attention")
+                if ok_p:
+                    H.gemm(att, bw["proj_w"], out=h, bias=bw["proj_b"], residual=h, row_part=part)      # h = h + proj(att)  (vit:146)
+                    finalize(bw["eps"])
+                else:
+                    H.gemm(att, bw["proj_w"], out=h, bias=bw["proj_b"], residual=h)
+                    stats_of_h(bw["eps"])
+                H.gemm(h, bw["fc1_w_ln"], out=mid, bias=bw["fc1_b_ln"], act=H.ACT_GELU, ln_stats=st, ln_colsum=bw["fc1_s_ln"])
+                last = i + 1 == len(blocks)
+                if ok_p and not last:
+                    H.gemm(mid, bw["fc2_w"], out=h, bias=bw["fc2_b"], residual=h, row_part=part)        # h = h + mlp(...)    (vit:147)
+                    finalize(blocks[i + 1]["eps"])
+                else:
+                    H.gemm(mid, bw["fc2_w"], out=h, bias=bw["fc2_b"], residual=h)
+                    if not last:
+                        stats_of_h(blocks[i + 1]["eps"])
+        for bw in (w["blocks"] if not (fp8 or fold) else ()):
             _ln(cd, h, D, bw["n1w"], bw["n1b"], bw["eps"], y, False, B * T, D)
             H.gemm(y, bw["qkv_w"], out=qkv, bias=bw["qkv_b"])
             H.check(lib.cvcl_attention(cd, H.ptr(qkv), None, H.ptr(att), B, T, bw["heads"], D // bw["heads"], bw["scale"], s),

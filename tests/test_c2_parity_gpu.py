@@ -255,3 +255,15 @@ def test_loss_trajectory_bf16_vs_fp32(dev, finetune, B, lr):
         # (through the steep part of the descent -- lr 2e-3, the loss halves every few steps -- the curves differ by their local
         # noise: measured |gap| <= 0.12 at loss ~1 (round 3: 1.049 vs 0.932 at step 32), 0.002 on the plateau before and 0.005 at the end)
         assert all(abs(a - b) <= 0.15 * max(a, b) + 0.03 for a, b in zip(f32, b16)), gap
+        # the pointwise tolerance above was widened (0.10 x + 0.02 -> 0.15 x + 0.03) in the change that introduced centred
+        # storage.  The same curve with plain storage ($CVCL_CENTRED_STORAGE=0, the round-2 numerics) is the control: the centred
+        # run must not track fp32 worse than the plain one does (the steep part of the descent gives both the same local noise)
+        import os
+        os.environ["CVCL_CENTRED_STORAGE"] = "0"
+        try:
+            plain = _trajectory(dev, "bf16", finetune, B, steps, lr)
+        finally:
+            del os.environ["CVCL_CENTRED_STORAGE"]
+        gap_plain = max(abs(a - b) for a, b in zip(f32, plain))
+        print(f"plain storage: max gap {gap_plain:.4f} (centred {gap:.4f})")
+        assert gap <= 1.25 * gap_plain + 0.02, (gap, gap_plain)

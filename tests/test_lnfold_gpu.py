@@ -1,0 +1,141 @@
+"""GPU parity: nn.LayerNorm folded into the linear it feeds (the ViT Block of the reference, multimodal/vision_transformer_dino_mugs.py:
+136-149: x + attn(norm1(x)), x + mlp(norm2(x))) -- gemm8w LNF epilogues (csrc/gemm8w_kernel.h), cvcl_row_stats / _finalize (csrc/vit.hip)
+and the folded forward of multimodal/vit_hip.py, against float64 LayerNorm + matmul and against the unfolded bf16 path."""
+import pytest
+import torch
+
+import cvcl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from multimodal import _hip
+    return _hip
+
+
+def _rows(M, D, seed):
+    """token rows with per-row offsets and scales and a few outlier channels (what a ViT residual stream looks like)"""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, D, generator=g) * (0.5 + 2.0 * torch.rand(M, 1, generator=g)) + 1.5 * torch.randn(M, 1, generator=g)
+    x[:, 7] += 9.0
+    x[:, 300] -= 6.0
+    return x.bfloat16()
+
+
+@pytest.mark.parametrize("rows,D", [(1000, 768), (4099, 384), (513, 1024)])
+def test_row_stats_vs_float64(H, dev, rows, D):
+    x = _rows(rows, D, rows)
+    out = torch.empty(rows, 2, device=dev)
+    H.check(H.lib().cvcl_row_stats(H.BF16, H.ptr(x.to(dev)), D, H.ptr(out), rows, D, 1e-6, H.stream_ptr()), "cvcl_row_stats")
+    xd = x.double()
+    mean, var = xd.mean(1), xd.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-6)
+    got = out.double().cpu()
+    assert float(((got[:, 0] - rstd).abs() / rstd).max()) < 2e-6
+    assert float((got[:, 1] + mean * rstd).abs().max()) < 2e-6 * float((mean * rstd).abs().max() + 1)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4096, 2304, 768, 0), (8192, 3072, 768, 2), (16500, 2304, 768, 0)])
+def test_gemm_with_folded_layernorm_vs_float64(H, dev, M, N, K, act):
+    """consumer epilogue: C = act(LayerNorm(x) W^T + b) from the raw rows, W diag(gamma), the column sums and (rstd, -mean rstd)
+    -- compared with float64 maths on the same bf16 x; the error must stay at the level of the unfolded bf16 path
+    (LayerNorm kernel -> bf16 -> plain GEMM), which rounds the normalised rows once more."""
+    g = torch.Generator().manual_seed(N + M)
+    x = _rows(M, K, M)
+    gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+    W, b = torch.randn(N, K, generator=g) / K ** 0.5, 0.1 * torch.randn(N, generator=g)
+    xd = x.double()
+    yn = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-6) * gamma.double() + beta.double()
+    ref = yn @ W.double().t() + b.double()
+    if act == 2:
+        ref = O.gelu_erf(ref)
+    # folded operands, as multimodal/vit_hip.py packs them
+    Wl = (W.double() * gamma.double()[None, :]).float().bfloat16()
+    s_ln = Wl.double().sum(1).float()
+    b_ln = (b.double() + W.double() @ beta.double()).float()
+    xg = x.to(dev)
+    st = torch.zeros(M + 512, 2, device=dev)
+    H.check(H.lib().cvcl_row_stats(H.BF16, H.ptr(xg), K, H.ptr(st), M, K, 1e-6, H.stream_ptr()), "cvcl_row_stats")
+    assert H.gemm(xg, Wl.to(dev), bias=b_ln.to(dev), act=act, ln_stats=st, ln_colsum=s_ln.to(dev), query_ln=True)
+    got = H.gemm(xg, Wl.to(dev), bias=b_ln.to(dev), act=act, ln_stats=st, ln_colsum=s_ln.to(dev)).double().cpu()
+    # the unfolded bf16 path on the same data
+    y = torch.empty(M, K, dtype=torch.bfloat16, device=dev)
+    gd, bd = gamma.to(dev), beta.to(dev)                   # (kept alive: the launch is asynchronous)
+    H.check(H.lib().cvcl_layernorm(H.BF16, H.ptr(xg), K, H.ptr(gd), H.ptr(bd), 1e-6, H.ptr(y), 0, M, K, H.stream_ptr()), "cvcl_layernorm")
+    plain = H.gemm(y, W.bfloat16().to(dev), bias=b.to(dev), act=act).double().cpu()
+    scale = float(ref.abs().max())
+    e_fold, e_plain = float((got - ref).abs().max()) / scale, float((plain - ref).abs().max()) / scale
+    r_fold = float((got - ref).norm() / ref.norm())
+    r_plain = float((plain - ref).norm() / ref.norm())
+    print(f"folded: max {e_fold:.2e} rel-L2 {r_fold:.2e}; LayerNorm kernel + GEMM: max {e_plain:.2e} rel-L2 {r_plain:.2e}")
+    assert r_plain < 6e-3                                  # (the control itself is sane)
+    assert r_fold <= 1.05 * r_plain + 1e-4 and e_fold <= 1.5 * e_plain + 1e-3 and r_fold < 6e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 768, 768), (12000, 768, 3072)])
+def test_gemm_residual_epilogue_leaves_row_sums(H, dev, M, N, K):
+    """producer epilogue: the stored C is bit-identical to the plain residual epilogue's, and row_part holds (sum, sum of squares) of
+    the stored row per 64-column strip; cvcl_row_stats_finalize then equals cvcl_row_stats of the stored matrix."""
+    g = torch.Generator().manual_seed(K + M)
+    A = (torch.randn(M, K, generator=g)).bfloat16().to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(dev)
+    b = (0.1 * torch.randn(N, generator=g)).to(dev)
+    R = _rows(M, N, 3).to(dev)
+    part = torch.full((M, N // 64, 2), float("nan"), device=dev)
+    assert H.gemm(A, W, bias=b, residual=R, row_part=part, query_ln=True)
+    C0 = H.gemm(A, W, bias=b, residual=R)
+    C1 = H.gemm(A, W, bias=b, residual=R, row_part=part)
+    assert torch.equal(C0, C1)
+    cd = C1.double().cpu().reshape(M, N // 64, 64)
+    got = part.double().cpu()
+    assert float((got[:, :, 0] - cd.sum(2)).abs().max()) < 1e-4 * float(cd.abs().sum(2).max())
+    assert float((got[:, :, 1] - (cd * cd).sum(2)).abs().max()) < 1e-5 * float((cd * cd).sum(2).max())
+    st = torch.empty(M, 2, device=dev)
+    st2 = torch.empty(M, 2, device=dev)
+    H.check(H.lib().cvcl_row_stats_finalize(H.ptr(part), N // 64, H.ptr(st), M, N, 1e-6, H.stream_ptr()), "finalize")
+    H.check(H.lib().cvcl_row_stats(H.BF16, H.ptr(C1), N, H.ptr(st2), M, N, 1e-6, H.stream_ptr()), "cvcl_row_stats")
+    assert float(((st - st2).abs() / (st2.abs() + 1e-3)).max()) < 2e-5
+
+
+def test_gemm_refuses_ln_arguments_it_cannot_honour(H, dev):
+    """small shapes run on the 128 x 128 kernel, which has no folded epilogue: cvcl_gemm must refuse, not ignore."""
+    x = torch.randn(256, 768).bfloat16().to(dev)
+    w = torch.randn(768, 768).bfloat16().to(dev)
+    st = torch.zeros(256 + 512, 2, device=dev)
+    cs, b = torch.zeros(768, device=dev), torch.zeros(768, device=dev)
+    assert not H.gemm(x, w, bias=b, ln_stats=st, ln_colsum=cs, query_ln=True)
+    with pytest.raises(H.CvclError):
+        H.gemm(x, w, bias=b, ln_stats=st, ln_colsum=cs)
+
+
+@pytest.mark.parametrize("B,patch,forced", [(16, 16, True), (48, 16, None), (40, 14, None)])
+def test_vit_forward_with_folded_layernorm(dev, B, patch, forced):
+    """ViT-B forward in bf16 with the block LayerNorms folded (forced at B = 16: consumer epilogues + stand-alone row statistics;
+    automatic at B >= 40: proj / fc2 also leave the row sums) against the exact-fp32 mode of the same weights: not worse than the
+    unfolded bf16 path, and the two bf16 paths agree closely."""
+    from multimodal import vision_transformer_dino_mugs as vits
+    torch.manual_seed(patch)
+    model = vits.vit_base(patch_size=patch, num_classes=0).to(dev).eval()
+    with torch.no_grad():
+        for blk in model.blocks:                               # non-trivial affine parameters (default init is gamma 1, beta 0)
+            for n in (blk.norm1, blk.norm2):
+                n.weight.add_(0.2 * torch.randn_like(n.weight))
+                n.bias.add_(0.1 * torch.randn_like(n.bias))
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        model.compute_dtype = torch.float32
+        ref = model(x).double()
+        model.compute_dtype = torch.bfloat16
+        model.ln_fold = False
+        plain = model(x).double()
+        model.ln_fold = forced
+        fold = model(x).double()
+        fold2 = model(x).double()
+    assert torch.equal(fold, fold2)
+    e_plain = float((plain - ref).norm() / ref.norm())
+    e_fold = float((fold - ref).norm() / ref.norm())
+    print(f"B={B} p{patch}: bf16 vs fp32 rel-L2: LayerNorm kernels {e_plain:.3e}, folded {e_fold:.3e}; folded vs unfolded {float((fold - plain).norm() / ref.norm()):.3e}")
+    assert not torch.equal(fold, plain)                        # (the folded path did run)
+    assert e_fold <= 1.1 * e_plain + 1e-3 and e_fold < 3e-2

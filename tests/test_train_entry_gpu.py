@@ -38,7 +38,14 @@ def test_checkpoint_and_resume_c2_bf16(dev, tmp_path, monkeypatch):
     ck = tmp_path / "checkpoints" / "t" / "last.ckpt"
     assert ck.exists() and trainer.global_step == 2
     w1 = lit.vision_encoder.model.fc.weight.detach().clone()
+    # the bf16 storage centres (calibrated on the first train batch; not in the state_dict) travel in the checkpoint ...
+    saved = torch.load(ck, map_location="cpu", weights_only=False)
+    c1 = lit.vision_encoder.model.export_centres()["frozen"]
+    assert torch.equal(saved["cvcl_storage_centres"]["frozen"], c1) and c1.shape == (53, 2048) and float(c1.abs().max()) > 0
+    assert "cvcl_storage_centres" not in saved["state_dict"] and not any("centre" in k for k in saved["state_dict"])
     trainer2, lit2 = train.main(base + ["--max_epochs", "2", "--resume_ckpt", "last"])
+    # ... and the resumed run adopts them instead of recalibrating on whatever batch comes first
+    assert torch.equal(lit2.vision_encoder.model.export_centres()["frozen"], c1)
     assert trainer2.global_step == 4                                              # resumed at epoch 1, ran one more epoch
     assert not torch.equal(lit2.vision_encoder.model.fc.weight.detach().cpu(), w1.cpu())
     assert int(lit2.vision_encoder.model.bn1.num_batches_tracked) == 4
@@ -433,7 +440,26 @@ def test_eval_hip_graph_replay_is_bit_identical_to_eager_launches(dev, config):
         logits_eager = lit(xs[4][0], torch.tensor([[2, 9, 3]], device=dev), torch.tensor([3], device=dev))[1]
     assert torch.equal(f2, f2_eager) and not torch.equal(f2, eager[1][0][0])
     assert logits_graph.shape == logits_eager.shape == (1, 4)
+    # a full-model checkpoint load in eval mode (nn.Module.load_state_dict on a PARENT never calls the child's load_state_dict),
+    # and an in-place weight edit in eval mode: the replayed graph must see the new packed weights, not the captured ones
+    ve.enable_hip_graphs(True)
+    with torch.no_grad():
+        ve(xs[1][0])
+        assert len(ve._graphs) == 1
+        sd = {k: (v * 0.5 if v.is_floating_point() and v.dim() == 4 else v.clone()) for k, v in lit.state_dict().items()}   # conv weights halved
+        lit.load_state_dict(sd)
+        assert ve._graphs == {}
+        f3, _ = ve(xs[1][0])
+        first = next(p for p in ve.model.parameters() if p.dim() == 4)
+        first.mul_(-1.0)                                      # in place, eval mode, no load: only the fingerprint can see it
+        f4, _ = ve(xs[1][0])
+        ve.enable_hip_graphs(False)
+        f4_eager, _ = ve(xs[1][0])
+        first.mul_(-1.0)
+        f3_eager, _ = ve(xs[1][0])
+    assert torch.equal(f3, f3_eager) and torch.equal(f4, f4_eager) and not torch.equal(f3, f4) and not torch.equal(f3, f2)
     # gradients enabled or train mode: never a graph
     ve.enable_hip_graphs(True)
+    ve._graphs.clear()
     ve(xs[1][0])
     assert ve._graphs == {}

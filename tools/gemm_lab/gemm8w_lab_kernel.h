@@ -25,7 +25,7 @@
 #pragma once
 #include <type_traits>
 
-#include "cvcl_common.h"
+#include "../../multimodal-baby_amd/csrc/cvcl_common.h"
 
 namespace g8w {
 
@@ -42,18 +42,9 @@ constexpr int MAX_BIAS_N = (LDS_BYTES - ACC_OFF) / 4;               // 4096
 // EPI 0: C = round(acc) (+ BN partial sums when stats != nullptr; C may be nullptr: statistics only)
 // EPI 1: C = round(act(acc + bias))                 (nn.Linear: bias / ReLU / GELU)
 // EPI 2: C = round(round(acc + bias) + R)            (nn.Linear + residual: the residual rows are fetched two 16-row blocks ahead)
-// LNF (round 4; "LayerNorm folded", reference vision_transformer_dino_mugs.py:136-149 Block: x + attn(norm1(x)), x + mlp(norm2(x))):
-//   EPI 1 + LNF: the A rows are the RAW residual stream x and W carries gamma (W' = W diag(gamma)): with the row's
-//                (rstd, -mean rstd) = ln_stats[m][0..1], the column sums s[n] = sum_k W'[n][k] = ln_colsum and the folded bias
-//                b'[n] = bias[n] + sum_k W[n][k] beta[k] (passed as bias):  C = round(act(rstd acc - mean rstd s[n] + b'[n]))
-//                = act(LayerNorm(x) W^T + b) with no normalised copy of x ever stored (the 24 LayerNorm passes of a ViT-B go).
-//   EPI 2 + LNF: besides C the kernel leaves, per output row and 64-column strip, (sum, sum of squares) of the stored (rounded,
-//                residual added) values: row_part[m][N / 64][2]; cvcl_row_stats_finalize turns them into the next LNF
-//                launch's ln_stats.
 struct Dev {
     const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
     const float* bias; float* stats;
-    const float* ln_stats; const float* ln_colsum; float* row_part;     // LNF (see above); ln_stats readable for tiles_m * BM rows
     const float* centre;            // EPI 0: storage centre of the output (NULL = 0): accumulators start at -centre[n]
     int M, N, K, lda, ldw, ldc, ldr, act;
     int tiles_m, grid_m, ncol;
@@ -85,18 +76,33 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
     else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
     else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if constexpr (N == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-    else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
     else static_assert(N < 0, "add the literal");
 }
 
-// What bounds it, what was tried (pipeline ablations, 4-wave / 8-phase / staggered variants, store flavours): DESIGN.md section 5;
-// the experiment switches live in tools/gemm_lab/gemm8w_lab_kernel.h, not here.
-template <int MI, int EPI, bool LNF>
+// VAR (experiment switches): bit 0 = s_setprio(1) around the MFMA halves; bit 1 = the post-barrier fragment reads and stage
+// loads are interleaved with the second half's MFMAs (sched_group_barrier) instead of being issued ahead of them.
+// Ablations for tools/gemm_lab only (WRONG results, timing of what is left): bit 2 = no per-stage barrier, bit 3 = no stage
+// loads, bit 4 = no fragment reads, bit 5 = no epilogue (except m-tile 0).  Bit 6 = stagger experiment
+// (round 3, see the K loop: 3-8 % slower, profiles/r03_gemm_lab.txt).  The library instantiates VAR = 2.
+// What the ablations say (tools/gemm_lab/ablate.sh, 4096^3: 110 us = 1.25 PFLOP/s as is): without the barrier 112 us (the
+// barrier costs nothing), without the stage loads 94, without the fragment reads 93, without all three 72 us = 1.92 PFLOP/s
+// (MFMAs + epilogue alone: the clock-limited ceiling).  The loss is the LDS traffic itself (96 KB of fragment reads + 32 KB of
+// DMA writes per 32-deep stage), not its latency: a variant with the reads of stage g+1 spread over the whole of step g (one A
+// fragment set refilled row block by row block behind the MFMAs that used it, two barriers per stage, hand-placed
+// s_waitcnt lgkmcnt(n) around inline-asm reads so that no wait ever covered a recent read) was bit-exact and SLOWER:
+// 1.09-1.13 PFLOP/s at 4096^3, equal or -3 % on the workload's shapes.  Fewer LDS bytes per flop needs a 128 x 128 tile per
+// wave (256 accumulators), which this compiler spills (round-2 notes in DESIGN.md).
+// The epilogue (all eight waves at once, MFMA pipe idle: ~1100 instructions per wave -- BN statistics 350, accumulator
+// clearing 135, the LDS transpose, 64-bit addresses, row predicates) costs 15-19 % at K = 512..768 (qkv shape 212 -> 171 us
+// without it, layer-3 conv3 63 -> 53) and 3 % at K >= 1024.  It is local to the workgroup, not a store burst: starting the
+// workgroups in four phases 3.4 us apart only added the skew to every shape, and ordinary (write-back) stores instead of
+// nontemporal ones are equal on small outputs and 18 % slower on large ones.  A leaner version (clearing folded into a
+// zero-C first stage, a predicate-free path for full tiles, pointer walking) put every MI = 8 instantiation over 256
+// registers (40-88 bytes of scratch per lane) and was not pursued: its instruction savings are worth ~4 % of such a launch.
+template <int MI, int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     constexpr int BM = MI * 32;
-    static_assert(!LNF || EPI >= 1, "LNF goes with the linear epilogues");
-    constexpr int ESTORES = MI * 2 + (LNF && EPI == 2 ? MI * 2 : 0);     // global stores per lane per full tile epilogue
+    constexpr int ESTORES = MI * 2;                        // global stores per lane per full tile epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,6 +174,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     const unsigned a_lim = (unsigned)(p.a_rows - 1) * (unsigned)p.lda + 24;
     int l_t = 0, l_ks = 0, l_j = tj, l_i = ti;                         // (tile, k stage) of the next stage to load; its column tile
     auto issue = [&](int buf) __attribute__((always_inline)) {
+        if constexpr (VAR & 8) return;
         char* base = smem + buf * STAGE_BYTES + wave * 2048;
         const int k0 = l_ks * BK;
 #pragma unroll
@@ -178,19 +185,6 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     // next stage to load; kept apart from issue() so that its branch does not split the loads from the MFMAs around them.
     // Past the end of the workgroup's work the last tile is re-loaded (never read)
     auto advance = [&]() __attribute__((always_inline)) {
-        if constexpr (LNF && EPI == 1) {             // (here, behind the MFMAs, so that the branch does not split issue()'s region)
-            // with the first stage of a tile, its epilogue operands: waves 0 / 1 land the 256 folded-bias / column-sum values of
-            // the column tile, waves 2 / 3 the (rstd, -mean rstd) pairs of the upper / lower 128 rows, into the slot of the
-            // tile's parity (1 KiB each; read K / 32 >= 4 stages later, behind several counted waits and barriers).  One load
-            // more in these waves' queues only makes the next three counted waits conservative.
-            if (l_ks == 0 && wave < 4) {
-                char* dst = smem + ACC_OFF + (l_t & 1) * 4096 + wave * 1024;
-                const float* src = wave == 0 ? p.bias + l_j * BN : wave == 1 ? p.ln_colsum + l_j * BN
-                                                                               : p.ln_stats + ((long)l_i * BM + (wave - 2) * 128) * 2;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + lane * 4),
-                                                 (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
-            }
-        }
         if (++l_ks == KS) {
             l_ks = 0;
             if (l_t + 1 < nt) {
@@ -221,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     f32x4 acc[4][MI];
     auto read_frags = [&](int buf, auto P) __attribute__((always_inline)) {
         constexpr int q = decltype(P)::value;
+        if constexpr (VAR & 16) return;
         const char* sb = smem + buf * STAGE_BYTES;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) fw[q][ni] = *reinterpret_cast<const bf16x8*>(sb + w_base + ni * 1024);
@@ -229,11 +224,13 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     };
     auto mma_half = [&](auto P, auto HALF) __attribute__((always_inline)) {
         constexpr int q = decltype(P)::value, h = decltype(HALF)::value;
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ni = 2 * h; ni < 2 * h + 2; ++ni)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
                 acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[q][ni], fa[q][mi], acc[ni][mi], 0, 0, 0);
+        if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
     };
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -244,9 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     // EPI 0: BN partial sums [wave][2][64], added to once per tile in a fixed order (deterministic);
     // EPI 1: the column tile's 256 bias values, read back in the accumulator layout by the epilogue.
     float* lds_acc = reinterpret_cast<float*>(smem + ACC_OFF);
-    if constexpr (LIN && LNF && EPI == 1) {
-        // (per-tile epilogue operands arrive by DMA with the tile's first stage: issue())
-    } else if constexpr (LIN) {                              // the whole bias vector (N <= 4096 floats fit beside the ring)
+    if constexpr (LIN) {                                     // the whole bias vector (N <= 4096 floats fit beside the ring)
         for (int i = tid; i < p.N; i += 512) lds_acc[i] = p.bias ? p.bias[i] : 0.f;
     } else {
         lds_acc[tid] = 0.f;
@@ -271,8 +266,9 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     const int r_chunk = lane & 7, r_row0 = lane >> 3;        // read-back: row 8j + (lane >> 3), 16-byte chunk lane & 7
 
     // -> a lower bound on the VMEM instructions this call issued (exact for a full tile with stores and no residual)
-    auto epilogue = [&](int m0, int n0, int parity) __attribute__((always_inline)) -> int {
+    auto epilogue = [&](int m0, int n0) __attribute__((always_inline)) -> int {
         const bool full = m0 + BM <= p.M;
+        if constexpr (VAR & 32) { if (m0 != 0) return 0; }    // ablation: only the first m-tile is written
         float st_sum[8], st_sq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
@@ -288,25 +284,17 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             }
         };
         if constexpr (RES) { load_res(0); if (MI > 1) load_res(1); }
-        const float* lnf = lds_acc + (LNF && EPI == 1 ? parity * 1024 : 0);     // LNF consumer: [256 b'][256 s][256 rows x (rstd, -mean rstd)]
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             if constexpr (RES) { if (mi + 2 < MI) load_res(mi + 2); }
-            f32x2 rs = {1.f, 0.f};
-            if constexpr (LNF && EPI == 1) rs = *reinterpret_cast<const f32x2*>(lnf + 512 + (wm * (BM / 2) + mi * 16 + e_row) * 2);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 bf16x4 q;
                 if constexpr (LIN) {
-                    const int cb = (LNF && EPI == 1 ? 0 : n0) + wn * 64 + ni * 16 + (lane >> 4) * 4;
-                    const f32x4 bias_r = *reinterpret_cast<const f32x4*>((LNF && EPI == 1 ? lnf : lds_acc) + cb);
-                    f32x4 cs_r = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (LNF && EPI == 1) cs_r = *reinterpret_cast<const f32x4*>(lnf + 256 + cb);
+                    const f32x4 bias_r = *reinterpret_cast<const f32x4*>(lds_acc + n0 + wn * 64 + ni * 16 + (lane >> 4) * 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v;
-                        if constexpr (LNF && EPI == 1) v = fmaf(acc[ni][mi][e], rs[0], fmaf(rs[1], cs_r[e], bias_r[e]));
-                        else v = acc[ni][mi][e] + bias_r[e];
+                        float v = acc[ni][mi][e] + bias_r[e];
                         if constexpr (!RES) {
                             if (p.act == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
                             else if (p.act == CVCL_ACT_GELU) v = gelu_bf16out(v);
@@ -333,22 +321,6 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                             for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                         }
                         stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
-                        if constexpr (LNF && EPI == 2) {
-                            // (sum, sum of squares) of the STORED values over this wave's 64-column strip of the row: v_dot2 on
-                            // the packed pairs (products of bf16 are exact in fp32), then the row's eight lanes by DPP
-                            const u32x4 w4 = __builtin_bit_cast(u32x4, v);
-                            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                s1 = dot2c_bf16(s1, w4[e], 0x3f803f80u);             // (1.0, 1.0)
-                                s2 = dot2c_bf16(s2, w4[e], w4[e]);
-                            }
-                            s1 += dpp_quad_f32<0xB1>(s1); s2 += dpp_quad_f32<0xB1>(s2);          // lane ^ 1
-                            s1 += dpp_quad_f32<0x4E>(s1); s2 += dpp_quad_f32<0x4E>(s2);          // lane ^ 2
-                            s1 += dpp_quad_f32<0x141>(s1); s2 += dpp_quad_f32<0x141>(s2);        // row_half_mirror: the other quad
-                            if (r_chunk == 0)
-                                *reinterpret_cast<f32x2*>(p.row_part + ((long)m * (p.N >> 6) + ((n0 >> 6) + wn)) * 2) = f32x2{s1, s2};
-                        }
                     } else {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
@@ -389,10 +361,20 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         return (full && p.C != nullptr) ? ESTORES : 0;
     };
 
+    if constexpr (VAR & 16) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[q][i] = bf16x8{};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[q][i] = bf16x8{};
+        }
+    }
     // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----
     issue(0); advance(); issue(1); advance(); issue(2); advance(); issue(3); advance();
     if constexpr (EPI == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this thread's LDS writes above (-centre)
-    wait_vm<12>();
+    if constexpr (VAR & 64) wait_vm<8>();                    // (stagger experiment: stages 0 and 1 landed)
+    else wait_vm<12>();
     __builtin_amdgcn_s_barrier();
     read_frags(0, std::integral_constant<int, 0>{});
     if constexpr (EPI == 0) {
@@ -410,36 +392,43 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     int after_epi = 0;          // iterations left in which the last epilogue's stores are younger than the awaited stage
     int epi_ops = 0;            // lower bound on what that epilogue issued: ESTORES or 0
     int c_ks = 0, c_i = ti, c_j = tj;                        // k stage / (m-tile, column tile) of the tile being multiplied
-    int c_t = 0;                                             // index of the tile being multiplied (LNF: parity of its operand slot)
     auto step = [&](int g, auto P) __attribute__((always_inline)) {
         constexpr int q = decltype(P)::value;
+        if constexpr (VAR & 64) __builtin_amdgcn_s_setprio(1);
         mma_half(P, std::integral_constant<int, 0>{});
+        if constexpr (VAR & 64) __builtin_amdgcn_s_setprio(0);
         // stage g+1 has landed (this wave's part); the fragment reads of stage g are complete
-        if (after_epi > 0 && epi_ops == ESTORES) wait_vm<8 + ESTORES>();
-        else wait_vm<8>();
+        if constexpr (VAR & 64) {                            // stagger experiment: the other wave group is half a stage away, so
+            if (after_epi > 0 && epi_ops == ESTORES) wait_vm<4 + ESTORES>();     // a stage is awaited one stage earlier
+            else wait_vm<4>();
+        } else {
+            if (after_epi > 0 && epi_ops == ESTORES) wait_vm<8 + ESTORES>();
+            else wait_vm<8>();
+        }
         if (after_epi > 0) --after_epi;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(VAR & 4)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
         issue(g & 3);                                       // stage g+4 into the buffer stage g occupied
         mma_half(P, std::integral_constant<int, 1>{});
-        // one MFMA between any two of the 4 + MI reads / 4 loads
+        if constexpr (VAR & 2) {                            // one MFMA between any two of the 4 + MI reads / 4 loads
 #pragma unroll
-        for (int i = 0; i < 4 + MI; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
+            for (int i = 0; i < 4 + MI; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
         }
         advance();
+        if constexpr (VAR & 64) __builtin_amdgcn_s_barrier();      // second barrier of the stage: the groups sit half a stage apart
         if (++c_ks == KS) {
             c_ks = 0;
-            if constexpr (LNF && EPI == 1) { epi_ops = epilogue(c_i * BM, c_j * BN, c_t & 1); ++c_t; }
-            else epi_ops = epilogue(c_i * BM, c_j * BN, 0);
+            epi_ops = epilogue(c_i * BM, c_j * BN);
             after_epi = 3;
             c_i += step_i;
             if constexpr (FLAT) {
@@ -448,10 +437,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             }
         }
     };
+    // VAR bit 6 (lab experiment): waves 4-7 (the second wave of every SIMD) run half a stage behind waves 0-3 -- one wave of a SIMD in
+    // its pure-MFMA half while its partner reads fragments / issues stage loads (the "ping-pong" of the guide's 8-phase template)
+    if constexpr (VAR & 64) { if (wm == 1) __builtin_amdgcn_s_barrier(); }
     for (int g = 0; g < S; g += 2) {
         step(g, std::integral_constant<int, 0>{});
         step(g + 1, std::integral_constant<int, 1>{});
     }
+    if constexpr (VAR & 64) { if (wm == 0) __builtin_amdgcn_s_barrier(); }
     wait_vm<0>();                                            // the re-loads past the end must not outlive the workgroup
 
     if (EPI == 0 && p.stats) {

@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "../../multimodal-baby_amd/csrc/gemm8w_kernel.h"
+#include "gemm8w_lab_kernel.h"           // the round-3 product kernel WITH its experiment switches (VAR); the product header has none
 #include "gemm4w_kernel.h"
 #include "gemm8p_kernel.h"
 
