@@ -42,7 +42,7 @@ EMBEDDING_DIM = 512
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA)
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 WORKLOADS = {
     "c2": "C2 = BASELINE configs[1]: CVCL saycam_contrastive, frozen random-init ResNeXt-50 32x4d (BN train mode) + embedding "
@@ -118,6 +118,52 @@ def synthetic_batch_on_device(batch, seed, device, vocab=2350):
     return img, tok.contiguous(), ln
 
 
+def structured_batch_on_device(batch, seed, device, vocab=2350):
+    """A second, NON-CHAOTIC parity input (still synthetic): every frame is a smooth random field -- 3 x 7 x 7 uniform noise
+    upsampled bicubically to 224 x 224 -- with its own contrast and brightness, clamped to [0, 1], then ImageNet-normalised.
+    Unlike iid pixel noise (every sample nearly identical after the stem: BatchNorm amplifies any rounding ~100x) the samples
+    differ at every scale, so the batch statistics are well conditioned and a bf16 forward deviates from fp32 by ~1e-2."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    coarse = torch.rand(batch, 3, 7, 7, generator=g, device=device)
+    img = torch.nn.functional.interpolate(coarse, size=(224, 224), mode="bicubic", align_corners=False)
+    contrast = 0.3 + 1.4 * torch.rand(batch, 1, 1, 1, generator=g, device=device)
+    bright = 0.25 + 0.5 * torch.rand(batch, 1, 1, 1, generator=g, device=device)
+    img = ((img - 0.5) * contrast + bright).clamp_(0.0, 1.0)
+    mean = torch.tensor([0.485, 0.456, 0.406], device=device).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], device=device).view(1, 3, 1, 1)
+    img = ((img - mean) / std).contiguous()
+    words = torch.randint(4, vocab, (batch, 3), generator=g, device=device)
+    tok = torch.cat([torch.full((batch, 1), 2, device=device), words, torch.full((batch, 1), 3, device=device)], 1).long()
+    ln = torch.full((batch,), 5, dtype=torch.long, device=device)
+    return img, tok.contiguous(), ln
+
+
+def structured_parity(lit, ve, batch_size, device, rank=0, yardstick=True):
+    """bf16 vs fp32 (and torch autocast vs torch fp32) on structured frames, the storage centres calibrated on ANOTHER structured
+    batch; BatchNorm buffers restored and the centres dropped afterwards (the timed steps recalibrate on their own data)."""
+    keep = {k: v.clone() for k, v in lit.state_dict().items() if "running_" in k or "num_batches_tracked" in k}
+    evalb = structured_batch_on_device(batch_size, seed=4242 + rank, device=device)
+    calib = structured_batch_on_device(batch_size, seed=1717 + rank, device=device)
+    if hasattr(ve.model, "recalibrate_centres"):
+        ve.model.recalibrate_centres()
+    gn, lit.model.global_negatives = lit.model.global_negatives, False
+    try:
+        with torch.no_grad():
+            lit.model(calib[0], calib[1], calib[2])
+        lit.load_state_dict(keep, strict=False)
+        out = {k: float(f"{v:.4g}") for k, v in logits_vs_fp32(lit, evalb, "bf16").items()}
+        if yardstick:
+            ty, _ = torch_yardstick(lit, evalb)
+            out["torch_autocast_bf16_vs_torch_fp32"] = {k: float(f"{v:.4g}") for k, v in ty.items()}
+    finally:
+        lit.model.global_negatives = gn
+        lit.load_state_dict(keep, strict=False)
+        if hasattr(ve.model, "recalibrate_centres"):
+            ve.model.recalibrate_centres()
+    out["input"] = "smooth random fields (3 x 7 x 7 noise, bicubic to 224 x 224) with per-frame contrast / brightness"
+    return out
+
+
 def logits_vs_fp32(lit, batch, precision):
     """Deviation of the benchmarked precision from the exact-fp32 parity mode (the mode that meets the 1e-3 gate against the
     reference forward, multimodal.py:746-794) on the SAME weights and batch, module in train mode as benchmarked (BatchNorm on
@@ -156,17 +202,14 @@ def resnext_gemm_work(B):
     """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode), per
     kernel: every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
     enqueues: conv1 and downsample (A + W + C); conv3 of layers 3-4 (A + W + C); conv3 of layers 1-2 twice -- a
-    statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The number of leading
-    stages that use the fused tail is the library's $CVCL_FUSED_TAIL_STAGES, default 2.)  Which kernel runs a launch mirrors
+    statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The two leading stages use the fused tail.)  Which kernel runs a launch mirrors
     the dispatcher of csrc/gemm.hip: gemm_pro = conv3 with the BN2+ReLU operand prologue (layers 1-2), gemm8w = plain operands,
     K >= 256, N % 256 == 0, >= 96 tiles of 256 x 256, N K >= 170 (N + K) (strided-gather downsamples included); the rest on gemm_glds ("gemm").
     -> {kernel: [bytes, flops, launches]} and the totals."""
-    fused_stages = int(os.environ.get("CVCL_FUSED_TAIL_STAGES", "2"))
-    pro_stages = int(os.environ.get("CVCL_CONV3_PRO_STAGES", "2"))
+    fused_stages, pro_stages = 2, 2                  # (lab switches of the library, fixed in the product build: csrc/resnext.hip)
     # layer1.0: the downsample launch is a statistics-only pass (A + W) and the tail pass recomputes the branch from the block
-    # input (reads X [M, 64] + W2 instead of the stored [M, 256] branch) -- csrc/resnext.hip, $CVCL_DS_RECOMPUTE
-    ds_recompute = (os.environ.get("CVCL_DS_RECOMPUTE", "1") != "0" and os.environ.get("CVCL_GEMM_PRO", "1") != "0"
-                    and fused_stages >= 1 and pro_stages >= 1)
+    # input (reads X [M, 64] + W2 instead of the stored [M, 256] branch) -- csrc/resnext.hip
+    ds_recompute = os.environ.get("CVCL_GEMM_PRO", "1") != "0"
     per = {"gemm": [0, 0, 0], "gemm8w": [0, 0, 0], "gemm_pro": [0, 0, 0]}
 
     def add(kernel, nbytes, flops):
@@ -289,6 +332,50 @@ def spawn_ranks(a, argv):
     return subprocess.call(cmd, env=env)
 
 
+def dist_selfcheck(device, world, rank, local_rank):
+    """What the multi-rank line carries so that the first 8-GPU run verifies itself: the backend torch.distributed resolved, how many
+    ranks an all-reduce of ones saw, which physical device every rank sits on (two ranks on one device under RCCL = a mis-launch:
+    fail loudly), and the two collectives of the path timed on their own -- all-gather of the normalised features (2 x [256, 512]
+    f32 per rank) and all-reduce of the frozen configuration's gradient bucket (9 MB) -- with HIP events around collective + wait."""
+    backend = dist.get_backend()
+    ones = torch.ones(1, device=device)
+    dist.all_reduce(ones)
+    props = torch.cuda.get_device_properties(device)
+    ident = str(getattr(props, "uuid", "")) or f"{props.name}#{getattr(props, 'pci_bus_id', device.index)}"
+    mine = {"rank": rank, "local_rank": local_rank, "device_index": device.index, "device": ident}
+    seen = [None] * world
+    dist.all_gather_object(seen, mine)
+    dup = len({(d["device"], d["device_index"]) for d in seen}) < world
+    if dup and backend == "nccl":
+        raise SystemExit(f"bench.py: two ranks resolved to one device under RCCL: {seen}")
+
+    def timed(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier()
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        t = torch.tensor([a.elapsed_time(b) / n * 1e3], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t.item()), 1)
+    feat = torch.randn(2 * PER_GPU_BATCH, EMBEDDING_DIM, device=device)
+    gathered = torch.empty(world * 2 * PER_GPU_BATCH, EMBEDDING_DIM, device=device)
+    bucket = torch.randn(9 * 1024 * 1024 // 4, device=device)
+    out = {"backend": backend, "ranks_seen": int(ones.item()), "ranks": seen, "shared_devices": dup,
+           "allgather_us": timed(lambda: dist.all_gather_into_tensor(gathered, feat)),
+           "allreduce_us": timed(lambda: dist.all_reduce(bucket)),
+           "collectives_note": "max over ranks of the HIP-event time per call (collective + the current stream's wait for it), 20 calls "
+                               "back to back: all-gather of 2 x [256, 512] f32 features per rank; all-reduce of a 9 MB f32 gradient bucket"}
+    if out["ranks_seen"] != world:
+        raise SystemExit(f"bench.py: an all-reduce of ones over {world} ranks returned {out['ranks_seen']}")
+    return out
+
+
 # whole-step algorithmic work per pair (SURVEY.md 8(d)): forward flops (2 x MAC) of the frozen trunk and, for C2, the bytes
 # of a perfectly fused bf16 forward (0.3 MB input + 2 x 28.8 MB activations)
 STEP_FLOPS_PER_PAIR = {"c2": 8.46e9, "c4": 35.1e9, "c5": 35.1e9, "c4p14": 46.3e9}
@@ -301,7 +388,7 @@ def static_traffic(kernel_name):
     """PMC L2 <-> fabric bytes per launch of one kernel from the tracked summary of separate rocprofv3 --pmc passes of this
     command (tools/pmc_bench.sh + tools/pmc_summary.py; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  STATIC: collected on an
     earlier box of this round, not in the run that prints the line.  -> (bytes per launch | None, source)."""
-    for rnd in (PROFILE_ROUND, "r02"):
+    for rnd in (PROFILE_ROUND, "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.json")
         try:
             with open(path) as f:
@@ -310,6 +397,27 @@ def static_traffic(kernel_name):
                     f"profiles/{rnd}_pmc_hbm_traffic.json (static: separate rocprofv3 --pmc passes on an earlier box, tools/pmc_bench.sh)")
         except Exception:
             continue
+    return None, None
+
+
+def static_traffic_vit(cfg):
+    """The same for the ViT configurations: HBM bytes per launch averaged over the trunk's GEMM launches (the bf16 8-wave kernel, or
+    the two e4m3 kernels), from the tracked per-kernel summary of tools/pmc_cfg.sh <cfg> (FETCH_SIZE x 2 + WRITE_SIZE; STATIC).
+    -> (bytes per launch | None, source)."""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{cfg}_summary.json")
+    try:
+        with open(path) as f:
+            pm = json.load(f)
+        n = tot = 0.0
+        for k, v in pm.items():
+            if k.startswith(("gemm8w_kernel", "gemm8f_kernel", "gemm_fp8_kernel")) and "hbm_read_MB_x2" in v:
+                n += v["dispatches_per_pass"]
+                tot += (v["hbm_read_MB_x2"] + v["hbm_write_MB"]) * 1e6 * v["dispatches_per_pass"]
+        if n:
+            return int(tot / n), (f"profiles/{PROFILE_ROUND}_pmc_{cfg}_summary.json (static: separate rocprofv3 --pmc passes on an earlier "
+                                  "box, tools/pmc_cfg.sh; mean over the trunk's GEMM launches)")
+    except Exception:
+        pass
     return None, None
 
 
@@ -409,6 +517,8 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
             a_, b_ = li.double(), torch_logits.double()
             par["hip_fp32_logits_rel_vs_torch_fp32"] = float((a_ - b_).abs().max() / b_.abs().max())
             par["torch_autocast_bf16_vs_torch_fp32"] = {k: float(f"{v:.4g}") for k, v in ty.items()}
+            if precision == "bf16":
+                par["structured_frames"] = structured_parity(lit, ve, batch_size, device, rank)
         torch.cuda.synchronize()
         set_trunk_streams(trunk_streams)
         res["parity"] = par
@@ -424,9 +534,11 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        per_rank = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(per_rank, torch.tensor([elapsed], device=device, dtype=torch.float64))
+        per_rank = [float(t.item()) for t in per_rank]
+        res["ms_per_step_per_rank"] = {"min": round(min(per_rank) / steps * 1e3, 3), "max": round(max(per_rank) / steps * 1e3, 3)}
+        elapsed = max(per_rank)
     res["elapsed"] = elapsed
     res["final_loss"] = float(out["loss"].detach())
     res["value"] = world * batch_size * steps / elapsed
@@ -525,10 +637,12 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
         if cfg != "c2":
             # ViT configurations: the trunk's 49 GEMM launches (patch embedding + 4 linears x 12 blocks) are ONE kernel -- the bf16
             # linear-epilogue gemm8w, or the e4m3 gemm_fp8 (profiled under the class "gemm") -- so the family figure is the kernel's
-            rl = {"kernel": ("gemm_fp8_kernel (e4m3 x e4m3 ViT linears on v_mfma_scale_f32_32x32x64_f8f6f4)" if precision == "fp8"
+            rl = {"kernel": ("gemm8f_kernel / gemm_fp8_kernel (e4m3 x e4m3 ViT linears on v_mfma_scale_f32_32x32x64_f8f6f4: 8-wave 256|192 x 256 "
+                              "tiles for qkv / fc1, 128 x 128 tiles for proj / fc2)" if precision == "fp8"
                              else "gemm8w_kernel<linear epilogue> (bf16 ViT linears: bias / GELU / residual; 8-wave 256|224 x 256 tiles)"),
                   "dominant_class_by_time": dom, "bound": "mfma", "achieved": family["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
-                  "frac": family["mfma_frac"], "traffic": None, "traffic_source": None, "other_bound_frac": family["hbm_frac"],
+                  "frac": family["mfma_frac"], "traffic": static_traffic_vit(cfg)[0], "traffic_source": static_traffic_vit(cfg)[1],
+                  "other_bound_frac": family["hbm_frac"],
                   "avg_launch_us": family["avg_launch_us"], "launches_per_step": family["launches_per_step"],
                   "algorithmic_bytes_per_launch": int(nbytes / launches), "algorithmic_flops_per_launch": int(flops / launches)}
         elif d is not None and "tflops" in d:
@@ -661,12 +775,18 @@ def main(argv=None):
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the CVCL hot path has no CPU fallback")
-    device = torch.device("cuda", local_rank % torch.cuda.device_count())
+    backend = os.environ.get("CVCL_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo lets two ranks share one GPU (smoke test of the N > 1 path)
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"bench.py: LOCAL_RANK {local_rank} but only {ndev} visible device(s): one rank per GPU under RCCL "
+                         "(CVCL_DIST_BACKEND=gloo shares a device for smoke tests)")
+    device = torch.device("cuda", local_rank % ndev)
     torch.cuda.set_device(device)
+    selfcheck = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # "nccl" is RCCL on ROCm; CVCL_DIST_BACKEND=gloo lets two ranks share one GPU to smoke-test the N>1 path
-        dist.init_process_group(backend=os.environ.get("CVCL_DIST_BACKEND", "nccl"))
+        dist.init_process_group(backend=backend)
+        selfcheck = dist_selfcheck(device, world, rank, local_rank)
 
     cfg = a.config
     precision = a.precision or ("fp8" if cfg == "c5" else "bf16")
@@ -715,6 +835,8 @@ def main(argv=None):
                            "negatives": "global (RCCL all-gather)" if world > 1 else "local (single GPU)",
                            "parallelism": f"dp{world}", "trunk_streams": r["trunk_streams"]},
                 "final_loss": round(r["final_loss"], 5), "hbm_peak_gb": r["hbm_peak_gb"], "whole_step": r["whole_step"]}
+        if selfcheck is not None:
+            line["distributed"] = dict(selfcheck, ms_per_step_per_rank=r.get("ms_per_step_per_rank"))
         par = r.get("parity")
         if par:
             line.update({k: float(f"{v:.4g}") for k, v in par.items() if isinstance(v, float)})

@@ -19,6 +19,16 @@
  *  - image activations inside the library are NHWC ("channels last"); the API takes the
  *    reference's NCHW fp32 images (multimodal_data_module.py:98-109) and hands back the layer4
  *    map in NHWC memory, which the host exposes as a logical NCHW tensor view.
+ *
+ * Run-time switches -- the ONLY environment variables the product library reads (once per process, csrc/api.cpp):
+ *    variable               default  "0" means
+ *    CVCL_CENTRED_STORAGE   on       plain (un-centred) bf16 storage of the raw convolution outputs (the round-2 numerics)
+ *    CVCL_GEMM8W            on       cvcl_gemm never selects the 8-wave 256 x 256 kernel (everything on the 128 x 128 kernels)
+ *    CVCL_GEMM_PRO          on       cvcl_gemm refuses the BN-prologue kernel (callers normalise the operand themselves)
+ *    CVCL_F32_TILED         on       fp32 parity mode: the direct (one thread per output) stem / grouped-conv kernels
+ *  Experiment switches of earlier rounds (CVCL_FUSED_TAIL_STAGES, CVCL_CONV3_PRO_STAGES, CVCL_DS_RECOMPUTE, CVCL_BN3_GRAM,
+ *  CVCL_PRO_DEPTH, CVCL_GCONV_LDS_KB, CVCL_GEMM_MINW, CVCL_GEMM_GLDS, CVCL_GCONV_WGRAD_BAND) exist only in a library built with
+ *  -DCVCL_LAB (tools/README.md); the kernel-variant switches of the 8-wave GEMM live in tools/gemm_lab/.
  */
 #ifndef CVCL_HIP_H
 #define CVCL_HIP_H
@@ -146,7 +156,7 @@ typedef struct {
      *   consumer (ln_stats != NULL; bias / activation epilogue, no residual): A = the RAW rows x, W = W diag(gamma) (rounded to
      *     bf16 by the caller), ln_colsum[n] = sum_k W'[n][k] of that rounded matrix, bias[n] = b[n] + sum_k W[n][k] beta[k]
      *     (required), ln_stats[m] = (rstd_m, -mean_m rstd_m):  C = round(act(rstd acc - mean rstd ln_colsum[n] + bias[n])).
-     *     ln_stats must be readable for M + 512 rows (whole tiles are fetched).
+     *     (M >= 2.)
      *   producer (row_part != NULL; bias + residual epilogue): additionally row_part[m][N / 64][2] f32 = (sum, sum of squares) of
      *     the STORED row over each 64-column strip; cvcl_row_stats_finalize reduces them to the next consumer's ln_stats.
      * cvcl_gemm_ln_supported tells whether cvcl_gemm routes these arguments to the kernel that honours them. */

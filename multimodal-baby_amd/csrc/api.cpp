@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/cvcl_hip.h"
@@ -15,6 +16,20 @@ void cvcl_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+bool cvcl_env_on(const char* name) {
+    const char* e = getenv(name);
+    return !(e && e[0] == '0');
+}
+int cvcl_lab_int(const char* name, int dflt) {
+#ifdef CVCL_LAB
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 extern "C" int cvcl_abi_version(void) { return CVCL_ABI_VERSION; }

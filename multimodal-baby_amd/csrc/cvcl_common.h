@@ -18,6 +18,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // thread-local last error text (cvcl_last_error)
 void cvcl_set_error(const char* fmt, ...);
 
+// Run-time switches (api.cpp holds the only getenv calls of the library).  The PRODUCT reads four environment variables -- the
+// table "Run-time switches" in include/cvcl_hip.h: cvcl_env_on(name) is false when $name starts with '0'.  Everything else that
+// earlier rounds could toggle is a LAB switch: cvcl_lab_int(name, default) reads $name only in a library built with -DCVCL_LAB
+// (tools/README.md) and is the constant `default` in the product build.
+bool cvcl_env_on(const char* name);
+int cvcl_lab_int(const char* name, int dflt);
+
 // optional HIP-event timing of a launch (see cvcl_prof_enable in include/cvcl_hip.h)
 bool cvcl_prof_on();
 void* cvcl_prof_begin(void* stream, int cls);

@@ -715,7 +715,7 @@ __global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* __restric
 template <typename T> int min_waves() {
     if (sizeof(T) != 2) return 1;
     static int v = 0;
-    if (!v) { const char* e = getenv("CVCL_GEMM_MINW"); v = (e && e[0] == '3') ? 3 : 2; }
+    if (!v) v = cvcl_lab_int("CVCL_GEMM_MINW", 2) == 3 ? 3 : 2;
     return v;
 }
 
@@ -862,7 +862,7 @@ namespace {
 // and ViT-B linears 10-25 % faster than the 128 x 128 kernel below; $CVCL_GEMM8W=0 switches it off.
 // Returns -1 (not selected) or the epilogue id.
 inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
-    static const bool on = [] { const char* e = getenv("CVCL_GEMM8W"); return !(e && e[0] == '0'); }();
+    static const bool on = cvcl_env_on("CVCL_GEMM8W");
     if (!on || dtype != CVCL_BF16) return -1;
     if (!cvcl_gemm8w_supported(a->M, a->N, a->K, a->lda, a->ldw, a->ldc) || a->K < 256) return -1;
     if (a->a_scale || a->exp_scale || a->c_scale || a->C_pre || a->G) return -1;
@@ -893,7 +893,7 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
 // Bandwidth-bound 1x1 convolution with the producer's BN + ReLU on its input (gemm_pro.hip): conv3 of ResNeXt layers 1-2.
 // $CVCL_GEMM_PRO=0 refuses it (callers then have to normalise the operand themselves).
 inline bool pick_gemm_pro(int dtype, const cvcl_gemm_args* a) {
-    static const bool on = [] { const char* e = getenv("CVCL_GEMM_PRO"); return !(e && e[0] == '0'); }();
+    static const bool on = cvcl_env_on("CVCL_GEMM_PRO");
     if (!on || dtype != CVCL_BF16 || !cvcl_gemm_pro_supported(a)) return false;
     return !a->stats || a->stats_rows >= cvcl_gemm_pro_stats_rows(a->M, a->N);
 }
@@ -944,7 +944,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
         if (pick_gemm_pro(CVCL_BF16, a)) return cvcl_gemm_pro(a, stream);
         const int e8 = pick_gemm8w(CVCL_BF16, a);
         if (e8 >= 0) return cvcl_gemm8w(e8, a, stream);
-        static const bool use_glds = [] { const char* e = getenv("CVCL_GEMM_GLDS"); return !(e && e[0] == '0'); }();
+        static const bool use_glds = cvcl_lab_int("CVCL_GEMM_GLDS", 1) != 0;
         if (use_glds && a->c_scale) {                // Bottleneck tail epilogue: only the direct-to-LDS kernel implements it
             CVCL_CHECK_ARG(d.vec_in && d.vec_out && pro_kind(a) == 0 && a->K % 64 == 0 && a->N % BN == 0 && a->R && a->c_shift &&
                                !a->bias && !a->exp_scale && !a->stats && (a->r_scale == nullptr) == (a->r_shift == nullptr),
@@ -976,7 +976,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     CVCL_CHECK_ARG(a->C && !a->c_scale, "cvcl_gemm: statistics-only / BN-tail epilogues need the direct-to-LDS bf16 path");
     if constexpr (sizeof(T) == 4) {
         auto al16p = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
-        if (pro_kind(a) == 0 && !(a->gather_stride > 1) && !a->stats && !a->R && a->act == CVCL_ACT_NONE && a->K % 4 == 0 &&
+        if (pro_kind(a) == 0 && !(a->gather_stride > 1) && !a->stats && !a->R && !a->centre && a->act == CVCL_ACT_NONE && a->K % 4 == 0 &&
             a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) &&
             // measured cost models (us, MI355X): the split-K VALU kernel runs ~13.4 GMAC/s-per-us of work on any shape; the
             // 128-tile fp32 MFMA kernel needs ~4.6 us per 64-deep K step per round of <= 256 tiles, whatever M and N are

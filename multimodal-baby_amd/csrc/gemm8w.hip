@@ -20,11 +20,18 @@ int g8_num_cus() {
 
 // grid rows (workgroups per column tile): a multiple of 8 so that the column tiles of one m-tile share an XCD, at most one
 // workgroup per CU in total, no more than there are m-tiles (rounded up to 8)
+// (round 4) ... and no more workgroups than the number of rounds needs: 224 m-tiles on 64 grid rows are 3.5 -> 4 rounds, which 56
+// grid rows also do in 4 -- the same launch time, but the 32 CUs left out are free for the OTHER trunk stream's kernels for the
+// whole launch instead of idling through the tail of the last round.
 int g8_grid_m(int tiles_m, int ncol) {
     int gm = (g8_num_cus() / ncol) & ~7;
     if (gm < 8) gm = 8;
     const int need = (tiles_m + 7) & ~7;
-    return gm > need ? need : gm;
+    if (gm > need) gm = need;
+    static const bool lean_on = cvcl_lab_int("CVCL_LEAN_GRID", 1) != 0;
+    const int rounds = cvcl_div_up(tiles_m, gm);
+    const int lean = (cvcl_div_up(tiles_m, rounds) + 7) & ~7;      // the smallest multiple of 8 with the same number of rounds
+    return lean_on && lean < gm ? lean : gm;
 }
 
 template <int MI, int EPI, bool LNF = false>
@@ -123,6 +130,12 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
         d.tiles_m = cvcl_div_up(a->M, bm);
         const long total = (long)d.tiles_m * d.ncol;
         grid = total < g8_num_cus() ? (int)((total + 7) & ~7L) : (g8_num_cus() & ~7);
+        {                                                    // as g8_grid_m: the smallest grid with the same number of rounds
+            static const bool lean_on = cvcl_lab_int("CVCL_LEAN_GRID", 1) != 0;
+            const long rounds = (total + grid - 1) / grid;
+            const int lean = (int)(((total + rounds - 1) / rounds + 7) & ~7L);
+            if (lean_on && lean < grid) grid = lean;
+        }
         d.grid_m = 0;
     }
     CvclProfScope prof(stream, CVCL_K_GEMM8W);

@@ -53,7 +53,7 @@ constexpr int MAX_BIAS_N = (LDS_BYTES - ACC_OFF) / 4;               // 4096
 struct Dev {
     const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
     const float* bias; float* stats;
-    const float* ln_stats; const float* ln_colsum; float* row_part;     // LNF (see above); ln_stats readable for tiles_m * BM rows
+    const float* ln_stats; const float* ln_colsum; float* row_part;     // LNF (see above)
     const float* centre;            // EPI 0: storage centre of the output (NULL = 0): accumulators start at -centre[n]
     int M, N, K, lda, ldw, ldc, ldr, act;
     int tiles_m, grid_m, ncol;
@@ -185,9 +185,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             // more in these waves' queues only makes the next three counted waits conservative.
             if (l_ks == 0 && wave < 4) {
                 char* dst = smem + ACC_OFF + (l_t & 1) * 4096 + wave * 1024;
-                const float* src = wave == 0 ? p.bias + l_j * BN : wave == 1 ? p.ln_colsum + l_j * BN
-                                                                               : p.ln_stats + ((long)l_i * BM + (wave - 2) * 128) * 2;
-                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + lane * 4),
+                // (rows past M, ragged last tile: clamped to the last two rows of ln_stats -- masked at the store)
+                const float* src = wave == 0 ? p.bias + l_j * BN + lane * 4 : wave == 1 ? p.ln_colsum + l_j * BN + lane * 4
+                                 : p.ln_stats + min(((long)l_i * BM + (wave - 2) * 128) * 2 + lane * 4, (long)p.M * 2 - 4);
+                __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                                  (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
             }
         }

@@ -14,6 +14,7 @@
 // for one MFMA is 32 consecutive k bytes of its row (two swizzled 16-byte chunks); A and B use the same (lane, byte) -> k
 // assignment, which is all a contraction needs.
 #include "cvcl_common.h"
+#include "gemm8f_kernel.h"
 
 namespace {
 
@@ -409,6 +410,30 @@ extern "C" int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stri
 }
 
 namespace {
+// ---- the 8-wave 256 (192) x 256 kernel (gemm8f_kernel.h) for the large ViT shapes ----
+template <int MT, int KIND, int ACT>
+int launch_8f(const g8f::Dev& d, int grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)g8f::gemm8f_kernel<MT, KIND, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, g8f::LDS_BYTES) != hipSuccess) {
+            cvcl_set_error("cvcl_gemm_fp8: cannot raise the dynamic LDS limit to %d", g8f::LDS_BYTES);
+            return CVCL_ELAUNCH;
+        }
+        attr = true;
+    }
+    hipLaunchKernelGGL((g8f::gemm8f_kernel<MT, KIND, ACT>), dim3(grid), dim3(512), g8f::LDS_BYTES, st, d);
+    return CVCL_OK;
+}
+// -1: not for this kernel; else the kind (0 per-row scales -> bf16, 1 MX input + residual -> bf16, 2 per-row scales -> MX output)
+int pick_8f(const float* a_scale, const void* a_bs, const void* C, const void* c8, int act, const void* R, int M, int N, int K, int lda,
+            int ldw) {
+    if (N % 256 || K % 128 || K < 256 || lda % 16 || ldw % 16) return -1;
+    if ((long)cvcl_div_up(M, 256) * (N / 256) < 96 || (long)M * lda >= (1L << 31) || (long)N * ldw >= (1L << 31)) return -1;
+    if (a_bs) return (C && R && act == CVCL_ACT_NONE) ? 1 : -1;
+    if (c8) return (!R && (act == CVCL_ACT_NONE || act == CVCL_ACT_GELU)) ? 2 : -1;
+    return (C && !R && (act == CVCL_ACT_NONE || act == CVCL_ACT_GELU)) ? 0 : -1;
+}
+
 template <int ACT, bool MXA, bool MXOUT>
 int launch_fp8(const F8Dev& d, dim3 grid, hipStream_t st) {
     static bool attr_set = false;
@@ -440,6 +465,48 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
                        (((uintptr_t)a_block_scales & 3) == 0), "cvcl_gemm_fp8: operands must be 16-byte aligned");
     CVCL_CHECK_ARG(act == CVCL_ACT_NONE || act == CVCL_ACT_RELU || act == CVCL_ACT_GELU, "cvcl_gemm_fp8: activation %d", act);
     CVCL_CHECK_ARG(!c8 || !R, "cvcl_gemm_fp8: the MX output mode takes no residual");
+    hipStream_t st = (hipStream_t)stream;
+    // Large shapes: the 8-wave kernel (gemm8f_kernel.h)
+    const int kind = M >= 4 ? pick_8f(a_scale, a_block_scales, C, c8, act, R, M, N, K, lda, ldw) : -1;
+    if (kind >= 0) {
+        bool use8f = true;
+        g8f::Dev g;
+        g.A = (const unsigned char*)A8; g.W = (const unsigned char*)W8; g.C = (bf16_t*)C; g.R = (const bf16_t*)R;
+        g.sa = a_scale; g.sw = w_scale; g.bias = bias; g.a_bs = (const unsigned char*)a_block_scales;
+        g.C8 = (unsigned char*)c8; g.c_bs = (unsigned char*)c_block_scales;
+        g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.ldc8 = ldc8; g.act = act;
+        g.ncol = N / 256;
+        const int cus = f8_num_cus();
+        int bm = 256;
+        long best = -1;
+        for (int hgt : {256, 192}) {                         // rounds x tile height decides (as the bf16 kernel's 256 | 224);
+            const long total = (long)cvcl_div_up(M, hgt) * g.ncol;       // ties: 256, except the MX-input kind (its 256-row
+            const long gg = total < cus ? ((total + 7) & ~7L) : (cus & ~7);      // instantiation spills 5 registers)
+            const long cost = ((total + gg - 1) / gg) * hgt;
+            if (best < 0 || cost < best || (cost == best && kind == 1)) { best = cost; bm = hgt; }
+        }
+        g.tiles_m = cvcl_div_up(M, bm);
+        const long total = (long)g.tiles_m * g.ncol;
+        const int grid8 = total < cus ? (int)((total + 7) & ~7L) : (cus & ~7);
+        // the last round of 256-wide tiles must be reasonably full: at N = 768 (proj / fc2 of ViT-B, 2.3 rounds of 256-row tiles
+        // = 77 % of the slots) the 128 x 128 kernel below (two workgroups per CU, 4.6 rounds = 92 %) is the faster one
+        use8f = (double)total / ((double)((total + grid8 - 1) / grid8) * grid8) >= 0.85;
+      if (use8f) {
+        CvclProfScope prof(stream, CVCL_K_GEMM);
+        int rc;
+        if (bm == 256)
+            rc = kind == 1 ? launch_8f<4, 1, CVCL_ACT_NONE>(g, grid8, st)
+               : kind == 2 ? (act == CVCL_ACT_GELU ? launch_8f<4, 2, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<4, 2, CVCL_ACT_NONE>(g, grid8, st))
+                           : (act == CVCL_ACT_GELU ? launch_8f<4, 0, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<4, 0, CVCL_ACT_NONE>(g, grid8, st));
+        else
+            rc = kind == 1 ? launch_8f<3, 1, CVCL_ACT_NONE>(g, grid8, st)
+               : kind == 2 ? (act == CVCL_ACT_GELU ? launch_8f<3, 2, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<3, 2, CVCL_ACT_NONE>(g, grid8, st))
+                           : (act == CVCL_ACT_GELU ? launch_8f<3, 0, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<3, 0, CVCL_ACT_NONE>(g, grid8, st));
+        if (rc) return rc;
+        CVCL_LAUNCH_CHECK();
+        return CVCL_OK;
+      }
+    }
     F8Dev d;
     d.A = (const unsigned char*)A8; d.W = (const unsigned char*)W8; d.C = (bf16_t*)C; d.R = (const bf16_t*)R;
     d.sa = a_scale; d.sw = w_scale; d.bias = bias;
@@ -458,7 +525,6 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
         g = (int)total_tiles;
     }
     dim3 grid(g);
-    hipStream_t st = (hipStream_t)stream;
     CvclProfScope prof(stream, CVCL_K_GEMM);
     const bool mxa = a_block_scales != nullptr, mxo = c8 != nullptr;
     int rc;

@@ -479,7 +479,7 @@ extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // tiles of A in flight: 3 (K = 128) / 2 (K = 256: the register budget); $CVCL_PRO_DEPTH overrides (measured on C2: depth 1
     // 1.502 ms per step over the 14 launches, default 1.471)
-    static const int depth = [] { const char* e = getenv("CVCL_PRO_DEPTH"); return e ? atoi(e) : 0; }();
+    static const int depth = cvcl_lab_int("CVCL_PRO_DEPTH", 0);
     if (mode == PRO_TAIL_DS) {                               // K = 128 only; two tiles of A and X in flight (the register budget)
         return pro_launch<4, PRO_TAIL_DS, 2>(d, grid, st);
     }

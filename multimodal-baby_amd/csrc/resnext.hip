@@ -1087,7 +1087,7 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
         auto lds_of = [&](int th) { return (size_t)(147 * 64 + 64 + 3 * (2 * th + 5) * (W + 6)) * 4; };
         int TH = Ho < 8 ? Ho : 8;
         while (TH > 1 && lds_of(TH) > 150 * 1024) --TH;
-        static const bool tiled_on = [] { const char* e = getenv("CVCL_F32_TILED"); return !(e && e[0] == '0'); }();
+        static const bool tiled_on = cvcl_env_on("CVCL_F32_TILED");
         if (tiled_on && lds_of(TH) <= 150 * 1024) {
             static bool attr = false;
             if (!attr) {
@@ -1136,7 +1136,7 @@ GconvPlan gconv_plan(int B, int H, int W, int C, int stride) {
     // output rows per work item: staged input band + output band within ~52 KiB (3 workgroups per CU) and the
     // input pixel count within the 10 x 32 register-prefetch slots of the kernel
     auto bytes = [&](int th) { return (size_t)(((th - 1) * stride + 3) * Wp + th * Wo) * GC_PIXB; };
-    static const int lds_kb = [] { const char* e = getenv("CVCL_GCONV_LDS_KB"); return e ? atoi(e) : 52; }();
+    static const int lds_kb = cvcl_lab_int("CVCL_GCONV_LDS_KB", 52);
     int TH = Ho;
     while (TH > 1 && (bytes(TH) > (size_t)lds_kb * 1024 || ((TH - 1) * stride + 3) * Wp > 10 * 32 || TH * Wo > 128)) TH = (TH + 1) / 2;
     g.TH = TH;
@@ -1223,7 +1223,7 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         auto lds_of = [&](int th) { return (size_t)(64 * 9 * cg + 64 + 64 * plane_p_of(th)) * 4; };
         int TH = Ho;
         while (TH > 1 && lds_of(TH) > 150 * 1024) --TH;
-        static const bool tiled_on = [] { const char* e = getenv("CVCL_F32_TILED"); return !(e && e[0] == '0'); }();
+        static const bool tiled_on = cvcl_env_on("CVCL_F32_TILED");
         const bool tiled = tiled_on && C % 64 == 0 && (cg == 4 || cg == 8 || cg == 16 || cg == 32) && lds_of(TH) <= 150 * 1024 &&
                            ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)a_scale & 15) == 0 && ((uintptr_t)a_shift & 15) == 0;
         if (tiled) {
@@ -1400,7 +1400,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // operand load (gemm_pro.hip: applied once per element, W resident in registers) -- no pass of its own over the tensor.
     // Layers 3-4 (MFMA-bound, 4-8 column-tile workgroups per A tile): BN2 + ReLU is applied in place first (one pass over the
     // narrow tensor), which is cheaper than repeating it in every column tile's operand path.
-    static const int pro_stages = [] { const char* e = getenv("CVCL_CONV3_PRO_STAGES"); return e ? atoi(e) : 2; }();
+    static const int pro_stages = cvcl_lab_int("CVCL_CONV3_PRO_STAGES", 2);
     const bool pro = dtype == CVCL_BF16 && stage < pro_stages && (width == 128 || width == 256);
     if (!pro) {
         if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
@@ -1412,7 +1412,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // on the operand load (gemm_pro.hip).  Measured per step at B = 256 (round 2, with gemm_pro): 1 stage 5.47 ms, 2 stages
     // 5.46 ms and 1.2 GB less HBM traffic; layers 3-4 are MFMA-bound and keep the materialised form.
     // In eval mode there is no statistics pass at all, so the fused tail is used in every stage.
-    static const int fused_stages = [] { const char* e = getenv("CVCL_FUSED_TAIL_STAGES"); return e ? atoi(e) : 2; }();
+    static const int fused_stages = cvcl_lab_int("CVCL_FUSED_TAIL_STAGES", 2);
     const bool fused_tail = dtype == CVCL_BF16 && (stage < fused_stages || !training);
     auto conv3_args = [&]() {
         cvcl_gemm_args a = {};
@@ -1424,7 +1424,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     };
     // opt-in ($CVCL_BN3_GRAM=1): measured SLOWER than the statistics-only GEMM pass on MI355X at B=256 (8.14 vs 7.74
     // ms/step: the Gram TN GEMM runs at ~400 TFLOP/s and needs two small follow-up kernels), kept as an experiment
-    static const bool use_gram = [] { const char* e = getenv("CVCL_BN3_GRAM"); return e && e[0] == '1'; }();
+    static const bool use_gram = cvcl_lab_int("CVCL_BN3_GRAM", 0) == 1;
     if (fused_tail && training && use_gram && c.gram_ws && !cen) {
         // BN3 statistics from the Gram matrix of conv3's (narrow) input: one read of R2 instead of a statistics-only
         // GEMM pass (the conv is linear: sum_y = W colsum(R2), sum_y2[n] = w_n^T (R2^T R2) w_n)
@@ -1443,11 +1443,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // layer1.0 (bf16, fused tail, BN-prologue kernel): the downsample branch is a K = 64 product of the block input, recomputed
     // inside the tail pass (gemm_pro.hip PRO_TAIL_DS) instead of being written to HBM (411 MB at B = 256) and read back; its own
     // launch shrinks to a statistics-only pass (train mode) or disappears (eval mode).  $CVCL_DS_RECOMPUTE=0: the stored form.
-    static const bool ds_recompute_on = [] {
-        const char* e = getenv("CVCL_DS_RECOMPUTE");
-        const char* g = getenv("CVCL_GEMM_PRO");
-        return !(e && e[0] == '0') && !(g && g[0] == '0');
-    }();
+    static const bool ds_recompute_on = cvcl_lab_int("CVCL_DS_RECOMPUTE", 1) != 0 && cvcl_env_on("CVCL_GEMM_PRO");
     const bool ds_recompute = ds_recompute_on && first && stride == 1 && inplanes == 64 && fused_tail && pro && width == 128;
     if (first) {
         // downsample 1x1 stride s: X -> RD [m_out, outc]
@@ -1577,7 +1573,7 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
         CvclProfScope prof(stream, CVCL_K_BN_FINALIZE);
         // eval mode in bf16 stores every raw conv output as y - running_mean unless the caller brings its own centres
         // ($CVCL_CENTRED_STORAGE=0: plain storage; fp32 keeps plain storage -- nothing to gain there)
-        static const bool centred = [] { const char* e = getenv("CVCL_CENTRED_STORAGE"); return !(e && e[0] == '0'); }();
+        static const bool centred = cvcl_env_on("CVCL_CENTRED_STORAGE");
         float* own = (!centres && centred && dtype == CVCL_BF16) ? eval_centres : nullptr;
         hipLaunchKernelGGL(bn_eval_affine_all_kernel, dim3(53), dim3(256), 0, (hipStream_t)stream, t, eps, affine, centres, own);
         CVCL_LAUNCH_CHECK();

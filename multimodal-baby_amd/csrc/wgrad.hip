@@ -750,7 +750,7 @@ extern "C" int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int
     CVCL_CHECK_ARG(M < (1L << 31), "cvcl_gconv3x3_wgrad: B * Ho * Wo must be below 2^31");
     hipStream_t st = (hipStream_t)stream;
     // one pass over the operands with all nine taps (band kernel) when a band fits the LDS; $CVCL_GCONV_WGRAD_BAND=0: the tap-at-a-time form
-    static const bool band_on = [] { const char* e = getenv("CVCL_GCONV_WGRAD_BAND"); return !(e && e[0] == '0'); }();
+    static const bool band_on = cvcl_lab_int("CVCL_GCONV_WGRAD_BAND", 1) != 0;
     const GwPlan gw = gw_plan(B, H, W, C, stride);
     if (band_on && gw.ok && cg <= 32 && 32 % cg == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0) {
         if (workspace_bytes < gw.ws) {

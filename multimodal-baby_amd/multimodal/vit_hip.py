@@ -203,7 +203,7 @@ def _vit_forward(model, x: torch.Tensor, slot) -> torch.Tensor:
         fold = False
         if not fp8 and dt == torch.bfloat16 and w["blocks"] and ln_fold_mode(model) is not False:
             bw0 = w["blocks"][0]
-            st = torch.empty(M + 512, 2, dtype=torch.float32, device=dev)
+            st = torch.empty(M, 2, dtype=torch.float32, device=dev)
             part = torch.empty(M, D // 64, 2, dtype=torch.float32, device=dev) if D % 64 == 0 else None
             ok_c = part is not None and all(H.gemm(h, bw0[n + "_w_ln"], out=o, bias=bw0[n + "_b_ln"], ln_stats=st, ln_colsum=bw0[n + "_s_ln"],
                                                    act=a, query_ln=True) for n, o, a in (("qkv", qkv, H.ACT_NONE), ("fc1", mid, H.ACT_GELU)))

@@ -56,7 +56,7 @@ def test_gemm_with_folded_layernorm_vs_float64(H, dev, M, N, K, act):
     s_ln = Wl.double().sum(1).float()
     b_ln = (b.double() + W.double() @ beta.double()).float()
     xg = x.to(dev)
-    st = torch.zeros(M + 512, 2, device=dev)
+    st = torch.zeros(M, 2, device=dev)
     H.check(H.lib().cvcl_row_stats(H.BF16, H.ptr(xg), K, H.ptr(st), M, K, 1e-6, H.stream_ptr()), "cvcl_row_stats")
     assert H.gemm(xg, Wl.to(dev), bias=b_ln.to(dev), act=act, ln_stats=st, ln_colsum=s_ln.to(dev), query_ln=True)
     got = H.gemm(xg, Wl.to(dev), bias=b_ln.to(dev), act=act, ln_stats=st, ln_colsum=s_ln.to(dev)).double().cpu()
@@ -103,7 +103,7 @@ def test_gemm_refuses_ln_arguments_it_cannot_honour(H, dev):
     """small shapes run on the 128 x 128 kernel, which has no folded epilogue: cvcl_gemm must refuse, not ignore."""
     x = torch.randn(256, 768).bfloat16().to(dev)
     w = torch.randn(768, 768).bfloat16().to(dev)
-    st = torch.zeros(256 + 512, 2, device=dev)
+    st = torch.zeros(256, 2, device=dev)
     cs, b = torch.zeros(768, device=dev), torch.zeros(768, device=dev)
     assert not H.gemm(x, w, bias=b, ln_stats=st, ln_colsum=cs, query_ln=True)
     with pytest.raises(H.CvclError):

@@ -193,3 +193,21 @@ def test_bench_spawns_its_own_ranks(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 512 and line["config"]["trunk_streams"] == 1
     assert line["value"] > 0 and line["config"]["negatives"].startswith("global") and "logits_rel_vs_fp32" in line
+    # the self-verification block of a multi-rank line (what the first 8-GPU RCCL run will be read by)
+    d = line["distributed"]
+    assert d["backend"] == "gloo" and d["ranks_seen"] == 2 and [x["rank"] for x in d["ranks"]] == [0, 1]
+    assert d["shared_devices"] is True and d["ranks"][0]["device"] == d["ranks"][1]["device"]        # (this box: two ranks, one GPU, gloo)
+    assert d["allgather_us"] > 0 and d["allreduce_us"] > 0
+    assert 0 < d["ms_per_step_per_rank"]["min"] <= d["ms_per_step_per_rank"]["max"] <= line["ms_per_step"] * 1.0001
+
+
+def test_bench_refuses_two_rccl_ranks_on_one_device():
+    """A rank whose LOCAL_RANK has no device of its own must not silently wrap onto device 0 under RCCL (the mis-launch would
+    still print a throughput line): bench.py exits non-zero before it initialises the process group."""
+    env = dict(os.environ)
+    env.update(RANK="1", WORLD_SIZE="2", LOCAL_RANK=str(torch.cuda.device_count()), MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    env.pop("CVCL_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one rank per GPU" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
