@@ -119,10 +119,9 @@ def synthetic_batch_on_device(batch, seed, device, vocab=2350):
 
 
 def structured_batch_on_device(batch, seed, device, vocab=2350):
-    """A second, NON-CHAOTIC parity input (still synthetic): every frame is a smooth random field -- 3 x 7 x 7 uniform noise
-    upsampled bicubically to 224 x 224 -- with its own contrast and brightness, clamped to [0, 1], then ImageNet-normalised.
-    Unlike iid pixel noise (every sample nearly identical after the stem: BatchNorm amplifies any rounding ~100x) the samples
-    differ at every scale, so the batch statistics are well conditioned and a bf16 forward deviates from fp32 by ~1e-2."""
+    """A second synthetic input: every frame is a smooth random field -- 3 x 7 x 7 uniform noise upsampled bicubically to
+    224 x 224 -- with its own contrast and brightness, clamped to [0, 1], then ImageNet-normalised: the samples differ at every
+    scale (iid pixel noise makes them nearly identical after the stem).  Used by structured_parity."""
     g = torch.Generator(device=device).manual_seed(seed)
     coarse = torch.rand(batch, 3, 7, 7, generator=g, device=device)
     img = torch.nn.functional.interpolate(coarse, size=(224, 224), mode="bicubic", align_corners=False)
@@ -138,16 +137,25 @@ def structured_batch_on_device(batch, seed, device, vocab=2350):
     return img, tok.contiguous(), ln
 
 
-def structured_parity(lit, ve, batch_size, device, rank=0, yardstick=True):
-    """bf16 vs fp32 (and torch autocast vs torch fp32) on structured frames, the storage centres calibrated on ANOTHER structured
-    batch; BatchNorm buffers restored and the centres dropped afterwards (the timed steps recalibrate on their own data)."""
+def structured_parity(lit, ve, batch_size, device, rank=0, yardstick=True, gamma3=0.25):
+    """A WELL-CONDITIONED parity point for the ResNeXt configuration: bf16 vs fp32 (and torch autocast vs torch fp32) with the
+    residual-branch gains set to ``gamma3`` (every Bottleneck's bn3.weight: random init leaves them at 1, where each of the 16 blocks
+    doubles the signal's variance and the 50-layer train-mode-BatchNorm network amplifies ANY rounding ~100x whatever the input --
+    measured: 0.18 on noise frames, 0.16 on smooth frames; trained / zero-init-residual networks sit near 0.1-0.3) on structured
+    frames.  There torch's own autocast deviates ~2e-2 and a systematic error of a few per cent in any layer would show.
+    Storage centres calibrated on ANOTHER structured batch; weights, BatchNorm buffers and centres restored afterwards."""
     keep = {k: v.clone() for k, v in lit.state_dict().items() if "running_" in k or "num_batches_tracked" in k}
+    bn3 = [m.bn3 for m in ve.model.modules() if hasattr(m, "bn3")]
+    g_keep = [b.weight.detach().clone() for b in bn3]
     evalb = structured_batch_on_device(batch_size, seed=4242 + rank, device=device)
     calib = structured_batch_on_device(batch_size, seed=1717 + rank, device=device)
-    if hasattr(ve.model, "recalibrate_centres"):
-        ve.model.recalibrate_centres()
     gn, lit.model.global_negatives = lit.model.global_negatives, False
     try:
+        with torch.no_grad():
+            for b in bn3:
+                b.weight.fill_(gamma3)
+        if hasattr(ve.model, "recalibrate_centres"):
+            ve.model.recalibrate_centres()
         with torch.no_grad():
             lit.model(calib[0], calib[1], calib[2])
         lit.load_state_dict(keep, strict=False)
@@ -156,11 +164,15 @@ def structured_parity(lit, ve, batch_size, device, rank=0, yardstick=True):
             ty, _ = torch_yardstick(lit, evalb)
             out["torch_autocast_bf16_vs_torch_fp32"] = {k: float(f"{v:.4g}") for k, v in ty.items()}
     finally:
+        with torch.no_grad():
+            for b, g in zip(bn3, g_keep):
+                b.weight.copy_(g)
         lit.model.global_negatives = gn
         lit.load_state_dict(keep, strict=False)
         if hasattr(ve.model, "recalibrate_centres"):
             ve.model.recalibrate_centres()
-    out["input"] = "smooth random fields (3 x 7 x 7 noise, bicubic to 224 x 224) with per-frame contrast / brightness"
+    out["setting"] = (f"every Bottleneck's bn3.weight = {gamma3} (residual-branch gain of a trained / zero-init-residual network; random init "
+                      "leaves 1.0), frames = smooth random fields (3 x 7 x 7 noise, bicubic to 224 x 224) with per-frame contrast / brightness")
     return out
 
 
@@ -518,7 +530,7 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
             par["hip_fp32_logits_rel_vs_torch_fp32"] = float((a_ - b_).abs().max() / b_.abs().max())
             par["torch_autocast_bf16_vs_torch_fp32"] = {k: float(f"{v:.4g}") for k, v in ty.items()}
             if precision == "bf16":
-                par["structured_frames"] = structured_parity(lit, ve, batch_size, device, rank)
+                par["conditioned"] = structured_parity(lit, ve, batch_size, device, rank)
         torch.cuda.synchronize()
         set_trunk_streams(trunk_streams)
         res["parity"] = par

@@ -182,6 +182,13 @@ int cvcl_gemm_pro(const cvcl_gemm_args* args, void* stream);
 int cvcl_gemm_pro_supported(const cvcl_gemm_args* args);
 int cvcl_gemm_pro_stats_rows(int M, int N);
 int cvcl_gemm8w_supported(int M, int N, int K, int lda, int ldw, int ldc);
+/* Co-scheduling hint (round 4): the 8-wave GEMM kernels (bf16 and e4m3) run one 160-KiB-LDS workgroup per CU, so a launch that
+ * fills the chip keeps every other stream's kernels out until its last round.  A host that keeps TWO passes of a frozen trunk in
+ * flight on two streams sets cus = half the chip: each launch then takes twice as long on half the CUs and the two passes really run
+ * side by side (ViT-B/16, B = 256, two trunk streams: 12.1 -> 11.9 ms per step; the ResNeXt trunk is faster with full grids).
+ * Process-global, read at launch time (one host thread per process, as everything here); 0 = all CUs; returns the previous value.
+ * Results do not depend on it (tile order only), except that BN-statistics row counts do: cvcl_gemm8w_stats_rows follows it. */
+int cvcl_set_gemm_cu_share(int cus);
 /* 1 when cvcl_gemm(CVCL_BF16, args) runs the 8-wave kernel for these arguments (shape policy included), i.e. ln_stats / row_part
  * would be honoured; 0 otherwise (cvcl_gemm then refuses arguments that carry them: CVCL_EUNSUPPORTED).  No GPU needed. */
 int cvcl_gemm_ln_supported(const cvcl_gemm_args* args);

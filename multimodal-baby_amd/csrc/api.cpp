@@ -32,6 +32,15 @@ int cvcl_lab_int(const char* name, int dflt) {
 #endif
 }
 
+// co-scheduling hint for the one-workgroup-per-CU GEMM kernels (cvcl_hip.h): how many CUs a launch may fill; 0 = all
+static int g_gemm_cu_share = 0;
+int cvcl_gemm_cu_share() { return g_gemm_cu_share; }
+extern "C" int cvcl_set_gemm_cu_share(int cus) {
+    const int prev = g_gemm_cu_share;
+    g_gemm_cu_share = cus > 0 ? (cus & ~7) : 0;
+    return prev;
+}
+
 extern "C" int cvcl_abi_version(void) { return CVCL_ABI_VERSION; }
 extern "C" const char* cvcl_last_error(void) { return g_err; }
 

@@ -22,6 +22,7 @@ void cvcl_set_error(const char* fmt, ...);
 // table "Run-time switches" in include/cvcl_hip.h: cvcl_env_on(name) is false when $name starts with '0'.  Everything else that
 // earlier rounds could toggle is a LAB switch: cvcl_lab_int(name, default) reads $name only in a library built with -DCVCL_LAB
 // (tools/README.md) and is the constant `default` in the product build.
+int cvcl_gemm_cu_share();                                   // the value set by cvcl_set_gemm_cu_share (0 = all CUs)
 bool cvcl_env_on(const char* name);
 int cvcl_lab_int(const char* name, int dflt);
 

@@ -14,8 +14,11 @@ int g8_num_cus() {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
             n = 256;
+        const int cap = cvcl_lab_int("CVCL_G8_CUS", 0);      // (lab: run the 8-wave kernels on part of the chip)
+        if (cap > 0 && cap < n) n = cap;
     }
-    return n;
+    const int share = cvcl_gemm_cu_share();                  // cvcl_set_gemm_cu_share: the host's co-scheduling hint
+    return share > 0 && share < n ? share : n;
 }
 
 // grid rows (workgroups per column tile): a multiple of 8 so that the column tiles of one m-tile share an XCD, at most one

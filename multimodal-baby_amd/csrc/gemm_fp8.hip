@@ -476,7 +476,8 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
         g.C8 = (unsigned char*)c8; g.c_bs = (unsigned char*)c_block_scales;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.ldc8 = ldc8; g.act = act;
         g.ncol = N / 256;
-        const int cus = f8_num_cus();
+        const int share = cvcl_gemm_cu_share();
+        const int cus = share > 0 && share < f8_num_cus() ? share : f8_num_cus();
         int bm = 256;
         long best = -1;
         for (int hgt : {256, 192}) {                         // rounds x tile height decides (as the bf16 kernel's 256 | 224);
@@ -515,7 +516,8 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
     d.num_m_tiles = cvcl_div_up(M, F8_BM);
     const int ntn = N / F8_BN;
     const long total_tiles = (long)d.num_m_tiles * ntn;
-    int g = 2 * f8_num_cus();                              // persistent: two workgroups per CU
+    const int share2 = cvcl_gemm_cu_share();
+    int g = 2 * (share2 > 0 && share2 < f8_num_cus() ? share2 : f8_num_cus());      // persistent: two workgroups per CU (of the caller's share)
     d.xcd_split = d.num_m_tiles >= 16 ? 1 : 0;
     if (d.xcd_split) {
         const long per_xcd = (long)cvcl_div_up(d.num_m_tiles, 8) * ntn;      // the longest per-XCD list

@@ -380,7 +380,12 @@ __device__ inline bf16x4 att_tr_read(const char* p) {
 //  v2: per-head workgroup, 16-query tiles, all of S in registers, P through LDS, 1 workgroup/CU: 190 us.)
 // MX = true: the output is written as e4m3 with one e8m0 scale per (row, 32 d) instead of bf16 (cvcl_gemm_fp8_mx's input format:
 // bytes [B*T][D], scales tiled [D/128][B*T][4]) -- a lane and its partner lane ^ 32 hold the 32 d of one block of one query.
-template <bool MX>
+// NTC > 0 (round 4): the number of 32-key tiles is the compile-time NTC (7: ViT patch 16 at 224 x 224, 197 tokens; 9: patch 14, 257
+// tokens) and the softmax is TWO-PASS: all NTC score tiles of a query tile stay in registers (16 NTC accumulators), the row maximum
+// is taken once, then every tile is exponentiated and multiplied with V -- no running maximum, no rescale of O: ~50 VALU
+// instructions per key tile instead of ~100 in a loop that is VALU-issue-bound (profiles/r04_pmc_c4_summary.txt: 17.8 VALU
+// instructions per MFMA, matrix pipe 19 % busy).  NTC = 0: the online-softmax loop for any other token count.
+template <bool MX, int NTC>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                 unsigned char* __restrict__ out8, unsigned char* __restrict__ out_bs,
                                                                 float* __restrict__ lse, int B, int Tn, int heads, float scale, int NT) {
@@ -439,7 +444,62 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
             for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;                       // l_run: this lane's share of the row sum
 
-        for (int t = 0; t < NT; ++t) {
+        if constexpr (NTC > 0) {
+            // ---- two-pass form: S^T for all NTC key tiles, one row maximum, then exp + O^T += V^T P^T per tile ----
+            f32x16 sc[NTC];
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sc[t][e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (t * 32 + l31) * ATT_KP + ks * 32 + h * 16);
+                    sc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[t], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);                  // (tile by tile: hoisting every tile's reads spills)
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                          // keys >= Tn exist in the last tile only
+                const int key = (NTC - 1) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+                sc[NTC - 1][r] = key < Tn ? sc[NTC - 1][r] : -INFINITY;
+            }
+            float mx = sc[0][0];
+#pragma unroll
+            for (int t = 0; t < NTC; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sc[t][r]), sc[t][r + 1]);        // v_max3_f32
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            m_run = mx * scale2;                                    // finite: key 0 is always valid
+            const f32x2 sc2 = {scale2, scale2}, nm2 = {-m_run, -m_run};
+            f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < NTC; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 a = __builtin_elementwise_fma(f32x2{sc[t][r], sc[t][r + 1]}, sc2, nm2);
+                    sc[t][r] = __builtin_amdgcn_exp2f(a[0]);
+                    sc[t][r + 1] = __builtin_amdgcn_exp2f(a[1]);
+                    ps2 += f32x2{sc[t][r], sc[t][r + 1]};
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[e] = (bf16_t)sc[t][8 * u + e];
+                    const char* vb = sV + (t * 32 + 16 * u) * ATT_VP + v_lane_off;
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) {
+                        const bf16x4 v0 = att_tr_read(vb + dt * 64);
+                        const bf16x4 v1 = att_tr_read(vb + 8 * ATT_VP + dt * 64);
+                        const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dt], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            l_run = ps2[0] + ps2[1];
+        }
+        for (int t = 0; t < (NTC > 0 ? 0 : NT); ++t) {
             f32x16 acc;
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -720,22 +780,30 @@ extern "C" int cvcl_row_stats_finalize(const float* row_part, int strips, float*
 }
 
 namespace {
-template <bool MX>
-int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, float* lse, int B, int T, int heads, float scale,
-                          hipStream_t s) {
+template <bool MX, int NTC>
+int launch_attention_mfma_n(const void* qkv, void* out, void* out8, void* out_bs, float* lse, int B, int T, int heads, float scale,
+                            hipStream_t s) {
     const int nt = (T + 31) / 32;
     const size_t lds = (size_t)nt * 32 * (ATT_KP + ATT_VP);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attention_mfma_kernel<MX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)attention_mfma_kernel<MX, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             cvcl_set_error("cvcl_attention: cannot raise the dynamic LDS limit");
             return CVCL_ELAUNCH;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_mfma_kernel<MX>, dim3(B * heads), dim3(ATT_THREADS), lds, s, (const bf16_t*)qkv, (bf16_t*)out, (unsigned char*)out8,
-                       (unsigned char*)out_bs, lse, B, T, heads, scale, nt);
+    hipLaunchKernelGGL((attention_mfma_kernel<MX, NTC>), dim3(B * heads), dim3(ATT_THREADS), lds, s, (const bf16_t*)qkv, (bf16_t*)out,
+                       (unsigned char*)out8, (unsigned char*)out_bs, lse, B, T, heads, scale, nt);
     return CVCL_OK;
+}
+template <bool MX>
+int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, float* lse, int B, int T, int heads, float scale,
+                          hipStream_t s) {
+    const int nt = (T + 31) / 32;                            // the two-pass form for the token counts of ViT patch 16 / 14 at 224 x 224
+    if (nt == 7) return launch_attention_mfma_n<MX, 7>(qkv, out, out8, out_bs, lse, B, T, heads, scale, s);
+    if (nt == 9) return launch_attention_mfma_n<MX, 9>(qkv, out, out8, out_bs, lse, B, T, heads, scale, s);
+    return launch_attention_mfma_n<MX, 0>(qkv, out, out8, out_bs, lse, B, T, heads, scale, s);
 }
 }  // namespace
 

@@ -130,6 +130,7 @@ SIGNATURES = {
     "cvcl_gemm8w": (_I, [_I, _P, _P]),
     "cvcl_gemm8w_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cvcl_gemm_ln_supported": (_I, [C.POINTER(GemmArgs)]),
+    "cvcl_set_gemm_cu_share": (_I, [_I]),
     "cvcl_row_stats": (_I, [_I, _P, C.c_long, _P, C.c_long, _I, _F, _P]),
     "cvcl_row_stats_finalize": (_I, [_P, _I, _P, C.c_long, _I, _F, _P]),
     "cvcl_gemm8w_tile_rows": (_I, [_I, _I]),

@@ -85,21 +85,23 @@ def test_c2_bf16_logits_vs_fp32_at_benchmark_batch(dev):
     assert e < LOGITS_REL_FP32_VS_TORCH
 
 
-def test_c2_bf16_logits_vs_fp32_on_structured_frames(dev):
-    """The same comparison on a NON-CHAOTIC input (bench.structured_batch_on_device: smooth random fields with per-frame contrast):
-    the batch statistics are well conditioned, torch's own autocast deviates by ~1e-2 instead of 0.15, and a systematic error of
-    a few per cent in any layer would show.  Gate: HIP bf16 <= 1.1 x torch autocast on the same weights and frames."""
+def test_c2_bf16_logits_vs_fp32_well_conditioned(dev):
+    """The same comparison at a WELL-CONDITIONED point (bench.structured_parity: residual-branch gains bn3.weight = 0.25 as in a
+    trained / zero-init-residual network instead of random init's 1.0, smooth frames with per-frame contrast): the 50-layer network no
+    longer amplifies every rounding ~100x (that is a property of the random-init weights, not of the input: measured 0.16-0.18 on
+    smooth and noise frames alike), torch's own autocast deviates ~2e-2, and a systematic error of a few per cent in any layer would
+    show.  Gate: HIP bf16 <= 1.1 x torch autocast on the same weights and frames (measured 0.015 vs 0.019)."""
     import bench
     lit, ve, _opt = bench.build_model("c2", dev, "bf16")
-    before = {k: v.clone() for k, v in lit.state_dict().items() if "running_" in k}
+    before = {k: v.clone() for k, v in lit.state_dict().items()}
     r = bench.structured_parity(lit, ve, bench.PER_GPU_BATCH, dev)
     ty = r["torch_autocast_bf16_vs_torch_fp32"]
-    print("C2 B=256 structured frames: HIP bf16 vs fp32", {k: v for k, v in r.items() if isinstance(v, float)}, "| torch autocast:", ty)
+    print("C2 B=256 well-conditioned: HIP bf16 vs fp32", {k: v for k, v in r.items() if isinstance(v, float)}, "| torch autocast:", ty)
     assert r["logits_rel_vs_fp32"] <= LOGITS_REL_BF16_VS_TORCH_AUTOCAST * ty["logits_rel"] + 1e-3
-    assert r["logits_cosine_vs_fp32"] >= ty["logits_cosine"] - 1e-3
-    assert ty["logits_rel"] < 0.08                            # (the input is indeed the well-conditioned one)
+    assert r["logits_cosine_vs_fp32"] >= ty["logits_cosine"] - 1e-4
+    assert ty["logits_rel"] < 0.05 and r["logits_rel_vs_fp32"] < 0.03          # (the point is indeed the well-conditioned one)
     after = lit.state_dict()
-    assert all(torch.equal(v, after[k]) for k, v in before.items())
+    assert all(torch.equal(v, after[k]) for k, v in before.items())          # weights and BatchNorm buffers restored
 
 
 @pytest.mark.parametrize("cfg,rel,cos", [("c4", LOGITS_REL_C4, LOGITS_COS_C4), ("c5", LOGITS_REL_C5, LOGITS_COS_C5),
