@@ -879,7 +879,8 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
     if ((long)cvcl_div_up(a->M, 256) * (a->N / 256) < 96) return -1;
     // bandwidth-bound shapes stay with the 128 x 128 kernel (two workgroups per CU keep more bytes in flight): layer-2 block-0
     // conv1, M 802816 x N 256 x K 256, measured 176 us there vs 191-197 us here; N K / (N + K) = flop per byte of A + C traffic
-    if ((long)a->N * a->K < 170L * (a->N + a->K)) return -1;
+    static const long min_intensity = cvcl_lab_int("CVCL_G8_MIN_INTENSITY", 170);
+    if ((long)a->N * a->K < min_intensity * (a->N + a->K)) return -1;
     const bool plain = !a->bias && !a->R && a->act == CVCL_ACT_NONE;
     if (a->stats) {
         if (!plain || a->stats_rows < cvcl_gemm8w_stats_rows(a->M, a->N)) return -1;

@@ -380,8 +380,8 @@ __device__ inline bf16x4 att_tr_read(const char* p) {
 //  v2: per-head workgroup, 16-query tiles, all of S in registers, P through LDS, 1 workgroup/CU: 190 us.)
 // MX = true: the output is written as e4m3 with one e8m0 scale per (row, 32 d) instead of bf16 (cvcl_gemm_fp8_mx's input format:
 // bytes [B*T][D], scales tiled [D/128][B*T][4]) -- a lane and its partner lane ^ 32 hold the 32 d of one block of one query.
-// NTC > 0 (round 4): the number of 32-key tiles is the compile-time NTC (7: ViT patch 16 at 224 x 224, 197 tokens; 9: patch 14, 257
-// tokens) and the softmax is TWO-PASS: all NTC score tiles of a query tile stay in registers (16 NTC accumulators), the row maximum
+// NTC > 0 (round 4): the number of 32-key tiles is the compile-time NTC (9: ViT patch 14 at 224 x 224, 257 tokens) and the softmax
+// is TWO-PASS: all NTC score tiles of a query tile stay in registers (16 NTC accumulators), the row maximum
 // is taken once, then every tile is exponentiated and multiplied with V -- no running maximum, no rescale of O: ~50 VALU
 // instructions per key tile instead of ~100 in a loop that is VALU-issue-bound (profiles/r04_pmc_c4_summary.txt: 17.8 VALU
 // instructions per MFMA, matrix pipe 19 % busy).  NTC = 0: the online-softmax loop for any other token count.
@@ -801,7 +801,10 @@ template <bool MX>
 int launch_attention_mfma(const void* qkv, void* out, void* out8, void* out_bs, float* lse, int B, int T, int heads, float scale,
                           hipStream_t s) {
     const int nt = (T + 31) / 32;                            // the two-pass form for the token counts of ViT patch 16 / 14 at 224 x 224
-    if (nt == 7) return launch_attention_mfma_n<MX, 7>(qkv, out, out8, out_bs, lse, B, T, heads, scale, s);
+    static const bool two_pass = cvcl_lab_int("CVCL_ATT_TWOPASS", 1) != 0;
+    if (!two_pass) return launch_attention_mfma_n<MX, 0>(qkv, out, out8, out_bs, lse, B, T, heads, scale, s);
+    // Measured (same box, B = 256, 12 layers): 257 tokens (one workgroup per CU: 97 KB of K / V, nobody to overlap with) 2.47 -> 2.13 ms;
+    // 197 tokens (two workgroups per CU overlap each other's VALU and MFMA phases) 1.23 -> 1.44 ms: the online loop stays there
     if (nt == 9) return launch_attention_mfma_n<MX, 9>(qkv, out, out8, out_bs, lse, B, T, heads, scale, s);
     return launch_attention_mfma_n<MX, 0>(qkv, out, out8, out_bs, lse, B, T, heads, scale, s);
 }
