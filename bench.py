@@ -329,6 +329,41 @@ def torch_yardstick(lit, batch):
              "loss_abs": abs(loss(got) - loss(ref))}, ref)
 
 
+def fp8_yardstick(ve, images, patch=16):
+    """CHECKER for C5 (oracle/cvcl_oracle.py::vit_forward on torch's own GPU ops): what the e4m3 STORAGE POINTS themselves cost --
+    the oracle's ViT forward with torch.float8_e4m3fn roundings at the operands of the four linears of every block (per-row scales
+    for the LayerNorm outputs and the weights, e8m0 block scales per 32 elements for the attention and GELU outputs) and bf16 at
+    the other storage points, against the same forward in fp32 -- next to the HIP e4m3 path against the HIP fp32 mode, both on the
+    ViT's output features [B, 768] of the benchmark's weights and frames.  -> dict of rel-L2 / max-rel / cosine for both."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cvcl_oracle as O
+    model = ve.model
+    p = {k: v.detach().float() for k, v in model.state_dict().items() if not k.startswith("head.")}
+    heads = model.blocks[0].attn.num_heads
+
+    def dev(a, b):
+        a, b = a.double(), b.double()
+        return {"rel_l2": float((a - b).norm() / b.norm()), "max_rel": float((a - b).abs().max() / b.abs().max()),
+                "cosine_min": float(torch.nn.functional.cosine_similarity(a, b, dim=1).min())}
+    out = {}
+    with torch.no_grad():
+        chunks = [images[i:i + 64] for i in range(0, images.shape[0], 64)]          # (the fp32 attention matrix of 64 frames: 0.36 GB)
+        ref = torch.cat([O.vit_forward(p, c, patch, heads) for c in chunks])
+        emu = torch.cat([O.vit_forward(p, c, patch, heads, quant=O.bf16_round, fp8=True) for c in chunks])
+        out["emulation_vs_torch_fp32"] = dev(emu, ref)
+        keep_dt, keep_f8 = model.compute_dtype, getattr(model, "fp8_linears", False)
+        try:
+            model.compute_dtype, model.fp8_linears = torch.float32, False
+            h32 = model(images).float()
+            model.compute_dtype, model.fp8_linears = torch.bfloat16, True
+            h8 = model(images).float()
+        finally:
+            model.compute_dtype, model.fp8_linears = keep_dt, keep_f8
+        out["hip_fp8_vs_hip_fp32"] = dev(h8, h32)
+        out["hip_fp32_vs_torch_fp32"] = dev(h32, ref)
+    return {k: {kk: float(f"{vv:.4g}") for kk, vv in v.items()} for k, v in out.items()}
+
+
 def spawn_ranks(a, argv):
     """``python bench.py --gpus N`` outside torch.distributed.run: start N fresh ranks as a child process.  Nothing in this
     process has initialised the GPU at this point (torch.cuda.device_count() does not), and the child is a child -- no exec."""
@@ -531,6 +566,8 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
             par["torch_autocast_bf16_vs_torch_fp32"] = {k: float(f"{v:.4g}") for k, v in ty.items()}
             if precision == "bf16":
                 par["conditioned"] = structured_parity(lit, ve, batch_size, device, rank)
+        if cfg == "c5" and precision == "fp8":
+            par["fp8_features_yardstick"] = fp8_yardstick(ve, batch[0], patch_of(cfg))
         torch.cuda.synchronize()
         set_trunk_streams(trunk_streams)
         res["parity"] = par

@@ -528,13 +528,34 @@ def vit_interpolate_pos_encoding(pos_embed: Tensor, gh: int, gw: int) -> Tensor:
     return torch.cat([pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, gh * gw, D)], dim=1)
 
 
+def fp8_rows(y: Tensor) -> Tensor:
+    """e4m3 storage-point emulation with one scale per row (amax / 448; 1 for an all-zero row): the per-token activation scales and
+    per-output-channel weight scales of the product's fp8 linears (BASELINE configs[4]; this repo's storage points, not the reference's)."""
+    amax = y.abs().amax(dim=-1, keepdim=True)
+    s = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    return (y / s).clamp(-448, 448).to(torch.float8_e4m3fn).to(y.dtype) * s
+
+
+def fp8_mx(y: Tensor) -> Tensor:
+    """e4m3 with one power-of-two (e8m0) scale per 32 consecutive elements of the last dimension: 2^ceil(log2(amax / 448))."""
+    shp = y.shape
+    blk = y.reshape(-1, shp[-1] // 32, 32)
+    x = (blk.abs().amax(dim=2) / 448.0).float()
+    bits = x.view(torch.int32)
+    e = ((bits >> 23) & 0xff) + ((bits & 0x7fffff) != 0).int()
+    e = e.clamp(1, 254)
+    scale = torch.pow(2.0, (e - 127).double()).to(y.dtype)[:, :, None]
+    return ((blk / scale).clamp(-448, 448).to(torch.float8_e4m3fn).to(y.dtype) * scale).reshape(shp)
+
+
 def vit_forward(p: Dict[str, Tensor], x: Tensor, patch: int, num_heads: int, quant: Quant = None,
-                prefix: str = "", eps: float = 1e-6, taps: Optional[Dict[str, Tensor]] = None) -> Tensor:
+                prefix: str = "", eps: float = 1e-6, taps: Optional[Dict[str, Tensor]] = None, fp8: bool = False) -> Tensor:
     """``VisionTransformer.forward`` (vit:245-250): prepare_tokens (:232-243; pos-embed
     interpolation :210-230, the identity at the native resolution) -> depth x pre-LN
     ``Block`` (:133-149; attention :106-130 scale head_dim**-0.5, MLP :87-103 GELU-erf)
     -> LayerNorm -> cls token.  Returns [B, D] (the ``head`` is applied by the caller,
-    multimodal.py:91-92)."""
+    multimodal.py:91-92).  ``fp8``: the e4m3 storage points of the product's configs[4] path on top of ``quant`` -- the operands of
+    the four linears of every block: LayerNorm outputs per row, attention and GELU outputs per 32-element block, weights per row."""
     pp = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)} if prefix else p
     B, C, H, W = x.shape
     D = pp["cls_token"].shape[-1]
@@ -550,17 +571,20 @@ def vit_forward(p: Dict[str, Tensor], x: Tensor, patch: int, num_heads: int, qua
     depth = 1 + max(int(k.split(".")[1]) for k in pp if k.startswith("blocks."))
     for i in range(depth):
         bp = f"blocks.{i}."
-        y = _q(quant, layer_norm(h, pp[bp + "norm1.weight"], pp[bp + "norm1.bias"], eps))
-        qkv = _q(quant, y @ _q(quant, pp[bp + "attn.qkv.weight"]).t() + pp[bp + "attn.qkv.bias"])
+        qa = (lambda t: fp8_rows(t)) if fp8 else (lambda t: _q(quant, t))           # per-row e4m3 | the bf16 storage point
+        qm = (lambda t: fp8_mx(_q(quant, t))) if fp8 else (lambda t: _q(quant, t))  # MX e4m3 of the bf16-rounded tensor
+        qw = (lambda t: fp8_rows(t)) if fp8 else (lambda t: _q(quant, t))
+        y = qa(layer_norm(h, pp[bp + "norm1.weight"], pp[bp + "norm1.bias"], eps))
+        qkv = _q(quant, y @ qw(pp[bp + "attn.qkv.weight"]).t() + pp[bp + "attn.qkv.bias"])
         qkv = qkv.reshape(B, T, 3, num_heads, hd).permute(2, 0, 3, 1, 4)                # :119
         q, k, v = qkv[0], qkv[1], qkv[2]
         a = torch.softmax((q @ k.transpose(-2, -1)) * (hd ** -0.5), dim=-1)             # :123-124
-        o = _q(quant, (_q(quant, a) @ v).transpose(1, 2).reshape(B, T, D))              # :127
-        o = o @ _q(quant, pp[bp + "attn.proj.weight"]).t() + pp[bp + "attn.proj.bias"]
+        o = qm((_q(quant, a) @ v).transpose(1, 2).reshape(B, T, D))                     # :127
+        o = o @ qw(pp[bp + "attn.proj.weight"]).t() + pp[bp + "attn.proj.bias"]
         h = _q(quant, h + _q(quant, o))                                                  # :146
-        y = _q(quant, layer_norm(h, pp[bp + "norm2.weight"], pp[bp + "norm2.bias"], eps))
-        f = _q(quant, gelu_erf(y @ _q(quant, pp[bp + "mlp.fc1.weight"]).t() + pp[bp + "mlp.fc1.bias"]))
-        f = f @ _q(quant, pp[bp + "mlp.fc2.weight"]).t() + pp[bp + "mlp.fc2.bias"]
+        y = qa(layer_norm(h, pp[bp + "norm2.weight"], pp[bp + "norm2.bias"], eps))
+        f = qm(gelu_erf(y @ qw(pp[bp + "mlp.fc1.weight"]).t() + pp[bp + "mlp.fc1.bias"]))
+        f = f @ qw(pp[bp + "mlp.fc2.weight"]).t() + pp[bp + "mlp.fc2.bias"]
         h = _q(quant, h + _q(quant, f))                                                  # :147
         if taps is not None:
             taps[bp + "out"] = h

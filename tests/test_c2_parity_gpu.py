@@ -117,6 +117,22 @@ def test_vit_configs_logits_vs_fp32_at_benchmark_batch(dev, cfg, rel, cos):
     assert r["logits_rel_vs_fp32"] < rel and r["logits_cosine_vs_fp32"] > cos and r["loss_abs_vs_fp32"] < 1e-2
 
 
+def test_c5_fp8_features_against_the_emulation_yardstick_at_benchmark_batch(dev):
+    """C5 at B = 256 had no yardstick: 0.14 against fp32 with a gate set from the measurement.  The yardstick is what
+    the e4m3 STORAGE POINTS themselves cost: the oracle's ViT forward on torch's GPU ops with torch.float8_e4m3fn roundings at the
+    same operand points (bench.fp8_yardstick), against the same forward in fp32.  The HIP e4m3 path must deviate from the HIP fp32
+    mode no more than that emulation deviates from torch fp32 (x 1.15: the two are different roundings of a 12-block network), on
+    the ViT's output features of the benchmark's weights and frames; and the HIP fp32 mode must match torch fp32."""
+    import bench
+    lit, ve, _opt = bench.build_model("c5", dev)
+    batch = bench.synthetic_batch_on_device(bench.PER_GPU_BATCH, seed=0, device=dev)
+    r = bench.fp8_yardstick(ve, batch[0])
+    print("C5 B=256 ViT features:", r)
+    e, h = r["emulation_vs_torch_fp32"], r["hip_fp8_vs_hip_fp32"]
+    assert h["rel_l2"] <= 1.15 * e["rel_l2"] + 2e-3 and h["cosine_min"] >= e["cosine_min"] - 5e-3
+    assert r["hip_fp32_vs_torch_fp32"]["rel_l2"] < 1e-4
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
