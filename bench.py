@@ -329,8 +329,9 @@ def torch_yardstick(lit, batch):
              "loss_abs": abs(loss(got) - loss(ref))}, ref)
 
 
-def fp8_yardstick(ve, images, patch=16):
-    """CHECKER for C5 (oracle/cvcl_oracle.py::vit_forward on torch's own GPU ops): what the e4m3 STORAGE POINTS themselves cost --
+def fp8_yardstick(ve, images, patch=16, fp8=True):
+    """CHECKER for the ViT configurations (oracle/cvcl_oracle.py::vit_forward on torch's own GPU ops; fp8 = False: bf16 storage points
+    only, C4).  C5: what the e4m3 STORAGE POINTS themselves cost --
     the oracle's ViT forward with torch.float8_e4m3fn roundings at the operands of the four linears of every block (per-row scales
     for the LayerNorm outputs and the weights, e8m0 block scales per 32 elements for the attention and GELU outputs) and bf16 at
     the other storage points, against the same forward in fp32 -- next to the HIP e4m3 path against the HIP fp32 mode, both on the
@@ -349,17 +350,17 @@ def fp8_yardstick(ve, images, patch=16):
     with torch.no_grad():
         chunks = [images[i:i + 64] for i in range(0, images.shape[0], 64)]          # (the fp32 attention matrix of 64 frames: 0.36 GB)
         ref = torch.cat([O.vit_forward(p, c, patch, heads) for c in chunks])
-        emu = torch.cat([O.vit_forward(p, c, patch, heads, quant=O.bf16_round, fp8=True) for c in chunks])
+        emu = torch.cat([O.vit_forward(p, c, patch, heads, quant=O.bf16_round, fp8=fp8) for c in chunks])
         out["emulation_vs_torch_fp32"] = dev(emu, ref)
         keep_dt, keep_f8 = model.compute_dtype, getattr(model, "fp8_linears", False)
         try:
             model.compute_dtype, model.fp8_linears = torch.float32, False
             h32 = model(images).float()
-            model.compute_dtype, model.fp8_linears = torch.bfloat16, True
+            model.compute_dtype, model.fp8_linears = torch.bfloat16, bool(fp8)
             h8 = model(images).float()
         finally:
             model.compute_dtype, model.fp8_linears = keep_dt, keep_f8
-        out["hip_fp8_vs_hip_fp32"] = dev(h8, h32)
+        out["hip_fp8_vs_hip_fp32" if fp8 else "hip_bf16_vs_hip_fp32"] = dev(h8, h32)
         out["hip_fp32_vs_torch_fp32"] = dev(h32, ref)
     return {k: {kk: float(f"{vv:.4g}") for kk, vv in v.items()} for k, v in out.items()}
 
@@ -568,6 +569,8 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
                 par["conditioned"] = structured_parity(lit, ve, batch_size, device, rank)
         if cfg == "c5" and precision == "fp8":
             par["fp8_features_yardstick"] = fp8_yardstick(ve, batch[0], patch_of(cfg))
+        elif cfg in ("c4", "c4p14") and precision == "bf16":                # the same with bf16 storage points only
+            par["bf16_features_yardstick"] = fp8_yardstick(ve, batch[0], patch_of(cfg), fp8=False)
         torch.cuda.synchronize()
         set_trunk_streams(trunk_streams)
         res["parity"] = par

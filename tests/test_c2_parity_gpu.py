@@ -133,6 +133,21 @@ def test_c5_fp8_features_against_the_emulation_yardstick_at_benchmark_batch(dev)
     assert r["hip_fp32_vs_torch_fp32"]["rel_l2"] < 1e-4
 
 
+@pytest.mark.parametrize("cfg", ["c4", "c4p14"])
+def test_c4_bf16_features_against_the_emulation_yardstick_at_benchmark_batch(dev, cfg):
+    """The same for the bf16 ViT (patch 16 and the reference's patch 14) at B = 256, LayerNorm folded into qkv / fc1: the HIP bf16 path
+    must be as close to fp32 as the oracle's bf16 storage-point emulation is (it rounds the normalised rows once more than the
+    folded path does)."""
+    import bench
+    lit, ve, _opt = bench.build_model(cfg, dev)
+    batch = bench.synthetic_batch_on_device(bench.PER_GPU_BATCH, seed=0, device=dev)
+    r = bench.fp8_yardstick(ve, batch[0], bench.patch_of(cfg), fp8=False)
+    print(f"{cfg} B=256 ViT features:", r)
+    e, h = r["emulation_vs_torch_fp32"], r["hip_bf16_vs_hip_fp32"]
+    assert h["rel_l2"] <= 1.15 * e["rel_l2"] + 1e-3 and h["cosine_min"] >= e["cosine_min"] - 1e-3
+    assert r["hip_fp32_vs_torch_fp32"]["rel_l2"] < 1e-4
+
+
 def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
