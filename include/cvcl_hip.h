@@ -156,7 +156,7 @@ typedef struct {
      *   consumer (ln_stats != NULL; bias / activation epilogue, no residual): A = the RAW rows x, W = W diag(gamma) (rounded to
      *     bf16 by the caller), ln_colsum[n] = sum_k W'[n][k] of that rounded matrix, bias[n] = b[n] + sum_k W[n][k] beta[k]
      *     (required), ln_stats[m] = (rstd_m, -mean_m rstd_m):  C = round(act(rstd acc - mean rstd ln_colsum[n] + bias[n])).
-     *     (M >= 2.)
+     *     ln_stats is fetched in 16-byte granules: it must be readable for an EVEN number of rows (M + (M & 1)).
      *   producer (row_part != NULL; bias + residual epilogue): additionally row_part[m][N / 64][2] f32 = (sum, sum of squares) of
      *     the STORED row over each 64-column strip; cvcl_row_stats_finalize reduces them to the next consumer's ln_stats.
      * cvcl_gemm_ln_supported tells whether cvcl_gemm routes these arguments to the kernel that honours them. */
@@ -505,7 +505,10 @@ int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stride, const f
 /* MX variants: a_block_scales = one e8m0 byte (2^(b-127)) per 32-element block of A instead of the per-row fp32 scale (the
  * scaled MFMA applies it in hardware), tiled [K/128][M][4] (block k/32 of row m at ((k/128)*M + m)*4 + (k/32)%4, so 32 rows'
  * words are contiguous); c8 / c_block_scales = e4m3 output [M][ldc8] + e8m0 scales in the same tiling [N/128][M][4]
- * (2^ceil(log2(amax/448)) per block) instead of bf16 C, ready to be the next GEMM's MX input -- no separate quantisation pass. */
+ * (2^ceil(log2(amax/448)) per block) instead of bf16 C, ready to be the next GEMM's MX input -- no separate quantisation pass.
+ * Large shapes (>= 96 tiles of 256 x 256 with a well-filled last round) run on the 8-wave kernel (csrc/gemm8f_kernel.h), which
+ * fetches a tile's a_scale / a_block_scales in 16-byte granules: both must be readable up to the next multiple of 16 bytes
+ * (a_scale: M rounded up to 4 floats; a_block_scales: 12 bytes past its end when M % 4 != 0).  Same results either way.            */
 int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void* a_block_scales, int lda, const void* W8,
                      const float* w_scale, int ldw, void* C, int ldc, void* c8, void* c_block_scales, int ldc8,
                      const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream);

@@ -118,9 +118,10 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
         // with the first stage of a tile, its epilogue operands (waves 0-2: sw / bias / sa of the tile, 1 KiB each, parity slot)
         if (l_ks == 0 && wave < (MXA ? 2 : 3)) {
             char* dst = smem + OPS_OFF + (l_t & 1) * 3072 + wave * 1024;
-            // (rows past M, ragged last tile: clamped to the last four floats of sa -- those rows are masked at the store)
+            // (ragged last tile: whole 4-row granules past M are clamped to the granule that holds row M - 1 -- their rows are
+            // masked at the store; that granule itself may reach up to 3 floats past sa[M - 1]: cvcl_hip.h asks for the padding)
             const float* src = wave == 0 ? p.sw + l_j * BN + lane * 4 : wave == 1 ? p.bias + l_j * BN + lane * 4
-                                                                                 : p.sa + min(l_i * BM + lane * 4, p.M - 4);
+                                                                                 : p.sa + min(l_i * BM + lane * 4, (p.M - 1) & ~3);
             if (wave == 1 && !p.bias) *reinterpret_cast<f32x4*>(dst + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};     // no bias: zeros
             else glds16(src, dst);
         }
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
         if constexpr (MXA) {
             if ((l_ks & 1) == 0) {
                 if (wave == 2 + (l_kt & 3))
-                    glds16(p.a_bs + min(((long)(l_ks >> 1) * p.M + (long)l_i * BM) * 4 + lane * 16, (long)(p.K >> 7) * p.M * 4 - 16),
+                    glds16(p.a_bs + ((long)(l_ks >> 1) * p.M + min(l_i * BM + lane * 4, (p.M - 1) & ~3)) * 4,     // (as sa: granules of 4 rows)
                            smem + MXS_OFF + (l_kt & 3) * 1024);
                 ++l_kt;
             }

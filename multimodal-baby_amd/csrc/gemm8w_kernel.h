@@ -185,9 +185,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             // more in these waves' queues only makes the next three counted waits conservative.
             if (l_ks == 0 && wave < 4) {
                 char* dst = smem + ACC_OFF + (l_t & 1) * 4096 + wave * 1024;
-                // (rows past M, ragged last tile: clamped to the last two rows of ln_stats -- masked at the store)
+                // (ragged last tile: whole 2-row granules past M are clamped to the granule that holds row M - 1 -- masked at the
+                // store; that granule may reach one row past ln_stats[M - 1]: cvcl_hip.h asks for an even number of rows)
                 const float* src = wave == 0 ? p.bias + l_j * BN + lane * 4 : wave == 1 ? p.ln_colsum + l_j * BN + lane * 4
-                                 : p.ln_stats + min(((long)l_i * BM + (wave - 2) * 128) * 2 + lane * 4, (long)p.M * 2 - 4);
+                                 : p.ln_stats + (long)min(l_i * BM + (wave - 2) * 128 + lane * 2, (p.M - 1) & ~1) * 2;
                 __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
                                                  (void __attribute__((address_space(3)))*)dst, 16, 0, 0);
             }

@@ -196,9 +196,10 @@ def _vit_forward_impl(model, x: torch.Tensor, slot) -> torch.Tensor:
             bw0 = w["blocks"][0]
             q_d = torch.empty(B * T, D, dtype=torch.uint8, device=dev)
             q_m = torch.empty(B * T, Dm, dtype=torch.uint8, device=dev)
-            sc = torch.empty(B * T, dtype=torch.float32, device=dev)
-            bs_m = torch.empty(Dm // 128, B * T, 4, dtype=torch.uint8, device=dev)
-            bs_d = torch.empty(D // 128, B * T, 4, dtype=torch.uint8, device=dev)
+            # (the 8-wave kernel fetches scales in 16-byte granules: a little slack behind each array, cvcl_hip.h)
+            sc = torch.empty(B * T + 4, dtype=torch.float32, device=dev)[:B * T]
+            bs_m = torch.empty(Dm // 128 * B * T * 4 + 16, dtype=torch.uint8, device=dev)[:Dm // 128 * B * T * 4].view(Dm // 128, B * T, 4)
+            bs_d = torch.empty(D // 128 * B * T * 4 + 16, dtype=torch.uint8, device=dev)[:D // 128 * B * T * 4].view(D // 128, B * T, 4)
             mx_att = D // bw0["heads"] == 64 and bw0["heads"] % 2 == 0 and T > 32
             for bw in w["blocks"]:
                 _quant(h, B * T, D, q_d, sc, (bw["n1w"], bw["n1b"], bw["eps"]))
@@ -223,7 +224,7 @@ def _vit_forward_impl(model, x: torch.Tensor, slot) -> torch.Tensor:
         fold = False
         if not fp8 and dt == torch.bfloat16 and w["blocks"] and ln_fold_mode(model) is not False:
             bw0 = w["blocks"][0]
-            st = torch.empty(M, 2, dtype=torch.float32, device=dev)
+            st = torch.empty(M + 1, 2, dtype=torch.float32, device=dev)[:M]       # (16-byte granules: an even number of rows readable)
             part = torch.empty(M, D // 64, 2, dtype=torch.float32, device=dev) if D % 64 == 0 else None
             ok_c = part is not None and all(H.gemm(h, bw0[n + "_w_ln"], out=o, bias=bw0[n + "_b_ln"], ln_stats=st, ln_colsum=bw0[n + "_s_ln"],
                                                    act=a, query_ln=True) for n, o, a in (("qkv", qkv, H.ACT_NONE), ("fc1", mid, H.ACT_GELU)))
