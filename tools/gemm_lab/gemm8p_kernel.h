@@ -25,7 +25,7 @@
 #pragma once
 #include <type_traits>
 
-#include "cvcl_common.h"
+#include "../../multimodal-baby_amd/csrc/cvcl_common.h"
 
 namespace g8p {
 
