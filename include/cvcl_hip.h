@@ -26,7 +26,7 @@
  *    CVCL_GEMM8W            on       cvcl_gemm never selects the 8-wave 256 x 256 kernel (everything on the 128 x 128 kernels)
  *    CVCL_GEMM_PRO          on       cvcl_gemm refuses the BN-prologue kernel (callers normalise the operand themselves)
  *    CVCL_F32_TILED         on       fp32 parity mode: the direct (one thread per output) stem / grouped-conv kernels
- *  Experiment switches of earlier rounds (CVCL_FUSED_TAIL_STAGES, CVCL_CONV3_PRO_STAGES, CVCL_DS_RECOMPUTE, CVCL_BN3_GRAM,
+ *  Experiment switches of earlier rounds (CVCL_FUSED_TAIL_STAGES, CVCL_CONV3_PRO_STAGES, CVCL_DS_RECOMPUTE,
  *  CVCL_PRO_DEPTH, CVCL_GCONV_LDS_KB, CVCL_GEMM_MINW, CVCL_GEMM_GLDS, CVCL_GCONV_WGRAD_BAND) exist only in a library built with
  *  -DCVCL_LAB (tools/README.md); the kernel-variant switches of the 8-wave GEMM live in tools/gemm_lab/.
  */

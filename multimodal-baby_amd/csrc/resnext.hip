@@ -1324,12 +1324,6 @@ namespace {
 struct Spec { int cin, cout, k, stride, groups; };
 constexpr int kLayers[4] = {3, 4, 6, 3};
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-// scratch of the Gram-matrix BN3 statistics (conv3 of layers 1 and 2: K = 128 at H/4 x W/4, K = 256 at H/8 x W/8)
-inline size_t gram_ws_bytes(int B, int H, int W) {
-    const size_t a = cvcl_conv1x1_bn_stats_gram_workspace_bytes((long)B * (H / 4) * (W / 4), 128);
-    const size_t b = cvcl_conv1x1_bn_stats_gram_workspace_bytes((long)B * (H / 8) * (W / 8), 256);
-    return al256(a > b ? a : b);
-}
 inline size_t act_elems(int B, int H, int W) {
     // largest activation: stem output [B, H/2, W/2, 64] == layer1 tensors [B, H/4, W/4, 256]
     return (size_t)B * (H / 2) * (W / 2) * 64;
@@ -1339,7 +1333,7 @@ inline size_t act_elems(int B, int H, int W) {
 extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W) {
     const size_t es = dtype == CVCL_BF16 ? 2 : 4;
     return 5 * al256(act_elems(B, H, W) * es) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)53 * 2 * 2048 * 4) +
-           gram_ws_bytes(B, H, W) + al256((size_t)53 * 2048 * 4);
+           al256((size_t)53 * 2048 * 4);
 }
 
 extern "C" size_t cvcl_resnext50_centres_floats(void) { return (size_t)53 * 2048; }
@@ -1355,7 +1349,6 @@ struct BlockCtx {
     int dtype, B, training;
     float momentum, eps;
     float* stats;
-    char* gram_ws; size_t gram_bytes;
     void* stream;
 };
 
@@ -1422,16 +1415,9 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         a.centre = centre_of(l3);
         return a;
     };
-    // opt-in ($CVCL_BN3_GRAM=1): measured SLOWER than the statistics-only GEMM pass on MI355X at B=256 (8.14 vs 7.74
-    // ms/step: the Gram TN GEMM runs at ~400 TFLOP/s and needs two small follow-up kernels), kept as an experiment
-    static const bool use_gram = cvcl_lab_int("CVCL_BN3_GRAM", 0) == 1;
-    if (fused_tail && training && use_gram && c.gram_ws && !cen) {
-        // BN3 statistics from the Gram matrix of conv3's (narrow) input: one read of R2 instead of a statistics-only
-        // GEMM pass (the conv is linear: sum_y = W colsum(R2), sum_y2[n] = w_n^T (R2^T R2) w_n)
-        if ((rc = cvcl_conv1x1_bn_stats_gram(R2, width, L[l3].w, width, m_out, outc, width, stats, c.gram_ws,
-                                             c.gram_bytes, stream))) return rc;
-        if ((rc = finalize(l3, 1, m_out, outc))) return rc;
-    } else if (!fused_tail || training) {
+    // (BN3 statistics from the Gram matrix of conv3's input -- cvcl_conv1x1_bn_stats_gram, still an exported op -- were measured
+    // slower than the statistics-only GEMM pass in round 2 and predate the BN-prologue kernel and centred storage: branch removed)
+    if (!fused_tail || training) {
         cvcl_gemm_args a = conv3_args();
         a.C = fused_tail ? nullptr : R3;
         a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
@@ -1515,7 +1501,7 @@ extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stag
             if (rc) return rc;
         }
     }
-    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, nullptr, 0, stream};
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, stream};
     return bottleneck_fwd(ctx, stage, first != 0, h, w, (const char*)x_nhwc, R1, R2, R1, RD, (char*)out_nhwc, layers, aff, nullptr,
                           centres);
 }
@@ -1538,8 +1524,6 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     for (int i = 0; i < 5; ++i) { buf[i] = w; w += al256(act_elems(B, H, W) * es); }
     float* stats = (float*)w; w += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
     float* affine = (float*)w; w += al256((size_t)53 * 2 * 2048 * 4);
-    char* gram_ws = w; w += gram_ws_bytes(B, H, W);
-    const size_t gram_bytes = gram_ws_bytes(B, H, W);
     float* eval_centres = (float*)w;                      // eval mode without caller centres: the running means (see below)
     int rc, li = 0;
 
@@ -1591,7 +1575,7 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     if ((rc = cvcl_bn_relu_maxpool(dtype, RAW, scale_of(0), shift_of(0), X, B, h, wd, 64, stream))) return rc;
     h /= 2; wd /= 2;
     li = 1;
-    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, gram_bytes, stream};
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, stream};
     for (int stage = 0; stage < 4; ++stage) {
         for (int bi = 0; bi < kLayers[stage]; ++bi) {
             const int stride = (stage > 0 && bi == 0) ? 2 : 1;
