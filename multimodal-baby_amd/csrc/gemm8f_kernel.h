@@ -301,22 +301,13 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
-        issue(g & 3);                                       // stage g+4 into the buffer stage g occupied
-        mma_half(P, std::integral_constant<int, 1>{}, c_ks);
-        // one MFMA between any two of the 2 (2 + MT) reads / 4 loads of this half (MT MFMAs: the rest follows them)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-        advance();
-        // the next stage's MX scales (its K tile's slot was filled >= 2 stages ago, behind a counted wait and this barrier)
-        if constexpr (MXA) {
-            if (c_ks & 1) { __builtin_amdgcn_sched_barrier(0); read_scales(); }        // (the next stage opens a K tile)
-        }
-        if (++c_ks == KS) {
+        // The LAST stage of a tile reads the next tile's first fragments only AFTER the epilogue: held across it they are 8 (2 + MT)
+        // registers the epilogue needs (the MT = 4 instantiations spilled 32-116 bytes per lane); the reads are then not hidden
+        // behind MFMAs once per tile (K / 64 >= 4 stages).
+        if (c_ks + 1 == KS) {
+            issue(g & 3);
+            mma_half(P, std::integral_constant<int, 1>{}, c_ks);
+            advance();
             c_ks = 0;
             epi_ops = epilogue(c_i * BM, c_j * BN, c_t & 1);
             ++c_t;
@@ -324,6 +315,26 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
             c_i += step_i;
             c_j += step_j;
             if (c_j >= p.ncol) { c_j -= p.ncol; ++c_i; }
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
+            if constexpr (MXA) read_scales();                    // (KS is even: the next stage opens a K tile)
+        } else {
+            read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
+            issue(g & 3);                                       // stage g+4 into the buffer stage g occupied
+            mma_half(P, std::integral_constant<int, 1>{}, c_ks);
+            // one MFMA between any two of the 2 (2 + MT) reads / 4 loads of this half (MT MFMAs: the rest follows them)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            advance();
+            // the next stage's MX scales (its K tile's slot was filled >= 2 stages ago, behind a counted wait and this barrier)
+            if constexpr (MXA) {
+                if (c_ks & 1) { __builtin_amdgcn_sched_barrier(0); read_scales(); }        // (the next stage opens a K tile)
+            }
+            ++c_ks;
         }
     };
     for (int g = 0; g < S; g += 2) {
