@@ -200,6 +200,20 @@ int cvcl_row_stats_finalize(const float* row_part, int strips, float* out, long 
 int cvcl_gemm8w_tile_rows(int M, int N);
 int cvcl_gemm8w_stats_rows(int M, int N);
 
+/* Train-mode BatchNorm statistics of a 1x1 convolution's output WITHOUT forming the output (round 4, csrc/bn_gram.hip): torchvision
+ * Bottleneck.forward bn3(conv3(relu(bn2(.)))) / downsample[1](downsample[0](x)), reached from multimodal/multimodal.py:101, where the
+ * convolution runs fused with its consumer and its statistics are needed first.  With a' = relu?(A * a_scale + a_shift) rounded to bf16
+ * (a_scale NULL: A as stored), cvcl_conv1x1_gram leaves G = sum_m a'[m] a'[m]^T (only its upper-triangle 32 x 32 tiles are computed) and
+ * s = sum_m a'[m] in fp64 inside the workspace (*gram_out: G [K][K] row-major, then s [K]); cvcl_bn_from_gram turns them into what
+ * cvcl_bn_finalize produces for y = a' W^T (W bf16 [N][ldw]): mean = w.s / M, var = w^T (G - s s^T / M) w / M, (scale, shift) of the
+ * stored tensor y - centre, running statistics or deferred moments.  bf16 rows, K = 64 | 128 | 256; deterministic.               */
+size_t cvcl_conv1x1_gram_workspace_bytes(int K);
+int cvcl_conv1x1_gram(const void* A, int lda, long M, int K, const float* a_scale, const float* a_shift, int a_relu, void* workspace,
+                      size_t workspace_bytes, const double** gram_out, void* stream);
+int cvcl_bn_from_gram(const double* gram, int K, long count, const void* W, int ldw, int N, const float* gamma, const float* beta,
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                      float* scale, float* shift, float* moments, int moments_ld, const float* centre, void* stream);
+
 /* out[c][r] = in[r][c], f32 (operand re-layout for the weight-gradient GEMMs). */
 int cvcl_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
 /* d_bias[n] = sum_m dY[m][n], f32. */

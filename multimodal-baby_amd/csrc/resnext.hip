@@ -1333,7 +1333,7 @@ inline size_t act_elems(int B, int H, int W) {
 extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W) {
     const size_t es = dtype == CVCL_BF16 ? 2 : 4;
     return 5 * al256(act_elems(B, H, W) * es) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)53 * 2 * 2048 * 4) +
-           al256((size_t)53 * 2048 * 4);
+           al256((size_t)53 * 2048 * 4) + al256(cvcl_conv1x1_gram_workspace_bytes(256));
 }
 
 extern "C" size_t cvcl_resnext50_centres_floats(void) { return (size_t)53 * 2048; }
@@ -1349,6 +1349,7 @@ struct BlockCtx {
     int dtype, B, training;
     float momentum, eps;
     float* stats;
+    void* gram_ws;                   // cvcl_conv1x1_gram workspace (K = 256)
     void* stream;
 };
 
@@ -1415,9 +1416,21 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         a.centre = centre_of(l3);
         return a;
     };
-    // (BN3 statistics from the Gram matrix of conv3's input -- cvcl_conv1x1_bn_stats_gram, still an exported op -- were measured
-    // slower than the statistics-only GEMM pass in round 2 and predate the BN-prologue kernel and centred storage: branch removed)
-    if (!fused_tail || training) {
+    // Train mode with the fused tail: BN3's batch statistics are needed before the product exists.  They come from the Gram matrix
+    // of the operand (bn_gram.hip: sum y = w.s, sum y^2 = w^T G w -- one read of the narrow tensor, K <= 256 <= N / 2) instead of
+    // a statistics-only run of the whole GEMM.  [lab: CVCL_BN_GRAM=0 the statistics-only pass]
+    static const bool gram_on = cvcl_lab_int("CVCL_BN_GRAM", 1) != 0;
+    auto gram_stats = [&](int l, const void* A, int K, const float* a_scale, const float* a_shift, int a_relu) -> int {
+        const double* g = nullptr;
+        int r = cvcl_conv1x1_gram(A, K, m_out, K, a_scale, a_shift, a_relu, c.gram_ws, cvcl_conv1x1_gram_workspace_bytes(256), &g, stream);
+        if (r) return r;
+        return cvcl_bn_from_gram(g, K, m_out, L[l].w, K, outc, L[l].gamma, L[l].beta, L[l].running_mean, L[l].running_var,
+                                 L[l].num_batches_tracked, c.momentum, c.eps, scale_of(l), shift_of(l), mom ? mom + (size_t)l * 4096 : nullptr,
+                                 2048, centre_of(l), stream);
+    };
+    if (fused_tail && training && pro && gram_on) {
+        if ((rc = gram_stats(l3, R2, width, scale_of(l2), shift_of(l2), 1))) return rc;
+    } else if (!fused_tail || training) {
         cvcl_gemm_args a = conv3_args();
         a.C = fused_tail ? nullptr : R3;
         a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
@@ -1439,8 +1452,12 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
         a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
         a.centre = centre_of(ld);
-        if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
-        if ((rc = finalize(ld, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
+        if (ds_recompute && training && gram_on) {
+            if ((rc = gram_stats(ld, X, inplanes, nullptr, nullptr, 0))) return rc;
+        } else {
+            if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
+            if ((rc = finalize(ld, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
+        }
     }
     if (fused_tail) {
         cvcl_gemm_args a = conv3_args();
@@ -1472,7 +1489,8 @@ inline size_t block_act_bytes(int dtype, int B, int h, int w, int stage) {
 }  // namespace
 
 extern "C" size_t cvcl_resnext50_block_workspace_bytes(int dtype, int B, int h, int w, int stage) {
-    return 3 * block_act_bytes(dtype, B, h, w, stage) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)4 * 4096 * 4);
+    return 3 * block_act_bytes(dtype, B, h, w, stage) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)4 * 4096 * 4) +
+           al256(cvcl_conv1x1_gram_workspace_bytes(256));
 }
 
 extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stage, int first, int training, const void* x_nhwc,
@@ -1490,7 +1508,8 @@ extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stag
     const size_t ab = block_act_bytes(dtype, B, h, w, stage);
     char* R1 = p; char* R2 = p + ab; char* RD = p + 2 * ab; p += 3 * ab;
     float* stats = (float*)p; p += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
-    float* aff = (float*)p;
+    float* aff = (float*)p; p += al256((size_t)4 * 4096 * 4);
+    void* gram_ws = p;
     if (!training) {                                      // eval mode: affines from the running statistics
         const int planes = 64 << stage;
         const int Cs[4] = {planes * 2, planes * 2, planes * 4, planes * 4};
@@ -1501,7 +1520,7 @@ extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stag
             if (rc) return rc;
         }
     }
-    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, stream};
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, stream};
     return bottleneck_fwd(ctx, stage, first != 0, h, w, (const char*)x_nhwc, R1, R2, R1, RD, (char*)out_nhwc, layers, aff, nullptr,
                           centres);
 }
@@ -1524,7 +1543,8 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     for (int i = 0; i < 5; ++i) { buf[i] = w; w += al256(act_elems(B, H, W) * es); }
     float* stats = (float*)w; w += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
     float* affine = (float*)w; w += al256((size_t)53 * 2 * 2048 * 4);
-    float* eval_centres = (float*)w;                      // eval mode without caller centres: the running means (see below)
+    float* eval_centres = (float*)w; w += al256((size_t)53 * 2048 * 4);   // eval mode without caller centres: the running means (see below)
+    void* gram_ws = w;
     int rc, li = 0;
 
     // (scale, shift) of layer l live at affine + l * 4096
@@ -1575,7 +1595,7 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     if ((rc = cvcl_bn_relu_maxpool(dtype, RAW, scale_of(0), shift_of(0), X, B, h, wd, 64, stream))) return rc;
     h /= 2; wd /= 2;
     li = 1;
-    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, stream};
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, stream};
     for (int stage = 0; stage < 4; ++stage) {
         for (int bi = 0; bi < kLayers[stage]; ++bi) {
             const int stride = (stage > 0 && bi == 0) ? 2 : 1;

@@ -131,6 +131,9 @@ SIGNATURES = {
     "cvcl_gemm8w_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "cvcl_gemm_ln_supported": (_I, [C.POINTER(GemmArgs)]),
     "cvcl_set_gemm_cu_share": (_I, [_I]),
+    "cvcl_conv1x1_gram_workspace_bytes": (C.c_size_t, [_I]),
+    "cvcl_conv1x1_gram": (_I, [_P, _I, C.c_long, _I, _P, _P, _I, _P, C.c_size_t, C.POINTER(C.c_void_p), _P]),
+    "cvcl_bn_from_gram": (_I, [_P, _I, C.c_long, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P]),
     "cvcl_row_stats": (_I, [_I, _P, C.c_long, _P, C.c_long, _I, _F, _P]),
     "cvcl_row_stats_finalize": (_I, [_P, _I, _P, C.c_long, _I, _F, _P]),
     "cvcl_gemm8w_tile_rows": (_I, [_I, _I]),
