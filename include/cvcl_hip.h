@@ -449,13 +449,6 @@ int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int B, int H, 
  * stem weight gradient = cvcl_gemm_tn(A = dY [P,64], B = col, k_keep = 147)                              */
 int cvcl_stem_im2col(const float* x_nchw, void* col_bf16, int B, int H, int W, void* stream);
 
-/* BatchNorm statistics (one row [2][N]: sum, sum of squares over the M rows) of Y = A W^T for a bf16 1x1 convolution
- * WITHOUT forming Y: sum = W colsum(A), sumsq[n] = w_n^T (A^T A) w_n.  K in {128, 256}.  Used for conv3 of ResNeXt
- * layers 1-2, whose output only feeds the fused BN3 + identity + ReLU pass (torchvision Bottleneck: bn3(conv3(out))). */
-size_t cvcl_conv1x1_bn_stats_gram_workspace_bytes(long M, int K);
-int cvcl_conv1x1_bn_stats_gram(const void* A, int lda, const void* W, int ldw, long M, int N, int K, float* stats,
-                               void* workspace, size_t workspace_bytes, void* stream);
-
 /* embedding_type == "spatial", sim == "max" (multimodal/multimodal.py:770-787).  mm [Bi*HW, Bt*L] f32 is the match map
  * <image location, word> (one cvcl_gemm of the per-location image rows [Bi*HW, E] against the per-word text rows
  * [Bt*L, E]);  logits[i][t] = exp(*neg_log_temp) * sum_l max_p mm[(i,p)][(t,l)] / len[t]  (all L positions, as the

@@ -306,64 +306,6 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
     }
 }
 
-// ---- BatchNorm statistics of Y = A W^T without forming Y (the conv is linear):
-//   sum_m y[m][n]   = sum_k w[n][k] * cs[k],               cs = column sums of A
-//   sum_m y[m][n]^2 = sum_k sum_k' w[n][k] G[k][k'] w[n][k'],   G = A^T A (K x K Gram matrix, from the TN kernel)
-// Used for conv3 of layers 1-2, whose output is consumed only by the fused BN3 + identity + ReLU tail pass: reading the
-// narrow A once (K = 128 / 256) replaces a full statistics-only GEMM pass.
-__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ P, const float* __restrict__ CS, int S, int K,
-                                                          int tiles, float* __restrict__ G, float* __restrict__ cs) {
-    const long total = (long)K * K;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total + K; i += (long)gridDim.x * blockDim.x) {
-        double a = 0.0;
-        if (i < total) {
-            for (int s = 0; s < S; ++s) a += (double)P[(long)s * total + i];
-            G[i] = (float)a;
-        } else {
-            const int k = (int)(i - total);
-            for (int s = 0; s < S; ++s) a += (double)CS[((long)s * tiles + k / TN_T) * TN_T + k % TN_T];
-            cs[k] = (float)a;
-        }
-    }
-}
-
-// 8 output channels per workgroup; thread k owns row k of the (symmetric) Gram matrix, read column-wise (coalesced)
-__global__ __launch_bounds__(256) void gram_bn_stats_kernel(const float* __restrict__ G, const float* __restrict__ cs,
-                                                            const bf16_t* __restrict__ W, int N, int K, int ldw,
-                                                            float* __restrict__ stats) {
-    __shared__ float sw[8][256];
-    __shared__ double red[2][8][4];
-    const int tid = threadIdx.x, n0 = blockIdx.x * 8;
-    for (int e = tid; e < 8 * K; e += 256) {
-        const int c = e / K, k = e % K;
-        sw[c][k] = (n0 + c < N) ? (float)W[(long)(n0 + c) * ldw + k] : 0.f;
-    }
-    __syncthreads();
-    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (tid < K) {
-        for (int k2 = 0; k2 < K; ++k2) {
-            const double g = (double)G[(long)k2 * K + tid];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) t[c] = fma(g, (double)sw[c][k2], t[c]);
-        }
-    }
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        double q = tid < K ? (double)sw[c][tid] * t[c] : 0.0;          // contribution of row k to w^T G w
-        double l = tid < K ? (double)sw[c][tid] * (double)cs[tid] : 0.0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { q += __shfl_xor(q, o, 64); l += __shfl_xor(l, o, 64); }
-        if (lane == 0) { red[0][c][wave] = l; red[1][c][wave] = q; }
-    }
-    __syncthreads();
-    if (tid < 16) {
-        const int which = tid >> 3, c = tid & 7;
-        const double v = (red[which][c][0] + red[which][c][1]) + (red[which][c][2] + red[which][c][3]);
-        if (n0 + c < N) stats[(long)which * N + n0 + c] = (float)v;
-    }
-}
-
 struct TnPlan { int S; long chunk; int tiles_n, tiles_k, ntile; };
 
 TnPlan tn_plan(long M, int N, int K, int taps, bool diag, int tile, int target_wgs = 512) {
@@ -803,48 +745,3 @@ extern "C" int cvcl_stem_im2col(const float* x_nchw, void* col_bf16, int B, int 
     return CVCL_OK;
 }
 
-// ---- BN statistics of a 1x1 convolution's output from the Gram matrix of its input (bf16) ---------------------------
-namespace {
-struct GramPlan { TnPlan pl; size_t off_cs, off_g, off_csr, total; };
-GramPlan gram_plan(long M, int K) {
-    GramPlan g;
-    g.pl = tn_plan(M, K, K, 1, false, TN_T, 256);
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    g.off_cs = al(tn_ws_bytes(g.pl, K, K, 1, false));
-    g.off_g = g.off_cs + al((size_t)g.pl.S * g.pl.tiles_n * TN_T * 4);
-    g.off_csr = g.off_g + al((size_t)K * K * 4);
-    g.total = g.off_csr + al((size_t)K * 4);
-    return g;
-}
-}  // namespace
-
-extern "C" size_t cvcl_conv1x1_bn_stats_gram_workspace_bytes(long M, int K) { return gram_plan(M, K).total; }
-
-extern "C" int cvcl_conv1x1_bn_stats_gram(const void* A, int lda, const void* W, int ldw, long M, int N, int K, float* stats,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
-    CVCL_CHECK_ARG(A && W && stats && workspace && M > 0 && N > 0, "cvcl_conv1x1_bn_stats_gram: bad args");
-    CVCL_CHECK_ARG(K > 0 && K <= 256 && K % TN_T == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0,
-                   "cvcl_conv1x1_bn_stats_gram: K must be 128 or 256 (got %d) with 16-byte aligned rows", K);
-    const GramPlan g = gram_plan(M, K);
-    if (workspace_bytes < g.total) {
-        cvcl_set_error("cvcl_conv1x1_bn_stats_gram: workspace too small");
-        return CVCL_EWORKSPACE;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    char* ws = (char*)workspace;
-    CvclProfScope prof(stream, CVCL_K_GEMM);
-    TnDev d = {};
-    d.A = (const bf16_t*)A; d.B = (const bf16_t*)A; d.P = (float*)ws;
-    d.M = M; d.N = K; d.K = K; d.lda = lda; d.ldb = lda; d.S = g.pl.S; d.chunk = g.pl.chunk;
-    d.tiles_n = g.pl.tiles_n; d.tiles_k = g.pl.tiles_k; d.diag = 0; d.taps = 1;
-    d.colsum = (float*)(ws + g.off_cs);
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, dim3(g.pl.ntile * g.pl.S, 1), dim3(256), 0, st, d);
-    CVCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(reduce_grid((long)K * K + K)), dim3(256), 0, st, (const float*)ws,
-                       (const float*)(ws + g.off_cs), g.pl.S, K, g.pl.tiles_n, (float*)(ws + g.off_g), (float*)(ws + g.off_csr));
-    CVCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gram_bn_stats_kernel, dim3(cvcl_div_up(N, 8)), dim3(256), 0, st, (const float*)(ws + g.off_g),
-                       (const float*)(ws + g.off_csr), (const bf16_t*)W, N, K, ldw, stats);
-    CVCL_LAUNCH_CHECK();
-    return CVCL_OK;
-}

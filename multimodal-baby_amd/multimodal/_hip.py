@@ -121,8 +121,6 @@ SIGNATURES = {
     "cvcl_gconv3x3_wgrad_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "cvcl_gconv3x3_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, C.c_size_t, _P]),
     "cvcl_stem_im2col": (_I, [_P, _P, _I, _I, _I, _P]),
-    "cvcl_conv1x1_bn_stats_gram_workspace_bytes": (C.c_size_t, [C.c_long, _I]),
-    "cvcl_conv1x1_bn_stats_gram": (_I, [_P, _I, _P, _I, C.c_long, _I, _I, _P, _P, C.c_size_t, _P]),
     "cvcl_gemm_stats_rows": (_I, [_I, _P]),
     "cvcl_gemm_pro": (_I, [_P, _P]),
     "cvcl_gemm_pro_supported": (_I, [_P]),

@@ -11,7 +11,7 @@ cp $O/yardstick.log $P/r04_parity_yardstick.txt 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do f=$(ls gpurun_out/pmc/$c/*counter_collection.csv gpurun_out/pmc/$c/*/*counter_collection.csv 2>/dev/null | head -1); [ -n "$f" ] && python3 - "$f" $P/r04_pmc_${c}_counter_collection.csv <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("gemm", "gconv", "bn_", "stem", "avgpool"))]
+keep = [r for r in rows if any(k in r["Kernel_Name"] for k in ("gemm", "gconv", "bn_", "stem", "avgpool", "gram"))]
 w = csv.DictWriter(open(sys.argv[2], "w"), fieldnames=["Dispatch_Id", "Kernel_Name", "Grid_Size", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"], extrasaction="ignore")
 w.writeheader(); w.writerows(keep)
 PY
