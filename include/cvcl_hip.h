@@ -149,7 +149,8 @@ typedef struct {
     /* Bottleneck tail with the downsample branch RECOMPUTED (bf16, the BN-prologue kernel, K = 128): instead of reading the
      * stored branch through R, identity = round(A2[M,K2] . W2[N,K2]^T - centre2[n]) * r_scale[n] + r_shift[n] with A2 = the block
      * input and W2 = the 1x1 downsample weight, K2 = 64 (torchvision Bottleneck.downsample of layer1.0: nn.Conv2d(64, 256, 1) +
-     * BatchNorm).  R must be NULL; the statistics behind r_scale / r_shift come from a statistics-only cvcl_gemm(A2, W2, C = NULL). */
+     * BatchNorm).  R must be NULL; the statistics behind r_scale / r_shift come from cvcl_conv1x1_gram(A2) + cvcl_bn_from_gram(W2)
+     * (or a statistics-only cvcl_gemm(A2, W2, C = NULL)). */
     const void* A2; const void* W2; int K2, lda2, ldw2; const float* centre2;
     /* LayerNorm folded into the linear (bf16, the 8-wave kernel only; reference vision_transformer_dino_mugs.py:136-149:
      * x + attn(norm1(x)), x + mlp(norm2(x)) -- nn.LayerNorm feeding nn.Linear).
