@@ -213,14 +213,14 @@ def logits_vs_fp32(lit, batch, precision):
 def resnext_gemm_work(B):
     """Algorithmic bytes / flops of the bf16 conv GEMM launches of one ResNeXt-50 forward at batch B (train mode), per
     kernel: every operand element moved once, 2 bytes each; 2*M*N*K flops per launch.  Launch list = what cvcl_resnext50_fwd
-    enqueues: conv1 and downsample (A + W + C); conv3 of layers 3-4 (A + W + C); conv3 of layers 1-2 twice -- a
-    statistics-only pass (A + W) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The two leading stages use the fused tail.)  Which kernel runs a launch mirrors
+    enqueues: conv1 and downsample (A + W + C); conv3 of layers 3-4 (A + W + C); conv3 of layers 1-2 as the Gram launch that
+    stands in for its BN3 statistics (A only; M K (K + 32) flops) and the fused BN3 + identity + ReLU pass (A + W + residual + C).  (The two leading stages use the fused tail.)  Which kernel runs a launch mirrors
     the dispatcher of csrc/gemm.hip: gemm_pro = conv3 with the BN2+ReLU operand prologue (layers 1-2), gemm8w = plain operands,
     K >= 256, N % 256 == 0, >= 96 tiles of 256 x 256, N K >= 170 (N + K) (strided-gather downsamples included); the rest on gemm_glds ("gemm").
     -> {kernel: [bytes, flops, launches]} and the totals."""
     fused_stages, pro_stages = 2, 2                  # (lab switches of the library, fixed in the product build: csrc/resnext.hip)
-    # layer1.0: the downsample launch is a statistics-only pass (A + W) and the tail pass recomputes the branch from the block
-    # input (reads X [M, 64] + W2 instead of the stored [M, 256] branch) -- csrc/resnext.hip
+    # layer1.0: the downsample launch is a Gram launch over the block input (statistics only) and the tail pass recomputes the branch
+    # from the block input (reads X [M, 64] + W2 instead of the stored [M, 256] branch) -- csrc/resnext.hip
     ds_recompute = os.environ.get("CVCL_GEMM_PRO", "1") != "0"
     per = {"gemm": [0, 0, 0], "gemm8w": [0, 0, 0], "gemm_pro": [0, 0, 0]}
 
@@ -242,14 +242,21 @@ def resnext_gemm_work(B):
             m, n, k = m_in, width, inplanes                          # conv1
             add(plain_kernel(m, n, k, False), 2 * (m * k + n * k + m * n), 2 * m * n * k)
             recompute = ds_recompute and stage == 0 and bi == 0
+            gram = lambda m, k: (2 * m * k, m * k * (k + 32))        # csrc/bn_gram.hip: one read of the operand, upper-triangle tiles of A^T A
             if bi == 0:                                              # downsample
                 m, n, k = m_out, outc, inplanes
-                add(plain_kernel(m, n, k, stride > 1), 2 * (m * k + n * k + (0 if recompute else m * n)), 2 * m * n * k)
+                if recompute:                                        # only its BN statistics are needed: Gram launch (timed with the gemm_pro class)
+                    add("gemm_pro", *gram(m, k))
+                else:
+                    add(plain_kernel(m, n, k, stride > 1), 2 * (m * k + n * k + m * n), 2 * m * n * k)
             m, n, k = m_out, outc, width                             # conv3
             pro = stage < pro_stages and width in (128, 256)
             kern = "gemm_pro" if pro else plain_kernel(m, n, k, False)
-            if stage < fused_stages:                                 # statistics pass + fused tail pass
-                add(kern if pro else "gemm", 2 * (m * k + n * k), 2 * m * n * k)
+            if stage < fused_stages:                                 # BN3 statistics (Gram launch; round 2-3: a statistics-only GEMM pass) + fused tail pass
+                if pro:
+                    add("gemm_pro", *gram(m, k))
+                else:
+                    add("gemm", 2 * (m * k + n * k), 2 * m * n * k)
                 if recompute:                                        # + X and W2 read, + the K2 = 64 product; no residual read
                     add(kern, 2 * (m * k + n * k + m * n + m * inplanes + n * inplanes), 2 * m * n * (k + inplanes))
                 else:
