@@ -351,6 +351,10 @@ __global__ __launch_bounds__(256) void attention_valu_kernel(const T* __restrict
 // (The first version ran one workgroup per 64 queries: V^T was rebuilt 4x per head with 2-byte LDS scatters, 4-way
 //  bank conflicted, and K was re-read from L2 by every wave: 440 us per ViT-B/16 layer at B = 256.)
 // ------------------------------------------------------------------------------------------------
+// phase ablation for timing studies (build option): 1 no query-tile loop (stage K / V only), 2 no K / V staging
+#ifndef CVCL_ATT_ABLATE
+#define CVCL_ATT_ABLATE 0
+#endif
 constexpr int ATT_TPAD_MAX = 288;      // keys padded to a multiple of 32 (T <= 288 covers ViT-B/14 at 224: 257)
 constexpr int ATT_THREADS = 512;       // 8 waves: the 7 query tiles of a 197-token ViT-B/16 head run in ONE round (4 waves needed two, the
                                        // second half empty), two workgroups per CU = 4 waves per SIMD
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
     // K and V rows -> LDS, 8 chunks of 16 B per row, zeros beyond Tn.  All of a thread's loads (<= ATT_STAGE_IT pairs) are issued
     // before the first LDS write: the plain loop waited for each pair (a dependent L2 round trip per iteration, ~half of the
     // workgroup's lifetime at 197 tokens)
-    {
+    if (!(CVCL_ATT_ABLATE & 2)) {
         u32x4 kv[ATT_STAGE_IT], vv[ATT_STAGE_IT];
 #pragma unroll
         for (int it = 0; it < ATT_STAGE_IT; ++it) {
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf
     const int l15 = lane & 15;
     const int v_lane_off = (4 * h + (l15 >> 2)) * ATT_VP + (((lane >> 4) & 1) * 16 + (l15 & 3) * 4) * 2;
 
-    for (int qt = wave; qt < nqt; qt += ATT_THREADS / 64) {
+    for (int qt = wave; qt < ((CVCL_ATT_ABLATE & 1) ? 0 : nqt); qt += ATT_THREADS / 64) {
         const int q0 = qt * 32;
         const int qrow = min(q0 + l31, Tn - 1);
         bf16x8 qf[4];
