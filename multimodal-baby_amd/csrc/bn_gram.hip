@@ -11,8 +11,8 @@
 // 6 ms trunk pass, at 1.4-2.8 TB/s of HBM).  The Gram matrix needs M K^2 MACs instead of M K N (K <= 256 <= N / 2) and no
 // per-element epilogue, so this pass is bound by reading the operand once.
 //
-//   gram_pro_kernel<NT>   K = 32 NT (64 | 128 | 256).  One 8-wave workgroup per CU, persistent over 64-row tiles, waves specialised:
-//                         waves 4-7 PRODUCE -- rows arrive as 16-byte chunks through registers (64 KiB per CU in flight), are
+//   gram_pro_kernel<NT>   K = 32 NT (64 | 128 | 256).  One workgroup per CU, persistent over 64-row tiles, waves specialised:
+//                         waves 4 .. (8 of them at K <= 128, 4 at K = 256) PRODUCE -- rows arrive as 16-byte chunks through registers (64 KiB per CU in flight), are
 //                         transformed exactly as gemm_pro.hip transforms them (scale, shift, ReLU, round to bf16; rows past M
 //                         contribute zeros), summed per column, and written row-major into a double-buffered LDS tile (pitch
 //                         K * 2 + 64 bytes: wgrad.hip's bank layout); waves 0-3 CONSUME -- the MFMA fragments (8 consecutive rows of
@@ -59,16 +59,22 @@ __host__ __device__ constexpr int gp_tile_index(int NT, int I, int J) { return I
 template <int NT> constexpr int gp_pitch() { return NT * 64 + 64; }
 template <int NT> constexpr int gp_lds_bytes() { return 2 * GP_PM * gp_pitch<NT>(); }      // (>= 16 KiB: reused for the final exchanges)
 
-// ---- producer wave (waves 4-7; 256 threads): chunk s_c of rows s_r + RPP * i of every tile; a thread's 8 columns never change
+// producer waves per workgroup: the staging arithmetic of ONE wave per SIMD is a dependent chain that issues at well under one
+// instruction per four cycles (PMC, K = 128: 18 us of VALU issue in a 44.7 us kernel whose matrix pipe is busy for 6.5) -- two
+// producer waves per SIMD interleave.  K = 256 keeps one (its nine accumulator tiles leave no registers for twelve waves)
+template <int NT> constexpr int gp_producer_threads() { return NT == 8 ? 256 : 512; }
+
+// ---- producer waves (waves 4 ..): chunk s_c of rows s_r + RPP * i of every tile; a thread's 8 columns never change
 template <int NT>
 __device__ __forceinline__ void gram_producer(const GramDev& p, char* smem, const int tid, const int rounds) {
+    constexpr int PT = gp_producer_threads<NT>();
     constexpr int K = NT * 32;
     constexpr int PITCH = gp_pitch<NT>();
     constexpr int CPR = K / 8;                          // 16-byte chunks per row (8 | 16 | 32)
-    constexpr int RPP = 256 / CPR;                      // rows per staging pass (32 | 16 | 8)
-    constexpr int NCH = GP_PM / RPP;                    // chunks per thread per tile (2 | 4 | 8)
+    constexpr int RPP = PT / CPR;                       // rows per staging pass (64 | 32 | 8)
+    constexpr int NCH = GP_PM / RPP;                    // chunks per thread per tile (1 | 2 | 8)
     constexpr int ABUF = GP_PM * PITCH;
-    constexpr int NPF = 16 / NT;                        // tiles in flight (8 | 4 | 2): 64 VGPRs of raw chunks, 64 KiB per CU
+    constexpr int NPF = 16 / NT;                        // tiles in flight (8 | 4 | 2): 64 KiB per CU
     const int s_c = tid % CPR, s_r = tid / CPR;
     const bool plain = p.a_scale == nullptr;            // (downsample branch: the operand is the block input as stored)
     f32x2 sc[4], sh[4];
@@ -141,7 +147,7 @@ __device__ __forceinline__ void gram_producer(const GramDev& p, char* smem, cons
         for (int t = 0; t < NT + 1; ++t) { __syncthreads(); __syncthreads(); }
     }
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);        // [RPP][K] floats (8 KiB)
+    float* red = reinterpret_cast<float*>(smem);        // [RPP][K] floats (<= 16 KiB)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { red[s_r * K + s_c * 8 + 2 * e] = csum[e][0]; red[s_r * K + s_c * 8 + 2 * e + 1] = csum[e][1]; }
     __syncthreads();                                    // (all eight waves meet it)
@@ -227,7 +233,7 @@ __device__ __forceinline__ void gram_consumer(const GramDev& p, char* smem, cons
 }
 
 template <int NT>
-__global__ __launch_bounds__(512, 2) void gram_pro_kernel(GramDev p) {
+__global__ __launch_bounds__(256 + gp_producer_threads<NT>()) void gram_pro_kernel(GramDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,7 +413,7 @@ int gram_launch(const GramDev& d, int grid, hipStream_t st) {
         }
         attr = true;
     }
-    hipLaunchKernelGGL(gram_pro_kernel<NT>, dim3(grid), dim3(512), gp_lds_bytes<NT>(), st, d);
+    hipLaunchKernelGGL(gram_pro_kernel<NT>, dim3(grid), dim3(256 + gp_producer_threads<NT>()), gp_lds_bytes<NT>(), st, d);
     return CVCL_OK;
 }
 
