@@ -217,13 +217,16 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
                     const f32x4 sw_r = *reinterpret_cast<const f32x4*>(ops + cb);
                     const f32x4 bias_r = *reinterpret_cast<const f32x4*>(ops + 256 + cb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = MXA ? fmaf(acc[n2][mt][4 * g + e], sw_r[e], bias_r[e])
-                                      : fmaf(acc[n2][mt][4 * g + e] * sa_r, sw_r[e], bias_r[e]);
-                        if (ACT == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
-                        if (ACT == CVCL_ACT_GELU) v = gelu_bf16out(v);
-                        qv[n2][g][e] = (bf16_t)v;
+                    for (int e = 0; e < 4; e += 2) {                       // pairs: packed fp32 arithmetic (bit-identical per element)
+                        f32x2 v = f32x2{acc[n2][mt][4 * g + e], acc[n2][mt][4 * g + e + 1]};
+                        if constexpr (!MXA) v = v * f32x2{sa_r, sa_r};
+                        v = __builtin_elementwise_fma(v, f32x2{sw_r[e], sw_r[e + 1]}, f32x2{bias_r[e], bias_r[e + 1]});
+                        if (ACT == CVCL_ACT_RELU) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+                        if (ACT == CVCL_ACT_GELU) v = gelu_bf16out2(v);
+                        qv[n2][g][e] = (bf16_t)v[0];
+                        qv[n2][g][e + 1] = (bf16_t)v[1];
                         acc[n2][mt][4 * g + e] = 0.f;
+                        acc[n2][mt][4 * g + e + 1] = 0.f;
                     }
                 }
             // 16 rows at a time through the wave's 2 KiB staging block (16 rows x 128 B, chunk ^ (row & 7)): the lanes of the other

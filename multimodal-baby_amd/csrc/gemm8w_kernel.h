@@ -305,15 +305,18 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                     f32x4 cs_r = {0.f, 0.f, 0.f, 0.f};
                     if constexpr (LNF && EPI == 1) cs_r = *reinterpret_cast<const f32x4*>(lnf + 256 + cb);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v;
-                        if constexpr (LNF && EPI == 1) v = fmaf(acc[ni][mi][e], rs[0], fmaf(rs[1], cs_r[e], bias_r[e]));
-                        else v = acc[ni][mi][e] + bias_r[e];
+                    for (int e = 0; e < 4; e += 2) {                       // pairs: packed fp32 arithmetic (bit-identical per element)
+                        f32x2 v = f32x2{acc[ni][mi][e], acc[ni][mi][e + 1]};
+                        const f32x2 b2 = f32x2{bias_r[e], bias_r[e + 1]};
+                        if constexpr (LNF && EPI == 1)
+                            v = __builtin_elementwise_fma(v, f32x2{rs[0], rs[0]}, __builtin_elementwise_fma(f32x2{rs[1], rs[1]}, f32x2{cs_r[e], cs_r[e + 1]}, b2));
+                        else v = v + b2;
                         if constexpr (!RES) {
-                            if (p.act == CVCL_ACT_RELU) v = fmaxf(v, 0.f);
-                            else if (p.act == CVCL_ACT_GELU) v = gelu_bf16out(v);
+                            if (p.act == CVCL_ACT_RELU) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+                            else if (p.act == CVCL_ACT_GELU) v = gelu_bf16out2(v);
                         }
-                        q[e] = (bf16_t)v;
+                        q[e] = (bf16_t)v[0];
+                        q[e + 1] = (bf16_t)v[1];
                     }
                 } else {
                     q = bf16x4{(bf16_t)acc[ni][mi][0], (bf16_t)acc[ni][mi][1], (bf16_t)acc[ni][mi][2], (bf16_t)acc[ni][mi][3]};
