@@ -1376,6 +1376,26 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
                                       mom ? mom + (size_t)l * 4096 : nullptr, 2048, centre_of(l), stream);
         return CVCL_OK;                                   // eval mode: every layer's affine was produced up front
     };
+    // (which forms this block takes -- the explanations sit at the launches below)
+    static const int pro_stages = cvcl_lab_int("CVCL_CONV3_PRO_STAGES", 2);
+    const bool pro = dtype == CVCL_BF16 && stage < pro_stages && (width == 128 || width == 256);
+    static const int fused_stages = cvcl_lab_int("CVCL_FUSED_TAIL_STAGES", 2);
+    const bool fused_tail = dtype == CVCL_BF16 && (stage < fused_stages || !training);
+    static const bool ds_recompute_on = cvcl_lab_int("CVCL_DS_RECOMPUTE", 1) != 0 && cvcl_env_on("CVCL_GEMM_PRO");
+    const bool ds_recompute = ds_recompute_on && first && stride == 1 && inplanes == 64 && fused_tail && pro && width == 128;
+    static const bool gram_on = cvcl_lab_int("CVCL_BN_GRAM", 1) != 0;
+    auto gram_stats = [&](int l, const void* A, int K, const float* a_scale, const float* a_shift, int a_relu) -> int {
+        const double* g = nullptr;
+        int r = cvcl_conv1x1_gram(A, K, m_out, K, a_scale, a_shift, a_relu, c.gram_ws, cvcl_conv1x1_gram_workspace_bytes(256), &g, stream);
+        if (r) return r;
+        return cvcl_bn_from_gram(g, K, m_out, L[l].w, K, outc, L[l].gamma, L[l].beta, L[l].running_mean, L[l].running_var,
+                                 L[l].num_batches_tracked, c.momentum, c.eps, scale_of(l), shift_of(l), mom ? mom + (size_t)l * 4096 : nullptr,
+                                 2048, centre_of(l), stream);
+    };
+    // layer1.0's recomputed downsample branch needs only its BN statistics: the Gram launch over the block input runs FIRST, while
+    // X (103 MB, just written by the max-pool) still sits in the Infinity Cache
+    const bool ds_gram = ds_recompute && training && gram_on;
+    if (ds_gram) { if ((rc = gram_stats(ld, X, inplanes, nullptr, nullptr, 0))) return rc; }
     // conv1 1x1: X [m_in, inplanes] -> R1 [m_in, width]
     {
         cvcl_gemm_args a = {};
@@ -1394,8 +1414,6 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // operand load (gemm_pro.hip: applied once per element, W resident in registers) -- no pass of its own over the tensor.
     // Layers 3-4 (MFMA-bound, 4-8 column-tile workgroups per A tile): BN2 + ReLU is applied in place first (one pass over the
     // narrow tensor), which is cheaper than repeating it in every column tile's operand path.
-    static const int pro_stages = cvcl_lab_int("CVCL_CONV3_PRO_STAGES", 2);
-    const bool pro = dtype == CVCL_BF16 && stage < pro_stages && (width == 128 || width == 256);
     if (!pro) {
         if ((rc = cvcl_bn_relu_apply(dtype, R2, scale_of(l2), shift_of(l2), R2, m_out, width, stream))) return rc;
     }
@@ -1406,8 +1424,6 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // on the operand load (gemm_pro.hip).  Measured per step at B = 256 (round 2, with gemm_pro): 1 stage 5.47 ms, 2 stages
     // 5.46 ms and 1.2 GB less HBM traffic; layers 3-4 are MFMA-bound and keep the materialised form.
     // In eval mode there is no statistics pass at all, so the fused tail is used in every stage.
-    static const int fused_stages = cvcl_lab_int("CVCL_FUSED_TAIL_STAGES", 2);
-    const bool fused_tail = dtype == CVCL_BF16 && (stage < fused_stages || !training);
     auto conv3_args = [&]() {
         cvcl_gemm_args a = {};
         a.A = R2; a.W = L[l3].w;
@@ -1419,15 +1435,6 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // Train mode with the fused tail: BN3's batch statistics are needed before the product exists.  They come from the Gram matrix
     // of the operand (bn_gram.hip: sum y = w.s, sum y^2 = w^T G w -- one read of the narrow tensor, K <= 256 <= N / 2) instead of
     // a statistics-only run of the whole GEMM.  [lab: CVCL_BN_GRAM=0 the statistics-only pass]
-    static const bool gram_on = cvcl_lab_int("CVCL_BN_GRAM", 1) != 0;
-    auto gram_stats = [&](int l, const void* A, int K, const float* a_scale, const float* a_shift, int a_relu) -> int {
-        const double* g = nullptr;
-        int r = cvcl_conv1x1_gram(A, K, m_out, K, a_scale, a_shift, a_relu, c.gram_ws, cvcl_conv1x1_gram_workspace_bytes(256), &g, stream);
-        if (r) return r;
-        return cvcl_bn_from_gram(g, K, m_out, L[l].w, K, outc, L[l].gamma, L[l].beta, L[l].running_mean, L[l].running_var,
-                                 L[l].num_batches_tracked, c.momentum, c.eps, scale_of(l), shift_of(l), mom ? mom + (size_t)l * 4096 : nullptr,
-                                 2048, centre_of(l), stream);
-    };
     if (fused_tail && training && pro && gram_on) {
         if ((rc = gram_stats(l3, R2, width, scale_of(l2), shift_of(l2), 1))) return rc;
     } else if (!fused_tail || training) {
@@ -1441,9 +1448,8 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     }
     // layer1.0 (bf16, fused tail, BN-prologue kernel): the downsample branch is a K = 64 product of the block input, recomputed
     // inside the tail pass (gemm_pro.hip PRO_TAIL_DS) instead of being written to HBM (411 MB at B = 256) and read back; its own
-    // launch shrinks to a statistics-only pass (train mode) or disappears (eval mode).  $CVCL_DS_RECOMPUTE=0: the stored form.
-    static const bool ds_recompute_on = cvcl_lab_int("CVCL_DS_RECOMPUTE", 1) != 0 && cvcl_env_on("CVCL_GEMM_PRO");
-    const bool ds_recompute = ds_recompute_on && first && stride == 1 && inplanes == 64 && fused_tail && pro && width == 128;
+    // launch shrinks to the Gram launch at the top of the block (train mode) or disappears (eval mode).  $CVCL_DS_RECOMPUTE=0: the
+    // stored form.
     if (first) {
         // downsample 1x1 stride s: X -> RD [m_out, outc]
         cvcl_gemm_args a = {};
@@ -1452,9 +1458,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
         a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
         a.centre = centre_of(ld);
-        if (ds_recompute && training && gram_on) {
-            if ((rc = gram_stats(ld, X, inplanes, nullptr, nullptr, 0))) return rc;
-        } else {
+        if (!ds_gram) {
             if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
             if ((rc = finalize(ld, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
         }
