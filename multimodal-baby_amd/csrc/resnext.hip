@@ -1392,10 +1392,27 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
                                  L[l].num_batches_tracked, c.momentum, c.eps, scale_of(l), shift_of(l), mom ? mom + (size_t)l * 4096 : nullptr,
                                  2048, centre_of(l), stream);
     };
-    // layer1.0's recomputed downsample branch needs only its BN statistics: the Gram launch over the block input runs FIRST, while
-    // X (103 MB, just written by the max-pool) still sits in the Infinity Cache
+    // The downsample branch of a stage's first block runs FIRST: its operand X was just written by the previous kernel and still
+    // sits in the Infinity Cache (after conv1 / conv2 / conv3 it no longer does).
+    // layer1.0 (bf16, fused tail, BN-prologue kernel): the branch is a K = 64 product of the block input, recomputed inside the tail
+    // pass (gemm_pro.hip PRO_TAIL_DS) instead of being written to HBM (411 MB at B = 256) and read back; its own launch shrinks to a
+    // Gram launch for its BN statistics (train mode) or disappears (eval mode).  $CVCL_DS_RECOMPUTE=0: the stored form.
     const bool ds_gram = ds_recompute && training && gram_on;
-    if (ds_gram) { if ((rc = gram_stats(ld, X, inplanes, nullptr, nullptr, 0))) return rc; }
+    if (first) {
+        if (ds_gram) {
+            if ((rc = gram_stats(ld, X, inplanes, nullptr, nullptr, 0))) return rc;
+        } else {
+            // downsample 1x1 stride s: X -> RD [m_out, outc]
+            cvcl_gemm_args a = {};
+            a.A = X; a.W = L[ld].w; a.C = ds_recompute ? nullptr : RD;
+            a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
+            if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
+            a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+            a.centre = centre_of(ld);
+            if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
+            if ((rc = finalize(ld, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
+        }
+    }
     // conv1 1x1: X [m_in, inplanes] -> R1 [m_in, width]
     {
         cvcl_gemm_args a = {};
@@ -1445,23 +1462,6 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
         if ((rc = finalize(l3, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
     } else {
         if ((rc = finalize(l3, 0, m_out, outc))) return rc;              // eval mode: affine from the running stats
-    }
-    // layer1.0 (bf16, fused tail, BN-prologue kernel): the downsample branch is a K = 64 product of the block input, recomputed
-    // inside the tail pass (gemm_pro.hip PRO_TAIL_DS) instead of being written to HBM (411 MB at B = 256) and read back; its own
-    // launch shrinks to the Gram launch at the top of the block (train mode) or disappears (eval mode).  $CVCL_DS_RECOMPUTE=0: the
-    // stored form.
-    if (first) {
-        // downsample 1x1 stride s: X -> RD [m_out, outc]
-        cvcl_gemm_args a = {};
-        a.A = X; a.W = L[ld].w; a.C = ds_recompute ? nullptr : RD;
-        a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
-        if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
-        a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
-        a.centre = centre_of(ld);
-        if (!ds_gram) {
-            if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
-            if ((rc = finalize(ld, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
-        }
     }
     if (fused_tail) {
         cvcl_gemm_args a = conv3_args();

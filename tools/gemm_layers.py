@@ -18,7 +18,7 @@ for stage, blocks in enumerate((3, 4, 6, 3)):
         stride = 2 if (stage > 0 and bi == 0) else 1
         ho = h // stride
         B = 256
-        ds_first = stage == 0 and bi == 0 and fused > 0          # layer1.0: the downsample's Gram launch runs at the top of the block
+        ds_first = bi == 0                                       # the downsample branch (layer1.0: its Gram launch) runs at the top of the block
         if ds_first:
             names.append((f"layer{stage+1}.{bi}.downsample", B * ho * ho, outc, inpl, 1))
         names.append((f"layer{stage+1}.{bi}.conv1", B * h * h, width, inpl, 1))
