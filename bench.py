@@ -105,6 +105,33 @@ def build_model(config, device, precision=None, seed=0, patch=None):
     return lit, ve, lit.configure_optimizers()
 
 
+@contextlib.contextmanager
+def frozen_trunk_cached(ve, cfg, images):
+    """The frozen image trunk replaced by its own (cached) output for ``images``: what is left of a step is the TRAINABLE TAIL --
+    fc / head, text encoder forward + backward, L2 normalise, logits, InfoNCE forward + backward, AdamW -- with nothing of the
+    trunk on the GPU beside it (``tail_ms_per_step``; the trunk stream must be off)."""
+    from multimodal import vit_hip
+    with torch.no_grad():
+        if cfg == "c2":
+            pooled, fmap = ve.model.trunk(images)
+            pooled, fmap = pooled.clone(), fmap.clone()
+        else:
+            cls = vit_hip._vit_forward(ve.model, images, None).clone()
+    torch.cuda.synchronize()
+    if cfg == "c2":
+        ve.model.trunk = lambda x, defer_wait=False: (pooled, fmap)
+    else:
+        orig = vit_hip._vit_forward
+        vit_hip._vit_forward = lambda model, x, slot: cls
+    try:
+        yield
+    finally:
+        if cfg == "c2":
+            del ve.model.trunk
+        else:
+            vit_hip._vit_forward = orig
+
+
 def synthetic_batch_on_device(batch, seed, device, vocab=2350):
     """rand -> ImageNet normalise; <sos> w1 w2 w3 <eos>, generated once on the device."""
     g = torch.Generator(device=device).manual_seed(seed)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define CVCL_ABI_VERSION 3
+#define CVCL_ABI_VERSION 4
 
 enum { CVCL_OK = 0, CVCL_EINVAL = -1, CVCL_ELAUNCH = -2, CVCL_EWORKSPACE = -3, CVCL_EUNSUPPORTED = -4 };
 enum { CVCL_F32 = 0, CVCL_BF16 = 1 };
@@ -93,6 +93,16 @@ size_t cvcl_sim_logits_bwd_workspace_bytes(int Ni, int Nt, int E);
 int cvcl_sim_logits_bwd(const float* img, const float* txt, const float* neg_log_temp, const float* logits,
                         const float* d_logits, float* d_img, float* d_txt, float* d_neg_log_temp,
                         int Ni, int Nt, int E, void* workspace, size_t workspace_bytes, void* stream);
+/* The same restricted to a range of rows (data-parallel global negatives, SURVEY.md 8e: every rank evaluates the replicated
+ * N_g x N_g loss on the all-gathered features and back-propagates through ITS OWN rows only):
+ *   d_img_rows [ni, E] = s * dS[i0 : i0 + ni, :] . txt          (image rows i0 .. i0 + ni - 1)
+ *   d_txt_rows [nt, E] = s * dS[:, t0 : t0 + nt]^T . img        (text rows  t0 .. t0 + nt - 1)
+ *   d_neg_log_temp = sum(dS * logits) over the WHOLE matrix (identical on every rank).
+ * Operands are read in place (K-major GEMM operands): no workspace.  cvcl_sim_logits_bwd = the full ranges.                  */
+int cvcl_sim_logits_bwd_rows(const float* img, const float* txt, const float* neg_log_temp, const float* logits,
+                             const float* d_logits, float* d_img_rows, float* d_txt_rows, float* d_neg_log_temp,
+                             int Ni, int Nt, int E, int i0, int ni, int t0, int nt, void* workspace, size_t workspace_bytes,
+                             void* stream);
 
 /* Symmetric InfoNCE with arange labels + accuracies + entropies in one pass over the logits
  * (multimodal/multimodal.py:801-818, multimodal/utils.py:106-108).
@@ -162,6 +172,14 @@ typedef struct {
      *     the STORED row over each 64-column strip; cvcl_row_stats_finalize reduces them to the next consumer's ln_stats.
      * cvcl_gemm_ln_supported tells whether cvcl_gemm routes these arguments to the kernel that honours them. */
     const float* ln_stats; const float* ln_colsum; float* row_part;
+    /* K-major operands and fused row sums (fp32 only, round 5): the gradient GEMMs of the trainable tail -- nn.Linear backward
+     * (dW = dY^T X, dX = dY W, db = sum_m dY; reference call sites multimodal/multimodal.py:192 fc, :553-573 text transformer) and of
+     * the similarity logits (:755) -- read their operands as they lie in memory instead of through transposed copies:
+     *   a_trans != 0: element (m, k) of A is at A[k * lda + m]   (A is stored [K][M]);  w_trans != 0: W[k * ldw + n] (stored [K][N]);
+     *   a_rowsum [M] f32 (needs a_trans): a_rowsum[m] = sum_k A'[m][k] -- with A' = dY^T this is the bias gradient, produced by the
+     *   weight-gradient GEMM's own operand loads (fixed summation order, deterministic).
+     * No prologue / gather / statistics / BN-tail options with these. */
+    int a_trans, w_trans; float* a_rowsum;
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);
@@ -200,6 +218,12 @@ int cvcl_row_stats(int dtype, const void* x, long x_row_stride, float* out, long
 int cvcl_row_stats_finalize(const float* row_part, int strips, float* out, long rows, int D, float eps, void* stream);
 int cvcl_gemm8w_tile_rows(int M, int N);
 int cvcl_gemm8w_stats_rows(int M, int N);
+/* How the 8-wave kernel's LINEAR epilogue (nn.Linear: vision_transformer_dino_mugs.py:92-94,113-115) tiles an [M, N] output under the
+ * current CU share (round 5): plan5 = {tile rows (256 | 224), workgroups, rows covered by the main launch, tile rows of the remainder
+ * launch (64 .. 256; 0 = one launch), its workgroups}.  When the last round of a launch would be poorly filled, the rows that whole
+ * rounds hold go first and the rest follows as one round of shorter tiles (folded != 0: the ln_stats / row_part epilogues, which have
+ * the short instantiations).  Results do not depend on the plan (every output element sums its K products in the same order). */
+int cvcl_gemm8w_linear_plan(int M, int N, int folded, int* plan5);
 
 /* Train-mode BatchNorm statistics of a 1x1 convolution's output WITHOUT forming the output (round 4, csrc/bn_gram.hip): torchvision
  * Bottleneck.forward bn3(conv3(relu(bn2(.)))) / downsample[1](downsample[0](x)), reached from multimodal/multimodal.py:101, where the

@@ -45,6 +45,7 @@ struct GemmDev {
     int vec_out;   // C/R rows are 16-byte aligned
     int num_m_tiles;
     void* C2;      // EPI 5: second output (the GELU pre-activation)
+    float* a_rowsum;   // TR & 1 (fp32): a_rowsum[m] = sum_k A'[m][k], written by the workgroups of column tile 0
 };
 
 template <typename T> struct FragOps;
@@ -94,8 +95,13 @@ template <typename T> struct TileRegs {
 // PRO: 0 = plain A, 1 = A*scale+shift, 2 = relu(A*scale+shift).
 // LEAN: the convolution fast path -- 16-byte aligned operands, N a multiple of 128, no bias / activation /
 // output scale / residual: the epilogue carries no per-element predicates.  !LEAN handles everything.
-template <typename T, int PRO, bool LEAN, int MINW>
+// TR (fp32 tail GEMMs, round 5): bit 0 = the A operand is given K-major (element (m, k) at A[k * lda + m]), bit 1 = the same for
+// W -- the gradient GEMMs of nn.Linear (dW = dY^T X, dX = dY W) and of the similarity logits read their operands as they lie,
+// no transposed copies.  A K-major tile is fetched as 32 k-rows x 128 contiguous elements (full 128-byte segments per k-row) and
+// scattered into the same [row][k] LDS image the fragment reads expect (ds_write_b32, 2-way banked = free).
+template <typename T, int PRO, bool LEAN, int MINW, int TR = 0>
 __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
+    static_assert(TR == 0 || (sizeof(T) == 4 && PRO == 0 && !LEAN), "K-major operands: fp32, no prologue");
     constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-B chunk
     constexpr int BK = 8 * EPC;
     constexpr int SROW = stage_rowb<T>();
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     const T* __restrict__ R = (const T*)p.R;
 
     const int kc = tid & 7, r0 = tid >> 3;          // staging role: chunk kc of rows r0 + 32 j
+                                                    // (K-major operand: k-rows kc + 8 j, elements 4 r0 .. 4 r0 + 3)
     const float out_scale = (!LEAN && p.exp_scale) ? expf(*p.exp_scale) : 1.f;
     const int ktiles = (p.K + BK - 1) / BK;
 
@@ -152,12 +159,28 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     float sc[EPC], sh[EPC];
     auto issue = [&]() {                            // global -> registers for tile (l_mt, l_kt); no waiting here
         const int k = l_kt * BK + kc * EPC;
+        // K-major operand: 4 consecutive rows (m | n) of k-row kk per 16-byte load; row-major operand: 4 | 8 consecutive k of a row
+        auto load_kmajor = [&](Chunk<T>& dst, const T* base, int ld, int kk, int r, int rows) __attribute__((always_inline)) {
+            if (kk < p.K && r + 3 < rows && p.vec_in) dst.load(base + (long)kk * ld + r);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst.set(e, (kk < p.K && r + e < rows) ? ElemTraits<T>::to_f(base[(long)kk * ld + r + e]) : 0.f);
+            }
+        };
+        if constexpr ((TR & 1) != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_kmajor(t.a[j], A, p.lda, l_kt * BK + kc + 8 * j, l_mt * BM + r0 * 4, p.M);
+        }
+        if constexpr ((TR & 2) != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_kmajor(t.w[j], W, p.ldw, l_kt * BK + kc + 8 * j, n0 + r0 * 4, p.N);
+        }
         if (LEAN || p.vec_in) {
             const bool k_ok = k < p.K;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (a_ok[j] && k_ok) t.a[j].load(A + a_off[j] + k); else t.a[j].zero();
-                if (w_ok[j] && k_ok) t.w[j].load(W + w_off[j] + k); else t.w[j].zero();
+                if constexpr ((TR & 1) == 0) { if (a_ok[j] && k_ok) t.a[j].load(A + a_off[j] + k); else t.a[j].zero(); }
+                if constexpr ((TR & 2) == 0) { if (w_ok[j] && k_ok) t.w[j].load(W + w_off[j] + k); else t.w[j].zero(); }
             }
         } else {
 #pragma unroll
@@ -165,8 +188,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
 #pragma unroll
                 for (int e = 0; e < EPC; ++e) {
                     const bool ok = (k + e) < p.K;
-                    t.a[j].set(e, (a_ok[j] && ok) ? ElemTraits<T>::to_f(A[a_off[j] + k + e]) : 0.f);
-                    t.w[j].set(e, (w_ok[j] && ok) ? ElemTraits<T>::to_f(W[w_off[j] + k + e]) : 0.f);
+                    if constexpr ((TR & 1) == 0) t.a[j].set(e, (a_ok[j] && ok) ? ElemTraits<T>::to_f(A[a_off[j] + k + e]) : 0.f);
+                    if constexpr ((TR & 2) == 0) t.w[j].set(e, (w_ok[j] && ok) ? ElemTraits<T>::to_f(W[w_off[j] + k + e]) : 0.f);
                 }
         }
         if constexpr (PRO != 0) {
@@ -194,6 +217,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
 
     for (int cm = blockIdx.x; cm < p.num_m_tiles; cm += gridDim.x) {
         const int m0 = cm * BM;
+        [[maybe_unused]] float rsum[4] = {0.f, 0.f, 0.f, 0.f};       // K-major A: this thread's share of sum_k A'[m0 + 4 r0 + e][k]
         f32x16 acc[2][2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -217,8 +241,19 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
             __syncthreads();                      // LDS free: previous tile consumed / epilogue staging drained
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                t.a[j].store((T*)(sA + (r0 + 32 * j) * ROWB + kc * 16));
-                t.w[j].store((T*)(sW + (r0 + 32 * j) * ROWB + kc * 16));
+                if constexpr ((TR & 1) == 0) t.a[j].store((T*)(sA + (r0 + 32 * j) * ROWB + kc * 16));
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        *(float*)(sA + (r0 * 4 + e) * ROWB + (kc + 8 * j) * 4) = t.a[j].get(e);
+                        rsum[e] += t.a[j].get(e);                  // (dead unless a_rowsum is asked for: see below)
+                    }
+                }
+                if constexpr ((TR & 2) == 0) t.w[j].store((T*)(sW + (r0 + 32 * j) * ROWB + kc * 16));
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) *(float*)(sW + (r0 * 4 + e) * ROWB + (kc + 8 * j) * 4) = t.w[j].get(e);
+                }
             }
             __syncthreads();
             // advance the load position and put the next tile's loads in flight under the MFMAs (and the epilogue)
@@ -244,6 +279,18 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
             }
         }
 
+        if constexpr ((TR & 1) != 0) {
+            // bias gradient of nn.Linear fused into its weight-gradient GEMM: row sums of A' = dY^T, i.e. column sums of dY.  The
+            // eight threads kc = 0..7 of a row group are adjacent lanes: fixed-order xor tree, deterministic
+            if (p.a_rowsum && blockIdx.y == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = rsum[e];
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                    if (kc == 0 && m0 + r0 * 4 + e < p.M) p.a_rowsum[m0 + r0 * 4 + e] = v;
+                }
+            }
+        }
         // ---- epilogue: registers -> (scale, bias, act, round) -> LDS -> full-row stores ----------
         __syncthreads();                          // every wave is done reading the operand tiles
         char* stg = smem + wave * 64 * SROW;
@@ -766,14 +813,14 @@ int grid_m_for(int M, int N, int capacity) {
 
 template <typename T> int grid_m_query(int M, int N);
 
-template <typename T, int PRO, bool LEAN, int MINW>
+template <typename T, int PRO, bool LEAN, int MINW, int TR = 0>
 int launch_gemm_w(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     const int gm = grid_m_query<T>(a->M, a->N);      // same capacity for every variant (see grid_m_query)
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
     static bool attr_set = false;
     constexpr int lds = gemm_lds_bytes<T>();
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_kernel<T, PRO, LEAN, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_kernel<T, PRO, LEAN, MINW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", lds);
             return CVCL_ELAUNCH;
         }
@@ -781,7 +828,7 @@ int launch_gemm_w(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     }
     dim3 grid(gm, cvcl_div_up(a->N, BN));
     CvclProfScope prof(stream, sizeof(T) == 2 ? CVCL_K_GEMM : CVCL_K_GEMM_F32);
-    hipLaunchKernelGGL((gemm_kernel<T, PRO, LEAN, MINW>), grid, dim3(256), lds, stream, d);
+    hipLaunchKernelGGL((gemm_kernel<T, PRO, LEAN, MINW, TR>), grid, dim3(256), lds, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
@@ -799,6 +846,7 @@ int launch_gemm_v(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
 // tiling would leave a handful of workgroups walking the whole K (8 workgroups for the fc layer = 160 us).  Here a
 // workgroup owns a 16 x 16 output tile and splits K over 16 thread slices (float4 loads straight from L2, 4 x 4
 // register micro-tiles), then reduces the 16 partial tiles through LDS in a fixed order -- deterministic, no scratch.
+template <int TR>
 __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __restrict__ A, const float* __restrict__ W,
                                                              float* __restrict__ C, int M, int N, int K, int lda, int ldw,
                                                              int ldc, const float* __restrict__ exp_scale,
@@ -813,13 +861,30 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
         ap[i] = A + (long)min(m0 + i, M - 1) * lda;          // rows past the edge are clamped; their results are not stored
         wp[i] = W + (long)min(n0 + i, N - 1) * ldw;
     }
+    // K-major operand (TR bit 0: A, bit 1: W; see gemm_kernel): the 4 x 4 block (4 rows x 4 k) is fetched as 4 k-rows of 4
+    // consecutive rows; rows past the edge read as zero (their results are not stored)
+    auto kmajor = [&](const float* base, int ld, int k, int r, int rows, f32x4 (&out)[4]) __attribute__((always_inline)) {
+        f32x4 t[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (r + 3 < rows) t[kk] = *reinterpret_cast<const f32x4*>(base + (long)(k + kk) * ld + r);
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[kk][e] = r + e < rows ? base[(long)(k + kk) * ld + r + e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = f32x4{t[0][i], t[1][i], t[2][i], t[3][i]};
+    };
     float acc[4][4] = {};
     for (int k = kl * 4; k < K; k += 64) {
         f32x4 a[4], w[4];
+        if constexpr ((TR & 1) != 0) kmajor(A, lda, k, m0, M, a);
+        if constexpr ((TR & 2) != 0) kmajor(W, ldw, k, n0, N, w);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[i] = *reinterpret_cast<const f32x4*>(ap[i] + k);
-            w[i] = *reinterpret_cast<const f32x4*>(wp[i] + k);
+            if constexpr ((TR & 1) == 0) a[i] = *reinterpret_cast<const f32x4*>(ap[i] + k);
+            if constexpr ((TR & 2) == 0) w[i] = *reinterpret_cast<const f32x4*>(wp[i] + k);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -940,6 +1005,15 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.vec_out = (a->ldc % EPC == 0) && al16(a->C) && (!a->R || ((a->ldr % EPC == 0) && al16(a->R)));
     d.num_m_tiles = cvcl_div_up(a->M, BM);
     d.C2 = nullptr;
+    d.a_rowsum = a->a_rowsum;
+    const int tr = (a->a_trans ? 1 : 0) | (a->w_trans ? 2 : 0);
+    if (tr || a->a_rowsum) {
+        // K-major operands / fused row sums: the fp32 gradient GEMMs of the trainable tail (no prologue, gather, statistics or BN tail)
+        CVCL_CHECK_ARG(sizeof(T) == 4, "cvcl_gemm: a_trans / w_trans / a_rowsum are fp32 options");
+        CVCL_CHECK_ARG(!a->a_rowsum || a->a_trans, "cvcl_gemm: a_rowsum goes with a_trans (the bias gradient beside dW = dY^T X)");
+        CVCL_CHECK_ARG(!a->a_scale && !(a->gather_stride > 1) && !a->stats && !a->centre && !a->c_scale && !a->C_pre && !a->G && a->C,
+                       "cvcl_gemm: K-major operands take no prologue / gather / statistics / BN-tail options");
+    }
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
         if (pick_gemm_pro(CVCL_BF16, a)) return cvcl_gemm_pro(a, stream);
@@ -978,17 +1052,27 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     if constexpr (sizeof(T) == 4) {
         auto al16p = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
         if (pro_kind(a) == 0 && !(a->gather_stride > 1) && !a->stats && !a->R && !a->centre && a->act == CVCL_ACT_NONE && a->K % 4 == 0 &&
-            a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) &&
+            a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) && !a->a_rowsum &&
             // measured cost models (us, MI355X): the split-K VALU kernel runs ~13.4 GMAC/s-per-us of work on any shape; the
             // 128-tile fp32 MFMA kernel needs ~4.6 us per 64-deep K step per round of <= 256 tiles, whatever M and N are
             (double)a->M * a->N * a->K / 13.4e6 + 5.0 <
                 12.0 + (a->K / 64.0) * 4.6 * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256)) {
             CvclProfScope prof(stream, CVCL_K_GEMM_F32);
-            hipLaunchKernelGGL(gemm_f32_small_kernel, dim3(cvcl_div_up(a->N, 16), cvcl_div_up(a->M, 16)), dim3(256), 0, stream,
-                               (const float*)a->A, (const float*)a->W, (float*)a->C, a->M, a->N, a->K, a->lda, a->ldw, a->ldc,
-                               a->exp_scale, a->bias);
+            const dim3 grid(cvcl_div_up(a->N, 16), cvcl_div_up(a->M, 16));
+#define CVCL_SMALL(TR_) hipLaunchKernelGGL(gemm_f32_small_kernel<TR_>, grid, dim3(256), 0, stream, (const float*)a->A, (const float*)a->W, \
+                                           (float*)a->C, a->M, a->N, a->K, a->lda, a->ldw, a->ldc, a->exp_scale, a->bias)
+            switch (tr) { case 0: CVCL_SMALL(0); break; case 1: CVCL_SMALL(1); break; case 2: CVCL_SMALL(2); break; default: CVCL_SMALL(3); }
+#undef CVCL_SMALL
             CVCL_LAUNCH_CHECK();
             return CVCL_OK;
+        }
+        if (tr) {
+            CVCL_CHECK_ARG(pro_kind(a) == 0, "cvcl_gemm: K-major operands take no prologue");
+            switch (tr) {
+                case 1: return launch_gemm_w<float, 0, false, 1, 1>(a, d, stream);
+                case 2: return launch_gemm_w<float, 0, false, 1, 2>(a, d, stream);
+                default: return launch_gemm_w<float, 0, false, 1, 3>(a, d, stream);
+            }
         }
     }
     switch (pro_kind(a)) {

@@ -2,6 +2,7 @@
 // Same interface as cvcl_gemm (include/cvcl_hip.h); selected by the dispatcher in gemm.hip for the MFMA-bound shapes --
 // the 1x1 convolutions of ResNeXt layers 2-4 (reference call site multimodal/multimodal.py:101) and the ViT linears
 // (multimodal/vision_transformer_dino_mugs.py:92-94,113-115).
+#include <algorithm>
 #include <cstdlib>
 
 #include "gemm8w_kernel.h"
@@ -52,6 +53,116 @@ int g8_launch(const g8w::Dev& d, int grid, hipStream_t stream) {
     return CVCL_OK;
 }
 
+// ---- linear epilogue (EPI 1 / 2): tile height, grid and -- round 5 -- the REMAINDER launch ----------------------------------
+// A launch of T tiles on G workgroups costs ceil(T / G) rounds whatever the last round holds (ViT-B/14 proj at B = 256: 771 tiles on
+// 256 CUs = 3.01 -> 4 rounds).  When the last round is poorly filled, the rows are cut in two: `rows_main` = the m-tiles that
+// whole rounds hold, at 256 | 224 rows per tile, and the remaining rows as ONE more round of shorter tiles (64 .. 256 rows, a
+// second launch of the same kernel at a smaller MI on the same stream).  Costs are in tile ROWS per workgroup (a round of MI-row
+// tiles ~ MI), the remainder's from the measured per-MI times (tools/g8_rem_bench.py): shorter tiles re-read the 256-column W
+// stage for fewer MFMAs, so a 64-row round costs about what a 130-row one does, plus the second launch's fill and drain.
+struct G8Plan { int bm, grid, rows_main, bm_rem, grid_rem; long cost; };
+
+long g8_rem_cost(int bm_rem) { return (bm_rem < 128 ? 128 : bm_rem) + 40; }
+
+int g8_lean(long total, int grid) {                          // the smallest grid (multiple of 8) with the same number of rounds
+    static const bool lean_on = cvcl_lab_int("CVCL_LEAN_GRID", 1) != 0;
+    const long rounds = (total + grid - 1) / grid;
+    const int lean = (int)(((total + rounds - 1) / rounds + 7) & ~7L);
+    return lean_on && lean < grid ? lean : grid;
+}
+
+G8Plan g8_plan(int M, int ncol, bool allow_remainder) {
+    const int cus = g8_num_cus() & ~7;
+    G8Plan best = {256, 8, M, 0, 0, -1};
+    for (int h : {256, 224}) {                               // one launch (rounds 2-4)
+        const long total = (long)cvcl_div_up(M, h) * ncol;
+        const int g = total < cus ? (int)((total + 7) & ~7L) : cus;
+        const long cost = ((total + g - 1) / g) * h;
+        if (best.cost < 0 || cost < best.cost) best = {h, g8_lean(total, g), M, 0, 0, cost};
+    }
+    static const bool rem_on = cvcl_lab_int("CVCL_G8_REMAINDER", 1) != 0;
+    if (!allow_remainder || !rem_on) return best;
+    for (int h : {256, 224}) {                               // whole rounds + one round of shorter tiles
+        const long total = (long)(M / h) * ncol;             // full tiles only
+        const long r = total / cus;
+        if (r < 1) continue;
+        const int mt = (int)std::min<long>(r * cus / ncol, M / h);
+        const int rows_main = mt * h, mr = M - rows_main;
+        if (mr <= 0) continue;
+        const int per_round = cus / ncol;                    // m-tiles one round holds
+        if (per_round < 1) continue;
+        int bm_rem = ((cvcl_div_up(mr, per_round) + 31) / 32) * 32;
+        if (bm_rem < 64) bm_rem = 64;
+        if (bm_rem > 256) continue;
+        const long main_tiles = (long)mt * ncol, rem_tiles = (long)cvcl_div_up(mr, bm_rem) * ncol;
+        const long cost = cvcl_div_up(main_tiles, cus) * h + g8_rem_cost(bm_rem);
+        if (cost < best.cost)
+            best = {h, g8_lean(main_tiles, cus), rows_main, bm_rem, (int)((rem_tiles + 7) & ~7L), cost};
+    }
+    return best;
+}
+
+// super-row height of the supertile walk (gemm8w_kernel.h): the G / 8 workgroups of an XCD multiply sr m-tiles x (G / 8) / sr
+// column tiles at a time -- 8 x 4 on a full chip; with fewer column tiles than that, all of them
+int g8_superrow(int grid, int ncol) {
+    const int cpx = grid >> 3;
+    int sr = 8;
+    if (ncol * sr < cpx) sr = cvcl_div_up(cpx, ncol);
+    static const int sr_lab = cvcl_lab_int("CVCL_G8_SUPERROW", 0);   // (lab: 0 = the rule above; 1 = the column-fastest list of rounds 2-4)
+    return sr_lab > 0 ? sr_lab : sr;
+}
+
+template <int EPI, bool LNF>
+int g8_launch_mi(int bm, const g8w::Dev& d, int grid, hipStream_t st) {
+    switch (bm / 32) {
+        case 8: return g8_launch<8, EPI, LNF>(d, grid, st);
+        case 7: return g8_launch<7, EPI, LNF>(d, grid, st);
+        default: break;
+    }
+    if constexpr (LNF) {                                     // the shorter remainder tiles: the ViT's folded linears only
+        switch (bm / 32) {
+            case 6: return g8_launch<6, EPI, LNF>(d, grid, st);
+            case 5: return g8_launch<5, EPI, LNF>(d, grid, st);
+            case 4: return g8_launch<4, EPI, LNF>(d, grid, st);
+            case 3: return g8_launch<3, EPI, LNF>(d, grid, st);
+            case 2: return g8_launch<2, EPI, LNF>(d, grid, st);
+            default: break;
+        }
+    }
+    cvcl_set_error("cvcl_gemm8w: no %d-row tile for this epilogue", bm);
+    return CVCL_EINVAL;
+}
+
+int g8_linear(g8w::Dev d, const cvcl_gemm_args* a, hipStream_t st) {
+    // the linear epilogue comes in two instantiations: activation (no residual) and residual (no activation) -- the only
+    // combinations nn.Linear call sites on the path use (vit:92-94 fc1 + GELU, :113-115 / :146-147 proj, fc2 + residual)
+    CVCL_CHECK_ARG(!(a->R && a->act != CVCL_ACT_NONE), "cvcl_gemm8w: activation and residual together are not implemented");
+    const bool lnf = a->ln_stats || a->row_part;
+    const G8Plan pl = g8_plan(a->M, d.ncol, lnf);
+    CvclProfScope prof(st, CVCL_K_GEMM8W);
+    auto launch = [&](const g8w::Dev& dd, int bm, int grid) -> int {
+        if (a->ln_stats) return g8_launch_mi<1, true>(bm, dd, grid, st);
+        if (a->row_part) return g8_launch_mi<2, true>(bm, dd, grid, st);
+        return a->R ? g8_launch_mi<2, false>(bm, dd, grid, st) : g8_launch_mi<1, false>(bm, dd, grid, st);
+    };
+    g8w::Dev m = d;
+    m.M = pl.rows_main; m.a_rows = pl.rows_main;
+    m.tiles_m = cvcl_div_up(m.M, pl.bm);
+    m.grid_m = g8_superrow(pl.grid, d.ncol);
+    int rc = launch(m, pl.bm, pl.grid);
+    if (rc != CVCL_OK || !pl.bm_rem) return rc;
+    g8w::Dev r = d;                                          // the remaining rows: every row-indexed operand moves down by rows_main
+    const long o = pl.rows_main;
+    r.A = d.A + o * d.lda; r.C = d.C + o * d.ldc;
+    if (d.R) r.R = d.R + o * d.ldr;
+    if (d.ln_stats) r.ln_stats = d.ln_stats + o * 2;
+    if (d.row_part) r.row_part = d.row_part + o * (d.N >> 6) * 2;
+    r.M = d.M - pl.rows_main; r.a_rows = r.M;
+    r.tiles_m = cvcl_div_up(r.M, pl.bm_rem);
+    r.grid_m = g8_superrow(pl.grid_rem, d.ncol);
+    return launch(r, pl.bm_rem, pl.grid_rem);
+}
+
 }  // namespace
 
 // shapes the kernel accepts (the dispatcher adds its own policy on top)
@@ -79,6 +190,15 @@ extern "C" int cvcl_gemm8w_tile_rows(int M, int N) {
 extern "C" int cvcl_gemm8w_stats_rows(int M, int N) {
     const int bm = cvcl_gemm8w_tile_rows(M, N);
     return g8_grid_m(cvcl_div_up(M, bm), N / 256);
+}
+
+// the launch plan of the linear epilogue for an [M, N] output under the current CU share: plan5 = {tile rows, workgroups, rows of the
+// main launch, tile rows of the remainder launch (0 = none), its workgroups}; folded = the ln_stats / row_part epilogues
+extern "C" int cvcl_gemm8w_linear_plan(int M, int N, int folded, int* plan5) {
+    CVCL_CHECK_ARG(plan5 && M >= 1 && N >= 256 && N % 256 == 0, "cvcl_gemm8w_linear_plan: bad args");
+    const G8Plan pl = g8_plan(M, N / 256, folded != 0);
+    plan5[0] = pl.bm; plan5[1] = pl.grid; plan5[2] = pl.rows_main; plan5[3] = pl.bm_rem; plan5[4] = pl.grid_rem;
+    return CVCL_OK;
 }
 
 // epi 0: convolution epilogue (round + BN partial sums; C may be NULL = statistics only); epi 1: bias / activation / residual
@@ -115,40 +235,20 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     d.gs = gather ? a->gather_stride : 1; d.g_hw = gather ? a->gather_ho * a->gather_wo : 1; d.g_wo = gather ? a->gather_wo : 1;
     d.g_hi = a->gather_hi; d.g_wi = a->gather_wi; d.a_rows = (int)a_rows;
     int bm, grid;
+    // a plain product without BN statistics has no reason to keep a column tile per workgroup: it takes the linear epilogue's
+    // supertile walk (bias NULL = 0) -- the large square products of tools/blaslt_compare.py; every convolution of the trunk asks
+    // for statistics and keeps the column-fixed mapping
+    if (epi == 0 && !a->stats && !a->centre && !gather && a->C) epi = 1;
     if (epi == 0) {                                          // column-fixed mapping: grid_m workgroups per column tile
         bm = cvcl_gemm8w_tile_rows(a->M, a->N);
         d.tiles_m = cvcl_div_up(a->M, bm);
         d.grid_m = g8_grid_m(d.tiles_m, d.ncol);
         if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= d.grid_m, "cvcl_gemm8w: stats_rows %d < %d", a->stats_rows, d.grid_m);
         grid = d.grid_m * d.ncol;
-    } else {                                                 // flat mapping: every CU takes tiles q, q + grid, ... of the column-fastest list
-        bm = 256;
-        long best = -1;
-        for (int h : {256, 224}) {
-            const long total = (long)cvcl_div_up(a->M, h) * d.ncol;
-            const long g = total < g8_num_cus() ? ((total + 7) & ~7L) : (g8_num_cus() & ~7);
-            const long cost = ((total + g - 1) / g) * h;
-            if (best < 0 || cost < best) { best = cost; bm = h; }
-        }
-        d.tiles_m = cvcl_div_up(a->M, bm);
-        const long total = (long)d.tiles_m * d.ncol;
-        grid = total < g8_num_cus() ? (int)((total + 7) & ~7L) : (g8_num_cus() & ~7);
-        {                                                    // as g8_grid_m: the smallest grid with the same number of rounds
-            static const bool lean_on = cvcl_lab_int("CVCL_LEAN_GRID", 1) != 0;
-            const long rounds = (total + grid - 1) / grid;
-            const int lean = (int)(((total + rounds - 1) / rounds + 7) & ~7L);
-            if (lean_on && lean < grid) grid = lean;
-        }
-        d.grid_m = 0;
+    } else {
+        return g8_linear(d, a, (hipStream_t)stream);
     }
     CvclProfScope prof(stream, CVCL_K_GEMM8W);
-    // the linear epilogue comes in two instantiations: activation (no residual) and residual (no activation) -- the only
-    // combinations nn.Linear call sites on the path use (vit:92-94 fc1 + GELU, :113-115 / :146-147 proj, fc2 + residual)
-    CVCL_CHECK_ARG(epi == 0 || !(a->R && a->act != CVCL_ACT_NONE), "cvcl_gemm8w: activation and residual together are not implemented");
-    const int k = epi == 0 ? 0 : (a->R ? 2 : 1);
     hipStream_t st = (hipStream_t)stream;
-    if (a->ln_stats) return bm == 256 ? g8_launch<8, 1, true>(d, grid, st) : g8_launch<7, 1, true>(d, grid, st);
-    if (a->row_part) return bm == 256 ? g8_launch<8, 2, true>(d, grid, st) : g8_launch<7, 2, true>(d, grid, st);
-    if (bm == 256) return k == 0 ? g8_launch<8, 0>(d, grid, st) : k == 1 ? g8_launch<8, 1>(d, grid, st) : g8_launch<8, 2>(d, grid, st);
-    return k == 0 ? g8_launch<7, 0>(d, grid, st) : k == 1 ? g8_launch<7, 1>(d, grid, st) : g8_launch<7, 2>(d, grid, st);
+    return bm == 256 ? g8_launch<8, 0>(d, grid, st) : g8_launch<7, 0>(d, grid, st);
 }

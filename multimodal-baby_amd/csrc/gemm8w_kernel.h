@@ -77,17 +77,7 @@ __device__ __forceinline__ int swz(int g) { return (0x78 >> (2 * g)) & 3; }
 
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if constexpr (N == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
-    else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-    else static_assert(N < 0, "add the literal");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // What bounds it, what was tried (pipeline ablations, 4-wave / 8-phase / staggered variants, store flavours): DESIGN.md section 5;
@@ -105,19 +95,38 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     // ---- this workgroup's output tiles ----
     // EPI 0 (BN statistics per column): fixed column tile j, m-tiles i, i + grid_m, ...; blocks of one XCD (blockIdx % 8) hold
     //   the column tiles of the same m-tiles, so an m-tile's A rows are fetched into one L2 once.
-    // EPI 1 (linear epilogue): the tiles in column-fastest order, q, q + G, ... with q = this block's rank in XCD-major order
-    //   (consecutive q = consecutive tiles = same A rows = same XCD); every CU busy whatever N / 256 is.
+    // EPI 1 / 2 (linear epilogue), round 5 -- the SUPERTILE walk.  The tiles are put in one list: super-rows of `sr` m-tiles
+    //   (p.grid_m), inside a super-row column by column (serpentine: odd super-rows right to left), inside a column the sr m-tiles.
+    //   XCD x (= blockIdx % 8) owns the x-th eighth of that list and its G / 8 workgroups take consecutive entries, G / 8 at a time:
+    //   the tiles an XCD multiplies AT ONE TIME form a block of sr m-tiles x (G / 8) / sr columns -- each of its A tiles is shared
+    //   by (G / 8) / sr CUs and each W tile by sr CUs of the same L2 (sr = 8, 32 CUs: 8 + 4 operand tiles feed 32 output tiles;
+    //   the column-fastest list of rounds 2-4 gave an XCD 3.5 m-tiles x all N / 256 columns: 12.5 operand tiles at N = 2304, 33 at
+    //   N = 8192 -- profiles/r04_pmc_c4_summary.json: qkv pulled 3.7 x, fc1 6.5 x its operand bytes across the L2) -- and from one
+    //   round to the next the A group stays while the W slab moves on.  Every CU busy whatever N / 256 is, as before.
     constexpr bool LIN = EPI >= 1, RES = EPI == 2;
     constexpr bool FLAT = LIN;
     const int b = blockIdx.x;
     const int G = gridDim.x;
     int ti, tj, nt;
+    int L0 = 0;                                              // FLAT: this workgroup's first list entry; the next is cpx further
+    const int cpx = G >> 3;
+    // list entry -> (m-tile, column tile)
+    auto decode = [&](int L, int& i_out, int& j_out) __attribute__((always_inline)) {
+        const int per = p.grid_m * p.ncol;
+        const int sr = L / per, rem = L - sr * per;
+        const int ah = min(p.grid_m, p.tiles_m - sr * p.grid_m);
+        const int col = rem / ah;
+        i_out = sr * p.grid_m + (rem - col * ah);
+        j_out = (sr & 1) ? p.ncol - 1 - col : col;
+    };
     if constexpr (FLAT) {
-        const int q = (b & 7) * (G >> 3) + (b >> 3);
+        const int xcd = b & 7;
         const int total = p.tiles_m * p.ncol;
-        nt = q < total ? (total - q + G - 1) / G : 0;
-        ti = q / p.ncol;
-        tj = q - ti * p.ncol;
+        const int S0 = (int)(((long)xcd * total) >> 3), S1 = (int)(((long)(xcd + 1) * total) >> 3);
+        L0 = S0 + (b >> 3);
+        nt = L0 < S1 ? (S1 - L0 + cpx - 1) / cpx : 0;
+        ti = 0; tj = 0;
+        if (nt > 0) decode(L0, ti, tj);
     } else {
         const int xcd = b & 7, s = b >> 3;
         tj = s % p.ncol;
@@ -133,9 +142,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         }
         return;
     }
-    // tile k of this workgroup -> the step to tile k + 1 in (m-tile, column tile); FLAT: G tiles further in column-fastest order
-    const int step_i = FLAT ? G / p.ncol : p.grid_m;         // (FLAT: + 1 more m-tile when the column index wraps)
-    const int step_j = FLAT ? G - step_i * p.ncol : 0;
+    // EPI 0: tile k of this workgroup -> tile k + 1 is grid_m m-tiles further in the same column
+    const int step_i = p.grid_m;
 
     const bf16_t* __restrict__ A = p.A;
     const bf16_t* __restrict__ W = p.W;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     if (p.gs > 1) { a_raw[0] = gathered(ti, 0); a_raw[1] = gathered(ti, 1); }
     // the next tile is a uniform step further; rows past M (ragged last tile) are clamped to an address inside the last row
     // (any valid address will do: those rows are masked at the store) -- no per-lane state beyond the offsets
-    const unsigned a_unit = (unsigned)BM * (unsigned)p.lda, w_unit = (unsigned)BN * (unsigned)p.ldw;
+    const unsigned a_unit = (unsigned)BM * (unsigned)p.lda;
     const unsigned a_lim = (unsigned)(p.a_rows - 1) * (unsigned)p.lda + 24;
     int l_t = 0, l_ks = 0, l_j = tj, l_i = ti;                         // (tile, k stage) of the next stage to load; its column tile
     auto issue = [&](int buf) __attribute__((always_inline)) {
@@ -197,18 +205,21 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             l_ks = 0;
             if (l_t + 1 < nt) {
                 ++l_t;
-                int di = step_i, dj = step_j;
                 if constexpr (FLAT) {
-                    if (l_j + dj >= p.ncol) { dj -= p.ncol; ++di; }
-                    l_j += dj;
-                }
-                const unsigned da = (unsigned)di * a_unit, dw = (unsigned)dj * w_unit;   // (negative steps wrap modulo 2^32: fine)
-                l_i += di;
+                    decode(L0 + l_t * cpx, l_i, l_j);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (p.gs > 1) a_raw[j] = gathered(l_i, j);
-                    else a_raw[j] += da;
-                    w_off[j] += dw;
+                    for (int j = 0; j < 2; ++j) {
+                        const int rw = (wave * 2 + j) * 16 + srow;
+                        a_raw[j] = (unsigned)(l_i * BM + min(rw, BM - 1)) * (unsigned)p.lda + slog * 8;
+                        w_off[j] = (unsigned)(l_j * BN + rw) * (unsigned)p.ldw + slog * 8;
+                    }
+                } else {
+                    l_i += step_i;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (p.gs > 1) a_raw[j] = gathered(l_i, j);
+                        else a_raw[j] += (unsigned)step_i * a_unit;
+                    }
                 }
             }
         }
@@ -446,11 +457,10 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             if constexpr (LNF && EPI == 1) { epi_ops = epilogue(c_i * BM, c_j * BN, c_t & 1); ++c_t; }
             else epi_ops = epilogue(c_i * BM, c_j * BN, 0);
             after_epi = 3;
-            c_i += step_i;
             if constexpr (FLAT) {
-                c_j += step_j;
-                if (c_j >= p.ncol) { c_j -= p.ncol; ++c_i; }
-            }
+                if constexpr (!(LNF && EPI == 1)) ++c_t;
+                if (c_t < nt) decode(L0 + c_t * cpx, c_i, c_j);
+            } else c_i += step_i;
         }
     };
     for (int g = 0; g < S; g += 2) {

@@ -394,50 +394,55 @@ extern "C" int cvcl_sim_logits_fwd(const float* img, const float* txt, const flo
 
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t cvcl_sim_logits_bwd_workspace_bytes(int Ni, int Nt, int E) {
-    return al256((size_t)E * Nt * 4) + al256((size_t)E * Ni * 4) + al256((size_t)Ni * Nt * 4) + al256(256 * 4);
-}
+// (round 5: the gradient GEMMs read their operands K-major in place -- the workspace only holds the 256 partial sums of the
+// temperature gradient; the arguments stay for ABI stability)
+extern "C" size_t cvcl_sim_logits_bwd_workspace_bytes(int, int, int) { return al256(256 * 4); }
 
-extern "C" int cvcl_sim_logits_bwd(const float* img, const float* txt, const float* neg_log_temp, const float* logits,
-                                   const float* d_logits, float* d_img, float* d_txt, float* d_neg_log_temp,
-                                   int Ni, int Nt, int E, void* workspace, size_t workspace_bytes, void* stream) {
-    CVCL_CHECK_ARG(img && txt && neg_log_temp && d_logits && workspace, "cvcl_sim_logits_bwd: null pointer");
-    if (workspace_bytes < cvcl_sim_logits_bwd_workspace_bytes(Ni, Nt, E)) {
-        cvcl_set_error("cvcl_sim_logits_bwd: workspace too small");
-        return CVCL_EWORKSPACE;
-    }
-    char* w = (char*)workspace;
-    float* txtT = (float*)w; w += al256((size_t)E * Nt * 4);
-    float* imgT = (float*)w; w += al256((size_t)E * Ni * 4);
-    float* dST = (float*)w;  w += al256((size_t)Ni * Nt * 4);
-    float* part = (float*)w;
+extern "C" int cvcl_sim_logits_bwd_rows(const float* img, const float* txt, const float* neg_log_temp, const float* logits,
+                                        const float* d_logits, float* d_img_rows, float* d_txt_rows, float* d_neg_log_temp,
+                                        int Ni, int Nt, int E, int i0, int ni, int t0, int nt, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    CVCL_CHECK_ARG(img && txt && neg_log_temp && d_logits, "cvcl_sim_logits_bwd: null pointer");
+    CVCL_CHECK_ARG(Ni > 0 && Nt > 0 && E > 0 && i0 >= 0 && ni >= 0 && i0 + ni <= Ni && t0 >= 0 && nt >= 0 && t0 + nt <= Nt,
+                   "cvcl_sim_logits_bwd: row ranges [%d, +%d) of %d / [%d, +%d) of %d", i0, ni, Ni, t0, nt, Nt);
     int rc;
-    if (d_img) {                                   // d_img = s * dS . txt
-        if ((rc = cvcl_transpose_f32(txt, txtT, Nt, E, stream))) return rc;
+    if (d_img_rows && ni > 0) {                    // d_img[i0 + r] = s * sum_t dS[i0 + r][t] txt[t]: W = txt as it lies ([K = Nt][N = E])
         cvcl_gemm_args a = {};
-        a.A = d_logits; a.W = txtT; a.C = d_img;
-        a.M = Ni; a.N = E; a.K = Nt; a.lda = Nt; a.ldw = Nt; a.ldc = E;
+        a.A = d_logits + (long)i0 * Nt; a.W = txt; a.C = d_img_rows;
+        a.M = ni; a.N = E; a.K = Nt; a.lda = Nt; a.ldw = E; a.ldc = E;
+        a.w_trans = 1;
         a.exp_scale = neg_log_temp;
         if ((rc = cvcl_gemm(CVCL_F32, &a, stream))) return rc;
     }
-    if (d_txt) {                                   // d_txt = s * dS^T . img
-        if ((rc = cvcl_transpose_f32(img, imgT, Ni, E, stream))) return rc;
-        if ((rc = cvcl_transpose_f32(d_logits, dST, Ni, Nt, stream))) return rc;
+    if (d_txt_rows && nt > 0) {                    // d_txt[t0 + r] = s * sum_i dS[i][t0 + r] img[i]: A = the column block of dS, K-major
         cvcl_gemm_args a = {};
-        a.A = dST; a.W = imgT; a.C = d_txt;
-        a.M = Nt; a.N = E; a.K = Ni; a.lda = Ni; a.ldw = Ni; a.ldc = E;
+        a.A = d_logits + t0; a.W = img; a.C = d_txt_rows;
+        a.M = nt; a.N = E; a.K = Ni; a.lda = Nt; a.ldw = E; a.ldc = E;
+        a.a_trans = 1; a.w_trans = 1;
         a.exp_scale = neg_log_temp;
         if ((rc = cvcl_gemm(CVCL_F32, &a, stream))) return rc;
     }
     if (d_neg_log_temp) {                          // d/d(log s) of s*M  =  sum(dS * logits)
         CvclProfScope prof(stream, CVCL_K_HEAD);
-        CVCL_CHECK_ARG(logits, "cvcl_sim_logits_bwd: logits needed for the temperature gradient");
+        CVCL_CHECK_ARG(logits && workspace, "cvcl_sim_logits_bwd: logits and a workspace are needed for the temperature gradient");
+        if (workspace_bytes < cvcl_sim_logits_bwd_workspace_bytes(Ni, Nt, E)) {
+            cvcl_set_error("cvcl_sim_logits_bwd: workspace too small");
+            return CVCL_EWORKSPACE;
+        }
+        float* part = (float*)workspace;
         hipLaunchKernelGGL(dot_partial_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, d_logits, logits,
                            (long)Ni * Nt, part);
         hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, 256, d_neg_log_temp);
         CVCL_LAUNCH_CHECK();
     }
     return CVCL_OK;
+}
+
+extern "C" int cvcl_sim_logits_bwd(const float* img, const float* txt, const float* neg_log_temp, const float* logits,
+                                   const float* d_logits, float* d_img, float* d_txt, float* d_neg_log_temp,
+                                   int Ni, int Nt, int E, void* workspace, size_t workspace_bytes, void* stream) {
+    return cvcl_sim_logits_bwd_rows(img, txt, neg_log_temp, logits, d_logits, d_img, d_txt, d_neg_log_temp, Ni, Nt, E, 0, Ni, 0, Nt,
+                                    workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t cvcl_infonce_workspace_bytes(int N) { return (size_t)6 * N * sizeof(float); }

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvcl_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
                   "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply", "bn_bwd", "wgrad", "gemm8w", "gemm_pro")
@@ -42,6 +42,7 @@ class GemmArgs(C.Structure):
         ("centre", C.c_void_p),
         ("A2", C.c_void_p), ("W2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldw2", C.c_int), ("centre2", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("row_part", C.c_void_p),
+        ("a_trans", C.c_int), ("w_trans", C.c_int), ("a_rowsum", C.c_void_p),
     ]
 
 
@@ -66,6 +67,7 @@ SIGNATURES = {
     "cvcl_sim_logits_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "cvcl_sim_logits_bwd_workspace_bytes": (_SZ, [_I, _I, _I]),
     "cvcl_sim_logits_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _SZ, _P]),
+    "cvcl_sim_logits_bwd_rows": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _SZ, _P]),
     "cvcl_infonce_workspace_bytes": (_SZ, [_I]),
     "cvcl_infonce_fwd": (_I, [_P, _I, _P, _P, _P, _P, _SZ, _P]),
     "cvcl_infonce_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P]),
@@ -134,6 +136,7 @@ SIGNATURES = {
     "cvcl_bn_from_gram": (_I, [_P, _I, C.c_long, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P]),
     "cvcl_row_stats": (_I, [_I, _P, C.c_long, _P, C.c_long, _I, _F, _P]),
     "cvcl_row_stats_finalize": (_I, [_P, _I, _P, C.c_long, _I, _F, _P]),
+    "cvcl_gemm8w_linear_plan": (_I, [_I, _I, _I, _P]),
     "cvcl_gemm8w_tile_rows": (_I, [_I, _I]),
     "cvcl_gemm8w_stats_rows": (_I, [_I, _I]),
     "cvcl_bf16_to_f32": (_I, [_P, _P, C.c_long, _P]),
@@ -338,14 +341,20 @@ def cvcl_dtype(t: torch.dtype) -> int:
 
 def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None, a_shift=None, a_relu=False,
          exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None, centre=None,
-         ln_stats=None, ln_colsum=None, row_part=None, query_ln=False):
+         ln_stats=None, ln_colsum=None, row_part=None, query_ln=False, a_trans=False, w_trans=False, a_rowsum=None):
     """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype.
-    ``centre`` [N] f32 (convolution epilogues): C = round(A' W^T - centre), statistics of that (cvcl_hip.h "Centred storage")."""
+    ``centre`` [N] f32 (convolution epilogues): C = round(A' W^T - centre), statistics of that (cvcl_hip.h "Centred storage").
+    fp32 only: ``a_trans`` -- A is given as [K, M]; ``w_trans`` -- W is given as [K, N] (the operands of a gradient GEMM as they
+    lie, no transposed copies); ``a_rowsum`` [M] f32 (with a_trans) receives sum_k A'[m][k] (the bias gradient beside dW)."""
     dt = cvcl_dtype(A.dtype)
     if W.dtype != A.dtype:
         raise CvclError("gemm operands must share a dtype")
-    K = W.shape[1]
-    N = W.shape[0]
+    K, N = (W.shape[0], W.shape[1]) if w_trans else (W.shape[1], W.shape[0])
+    ldw = W.shape[1]
+    if a_trans:
+        if A.dim() != 2 or A.shape[0] != K or M is not None or lda is not None:
+            raise CvclError("a_trans: A must be a [K, M] matrix")
+        M, lda = A.shape[1], A.shape[1]
     if M is None:
         M = A.numel() // A.shape[-1]
     lda = lda if lda is not None else A.shape[-1]
@@ -353,7 +362,8 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
         out = torch.empty((M, N), dtype=A.dtype, device=A.device)
     a = GemmArgs()
     a.A, a.W, a.C = ptr(A), ptr(W), ptr(out)
-    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, lda, K, N
+    a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, lda, ldw, N
+    a.a_trans, a.w_trans, a.a_rowsum = int(a_trans), int(w_trans), ptr(a_rowsum, torch.float32)
     a.a_scale, a.a_shift, a.a_relu = ptr(a_scale, torch.float32), ptr(a_shift, torch.float32), int(a_relu)
     if gather is not None:
         a.gather_ho, a.gather_wo, a.gather_hi, a.gather_wi, a.gather_stride = gather

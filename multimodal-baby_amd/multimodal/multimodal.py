@@ -451,8 +451,10 @@ class MultiModalModel(nn.Module):
             return ret
         fi, ft = image_features, text_features
         if self.training and self.global_negatives and parallel.is_distributed():
-            fi, ft = parallel.gather_features(fi, ft)                        # RCCL all-gather over xGMI
-        logits_per_image = ops.sim_logits(fi, ft, self._temperature_on(fi.device))   # reference :755, :783-786
+            # one RCCL all-gather over xGMI of the stacked features, the N_g x N_g logits, own-row gradient products backward
+            logits_per_image = parallel.global_sim_logits(fi, ft, self._temperature_on(fi.device))
+        else:
+            logits_per_image = ops.sim_logits(fi, ft, self._temperature_on(fi.device))   # reference :755, :783-786
         logits_per_text = logits_per_image.t()                               # reference :787 (bitwise the same values)
         ret = logits_per_image, logits_per_text
         if return_image_features:

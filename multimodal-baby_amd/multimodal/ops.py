@@ -135,13 +135,9 @@ class SpatialMaxLogits(torch.autograd.Function):
         H.check(H.lib().cvcl_spatial_max_bwd(H.ptr(d_logits.contiguous(), _F), H.ptr(arg), H.ptr(length), H.ptr(nlt), H.ptr(logits),
                                              H.ptr(d_mm), H.ptr(d_s), Bi, HW, Bt, L, s), "cvcl_spatial_max_bwd")
 
-        def transposed(t2d):
-            r, c = t2d.shape
-            out = torch.empty(c, r, dtype=_F, device=dev)
-            H.check(H.lib().cvcl_transpose_f32(H.ptr(t2d), H.ptr(out), r, c, s), "cvcl_transpose_f32")
-            return out
-        d_img = H.gemm(d_mm, transposed(txt_rows)) if need_i else None               # [Bi*HW, E] = d_mm . txt_rows
-        d_txt = H.gemm(transposed(d_mm), transposed(img_rows)) if need_t else None   # [Bt*L, E] = d_mm^T . img_rows
+        # the operands of both gradient GEMMs are read K-major in place (H.gemm a_trans / w_trans): no transposed copies
+        d_img = H.gemm(d_mm, txt_rows, w_trans=True) if need_i else None                    # [Bi*HW, E] = d_mm . txt_rows
+        d_txt = H.gemm(d_mm, img_rows, a_trans=True, w_trans=True) if need_t else None      # [Bt*L, E] = d_mm^T . img_rows
         return d_img, d_txt, None, (d_s.reshape(ctx.temp_shape) if need_s else None), None, None, None, None
 
 
@@ -248,22 +244,25 @@ class LinearF32(torch.autograd.Function):
         M, K = x.shape
         N = weight.shape[0]
         need_x, need_w, need_b = ctx.needs_input_grad
-        dx = dw = db = None
-        s = H.stream_ptr()
-        if need_w:                                   # dW[N,K] = dY^T[N,M] . X[M,K]  ->  A=dY^T, W'=X^T
-            dyT = torch.empty(N, M, dtype=_F, device=x.device)
-            xT = torch.empty(K, M, dtype=_F, device=x.device)
-            H.check(H.lib().cvcl_transpose_f32(H.ptr(dy), H.ptr(dyT), M, N, s), "cvcl_transpose_f32")
-            H.check(H.lib().cvcl_transpose_f32(H.ptr(x), H.ptr(xT), M, K, s), "cvcl_transpose_f32")
-            dw = H.gemm(dyT, xT)
-        if need_x:                                   # dX[M,K] = dY[M,N] . W[N,K]  ->  W' = W^T [K,N]
-            wT = torch.empty(K, N, dtype=_F, device=x.device)
-            H.check(H.lib().cvcl_transpose_f32(H.ptr(weight.contiguous()), H.ptr(wT), N, K, s), "cvcl_transpose_f32")
-            dx = H.gemm(dy, wT)
-        if need_b and ctx.has_bias:
-            db = torch.empty(N, dtype=_F, device=x.device)
-            H.check(H.lib().cvcl_colsum_f32(H.ptr(dy), H.ptr(db), M, N, s), "cvcl_colsum_f32")
-        return dx, dw, db
+        return linear_backward(x, weight, dy, (need_x, need_w, need_b and ctx.has_bias))
+
+
+def linear_backward(x, weight, dy, needs):
+    """(dx, dw, db) of y = x W^T + b for dy [M, N]: dW[N,K] = dY^T X and dX[M,K] = dY W as GEMMs over operands read K-major in
+    place; db = the column sums of dY comes out of the dW GEMM's own operand loads (a_rowsum).  needs = (dx, dw, db) wanted."""
+    M, K = x.shape
+    N = weight.shape[0]
+    need_x, need_w, need_b = needs
+    dx = dw = db = None
+    if need_b:
+        db = torch.empty(N, dtype=_F, device=x.device)
+    if need_w:                                       # A' = dY^T: dY is [K' = M][N] in memory; W' = X^T: X is [K' = M][K]
+        dw = H.gemm(dy, x, a_trans=True, w_trans=True, a_rowsum=db)
+    elif need_b:
+        H.check(H.lib().cvcl_colsum_f32(H.ptr(dy), H.ptr(db), M, N, H.stream_ptr()), "cvcl_colsum_f32")
+    if need_x:                                       # W' = W^T: W is [K' = N][K] in memory
+        dx = H.gemm(dy, weight.contiguous(), w_trans=True)
+    return dx, dw, db
 
 
 def token_cross_entropy(logits, labels, ignore_index=0):

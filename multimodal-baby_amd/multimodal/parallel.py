@@ -4,9 +4,10 @@ The reference has no distributed code; under Lightning DDP it would compute the 
 B x B block and average gradients.  Two modes here:
 
 * global negatives (default when world > 1): the L2-normalised image and text features of every rank are
-  all-gathered (2 x [B,E] fp32 per rank -> [world*B, E]); every rank evaluates the full symmetric InfoNCE
-  on the replicated matrices (4.3 GFLOP at 2048 x 2048 x 512 -- cheaper than a second collective) and
-  back-propagates only through its own rows.  The full-batch gradient is then the SUM over ranks of the
+  all-gathered in ONE collective ([2,B,E] fp32 per rank -> 2 x [world*B, E]); every rank evaluates the full
+  symmetric InfoNCE on the replicated matrices (4.3 GFLOP at 2048 x 2048 x 512 -- cheaper than a second
+  collective) and back-propagates only through its own rows (``global_sim_logits``: the two [B, N_g] x [N_g, E]
+  gradient products of its shard, not the full N_g x N_g x E ones).  The full-batch gradient is then the SUM over ranks of the
   per-rank parameter gradients (no division by world); parameters whose gradient is computed identically
   on every rank from the replicated loss (the learned temperature) are flagged ``_cvcl_replicated_grad``
   and averaged instead.  Parity definition: the reference's ``calculate_contrastive_loss`` math applied to
@@ -35,6 +36,11 @@ import torch
 import torch.distributed as dist
 
 
+# collectives issued by this module since import: {"all_gather": n, "all_reduce": n, "broadcast": n} -- read by bench.py's multi-rank
+# line (collectives per step) and by the tests (one feature all-gather per step)
+COLLECTIVES = {"all_gather": 0, "all_reduce": 0}
+
+
 def is_distributed() -> bool:
     """A process group with more than one rank -- or, with $CVCL_FORCE_DIST=1, any initialised process group: a world-size-1
     ``nccl`` (= RCCL) group then drives the whole multi-GPU path (feature all-gather, bucket all-reduce from the hooks,
@@ -53,26 +59,82 @@ def rank() -> int:
     return dist.get_rank() if is_distributed() else 0
 
 
-class _AllGatherRows(torch.autograd.Function):
-    """cat_r(x_r) along dim 0; backward hands each rank the gradient rows of its own shard.
+def _all_gather_pair(fi: torch.Tensor, ft: torch.Tensor):
+    """(image features, text features) [B, E] of every rank -> ([world*B, E], [world*B, E]), rank-major rows, in ONE collective:
+    the two matrices travel stacked as [2, B, E] (SURVEY.md 8e asks for an all-gather of the features; two collectives of
+    0.5 MB each are two latency-bound launches where one does)."""
+    world = dist.get_world_size()
+    x = torch.stack((fi, ft)).contiguous()                                      # [2, B, E]
+    out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    COLLECTIVES["all_gather"] += 1
+    if dist.get_backend() == "nccl":                       # RCCL: one fused all-gather into the output buffer
+        dist.all_gather_into_tensor(out, x)
+    else:                                                  # gloo (CPU tests, several ranks sharing one GPU)
+        dist.all_gather(list(out.unbind(0)), x)
+    B, E = fi.shape
+    return out[:, 0].reshape(world * B, E), out[:, 1].reshape(world * B, E)     # (copies: rank-major [world*B, E])
+
+
+class _AllGatherPair(torch.autograd.Function):
+    """(cat_r(fi_r), cat_r(ft_r)) along dim 0 from one collective; backward hands each rank the gradient rows of its own shard.
     (Every rank evaluates the same replicated loss, so no reduction is needed here.)"""
 
     @staticmethod
-    def forward(ctx, x):
-        x = x.contiguous()
-        world = dist.get_world_size()
-        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        if dist.get_backend() == "nccl":                   # RCCL: one fused all-gather into the output buffer
-            dist.all_gather_into_tensor(out, x)
-        else:                                              # gloo (CPU tests, single-GPU smoke of the N>1 path)
-            dist.all_gather(list(out.chunk(world, 0)), x)
-        ctx.rows = x.shape[0]
-        return out
+    def forward(ctx, fi, ft):
+        ctx.rows = fi.shape[0]
+        return _all_gather_pair(fi, ft)
 
     @staticmethod
-    def backward(ctx, grad):
+    def backward(ctx, gi, gt):
         r = dist.get_rank()
-        return grad[r * ctx.rows:(r + 1) * ctx.rows].contiguous()
+        sl = slice(r * ctx.rows, (r + 1) * ctx.rows)
+        return gi[sl].contiguous(), gt[sl].contiguous()
+
+
+class _GlobalSimLogits(torch.autograd.Function):
+    """all-gather of the (normalised) features + similarity logits of the global N_g x N_g batch, with the backward pass the
+    sharding asks for ("back-props only its own 256 rows"): a rank needs d_loss / d_fi for ITS image rows and
+    d_loss / d_ft for ITS text rows only, i.e. two [B, N_g] x [N_g, E] products (cvcl_sim_logits_bwd_rows) instead of the two
+    N_g x N_g x E ones whose other world - 1 shards the gather's backward would throw away.  The temperature gradient is the
+    full-matrix sum, identical on every rank (flagged ``_cvcl_replicated_grad`` -> averaged by the engine)."""
+
+    @staticmethod
+    def forward(ctx, fi, ft, neg_log_temp):
+        from . import _hip as H
+        gi, gt = _all_gather_pair(fi.contiguous(), ft.contiguous())
+        Ng, E = gi.shape
+        nlt = neg_log_temp.reshape(1).contiguous()
+        logits = torch.empty(Ng, Ng, dtype=torch.float32, device=gi.device)
+        H.check(H.lib().cvcl_sim_logits_fwd(H.ptr(gi, torch.float32), H.ptr(gt, torch.float32), H.ptr(nlt, torch.float32), H.ptr(logits),
+                                           Ng, Ng, E, H.stream_ptr()), "cvcl_sim_logits_fwd")
+        ctx.save_for_backward(gi, gt, nlt, logits)
+        ctx.rows = fi.shape[0]
+        ctx.temp_shape = neg_log_temp.shape
+        return logits
+
+    @staticmethod
+    def backward(ctx, d_logits):
+        from . import _hip as H
+        gi, gt, nlt, logits = ctx.saved_tensors
+        Ng, E = gi.shape
+        B, r = ctx.rows, dist.get_rank()
+        need_i, need_t, need_s = ctx.needs_input_grad
+        dev = gi.device
+        d_fi = torch.empty(B, E, dtype=torch.float32, device=dev) if need_i else None
+        d_ft = torch.empty(B, E, dtype=torch.float32, device=dev) if need_t else None
+        d_s = torch.empty(1, dtype=torch.float32, device=dev) if need_s else None
+        nb = H.lib().cvcl_sim_logits_bwd_workspace_bytes(Ng, Ng, E)
+        ws = torch.empty(max(int(nb), 16), dtype=torch.uint8, device=dev)
+        H.check(H.lib().cvcl_sim_logits_bwd_rows(H.ptr(gi), H.ptr(gt), H.ptr(nlt), H.ptr(logits), H.ptr(d_logits.contiguous(), torch.float32),
+                                                H.ptr(d_fi), H.ptr(d_ft), H.ptr(d_s), Ng, Ng, E, r * B, B, r * B, B, H.ptr(ws), nb,
+                                                H.stream_ptr()), "cvcl_sim_logits_bwd_rows")
+        return d_fi, d_ft, (d_s.reshape(ctx.temp_shape) if need_s else None)
+
+
+def global_sim_logits(image_features, text_features, neg_log_temp):
+    """logits_per_image [N_g, N_g] of the all-gathered batch (reference multimodal/multimodal.py:755 applied to cat_r(features_r)):
+    one collective forward, own-row gradient products backward.  Device tensors only (the HIP path)."""
+    return _GlobalSimLogits.apply(image_features, text_features, neg_log_temp)
 
 
 def local_term_scale(global_negatives: bool) -> float:
@@ -86,7 +148,7 @@ def gather_features(image_features: torch.Tensor, text_features: torch.Tensor):
     """[B,E] per rank -> [world*B, E] on every rank (rank-major row order)."""
     if not is_distributed():
         return image_features, text_features
-    return _AllGatherRows.apply(image_features), _AllGatherRows.apply(text_features)
+    return _AllGatherPair.apply(image_features, text_features)
 
 
 class DataParallelEngine:
@@ -206,6 +268,7 @@ class DataParallelEngine:
                     b["buf"][off:off + p.numel()].copy_(p.grad.reshape(-1))
                 else:
                     b["buf"][off:off + p.numel()].zero_()
+        COLLECTIVES["all_reduce"] += 1
         b["handle"] = dist.all_reduce(b["buf"], op=dist.ReduceOp.SUM, async_op=True)
 
     def reduce_gradients(self):

@@ -206,6 +206,12 @@ class ResNet(nn.Module):
         H.check(lib.cvcl_resnext50_fwd_deferred_stats(dt, B, Hh, Ww, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap), H.ptr(pooled),
                                                       BN_EPS, H.ptr(moments), None, H.stream_ptr()), "cvcl_resnext50_fwd_deferred_stats")
         centres = moments.view(53, 2, 2048)[:, 0, :].contiguous()
+        from . import parallel
+        if parallel.is_distributed():
+            # data parallel: every replica must evaluate the SAME bf16 forward function, so rank 0's calibration is adopted by all
+            # (a centre only has to be within ~sigma of a rank's batch mean; the ranks see shards of one distribution).  All ranks
+            # reach this point together: on their first train-mode pass, or after recalibrate_centres() / a change of weights
+            parallel.dist.broadcast(centres, src=0)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(x.device))
         self.__dict__["_centres"] = (key, centres, ready)

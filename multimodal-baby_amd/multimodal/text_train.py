@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import _hip as H
-from .ops import LinearF32, _F
+from .ops import LinearF32, _F, linear_backward
 
 
 def _seed() -> int:
@@ -93,24 +93,7 @@ class LinearReluF32(torch.autograd.Function):
 
 
 def _linear_bwd(x, weight, dy, needs, has_bias):
-    M, K = x.shape
-    N = weight.shape[0]
-    s = H.stream_ptr()
-    dx = dw = db = None
-    if needs[1]:
-        dyT = torch.empty(N, M, dtype=_F, device=x.device)
-        xT = torch.empty(K, M, dtype=_F, device=x.device)
-        H.check(H.lib().cvcl_transpose_f32(H.ptr(dy), H.ptr(dyT), M, N, s), "cvcl_transpose_f32")
-        H.check(H.lib().cvcl_transpose_f32(H.ptr(x), H.ptr(xT), M, K, s), "cvcl_transpose_f32")
-        dw = H.gemm(dyT, xT)
-    if needs[0]:
-        wT = torch.empty(K, N, dtype=_F, device=x.device)
-        H.check(H.lib().cvcl_transpose_f32(H.ptr(weight.contiguous()), H.ptr(wT), N, K, s), "cvcl_transpose_f32")
-        dx = H.gemm(dy, wT)
-    if needs[2] and has_bias:
-        db = torch.empty(N, dtype=_F, device=x.device)
-        H.check(H.lib().cvcl_colsum_f32(H.ptr(dy), H.ptr(db), M, N, s), "cvcl_colsum_f32")
-    return dx, dw, db
+    return linear_backward(x, weight, dy, (needs[0], needs[1], needs[2] and has_bias))
 
 
 class LayerNormF32(torch.autograd.Function):
@@ -260,8 +243,6 @@ class LstmCore(torch.autograd.Function):
         dc = torch.zeros(B, Hd, dtype=_F, device=dev)
         dG = torch.empty(B * L, 4 * Hd, dtype=_F, device=dev)
         carry = torch.empty(B, Hd, dtype=_F, device=dev)
-        w_hhT = torch.empty(Hd, 4 * Hd, dtype=_F, device=dev)
-        H.check(lib.cvcl_transpose_f32(H.ptr(w_hh), H.ptr(w_hhT), 4 * Hd, Hd, s), "cvcl_transpose_f32")
         dh_next = torch.empty_like(dh)
         if d_out is not None:
             d_out = d_out.contiguous()
@@ -271,30 +252,28 @@ class LstmCore(torch.autograd.Function):
             H.check(lib.cvcl_lstm_cell_bwd(H.ptr(gact), H.ptr(csave), H.ptr(length), t, H.ptr(dh), H.ptr(dc), H.ptr(dG), H.ptr(carry),
                                            B, L, Hd, s), "cvcl_lstm_cell_bwd")
             a = H.GemmArgs()                                                       # dh_{t-1} = dG_t . W_hh + carry
-            a.A, a.W, a.C = dG.data_ptr() + t * 4 * Hd * 4, H.ptr(w_hhT), H.ptr(dh_next)
-            a.M, a.N, a.K, a.lda, a.ldw, a.ldc = B, Hd, 4 * Hd, L * 4 * Hd, 4 * Hd, Hd
+            a.A, a.W, a.C = dG.data_ptr() + t * 4 * Hd * 4, H.ptr(w_hh), H.ptr(dh_next)      # W' = W_hh^T: W_hh read K-major in place
+            a.M, a.N, a.K, a.lda, a.ldw, a.ldc = B, Hd, 4 * Hd, L * 4 * Hd, Hd, Hd
+            a.w_trans = 1
             a.R, a.ldr = H.ptr(carry), Hd
             H.check(lib.cvcl_gemm(H.F32, a, s), "cvcl_gemm")
             dh, dh_next = dh_next, dh
         needs = ctx.needs_input_grad
         dx = dwi = dwh = db = None
-        dGT = torch.empty(4 * Hd, B * L, dtype=_F, device=dev)
-        H.check(lib.cvcl_transpose_f32(H.ptr(dG), H.ptr(dGT), B * L, 4 * Hd, s), "cvcl_transpose_f32")
-        if needs[1]:
-            xT = torch.empty(x.shape[1], B * L, dtype=_F, device=dev)
-            H.check(lib.cvcl_transpose_f32(H.ptr(x), H.ptr(xT), B * L, x.shape[1], s), "cvcl_transpose_f32")
-            dwi = H.gemm(dGT, xT)
-        if needs[2]:
-            hT = torch.empty(Hd, B * L, dtype=_F, device=dev)
-            H.check(lib.cvcl_transpose_f32(H.ptr(hprev), H.ptr(hT), B * L, Hd, s), "cvcl_transpose_f32")
-            dwh = H.gemm(dGT, hT)
-        if needs[3] or needs[4]:
+        want_b = needs[3] or needs[4]
+        if want_b:
             db = torch.empty(4 * Hd, dtype=_F, device=dev)
+        b_done = False
+        if needs[1]:                          # dW_ih = dG^T X (+ the bias gradient = row sums of dG^T from the same operand loads)
+            dwi = H.gemm(dG, x, a_trans=True, w_trans=True, a_rowsum=db if want_b else None)
+            b_done = want_b
+        if needs[2]:
+            dwh = H.gemm(dG, hprev, a_trans=True, w_trans=True, a_rowsum=db if (want_b and not b_done) else None)
+            b_done = want_b
+        if want_b and not b_done:
             H.check(lib.cvcl_colsum_f32(H.ptr(dG), H.ptr(db), B * L, 4 * Hd, s), "cvcl_colsum_f32")
         if needs[0]:
-            w_ihT = torch.empty(w_ih.shape[1], 4 * Hd, dtype=_F, device=dev)
-            H.check(lib.cvcl_transpose_f32(H.ptr(w_ih.contiguous()), H.ptr(w_ihT), 4 * Hd, w_ih.shape[1], s), "cvcl_transpose_f32")
-            dx = H.gemm(dG, w_ihT)
+            dx = H.gemm(dG, w_ih.contiguous(), w_trans=True)
         return dx, dwi, dwh, db, (db.clone() if db is not None else None), None, None, None
 
 

@@ -1,4 +1,4 @@
-"""Worker for the multi-rank GPU tests (tests/test_parallel_gpu.py): started by torch.distributed.run with two ranks that
+"""Worker for the multi-rank GPU tests (tests/test_parallel_gpu.py): started by torch.distributed.run with two (or eight) ranks that
 share the box's one GPU over the gloo backend (CVCL_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).
 
     dist_worker.py bench_step OUT            one C2 step at 256 pairs per rank through DataParallelEngine + OverlappedUpdate
@@ -34,6 +34,7 @@ def bench_step(out_dir):
         pooled = ve.model.trunk(batch[0])[0].clone()              # this rank's trunk output (train-mode BN over its own 256)
     before = {k: v.detach().clone() for k, v in lit.named_parameters() if v.requires_grad}
     losses = []
+    coll0 = dict(parallel.COLLECTIVES)
     for _ in range(2):                                            # step 2's trunk is enqueued before step 1's update is applied
         out = lit.training_step(batch, 0)
         upd.zero_grad()
@@ -46,8 +47,11 @@ def bench_step(out_dir):
             after1 = {k: v.detach().clone().cpu() for k, v in lit.named_parameters() if v.requires_grad}
     upd.flush()
     torch.cuda.synchronize()
+    centres = ve.model.export_centres()
     torch.save({"pooled": pooled.cpu(), "tok": batch[1].cpu(), "len": batch[2].cpu(), "losses": losses, "grads": grads,
-                "before": {k: v.cpu() for k, v in before.items()}, "after1": after1},
+                "before": {k: v.cpu() for k, v in before.items()}, "after1": after1,
+                "centres": None if centres is None else centres["frozen"],
+                "collectives_per_step": {k: (parallel.COLLECTIVES[k] - coll0[k]) / 2 for k in coll0}},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -71,7 +75,7 @@ def train(out_dir, argv):
 
 
 def rccl_w1(out_dir):
-    """World-size-1 RCCL process group driving _AllGatherRows, DataParallelEngine (hooks, bucket launch behind the producing
+    """World-size-1 RCCL process group driving global_sim_logits (the feature all-gather), DataParallelEngine (hooks, bucket launch behind the producing
     streams, handle.wait()), OverlappedUpdate and the two trunk streams; each schedule is run twice -- through the process group
     ($CVCL_FORCE_DIST=1) and as the plain single-process step -- from identical initial states, for the frozen C2 step and for
     --finetune_cnn (weight gradients arriving from trunk_train's side stream).  The caller compares bit for bit."""

@@ -109,3 +109,48 @@ def test_bn_from_gram_vs_float64_and_vs_the_statistics_pass(H, dev, M, K, N, cen
         # (the pass takes the statistics of the bf16-ROUNDED product: the two routes differ by the mean of the rounding errors)
         assert float(((scale - s2).abs() / s2.abs()).max()) < 2e-4
         assert float((shift - h2).abs().max()) < 2e-4 * float(h2.abs().max() + 1)
+
+
+@pytest.mark.parametrize("ratio", [10.0, 30.0, 100.0])
+@pytest.mark.parametrize("M,K,N", [(200704, 128, 512), (50176, 256, 1024)])
+def test_bn_from_gram_where_the_variance_can_cancel(H, dev, M, K, N, ratio):
+    """var = w^T G w / M - (w.s / M)^2 subtracts two numbers of size mean_y^2 to leave sigma_y^2: operand columns whose mean is
+    `ratio` x their spread, and weights of one sign so that the OUTPUT mean dominates too (|mean_y| / sigma_y ~ ratio sqrt(K): what a
+    trained BN2 -> conv3 with a large beta / gamma can present).  The Gram partials are fp32 MFMA accumulations over M / 256 rows;
+    the affine BatchNorm applies -- scale = gamma / sqrt(var + eps) -- must still agree with float64 on the explicit product."""
+    g = torch.Generator().manual_seed(int(ratio) + K)
+    sigma = 0.25
+    a = (torch.randn(M, K, generator=g) * sigma + ratio * sigma).bfloat16()         # plain operand (no prologue): columns mean / std = ratio
+    w = ((0.5 + torch.rand(N, K, generator=g)) / K).bfloat16()                      # all positive: y's mean = sum_k w_k mu_k dominates
+    gamma, beta = 0.75 + 0.5 * torch.rand(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    ad, wd, gd, bd = a.to(dev), w.to(dev), gamma.to(dev), beta.to(dev)
+    # float64 reference in two chunks (memory)
+    wdbl = w.double().to(dev)
+    s1 = torch.zeros(N, dtype=torch.float64, device=dev)
+    s2 = torch.zeros(N, dtype=torch.float64, device=dev)
+    mean0 = (ad[:4096].double() @ wdbl.t()).mean(0)                                  # shifted sums: no cancellation in the reference
+    for i in range(0, M, 16384):
+        y = ad[i:i + 16384].double() @ wdbl.t() - mean0
+        s1 += y.sum(0)
+        s2 += (y * y).sum(0)
+    mean = (s1 / M + mean0).cpu()
+    var = (s2 / M - (s1 / M) ** 2).cpu()
+    assert float((mean.abs() / var.sqrt()).min()) > ratio                           # the regime the test is about
+    G, s, ws, out = _gram(H, dev, ad, K)
+    scale, shift = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    rm, rv, nbt = torch.zeros(N, device=dev), torch.ones(N, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    cen = mean.float().to(dev)                                                       # centred storage near the batch mean, as in the trunk
+    H.check(H.lib().cvcl_bn_from_gram(out, K, M, H.ptr(wd), K, N, H.ptr(gd), H.ptr(bd), H.ptr(rm), H.ptr(rv), H.ptr(nbt), 0.1, 1e-5,
+                                      H.ptr(scale), H.ptr(shift), None, 0, H.ptr(cen), H.stream_ptr()), "cvcl_bn_from_gram")
+    torch.cuda.synchronize()
+    ref_scale = gamma.double() / torch.sqrt(var + 1e-5)
+    ref_shift = beta.double() - (mean - cen.double().cpu()) * ref_scale
+    rel_scale = float(((scale.double().cpu() - ref_scale).abs() / ref_scale).max())
+    err_shift = float((shift.double().cpu() - ref_shift).abs().max())
+    # the Gram entries themselves against float64 (what bounds everything downstream)
+    Gref = (ad.double().t() @ ad.double()).cpu()
+    rel_G = float(((G - Gref).abs() / Gref.abs()).max())
+    print(f"ratio {ratio} K {K}: |mean_y|/sigma_y >= {float((mean.abs() / var.sqrt()).min()):.0f}, G rel {rel_G:.2e}, "
+          f"scale rel {rel_scale:.2e}, shift abs {err_shift:.2e}")
+    assert rel_scale < 1e-3, (ratio, rel_scale, rel_G)
+    assert err_shift < 1e-3 * float(ref_shift.abs().max() + 1), (ratio, err_shift)

@@ -610,3 +610,45 @@ def test_gemm_pro_tail_with_recomputed_downsample(dev, M):
             err = (got.double() - ref.double()).abs()
             assert float((err / (ref.double().abs() + float(ref.abs().max()) * 5e-2) > 8e-3).double().mean()) < 2e-3, exact
             assert float((err / (mag * 2.0 ** -7 + 1e-3)).max()) < 1.5, exact
+
+
+# K-major operands + fused row sums (round 5): the gradient GEMMs of the trainable tail read dY / X / W as they lie.  Shapes cover
+# both kernels behind the flag (split-K VALU kernel for the small products, the 128 x 128 fp32 MFMA kernel for the large ones and
+# whenever row sums are asked for), ragged edges, and extents that are not multiples of 4 (scalar operand path).
+@pytest.mark.parametrize("M,N,K", [(256, 512, 256), (512, 512, 1280), (1536, 512, 1280), (130, 72, 300), (7, 5, 12), (513, 130, 77),
+                                   (2048, 512, 4096)])
+@pytest.mark.parametrize("ta,tw", [(True, True), (False, True), (True, False)])
+def test_gemm_f32_kmajor_operands_and_rowsum(H, dev, M, N, K, ta, tw):
+    g = torch.Generator().manual_seed(M * 3 + N * 5 + K * 7 + ta * 2 + tw)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Ad = (A.t().contiguous() if ta else A).to(dev)              # [K, M] in memory when ta
+    Wd = (W.t().contiguous() if tw else W).to(dev)              # [K, N] in memory when tw
+    rs = torch.full((M,), float("nan"), device=dev) if ta else None
+    y = H.gemm(Ad, Wd, a_trans=ta, w_trans=tw, a_rowsum=rs, bias=bias.to(dev))
+    ref = A.double() @ W.double().t() + bias.double()
+    assert y.shape == (M, N)
+    assert maxrel(y.cpu(), ref) < 2e-5
+    if ta:
+        ref_rs = A.double().sum(1)
+        assert float((rs.double().cpu() - ref_rs).abs().max()) < 2e-5 * float(A.abs().sum(1).max())
+        y2 = H.gemm(Ad, Wd, a_trans=ta, w_trans=tw, bias=bias.to(dev))          # without the row sums: the same product
+        assert maxrel(y2.cpu(), ref) < 2e-5
+
+
+def test_linear_backward_reads_operands_in_place(dev):
+    """nn.Linear backward through ops.linear_backward (dW = dY^T X with the bias gradient fused, dX = dY W) at the text
+    transformer's shapes (reference multimodal/multimodal.py:553-573: d_model 512, FFN 2048, B L = 1280 rows) vs float64."""
+    from multimodal import ops
+    g = torch.Generator().manual_seed(11)
+    for M, K, N in [(1280, 512, 1536), (1280, 2048, 512), (256, 2048, 512), (100, 24, 40)]:
+        x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(M, N, generator=g)
+        dx, dw, db = ops.linear_backward(x.to(dev), w.to(dev), dy.to(dev), (True, True, True))
+        assert maxrel(dx.cpu(), dy.double() @ w.double()) < 2e-5
+        assert maxrel(dw.cpu(), dy.double().t() @ x.double()) < 2e-5
+        assert maxrel(db.cpu(), dy.double().sum(0)) < 2e-5
+        _, dw2, db2 = ops.linear_backward(x.to(dev), w.to(dev), dy.to(dev), (False, True, False))
+        assert db2 is None and torch.equal(dw2, dw)
+        _, _, db3 = ops.linear_backward(x.to(dev), w.to(dev), dy.to(dev), (False, False, True))
+        assert maxrel(db3.cpu(), dy.double().sum(0)) < 2e-5

@@ -180,3 +180,37 @@ def test_edge_cases(ops, dev):
     lg = ops.sim_logits(f, f, torch.tensor(0.0, device=dev))
     loss, m = ops.infonce(lg)
     assert abs(float(loss) - math.log(4)) < 1e-5 and abs(float(m[0]) - 0.25) < 1e-6 and abs(float(m[1]) - 0.25) < 1e-6
+
+
+@pytest.mark.parametrize("Ng,B,rank", [(512, 256, 1), (2048, 256, 5), (96, 12, 0)])
+def test_sim_logits_bwd_rows_equals_the_rows_of_the_full_backward(dev, Ng, B, rank):
+    """cvcl_sim_logits_bwd_rows (data-parallel global negatives: a rank back-propagates through its own rows of the replicated
+    N_g x N_g logits only) against float64 and against the corresponding rows of the full backward."""
+    from multimodal import _hip as H
+    E = 512 if Ng > 100 else 40
+    g = torch.Generator().manual_seed(Ng + rank)
+    fi = torch.nn.functional.normalize(torch.randn(Ng, E, generator=g), dim=1)
+    ft = torch.nn.functional.normalize(torch.randn(Ng, E, generator=g), dim=1)
+    dS = torch.randn(Ng, Ng, generator=g) / Ng
+    nlt = torch.tensor([2.3])
+    s = float(nlt.exp())
+    d = lambda t: t.to(dev).contiguous()
+    fid, ftd, dSd, nltd = d(fi), d(ft), d(dS), d(nlt)
+    logits = torch.empty(Ng, Ng, device=dev)
+    H.check(H.lib().cvcl_sim_logits_fwd(H.ptr(fid), H.ptr(ftd), H.ptr(nltd), H.ptr(logits), Ng, Ng, E, H.stream_ptr()), "fwd")
+    nb = H.lib().cvcl_sim_logits_bwd_workspace_bytes(Ng, Ng, E)
+    ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+    d_i, d_t = torch.empty(B, E, device=dev), torch.empty(B, E, device=dev)
+    d_s = torch.empty(1, device=dev)
+    H.check(H.lib().cvcl_sim_logits_bwd_rows(H.ptr(fid), H.ptr(ftd), H.ptr(nltd), H.ptr(logits), H.ptr(dSd), H.ptr(d_i), H.ptr(d_t), H.ptr(d_s),
+                                            Ng, Ng, E, rank * B, B, rank * B, B, H.ptr(ws), nb, H.stream_ptr()), "bwd_rows")
+    sl = slice(rank * B, (rank + 1) * B)
+    ref_i = s * (dS.double()[sl] @ ft.double())
+    ref_t = s * (dS.double()[:, sl].t() @ fi.double())
+    assert maxrel(d_i.cpu(), ref_i) < 2e-5 and maxrel(d_t.cpu(), ref_t) < 2e-5
+    ref_s = float((dS.double() * (s * (fi.double() @ ft.double().t()))).sum())
+    assert abs(float(d_s) - ref_s) < 2e-5 * max(1.0, abs(ref_s))
+    full_i, full_t = torch.empty(Ng, E, device=dev), torch.empty(Ng, E, device=dev)
+    H.check(H.lib().cvcl_sim_logits_bwd(H.ptr(fid), H.ptr(ftd), H.ptr(nltd), H.ptr(logits), H.ptr(dSd), H.ptr(full_i), H.ptr(full_t), None,
+                                       Ng, Ng, E, H.ptr(ws), nb, H.stream_ptr()), "bwd")
+    assert maxrel(full_i[sl].cpu(), ref_i) < 2e-5 and maxrel(full_t[sl].cpu(), ref_t) < 2e-5

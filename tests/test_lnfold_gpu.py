@@ -139,3 +139,59 @@ def test_vit_forward_with_folded_layernorm(dev, B, patch, forced):
     print(f"B={B} p{patch}: bf16 vs fp32 rel-L2: LayerNorm kernels {e_plain:.3e}, folded {e_fold:.3e}; folded vs unfolded {float((fold - plain).norm() / ref.norm()):.3e}")
     assert not torch.equal(fold, plain)                        # (the folded path did run)
     assert e_fold <= 1.1 * e_plain + 1e-3 and e_fold < 3e-2
+
+
+@pytest.mark.parametrize("M,N,K,kind", [(65792, 768, 768, "producer"), (50432, 768, 768, "producer"), (50432, 3072, 768, "consumer"),
+                                       (65792, 2304, 768, "consumer"), (20000, 768, 3072, "producer")])
+def test_remainder_launch_and_supertile_walk_are_bit_identical(H, dev, M, N, K, kind):
+    """Round 5: the linear epilogue walks its tiles in L2-sized supertiles and, when the last round of a launch would be poorly
+    filled, runs the rows whole rounds hold first and the rest as one round of shorter tiles (cvcl_gemm8w_linear_plan).  Neither
+    changes the order in which an output element sums its K products: under every CU share (= another grid, another walk,
+    with and without a remainder launch) C -- and the producer's row partials -- must come out bit for bit the same."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(M + N)
+    x = _rows(M, K, M % 1000).to(dev)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(dev)
+    b = (0.1 * torch.randn(N, generator=g)).to(dev)
+    res = _rows(M, N, 7).to(dev) if kind == "producer" else None
+    st = torch.zeros(M + 1, 2, device=dev)[:M]
+    H.check(H.lib().cvcl_row_stats(H.BF16, H.ptr(x), K, H.ptr(st), M, K, 1e-6, H.stream_ptr()), "cvcl_row_stats")
+    cs = W.float().sum(1).contiguous()
+    outs, plans = [], []
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    for share in (0, cus // 2, 104, 64, 40):
+        prev = H.lib().cvcl_set_gemm_cu_share(share)
+        try:
+            plan = (C.c_int * 5)()
+            H.check(H.lib().cvcl_gemm8w_linear_plan(M, N, 1, plan), "plan")
+            plans.append(tuple(plan))
+            if kind == "producer":
+                part = torch.full((M, N // 64, 2), float("nan"), device=dev)
+                y = H.gemm(x, W, bias=b, residual=res, row_part=part)
+                outs.append((y, part))
+            else:
+                y = H.gemm(x, W, bias=b, act=H.ACT_GELU, ln_stats=st, ln_colsum=cs)
+                outs.append((y,))
+        finally:
+            H.lib().cvcl_set_gemm_cu_share(prev)
+    torch.cuda.synchronize()
+    print(plans)
+    assert any(p[3] > 0 for p in plans), plans                 # at least one share plans a remainder launch for this shape
+    assert any(p[3] == 0 for p in plans), plans
+    for p in plans:
+        assert p[2] % p[0] == 0 and (p[3] == 0) == (p[2] == M) and p[3] % 32 == 0 and p[3] <= 256
+    for o in outs[1:]:
+        for t0, t1 in zip(outs[0], o):
+            assert torch.equal(t0, t1)
+    # and the values are right (float64 on a sample of rows)
+    rows = torch.randint(0, M, (64,), generator=g)
+    rows[-1] = M - 1
+    xs = x[rows.to(dev)].double()
+    if kind == "producer":
+        ref = xs @ W.double().t() + b.double()
+        ref = ref.float().bfloat16().double() + res[rows.to(dev)].double()
+    else:
+        ln = (xs - xs.mean(1, keepdim=True)) / torch.sqrt(xs.var(1, unbiased=False, keepdim=True) + 1e-6)
+        ref = O.gelu_erf(ln @ W.double().t() + b.double())
+    got = outs[0][0][rows.to(dev)].double()
+    assert float((got - ref).abs().max()) < 0.03 * float(ref.abs().max())

@@ -41,16 +41,17 @@ def _run_ranks(args, world=2, timeout=600):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def test_two_ranks_global_negatives_n512_vs_oracle(tmp_path):
-    _run_ranks(["bench_step", str(tmp_path)])
-    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in range(2)]
-    pooled = torch.cat([r[0]["pooled"], r[1]["pooled"]]).float()
-    tok, ln = torch.cat([r[0]["tok"], r[1]["tok"]]), torch.cat([r[0]["len"], r[1]["len"]])
-    assert pooled.shape == (512, 2048) and not torch.equal(r[0]["pooled"], r[1]["pooled"])       # ranks saw different shards
+def _global_negatives_vs_oracle(tmp_path, world):
+    _run_ranks(["bench_step", str(tmp_path)], world=world, timeout=1500)
+    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in range(world)]
+    pooled = torch.cat([x["pooled"] for x in r]).float()
+    tok, ln = torch.cat([x["tok"] for x in r]), torch.cat([x["len"] for x in r])
+    assert pooled.shape == (256 * world, 2048) and not torch.equal(r[0]["pooled"], r[1]["pooled"])   # ranks saw different shards
     names = {"fc.weight": "vision_encoder.model.fc.weight", "fc.bias": "vision_encoder.model.fc.bias",
              "emb": "text_encoder.embedding.weight"}
     for k in names.values():
-        assert torch.equal(r[0]["before"][k], r[1]["before"][k]), k                               # replicas start identical
+        for i in range(1, world):
+            assert torch.equal(r[0]["before"][k], r[i]["before"][k]), (k, i)                          # replicas start identical
     w = r[0]["before"][names["fc.weight"]].clone().requires_grad_()
     b = r[0]["before"][names["fc.bias"]].clone().requires_grad_()
     emb = r[0]["before"][names["emb"]].clone().requires_grad_()
@@ -59,16 +60,35 @@ def test_two_ranks_global_negatives_n512_vs_oracle(tmp_path):
     lpi, lpt = O.similarity_logits(fi, ft, torch.tensor(-math.log(0.07)))
     loss = O.contrastive_loss(lpi, lpt)[0]
     loss.backward()
-    for i in range(2):
+    for i in range(world):
         assert abs(r[i]["losses"][0] - float(loss)) < 2e-4 * abs(float(loss)), (i, r[i]["losses"], float(loss))
         g = r[i]["grads"]
         assert maxrel(g[names["fc.weight"]], w.grad) < 2e-4, i
         assert maxrel(g[names["fc.bias"]], b.grad) < 2e-4, i
         assert maxrel(g[names["emb"]], emb.grad) < 2e-4, i
-    for k in names.values():                                                                      # replicas stay bit-identical
-        assert torch.equal(r[0]["grads"][k], r[1]["grads"][k]), k
-        assert torch.equal(r[0]["after1"][k], r[1]["after1"][k]) and not torch.equal(r[0]["after1"][k], r[0]["before"][k]), k
-    assert r[0]["losses"] == r[1]["losses"] and r[0]["losses"][1] < r[0]["losses"][0] + 0.5
+        # ONE feature all-gather (the stacked [2, B, E]) and one gradient bucket per step
+        assert r[i]["collectives_per_step"] == {"all_gather": 1.0, "all_reduce": 1.0}, r[i]["collectives_per_step"]
+        # every replica evaluates the same bf16 forward function: rank 0's calibrated storage centres, broadcast
+        assert r[i]["centres"] is not None and torch.equal(r[i]["centres"], r[0]["centres"]), i
+    for i in range(1, world):
+        for k in names.values():                                                                  # replicas stay bit-identical
+            assert torch.equal(r[0]["grads"][k], r[i]["grads"][k]), (k, i)
+            assert torch.equal(r[0]["after1"][k], r[i]["after1"][k]), (k, i)
+        assert r[0]["losses"] == r[i]["losses"]
+    for k in names.values():
+        assert not torch.equal(r[0]["after1"][k], r[0]["before"][k]), k
+    assert r[0]["losses"][1] < r[0]["losses"][0] + 0.5
+
+
+def test_two_ranks_global_negatives_n512_vs_oracle(tmp_path):
+    _global_negatives_vs_oracle(tmp_path, 2)
+
+
+def test_eight_ranks_global_negatives_n2048_vs_oracle(tmp_path):
+    """BASELINE configs[2]'s real shape -- 8 ranks x 256 pairs, 2048 global negatives -- through the product's distributed path
+    (gather order, own-row gradient products at [256, 2048] x [2048, 512], the replicated 2048^2 loss, SUM over 8 contributors),
+    eight processes sharing this box's one GPU over gloo; the oracle evaluates the reference's loss on the concatenated features."""
+    _global_negatives_vs_oracle(tmp_path, 8)
 
 
 def test_rccl_world1_drives_the_whole_multi_gpu_path_bit_identically(tmp_path):
