@@ -218,12 +218,6 @@ int cvcl_row_stats(int dtype, const void* x, long x_row_stride, float* out, long
 int cvcl_row_stats_finalize(const float* row_part, int strips, float* out, long rows, int D, float eps, void* stream);
 int cvcl_gemm8w_tile_rows(int M, int N);
 int cvcl_gemm8w_stats_rows(int M, int N);
-/* How the 8-wave kernel's LINEAR epilogue (nn.Linear: vision_transformer_dino_mugs.py:92-94,113-115) tiles an [M, N] output under the
- * current CU share (round 5): plan5 = {tile rows (256 | 224), workgroups, rows covered by the main launch, tile rows of the remainder
- * launch (64 .. 256; 0 = one launch), its workgroups}.  When the last round of a launch would be poorly filled, the rows that whole
- * rounds hold go first and the rest follows as one round of shorter tiles (folded != 0: the ln_stats / row_part epilogues, which have
- * the short instantiations).  Results do not depend on the plan (every output element sums its K products in the same order). */
-int cvcl_gemm8w_linear_plan(int M, int N, int folded, int* plan5);
 
 /* Train-mode BatchNorm statistics of a 1x1 convolution's output WITHOUT forming the output (round 4, csrc/bn_gram.hip): torchvision
  * Bottleneck.forward bn3(conv3(relu(bn2(.)))) / downsample[1](downsample[0](x)), reached from multimodal/multimodal.py:101, where the

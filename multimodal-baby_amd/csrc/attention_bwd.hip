@@ -292,14 +292,14 @@ extern "C" int cvcl_attention_bwd(const void* qkv, const void* o, const void* d_
     CVCL_CHECK_ARG(qkv && o && d_o && lse && d_qkv && B > 0 && heads > 0, "cvcl_attention_bwd: bad args");
     CVCL_CHECK_ARG(head_dim == 64 && T > 32 && T <= AB_TPAD_MAX_DKV,
                    "cvcl_attention_bwd: needs head_dim 64 and 32 < T <= %d (got hd %d, T %d)", AB_TPAD_MAX_DKV, head_dim, T);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CvclLdsAttr attr_set;
+    if (!attr_set.ready()) {
         if (hipFuncSetAttribute((const void*)attention_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)attention_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             cvcl_set_error("cvcl_attention_bwd: cannot raise the dynamic LDS limit");
             return CVCL_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     const int nt = (T + 31) / 32, Tpad = nt * 32;
     hipStream_t s = (hipStream_t)stream;

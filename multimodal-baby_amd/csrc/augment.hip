@@ -226,13 +226,13 @@ extern "C" int cvcl_augment_frames(const void* frames, int B, int H, int W, cons
     CVCL_CHECK_ARG(lds <= 160 * 1024,
                    "cvcl_augment_frames: a %d-row crop resampled to %d x %d needs %zu bytes of LDS (limit 163840): crop boxes that tall "
                    "are not supported by the single-pass plan", max_crop_h, out_h, out_w, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CvclLdsAttr attr_set;
+    if (!attr_set.ready()) {
         if (hipFuncSetAttribute((const void*)augment_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             cvcl_set_error("cvcl_augment_frames: cannot raise the dynamic LDS limit");
             return CVCL_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL(augment_frames_kernel, dim3(B * 3), dim3(1024), lds, (hipStream_t)stream, d);   // one workgroup per CU (LDS): 16 waves hide the LDS latency
     CVCL_LAUNCH_CHECK();

@@ -405,13 +405,13 @@ int gram_grid(long tiles) {
 
 template <int NT>
 int gram_launch(const GramDev& d, int grid, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
+    static CvclLdsAttr attr;
+    if (!attr.ready()) {
         if (hipFuncSetAttribute((const void*)gram_pro_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, gp_lds_bytes<NT>()) != hipSuccess) {
             cvcl_set_error("cvcl_conv1x1_gram: cannot raise the dynamic LDS limit");
             return CVCL_ELAUNCH;
         }
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL(gram_pro_kernel<NT>, dim3(grid), dim3(256 + gp_producer_threads<NT>()), gp_lds_bytes<NT>(), st, d);
     return CVCL_OK;

@@ -36,6 +36,19 @@ struct CvclProfScope {
     ~CvclProfScope() { cvcl_prof_end(h, s); }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE: a per-process "already done" flag makes the first launch on a
+// second GPU of the same process fail.  One bit per device ordinal, set after the attribute call succeeded
+// (two threads racing both make the call: harmless).
+#ifdef __cplusplus
+#include <atomic>
+struct CvclLdsAttr {
+    std::atomic<unsigned long long> devs{0};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 63; }
+    bool ready() const { return (devs.load(std::memory_order_acquire) >> dev()) & 1ull; }
+    void mark() { devs.fetch_or(1ull << dev(), std::memory_order_release); }
+};
+#endif
+
 #define CVCL_CHECK_ARG(cond, ...)                \
     do {                                         \
         if (!(cond)) {                           \
@@ -217,7 +230,10 @@ __device__ inline f32x2 gelu_bf16out2(f32x2 v) {
     const f32x2 d = f32x2{1.f, 1.f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
     return v * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
-// d gelu(v) / dv with the same erf approximation (backward of the fused GELU epilogue / cvcl_gelu_bf16)
+// d gelu(v) / dv in the erf form (backward of the fused GELU epilogue / cvcl_gelu_bf16).  NOTE: the bf16 FORWARD epilogues use the
+// fitted gelu_bf16out above (|gelu_bf16out - gelu_erf| <= 2.6e-5), the backward differentiates the erf form: the two are the same
+// function to ~1e-4 of the derivative -- far below the bf16 rounding of the gradients it multiplies, and it keeps the fine-tuning
+// path's gradients those of the function the fp32 parity mode evaluates.
 __device__ inline float gelu_grad_fast(float v) {
     const float x = fabsf(v) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.f));

@@ -817,14 +817,14 @@ template <typename T, int PRO, bool LEAN, int MINW, int TR = 0>
 int launch_gemm_w(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     const int gm = grid_m_query<T>(a->M, a->N);      // same capacity for every variant (see grid_m_query)
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
-    static bool attr_set = false;
+    static CvclLdsAttr attr_set;
     constexpr int lds = gemm_lds_bytes<T>();
-    if (!attr_set) {
+    if (!attr_set.ready()) {
         if (hipFuncSetAttribute((const void*)gemm_kernel<T, PRO, LEAN, MINW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", lds);
             return CVCL_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid(gm, cvcl_div_up(a->N, BN));
     CvclProfScope prof(stream, sizeof(T) == 2 ? CVCL_K_GEMM : CVCL_K_GEMM_F32);
@@ -973,13 +973,13 @@ template <int EPI>
 int launch_gemm_glds(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     const int gm = grid_m_query<bf16_t>(a->M, a->N);
     if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CvclLdsAttr attr_set;
+    if (!attr_set.ready()) {
         if (hipFuncSetAttribute((const void*)gemm_glds_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS) != hipSuccess) {
             cvcl_set_error("cvcl_gemm: cannot raise dynamic LDS limit to %d", GL_LDS);
             return CVCL_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid(gm, a->N / BN);
     CvclProfScope prof(stream, CVCL_K_GEMM);

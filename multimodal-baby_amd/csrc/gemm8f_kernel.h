@@ -37,16 +37,26 @@ constexpr int NSTAGE = 4;
 constexpr int A_BYTES = 16384;                     // 256 rows x 64 B
 constexpr int STAGE_BYTES = 2 * A_BYTES;
 constexpr int STG_BYTES = 2048;                    // per-wave epilogue staging: 32 rows x 32 columns bf16
-constexpr int OPS_OFF = NSTAGE * STAGE_BYTES + 8 * STG_BYTES;      // [2 parities][sw 256 f32 | bias 256 f32 | sa 256 f32] = 6 KiB
-constexpr int MXS_OFF = OPS_OFF + 2 * 3072;                        // [4 K-tile slots][256 rows x 4 scale bytes] = 4 KiB
+constexpr int OPS_SLOT = 5120;                                     // per parity: sw 256 f32 | bias 256 f32 | sa 256 f32 -- or, LayerNorm folded
+                                                                   // (KIND 3 / 4): sw | b' | column sums s | 256 x (rstd, -mean rstd)
+constexpr int OPS_OFF = NSTAGE * STAGE_BYTES + 8 * STG_BYTES;      // [2 parities][OPS_SLOT] = 10 KiB
+constexpr int MXS_OFF = OPS_OFF + 2 * OPS_SLOT;                    // [4 K-tile slots][256 rows x 4 scale bytes] = 4 KiB
+static_assert(MXS_OFF + 4096 <= 160 * 1024, "LDS budget");
 constexpr int LDS_BYTES = 160 * 1024;
 
 // KIND 0: per-row activation scales sa, bf16 output (+ bias, optional ReLU / GELU)                      (qkv)
 // KIND 1: MX input (e8m0 per 32 k of A, tiled [K/128][M][4]), bf16 output + bias + residual               (proj, fc2)
 // KIND 2: per-row activation scales, bias + activation, MX OUTPUT (e4m3 + e8m0 per 32 columns)           (fc1)
+// Round 5 -- nn.LayerNorm folded into the e4m3 linear it feeds (reference vision_transformer_dino_mugs.py:136-149; the bf16 form is
+// gemm8w_kernel.h's LNF): A = the RAW residual rows, MX-quantised (e8m0 per 32 k) by the epilogue of the linear that produced
+// them; W = e4m3(W diag(gamma)) with per-row scales sw; ln_colsum[n] = sw[n] sum_k W8[n][k]; bias = b + W beta;
+// ln_stats[m] = (rstd, -mean rstd):   y = rstd (A8 . W8^T) sw - mean rstd ln_colsum + bias  = LayerNorm(x) W^T + b
+// KIND 3: MX input + that affine, bf16 output                                                              (qkv)
+// KIND 4: MX input + that affine + activation, MX OUTPUT                                                   (fc1)
 struct Dev {
     const unsigned char* A; const unsigned char* W; bf16_t* C; const bf16_t* R;
     const float* sa; const float* sw; const float* bias;
+    const float* ln_stats; const float* ln_colsum;
     const unsigned char* a_bs; unsigned char* C8; unsigned char* c_bs;
     int M, N, K, lda, ldw, ldc, ldr, ldc8, act;
     int tiles_m, ncol;
@@ -59,20 +69,13 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-    else static_assert(N < 0, "add the literal");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 template <int MT, int KIND, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
     constexpr int BM = MT * 64;
-    constexpr bool MXA = KIND == 1, MXOUT = KIND == 2, RES = KIND == 1;
+    constexpr bool MXA = KIND == 1 || KIND >= 3, MXOUT = KIND == 2 || KIND == 4, RES = KIND == 1, LNF = KIND >= 3;
     constexpr int ESTORES = MT * 4 * (MXOUT ? 2 : 1);      // global stores per lane per full tile epilogue (MX: + the scale bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -116,19 +119,23 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
     };
     auto advance = [&]() __attribute__((always_inline)) {
         // with the first stage of a tile, its epilogue operands (waves 0-2: sw / bias / sa of the tile, 1 KiB each, parity slot)
-        if (l_ks == 0 && wave < (MXA ? 2 : 3)) {
-            char* dst = smem + OPS_OFF + (l_t & 1) * 3072 + wave * 1024;
+        if (l_ks == 0 && wave < (LNF ? 5 : MXA ? 2 : 3)) {
+            char* dst = smem + OPS_OFF + (l_t & 1) * OPS_SLOT + wave * 1024;
             // (ragged last tile: whole 4-row granules past M are clamped to the granule that holds row M - 1 -- their rows are
             // masked at the store; that granule itself may reach up to 3 floats past sa[M - 1]: cvcl_hip.h asks for the padding)
             const float* src = wave == 0 ? p.sw + l_j * BN + lane * 4 : wave == 1 ? p.bias + l_j * BN + lane * 4
                                                                                  : p.sa + min(l_i * BM + lane * 4, (p.M - 1) & ~3);
+            if constexpr (LNF) {                   // waves 2: the column sums; 3 / 4: (rstd, -mean rstd) of the upper / lower 128 rows
+                if (wave == 2) src = p.ln_colsum + l_j * BN + lane * 4;
+                else if (wave >= 3) src = p.ln_stats + (long)min(l_i * BM + (wave - 3) * 128 + lane * 2, (p.M - 1) & ~1) * 2;
+            }
             if (wave == 1 && !p.bias) *reinterpret_cast<f32x4*>(dst + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};     // no bias: zeros
             else glds16(src, dst);
         }
         // MX input: with the first stage of a 128-k tile, the 4 block-scale bytes of the tile's 256 rows (1 KiB; one wave per K tile)
         if constexpr (MXA) {
             if ((l_ks & 1) == 0) {
-                if (wave == 2 + (l_kt & 3))
+                if (wave == (LNF ? 4 : 2) + (l_kt & 3))
                     glds16(p.a_bs + ((long)(l_ks >> 1) * p.M + min(l_i * BM + lane * 4, (p.M - 1) & ~3)) * 4,     // (as sa: granules of 4 rows)
                            smem + MXS_OFF + (l_kt & 3) * 1024);
                 ++l_kt;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
     // -> a lower bound on the VMEM instructions this call issued (exact for a full tile)
     auto epilogue = [&](int m0, int n0, int parity) __attribute__((always_inline)) -> int {
         const bool full = m0 + BM <= p.M;
-        const float* ops = reinterpret_cast<const float*>(smem + OPS_OFF + parity * 3072);
+        const float* ops = reinterpret_cast<const float*>(smem + OPS_OFF + parity * OPS_SLOT);
         bf16x8 rr[2];
         auto load_res = [&](int blk) __attribute__((always_inline)) {       // blk = mt * 2 + half: 16 rows x 64 columns
 #pragma unroll
@@ -207,6 +214,8 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
         for (int mt = 0; mt < MT; ++mt) {
             float sa_r = 1.f;
             if constexpr (!MXA) sa_r = ops[512 + wm * (BM / 2) + mt * 32 + l31];
+            f32x2 rs = {1.f, 0.f};                 // LayerNorm folded: this lane's row (rstd, -mean rstd)
+            if constexpr (LNF) rs = *reinterpret_cast<const f32x2*>(ops + 768 + (wm * (BM / 2) + mt * 32 + l31) * 2);
             // scales, bias, activation -> bf16: this lane's 32 values of row l31 (8 pieces of 4 consecutive columns)
             bf16x4 qv[2][4];
 #pragma unroll
@@ -216,10 +225,17 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
                     const int cb = wn * 64 + n2 * 32 + 8 * g + 4 * h;
                     const f32x4 sw_r = *reinterpret_cast<const f32x4*>(ops + cb);
                     const f32x4 bias_r = *reinterpret_cast<const f32x4*>(ops + 256 + cb);
+                    f32x4 cs_r = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (LNF) cs_r = *reinterpret_cast<const f32x4*>(ops + 512 + cb);
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {                       // pairs: packed fp32 arithmetic (bit-identical per element)
                         f32x2 v = f32x2{acc[n2][mt][4 * g + e], acc[n2][mt][4 * g + e + 1]};
                         if constexpr (!MXA) v = v * f32x2{sa_r, sa_r};
+                        if constexpr (LNF)     // rstd (acc sw) + (-mean rstd) s + b'
+                            v = __builtin_elementwise_fma(v * f32x2{sw_r[e], sw_r[e + 1]}, f32x2{rs[0], rs[0]},
+                                                          __builtin_elementwise_fma(f32x2{rs[1], rs[1]}, f32x2{cs_r[e], cs_r[e + 1]},
+                                                                                    f32x2{bias_r[e], bias_r[e + 1]}));
+                        else
                         v = __builtin_elementwise_fma(v, f32x2{sw_r[e], sw_r[e + 1]}, f32x2{bias_r[e], bias_r[e + 1]});
                         if (ACT == CVCL_ACT_RELU) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
                         if (ACT == CVCL_ACT_GELU) v = gelu_bf16out2(v);

@@ -40,29 +40,27 @@ int g8_grid_m(int tiles_m, int ncol) {
 
 template <int MI, int EPI, bool LNF = false>
 int g8_launch(const g8w::Dev& d, int grid, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static CvclLdsAttr attr;
+    if (!attr.ready()) {
         if (hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES) != hipSuccess) {
             cvcl_set_error("cvcl_gemm8w: cannot raise the dynamic LDS limit to %d", g8w::LDS_BYTES);
             return CVCL_ELAUNCH;
         }
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, LNF>), dim3(grid), dim3(512), g8w::LDS_BYTES, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
 
-// ---- linear epilogue (EPI 1 / 2): tile height, grid and -- round 5 -- the REMAINDER launch ----------------------------------
-// A launch of T tiles on G workgroups costs ceil(T / G) rounds whatever the last round holds (ViT-B/14 proj at B = 256: 771 tiles on
-// 256 CUs = 3.01 -> 4 rounds).  When the last round is poorly filled, the rows are cut in two: `rows_main` = the m-tiles that
-// whole rounds hold, at 256 | 224 rows per tile, and the remaining rows as ONE more round of shorter tiles (64 .. 256 rows, a
-// second launch of the same kernel at a smaller MI on the same stream).  Costs are in tile ROWS per workgroup (a round of MI-row
-// tiles ~ MI), the remainder's from the measured per-MI times (tools/g8_rem_bench.py): shorter tiles re-read the 256-column W
-// stage for fewer MFMAs, so a 64-row round costs about what a 130-row one does, plus the second launch's fill and drain.
-struct G8Plan { int bm, grid, rows_main, bm_rem, grid_rem; long cost; };
-
-long g8_rem_cost(int bm_rem) { return (bm_rem < 128 ? 128 : bm_rem) + 40; }
+// ---- linear epilogue (EPI 1 / 2): tile height and grid ------------------------------------------------------------------------
+// (Round 5, measured and NOT kept -- profiles/r05_ab_walk.txt: a REMAINDER launch.  A launch of T tiles on G workgroups costs
+// ceil(T / G) rounds whatever the last round holds (ViT-B/14 proj at B = 256: 771 tiles on 256 CUs = 3.01 -> 4 rounds), so the rows
+// whole rounds hold were run first and the rest as one more round of 64..192-row tiles (MI 2..6 instantiations).  Same box, two
+// trunk passes in flight: C4 11.60 -> 11.66 ms, C4 at patch 14 15.30 -> 15.55 ms -- the short tiles re-read the 256-column W stage
+// for few MFMAs, and with two passes in flight the CUs a lean grid leaves idle in its last round are not idle: the other pass's
+// kernels run there.)
+struct G8Plan { int bm, grid; };
 
 int g8_lean(long total, int grid) {                          // the smallest grid (multiple of 8) with the same number of rounds
     static const bool lean_on = cvcl_lab_int("CVCL_LEAN_GRID", 1) != 0;
@@ -71,33 +69,15 @@ int g8_lean(long total, int grid) {                          // the smallest gri
     return lean_on && lean < grid ? lean : grid;
 }
 
-G8Plan g8_plan(int M, int ncol, bool allow_remainder) {
+G8Plan g8_plan(int M, int ncol) {
     const int cus = g8_num_cus() & ~7;
-    G8Plan best = {256, 8, M, 0, 0, -1};
-    for (int h : {256, 224}) {                               // one launch (rounds 2-4)
+    G8Plan best = {256, 8};
+    long best_cost = -1;
+    for (int h : {256, 224}) {
         const long total = (long)cvcl_div_up(M, h) * ncol;
         const int g = total < cus ? (int)((total + 7) & ~7L) : cus;
         const long cost = ((total + g - 1) / g) * h;
-        if (best.cost < 0 || cost < best.cost) best = {h, g8_lean(total, g), M, 0, 0, cost};
-    }
-    static const bool rem_on = cvcl_lab_int("CVCL_G8_REMAINDER", 1) != 0;
-    if (!allow_remainder || !rem_on) return best;
-    for (int h : {256, 224}) {                               // whole rounds + one round of shorter tiles
-        const long total = (long)(M / h) * ncol;             // full tiles only
-        const long r = total / cus;
-        if (r < 1) continue;
-        const int mt = (int)std::min<long>(r * cus / ncol, M / h);
-        const int rows_main = mt * h, mr = M - rows_main;
-        if (mr <= 0) continue;
-        const int per_round = cus / ncol;                    // m-tiles one round holds
-        if (per_round < 1) continue;
-        int bm_rem = ((cvcl_div_up(mr, per_round) + 31) / 32) * 32;
-        if (bm_rem < 64) bm_rem = 64;
-        if (bm_rem > 256) continue;
-        const long main_tiles = (long)mt * ncol, rem_tiles = (long)cvcl_div_up(mr, bm_rem) * ncol;
-        const long cost = cvcl_div_up(main_tiles, cus) * h + g8_rem_cost(bm_rem);
-        if (cost < best.cost)
-            best = {h, g8_lean(main_tiles, cus), rows_main, bm_rem, (int)((rem_tiles + 7) & ~7L), cost};
+        if (best_cost < 0 || cost < best_cost) { best = {h, g8_lean(total, g)}; best_cost = cost; }
     }
     return best;
 }
@@ -112,55 +92,19 @@ int g8_superrow(int grid, int ncol) {
     return sr_lab > 0 ? sr_lab : sr;
 }
 
-template <int EPI, bool LNF>
-int g8_launch_mi(int bm, const g8w::Dev& d, int grid, hipStream_t st) {
-    switch (bm / 32) {
-        case 8: return g8_launch<8, EPI, LNF>(d, grid, st);
-        case 7: return g8_launch<7, EPI, LNF>(d, grid, st);
-        default: break;
-    }
-    if constexpr (LNF) {                                     // the shorter remainder tiles: the ViT's folded linears only
-        switch (bm / 32) {
-            case 6: return g8_launch<6, EPI, LNF>(d, grid, st);
-            case 5: return g8_launch<5, EPI, LNF>(d, grid, st);
-            case 4: return g8_launch<4, EPI, LNF>(d, grid, st);
-            case 3: return g8_launch<3, EPI, LNF>(d, grid, st);
-            case 2: return g8_launch<2, EPI, LNF>(d, grid, st);
-            default: break;
-        }
-    }
-    cvcl_set_error("cvcl_gemm8w: no %d-row tile for this epilogue", bm);
-    return CVCL_EINVAL;
-}
-
 int g8_linear(g8w::Dev d, const cvcl_gemm_args* a, hipStream_t st) {
     // the linear epilogue comes in two instantiations: activation (no residual) and residual (no activation) -- the only
     // combinations nn.Linear call sites on the path use (vit:92-94 fc1 + GELU, :113-115 / :146-147 proj, fc2 + residual)
     CVCL_CHECK_ARG(!(a->R && a->act != CVCL_ACT_NONE), "cvcl_gemm8w: activation and residual together are not implemented");
-    const bool lnf = a->ln_stats || a->row_part;
-    const G8Plan pl = g8_plan(a->M, d.ncol, lnf);
+    const G8Plan pl = g8_plan(a->M, d.ncol);
     CvclProfScope prof(st, CVCL_K_GEMM8W);
-    auto launch = [&](const g8w::Dev& dd, int bm, int grid) -> int {
-        if (a->ln_stats) return g8_launch_mi<1, true>(bm, dd, grid, st);
-        if (a->row_part) return g8_launch_mi<2, true>(bm, dd, grid, st);
-        return a->R ? g8_launch_mi<2, false>(bm, dd, grid, st) : g8_launch_mi<1, false>(bm, dd, grid, st);
-    };
-    g8w::Dev m = d;
-    m.M = pl.rows_main; m.a_rows = pl.rows_main;
-    m.tiles_m = cvcl_div_up(m.M, pl.bm);
-    m.grid_m = g8_superrow(pl.grid, d.ncol);
-    int rc = launch(m, pl.bm, pl.grid);
-    if (rc != CVCL_OK || !pl.bm_rem) return rc;
-    g8w::Dev r = d;                                          // the remaining rows: every row-indexed operand moves down by rows_main
-    const long o = pl.rows_main;
-    r.A = d.A + o * d.lda; r.C = d.C + o * d.ldc;
-    if (d.R) r.R = d.R + o * d.ldr;
-    if (d.ln_stats) r.ln_stats = d.ln_stats + o * 2;
-    if (d.row_part) r.row_part = d.row_part + o * (d.N >> 6) * 2;
-    r.M = d.M - pl.rows_main; r.a_rows = r.M;
-    r.tiles_m = cvcl_div_up(r.M, pl.bm_rem);
-    r.grid_m = g8_superrow(pl.grid_rem, d.ncol);
-    return launch(r, pl.bm_rem, pl.grid_rem);
+    d.tiles_m = cvcl_div_up(d.M, pl.bm);
+    d.grid_m = g8_superrow(pl.grid, d.ncol);
+    const bool tall = pl.bm == 256;
+    if (a->ln_stats) return tall ? g8_launch<8, 1, true>(d, pl.grid, st) : g8_launch<7, 1, true>(d, pl.grid, st);
+    if (a->row_part) return tall ? g8_launch<8, 2, true>(d, pl.grid, st) : g8_launch<7, 2, true>(d, pl.grid, st);
+    if (a->R) return tall ? g8_launch<8, 2>(d, pl.grid, st) : g8_launch<7, 2>(d, pl.grid, st);
+    return tall ? g8_launch<8, 1>(d, pl.grid, st) : g8_launch<7, 1>(d, pl.grid, st);
 }
 
 }  // namespace
@@ -190,15 +134,6 @@ extern "C" int cvcl_gemm8w_tile_rows(int M, int N) {
 extern "C" int cvcl_gemm8w_stats_rows(int M, int N) {
     const int bm = cvcl_gemm8w_tile_rows(M, N);
     return g8_grid_m(cvcl_div_up(M, bm), N / 256);
-}
-
-// the launch plan of the linear epilogue for an [M, N] output under the current CU share: plan5 = {tile rows, workgroups, rows of the
-// main launch, tile rows of the remainder launch (0 = none), its workgroups}; folded = the ln_stats / row_part epilogues
-extern "C" int cvcl_gemm8w_linear_plan(int M, int N, int folded, int* plan5) {
-    CVCL_CHECK_ARG(plan5 && M >= 1 && N >= 256 && N % 256 == 0, "cvcl_gemm8w_linear_plan: bad args");
-    const G8Plan pl = g8_plan(M, N / 256, folded != 0);
-    plan5[0] = pl.bm; plan5[1] = pl.grid; plan5[2] = pl.rows_main; plan5[3] = pl.bm_rem; plan5[4] = pl.grid_rem;
-    return CVCL_OK;
 }
 
 // epi 0: convolution epilogue (round + BN partial sums; C may be NULL = statistics only); epi 1: bias / activation / residual

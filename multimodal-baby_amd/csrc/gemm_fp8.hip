@@ -413,13 +413,13 @@ namespace {
 // ---- the 8-wave 256 (192) x 256 kernel (gemm8f_kernel.h) for the large ViT shapes ----
 template <int MT, int KIND, int ACT>
 int launch_8f(const g8f::Dev& d, int grid, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
+    static CvclLdsAttr attr;
+    if (!attr.ready()) {
         if (hipFuncSetAttribute((const void*)g8f::gemm8f_kernel<MT, KIND, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, g8f::LDS_BYTES) != hipSuccess) {
             cvcl_set_error("cvcl_gemm_fp8: cannot raise the dynamic LDS limit to %d", g8f::LDS_BYTES);
             return CVCL_ELAUNCH;
         }
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((g8f::gemm8f_kernel<MT, KIND, ACT>), dim3(grid), dim3(512), g8f::LDS_BYTES, st, d);
     return CVCL_OK;
@@ -436,13 +436,13 @@ int pick_8f(const float* a_scale, const void* a_bs, const void* C, const void* c
 
 template <int ACT, bool MXA, bool MXOUT>
 int launch_fp8(const F8Dev& d, dim3 grid, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CvclLdsAttr attr_set;
+    if (!attr_set.ready()) {
         if (hipFuncSetAttribute((const void*)gemm_fp8_kernel<ACT, MXA, MXOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS) != hipSuccess) {
             cvcl_set_error("cvcl_gemm_fp8: cannot raise the dynamic LDS limit");
             return CVCL_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL((gemm_fp8_kernel<ACT, MXA, MXOUT>), grid, dim3(256), F8_LDS, st, d);
     return CVCL_OK;

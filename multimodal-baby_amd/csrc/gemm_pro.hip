@@ -421,14 +421,14 @@ int pro_num_cus() {
 
 template <int KT, int MODE, int D>
 int pro_launch(const ProDev& d, dim3 grid, hipStream_t stream) {
-    static bool attr = false;
+    static CvclLdsAttr attr;
     constexpr int lds = pro_lds_bytes<KT>();
-    if (!attr) {
+    if (!attr.ready()) {
         if (hipFuncSetAttribute((const void*)gemm_pro_kernel<KT, MODE, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             cvcl_set_error("cvcl_gemm_pro: cannot raise the dynamic LDS limit to %d", lds);
             return CVCL_ELAUNCH;
         }
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((gemm_pro_kernel<KT, MODE, D>), grid, dim3(512), lds, stream, d);
     CVCL_LAUNCH_CHECK();

@@ -1089,13 +1089,13 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
         while (TH > 1 && lds_of(TH) > 150 * 1024) --TH;
         static const bool tiled_on = cvcl_env_on("CVCL_F32_TILED");
         if (tiled_on && lds_of(TH) <= 150 * 1024) {
-            static bool attr = false;
-            if (!attr) {
+            static CvclLdsAttr attr;
+            if (!attr.ready()) {
                 if (hipFuncSetAttribute((const void*)stem_tiled_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     cvcl_set_error("cvcl_stem_conv7x7: cannot raise the dynamic LDS limit");
                     return CVCL_ELAUNCH;
                 }
-                attr = true;
+                attr.mark();
             }
             const int bands = cvcl_div_up(Ho, TH);
             const long items = (long)B * bands;
@@ -1190,15 +1190,15 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         CvclProfScope prof(stream, CVCL_K_GCONV);
         int rc;
         const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);
-        static bool attr_set[2][2][11] = {};                 // per instantiation (wide, short m-tile table, slots)
+        static CvclLdsAttr attr_set[2][2][11];                 // per instantiation (wide, short m-tile table, slots)
         auto launch = [&](auto kern) -> int {
-            bool& done = attr_set[cg == 32][g.TH * Wo <= 64][slots <= 4 ? 4 : slots <= 6 ? 6 : slots <= 8 ? 8 : 10];
-            if (!done) {
+            CvclLdsAttr& done = attr_set[cg == 32][g.TH * Wo <= 64][slots <= 4 ? 4 : slots <= 6 ? 6 : slots <= 8 ? 8 : 10];
+            if (!done.ready()) {
                 if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                     cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
                     return CVCL_ELAUNCH;
                 }
-                done = true;
+                done.mark();
             }
             hipLaunchKernelGGL(kern, dim3(g.grid_x, C / GC_CS), dim3(256), g.lds, s, d);
             return CVCL_OK;
@@ -1233,14 +1233,14 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
             long gx = 1024 / slabs;                          // ~4 workgroups per CU in total; each stages its weights once
             if (gx < 1) gx = 1;
             if (gx > items) gx = items;
-            static bool attr[4] = {};
+            static CvclLdsAttr attr[4];
             auto launch = [&](auto kern, int slot) -> int {
-                if (!attr[slot]) {
+                if (!attr[slot].ready()) {
                     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                         cvcl_set_error("cvcl_gconv3x3: cannot raise the dynamic LDS limit");
                         return CVCL_ELAUNCH;
                     }
-                    attr[slot] = true;
+                    attr[slot].mark();
                 }
                 hipLaunchKernelGGL(kern, dim3((unsigned)gx, slabs), dim3(256), lds_of(TH), s, (const float*)x, a_scale, a_shift,
                                    (const float*)w_packed, (float*)y, centre, B, H, W, C, stride, Ho, Wo, TH, bands, plane_p_of(TH), act_floor);

@@ -789,13 +789,13 @@ int launch_attention_mfma_n(const void* qkv, void* out, void* out8, void* out_bs
                             hipStream_t s) {
     const int nt = (T + 31) / 32;
     const size_t lds = (size_t)nt * 32 * (ATT_KP + ATT_VP);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static CvclLdsAttr attr_set;
+    if (!attr_set.ready()) {
         if (hipFuncSetAttribute((const void*)attention_mfma_kernel<MX, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             cvcl_set_error("cvcl_attention: cannot raise the dynamic LDS limit");
             return CVCL_ELAUNCH;
         }
-        attr_set = true;
+        attr_set.mark();
     }
     hipLaunchKernelGGL((attention_mfma_kernel<MX, NTC>), dim3(B * heads), dim3(ATT_THREADS), lds, s, (const bf16_t*)qkv, (bf16_t*)out,
                        (unsigned char*)out8, (unsigned char*)out_bs, lse, B, T, heads, scale, nt);

@@ -699,13 +699,13 @@ extern "C" int cvcl_gconv3x3_wgrad(const void* x, const void* dy, float* dw, int
             cvcl_set_error("cvcl_gconv3x3_wgrad: workspace too small");
             return CVCL_EWORKSPACE;
         }
-        static bool attr = false;
-        if (!attr) {
+        static CvclLdsAttr attr;
+        if (!attr.ready()) {
             if (hipFuncSetAttribute((const void*)gconv_wgrad_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
                 cvcl_set_error("cvcl_gconv3x3_wgrad: cannot raise the dynamic LDS limit");
                 return CVCL_ELAUNCH;
             }
-            attr = true;
+            attr.mark();
         }
         CvclProfScope prof(stream, CVCL_K_WGRAD);
         GwDev d = {(const bf16_t*)x, (const bf16_t*)dy, (float*)workspace, B, H, W, C, stride, Ho, Wo, gw.Wo_pad, gw.TH, gw.bands,

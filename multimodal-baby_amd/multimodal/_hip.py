@@ -136,7 +136,6 @@ SIGNATURES = {
     "cvcl_bn_from_gram": (_I, [_P, _I, C.c_long, _P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _I, _P, _P]),
     "cvcl_row_stats": (_I, [_I, _P, C.c_long, _P, C.c_long, _I, _F, _P]),
     "cvcl_row_stats_finalize": (_I, [_P, _I, _P, C.c_long, _I, _F, _P]),
-    "cvcl_gemm8w_linear_plan": (_I, [_I, _I, _I, _P]),
     "cvcl_gemm8w_tile_rows": (_I, [_I, _I]),
     "cvcl_gemm8w_stats_rows": (_I, [_I, _I]),
     "cvcl_bf16_to_f32": (_I, [_P, _P, C.c_long, _P]),
@@ -252,6 +251,7 @@ class TrunkStream:
         self.n_slots = len(self.streams) + 1
         self.stream_index = 0
         self._entries = []                                 # entry events of the last n_slots - 1 launches
+        self._last_done = {}                               # stream index -> completion event of its latest pass
 
     @property
     def n_streams(self):
@@ -291,10 +291,17 @@ class TrunkStream:
             outs = fn(slot)
             done = torch.cuda.Event()
             done.record(stream)
+        self._last_done[self.stream_index] = done
         for t in inputs:                                   # allocated on the caller's pool, read on the trunk stream
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(stream)
         return outs, done
+
+    def other_pass_in_flight(self) -> bool:
+        """While ``fn`` runs (stream ``stream_index``): is a pass enqueued on ANOTHER trunk stream still unfinished?  True in a
+        training loop (the host runs passes ahead of the device), False when every pass is awaited before the next starts
+        (validation with a host sync per batch, host-bound steps)."""
+        return any(i != self.stream_index and not ev.query() for i, ev in self._last_done.items())
 
     def wait(self, handle):
         outs, done = handle
@@ -379,7 +386,7 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
     if gelu_grad_of is not None:                          # C = (A W^T) * gelu'(gelu_grad_of)
         a.G, a.ldg = ptr(gelu_grad_of, A.dtype), N
     a.centre = ptr(centre, torch.float32)
-    # LayerNorm folded into the linear (cvcl_hip.h): consumer (ln_stats [>= M + 512, 2], ln_colsum [N], bias = folded) / producer (row_part)
+    # LayerNorm folded into the linear (cvcl_hip.h): consumer (ln_stats [M + (M & 1), 2], ln_colsum [N], bias = folded) / producer (row_part)
     a.ln_stats, a.ln_colsum, a.row_part = ptr(ln_stats, torch.float32), ptr(ln_colsum, torch.float32), ptr(row_part, torch.float32)
     if query_ln:                                          # would cvcl_gemm honour ln_stats / row_part for these arguments?
         return bool(lib().cvcl_gemm_ln_supported(C.byref(a)))

@@ -140,7 +140,9 @@ def _vit_forward(model, x: torch.Tensor, slot) -> torch.Tensor:
     # two passes' activations no longer share the Infinity Cache) -- hence the policy below; $CVCL_VIT_CU_SHARE=0 / 1 forces it
     ts = model.__dict__.get("_trunk_stream")
     share = 0
-    if ts is not None and ts.n_streams == 2 and x.is_cuda:
+    # (only while the OTHER stream's pass is really in flight: a validation loop with a host sync per batch, or a host-bound step,
+    # runs one pass at a time, and half-chip grids would then leave half the CUs idle)
+    if ts is not None and ts.n_streams == 2 and x.is_cuda and (ts.other_pass_in_flight() or os.environ.get("CVCL_VIT_CU_SHARE") == "1"):
         rows = x.shape[0] * ((x.shape[2] // model.patch_size) * (x.shape[3] // model.patch_size) + 1)
         auto = model.compute_dtype == torch.bfloat16 and not getattr(model, "fp8_linears", False) and rows <= 56 * 1024
         force = os.environ.get("CVCL_VIT_CU_SHARE")

@@ -649,6 +649,6 @@ def test_linear_backward_reads_operands_in_place(dev):
         assert maxrel(dw.cpu(), dy.double().t() @ x.double()) < 2e-5
         assert maxrel(db.cpu(), dy.double().sum(0)) < 2e-5
         _, dw2, db2 = ops.linear_backward(x.to(dev), w.to(dev), dy.to(dev), (False, True, False))
-        assert db2 is None and torch.equal(dw2, dw)
+        assert db2 is None and maxrel(dw2.cpu(), dw.cpu()) < 2e-5     # (without the row sums the small-product kernel may run: another summation order)
         _, _, db3 = ops.linear_backward(x.to(dev), w.to(dev), dy.to(dev), (False, False, True))
         assert maxrel(db3.cpu(), dy.double().sum(0)) < 2e-5

@@ -143,28 +143,26 @@ def test_vit_forward_with_folded_layernorm(dev, B, patch, forced):
 
 @pytest.mark.parametrize("M,N,K,kind", [(65792, 768, 768, "producer"), (50432, 768, 768, "producer"), (50432, 3072, 768, "consumer"),
                                        (65792, 2304, 768, "consumer"), (20000, 768, 3072, "producer")])
-def test_remainder_launch_and_supertile_walk_are_bit_identical(H, dev, M, N, K, kind):
-    """Round 5: the linear epilogue walks its tiles in L2-sized supertiles and, when the last round of a launch would be poorly
-    filled, runs the rows whole rounds hold first and the rest as one round of shorter tiles (cvcl_gemm8w_linear_plan).  Neither
-    changes the order in which an output element sums its K products: under every CU share (= another grid, another walk,
-    with and without a remainder launch) C -- and the producer's row partials -- must come out bit for bit the same."""
-    import ctypes as C
+def test_supertile_walk_is_bit_identical_under_every_grid(H, dev, M, N, K, kind):
+    """Round 5: the linear epilogue walks its tiles in supertiles (super-rows of m-tiles x column slabs, one eighth of the list per
+    XCD -- csrc/gemm8w_kernel.h).  The walk does not change the order in which an output element sums its K products: under every
+    CU share (= another grid, another super-row height, another assignment of tiles to workgroups) C -- and the producer's row
+    partials -- must come out bit for bit the same, and right."""
     g = torch.Generator().manual_seed(M + N)
     x = _rows(M, K, M % 1000).to(dev)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(dev)
     b = (0.1 * torch.randn(N, generator=g)).to(dev)
     res = _rows(M, N, 7).to(dev) if kind == "producer" else None
-    st = torch.zeros(M + 1, 2, device=dev)[:M]
-    H.check(H.lib().cvcl_row_stats(H.BF16, H.ptr(x), K, H.ptr(st), M, K, 1e-6, H.stream_ptr()), "cvcl_row_stats")
-    cs = W.float().sum(1).contiguous()
-    outs, plans = [], []
+    st = cs = None
+    if kind == "consumer":
+        st = torch.zeros(M + 1, 2, device=dev)[:M]
+        H.check(H.lib().cvcl_row_stats(H.BF16, H.ptr(x), K, H.ptr(st), M, K, 1e-6, H.stream_ptr()), "cvcl_row_stats")
+        cs = W.float().sum(1).contiguous()
+    outs = []
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     for share in (0, cus // 2, 104, 64, 40):
         prev = H.lib().cvcl_set_gemm_cu_share(share)
         try:
-            plan = (C.c_int * 5)()
-            H.check(H.lib().cvcl_gemm8w_linear_plan(M, N, 1, plan), "plan")
-            plans.append(tuple(plan))
             if kind == "producer":
                 part = torch.full((M, N // 64, 2), float("nan"), device=dev)
                 y = H.gemm(x, W, bias=b, residual=res, row_part=part)
@@ -175,11 +173,6 @@ def test_remainder_launch_and_supertile_walk_are_bit_identical(H, dev, M, N, K, 
         finally:
             H.lib().cvcl_set_gemm_cu_share(prev)
     torch.cuda.synchronize()
-    print(plans)
-    assert any(p[3] > 0 for p in plans), plans                 # at least one share plans a remainder launch for this shape
-    assert any(p[3] == 0 for p in plans), plans
-    for p in plans:
-        assert p[2] % p[0] == 0 and (p[3] == 0) == (p[2] == M) and p[3] % 32 == 0 and p[3] <= 256
     for o in outs[1:]:
         for t0, t1 in zip(outs[0], o):
             assert torch.equal(t0, t1)
