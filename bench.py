@@ -384,8 +384,15 @@ def fp8_yardstick(ve, images, patch=16, fp8=True):
     with torch.no_grad():
         chunks = [images[i:i + 64] for i in range(0, images.shape[0], 64)]          # (the fp32 attention matrix of 64 frames: 0.36 GB)
         ref = torch.cat([O.vit_forward(p, c, patch, heads) for c in chunks])
-        emu = torch.cat([O.vit_forward(p, c, patch, heads, quant=O.bf16_round, fp8=fp8) for c in chunks])
+        # (the product folds LayerNorm into the e4m3 qkv / fc1 at this size -- vit_hip.py fold8 -- and the emulation follows it)
+        from multimodal import _hip as H
+        D = model.embed_dim
+        rows = images.shape[0] * ((images.shape[2] // patch) * (images.shape[3] // patch) + 1)
+        fold8 = bool(fp8) and bool(H.lib().cvcl_gemm_fp8_ln_supported(rows, 3 * D, D)) and bool(H.lib().cvcl_gemm_fp8_ln_supported(rows, 4 * D, D))
+        emu = torch.cat([O.vit_forward(p, c, patch, heads, quant=O.bf16_round, fp8=fp8, fp8_fold=fold8) for c in chunks])
         out["emulation_vs_torch_fp32"] = dev(emu, ref)
+        if fp8:
+            out["layernorm_folded"] = fold8
         keep_dt, keep_f8 = model.compute_dtype, getattr(model, "fp8_linears", False)
         try:
             model.compute_dtype, model.fp8_linears = torch.float32, False
@@ -396,7 +403,7 @@ def fp8_yardstick(ve, images, patch=16, fp8=True):
             model.compute_dtype, model.fp8_linears = keep_dt, keep_f8
         out["hip_fp8_vs_hip_fp32" if fp8 else "hip_bf16_vs_hip_fp32"] = dev(h8, h32)
         out["hip_fp32_vs_torch_fp32"] = dev(h32, ref)
-    return {k: {kk: float(f"{vv:.4g}") for kk, vv in v.items()} for k, v in out.items()}
+    return {k: ({kk: float(f"{vv:.4g}") for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in out.items()}
 
 
 def spawn_ranks(a, argv):

@@ -538,6 +538,31 @@ int cvcl_quant_rows_fp8(int src_dtype, const void* x, long x_row_stride, const f
 int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void* a_block_scales, int lda, const void* W8,
                      const float* w_scale, int ldw, void* C, int ldc, void* c8, void* c_block_scales, int ldc8,
                      const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream);
+/* The same with every option in one block (round 5), plus nn.LayerNorm FOLDED into the e4m3 linear it feeds (reference
+ * vision_transformer_dino_mugs.py:136-149: x + attn(norm1(x)), x + mlp(norm2(x)); the bf16 form is cvcl_gemm_args.ln_stats):
+ *   producer (row_part != NULL; proj / fc2: MX input, bias + residual): besides the bf16 rows C = round(acc sw + bias) + R the kernel
+ *     writes their MX-quantised copy c8 / c_block_scales -- the RAW operand of the next qkv / fc1, e8m0 per 32 elements, no row-wide
+ *     amax needed -- and row_part[m][N / 64][2] = (sum, sum of squares) of the stored row per 64-column strip (cvcl_row_stats_finalize
+ *     turns them into ln_stats);
+ *   consumer (ln_stats != NULL; qkv / fc1: MX input = those raw rows): W8 = e4m3(W diag(gamma)) with row scales w_scale,
+ *     ln_colsum[n] = w_scale[n] * sum_k W8[n][k], bias[n] = b[n] + sum_k W[n][k] beta[k], ln_stats[m] = (rstd, -mean rstd):
+ *     y = act(rstd (A8 . W8^T) w_scale - mean rstd ln_colsum + bias), to bf16 C or (c8 != NULL) to MX output.  8-wave kernel only:
+ *     cvcl_gemm_fp8_ln_supported(M, N, K).  ln_stats readable for an even number of rows.
+ * The 24 LayerNorm + row-quantise passes of a ViT-B (1.0 ms of an 8.2 ms step at B = 256) go; cvcl_quant_rows_mx quantises the
+ * assembled tokens once per forward.                                                                                          */
+typedef struct {
+    const void* A8; const float* a_scale; const void* a_block_scales; int lda;
+    const void* W8; const float* w_scale; int ldw;
+    void* C; int ldc; void* c8; void* c_block_scales; int ldc8;
+    const float* bias; int act; const void* R; int ldr;
+    int M, N, K;
+    const float* ln_stats; const float* ln_colsum; float* row_part;
+} cvcl_gemm_fp8_args;
+int cvcl_gemm_fp8_ex(const cvcl_gemm_fp8_args* args, void* stream);
+int cvcl_gemm_fp8_ln_supported(int M, int N, int K);
+/* bf16 rows [rows][K] (K % 128 == 0) -> e4m3 q [rows][K] + e8m0 block scales tiled [K / 128][rows][4] (one per 32 elements; the
+ * quantiser of the MX-output epilogues, bit for bit). */
+int cvcl_quant_rows_mx(const void* x, long x_row_stride, void* q, void* block_scales, long rows, int K, void* stream);
 int cvcl_gemm_fp8(const void* A8, const float* a_scale, int lda, const void* W8, const float* w_scale, int ldw, void* C, int ldc,
                   const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream);
 

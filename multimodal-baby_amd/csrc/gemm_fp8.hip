@@ -13,6 +13,8 @@
 // global_load_lds_dwordx4 under the source-side XOR chunk swizzle, two buffers, one barrier per K tile.  A lane's fragment
 // for one MFMA is 32 consecutive k bytes of its row (two swizzled 16-byte chunks); A and B use the same (lane, byte) -> k
 // assignment, which is all a contraction needs.
+#include <algorithm>
+
 #include "cvcl_common.h"
 #include "gemm8f_kernel.h"
 
@@ -29,7 +31,8 @@ struct F8Dev {
     const unsigned char* A; const unsigned char* W; bf16_t* C; const bf16_t* R;
     const float* sa; const float* sw; const float* bias;
     const unsigned char* a_bs;        // MXA: e8m0 scale per 32-element block of A, tiled [K/128][M][4] (sa unused)
-    unsigned char* C8; unsigned char* c_bs;   // MXOUT: e4m3 output [M][ldc8] + e8m0 block scales [M][N/32] instead of bf16 C
+    unsigned char* C8; unsigned char* c_bs;   // MXOUT: e4m3 output [M][ldc8] + e8m0 block scales [M][N/32] instead of (1) / beside (2) bf16 C
+    float* row_part;                  // MXOUT == 2: (sum, sum of squares) of the stored row per 64-column strip, [M][N / 64][2]
     int M, N, K, lda, ldw, ldc, ldr, act, num_m_tiles, ldc8;
     int xcd_split;                    // 1: XCD x = blockIdx.x % 8 owns row tiles x, x + 8, ...; 0: one list over all tiles
 };
@@ -44,7 +47,10 @@ __device__ inline float f8_gelu(float v) { return gelu_bf16out(v); }      // the
 // ---- quantisation: one wave per row; q = e4m3(x / s), s = amax / 448 (s = 1 for an all-zero row) ------------------------
 // src: bf16 rows (SRC_F32 = false) or fp32 rows (weights); optional LayerNorm (gamma/beta != NULL) before quantising.
 // K % 8 == 0, K <= 4096 (8 chunks of 8 per lane)
-template <int ACT, bool MXA, bool MXOUT>
+// MXOUT: 0 = bf16 C; 1 = MX output only (e4m3 + e8m0 per 32 columns); 2 (round 5, the PRODUCER of a LayerNorm-folded e4m3 linear:
+// proj / fc2 of a ViT block, reference vision_transformer_dino_mugs.py:146-147) = the bf16 residual row AND its MX-quantised copy --
+// the raw operand of the next qkv / fc1 -- AND the row's (sum, sum of squares) per 64-column strip for cvcl_row_stats_finalize.
+template <int ACT, bool MXA, int MXOUT>
 __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,9 +248,25 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                 }
-                if constexpr (!MXOUT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                if constexpr (MXOUT != 1) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                if constexpr (MXOUT == 2) {
+                    // (sum, sum of squares) of the STORED values over this wave's 64-column strip of the row (as gemm8w's EPI 2 + LNF):
+                    // v_dot2 on the packed pairs (products of bf16 are exact in fp32), then the row's eight lanes by DPP
+                    const u32x4 w4 = __builtin_bit_cast(u32x4, v);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1 = dot2c_bf16(s1, w4[e], 0x3f803f80u);             // (1.0, 1.0)
+                        s2 = dot2c_bf16(s2, w4[e], w4[e]);
+                    }
+                    s1 += dpp_quad_f32<0xB1>(s1); s2 += dpp_quad_f32<0xB1>(s2);          // lane ^ 1
+                    s1 += dpp_quad_f32<0x4E>(s1); s2 += dpp_quad_f32<0x4E>(s2);          // lane ^ 2
+                    s1 += dpp_quad_f32<0x141>(s1); s2 += dpp_quad_f32<0x141>(s2);        // row_half_mirror: the other quad
+                    if (chunk == 0)
+                        *reinterpret_cast<f32x2*>(p.row_part + ((long)m * (p.N >> 6) + ((n0 >> 6) + wn)) * 2) = f32x2{s1, s2};
+                }
             }
-            if constexpr (MXOUT) {
+            if constexpr (MXOUT != 0) {
                 // e4m3 + one e8m0 scale per 32 columns of the row: the block = 4 adjacent lanes (chunks 4b .. 4b+3).  On the packed
                 // bf16 words (cvcl_common.h): |x| maximum as 15-bit integers, then v_cvt_scalef32_pk_fp8_bf16 by the block scale
                 const u32x4 vw = __builtin_bit_cast(u32x4, v);
@@ -373,6 +395,28 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const void* __restr
     }
 }
 
+// MX quantisation of bf16 rows (round 5: the raw residual rows that enter the first LayerNorm-folded qkv of a ViT -- every later
+// block gets them from the proj / fc2 epilogue): e4m3 with one e8m0 scale per 32 elements, the block-scale bytes tiled
+// [K / 128][rows][4] as the MX-input GEMMs read them.  Same helpers as the GEMM epilogues: bit-identical to their quantiser.
+// One 16-byte chunk per thread, four adjacent lanes = one block.
+__global__ __launch_bounds__(256) void quant_rows_mx_kernel(const bf16_t* __restrict__ x, long x_row_stride, unsigned char* __restrict__ q,
+                                                            unsigned char* __restrict__ bs, long rows, int K) {
+    const int cpr = K >> 3;                                  // chunks per row (a multiple of 16)
+    const long total = rows * cpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / cpr;
+        const int c = (int)(i - row * cpr);
+        const u32x4 vw = *reinterpret_cast<const u32x4*>(x + row * x_row_stride + c * 8);
+        unsigned mb = bf16x8_absmax_bits(vw);
+        mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0xB1, 0xf, 0xf, true));
+        mb = max(mb, (unsigned)__builtin_amdgcn_update_dpp(0, (int)mb, 0x4E, 0xf, 0xf, true));
+        const unsigned sb = mx_scale_byte(__uint_as_float(mb << 16));
+        const u32x2 w = bf16x8_to_fp8_scaled(vw, __uint_as_float(sb << 23));
+        *reinterpret_cast<u32x2*>(q + row * K + c * 8) = w;
+        if ((c & 3) == 0) bs[((long)(c >> 4) * rows + row) * 4 + ((c >> 2) & 3)] = (unsigned char)sb;
+    }
+}
+
 int f8_num_cus() {
     static int n = 0;
     if (!n) {
@@ -434,7 +478,7 @@ int pick_8f(const float* a_scale, const void* a_bs, const void* C, const void* c
     return (C && !R && (act == CVCL_ACT_NONE || act == CVCL_ACT_GELU)) ? 0 : -1;
 }
 
-template <int ACT, bool MXA, bool MXOUT>
+template <int ACT, bool MXA, int MXOUT>
 int launch_fp8(const F8Dev& d, dim3 grid, hipStream_t st) {
     static CvclLdsAttr attr_set;
     if (!attr_set.ready()) {
@@ -452,11 +496,35 @@ int launch_fp8(const F8Dev& d, dim3 grid, hipStream_t st) {
 // a_scale: per-row fp32 scales [M], or NULL with a_block_scales (e8m0, MX) tiled [K/128][M][4]: the four block scales of one
 // row's 128-wide K tile are one word, rows adjacent, so a wave's 32 rows read them coalesced.  C: bf16 [M][ldc], or NULL with
 // c8 [M][ldc8] e4m3 + c_block_scales [N/128][M][4] (MX output for the next fp8 GEMM; no residual in that mode).
-extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void* a_block_scales, int lda, const void* W8,
-                                const float* w_scale, int ldw, void* C, int ldc, void* c8, void* c_block_scales, int ldc8,
-                                const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream) {
-    CVCL_CHECK_ARG(A8 && W8 && w_scale && M > 0 && N > 0 && K > 0 && (!a_scale != !a_block_scales) && (!C != !c8) &&
+// Round 5: ln_stats / ln_colsum = the CONSUMER of a folded LayerNorm (MX input = the raw residual rows; the 8-wave kernel only:
+// cvcl_gemm_fp8_ln_supported); row_part = the PRODUCER (bf16 C + residual AND the MX copy c8 / c_block_scales of the stored rows
+// AND their strip sums; the 128 x 128 kernel).
+extern "C" int cvcl_gemm_fp8_ln_supported(int M, int N, int K) {
+    if (N % 256 || K % 128 || K < 256 || (long)cvcl_div_up(M, 256) * (N / 256) < 96 || (long)M * K >= (1L << 31) || (long)N * K >= (1L << 31)) return 0;
+    const int share = cvcl_gemm_cu_share();
+    const int cus = share > 0 && share < f8_num_cus() ? share : f8_num_cus();
+    const long total = (long)cvcl_div_up(M, 256) * (N / 256);
+    const long g = total < cus ? ((total + 7) & ~7L) : (cus & ~7);
+    return g > 0;
+}
+
+extern "C" int cvcl_gemm_fp8_ex(const cvcl_gemm_fp8_args* x, void* stream) {
+    CVCL_CHECK_ARG(x, "cvcl_gemm_fp8: null arguments");
+    const void* A8 = x->A8; const float* a_scale = x->a_scale; const void* a_block_scales = x->a_block_scales; const int lda = x->lda;
+    const void* W8 = x->W8; const float* w_scale = x->w_scale; const int ldw = x->ldw;
+    void* C = x->C; const int ldc = x->ldc; void* c8 = x->c8; void* c_block_scales = x->c_block_scales; const int ldc8 = x->ldc8;
+    const float* bias = x->bias; const int act = x->act; const void* R = x->R; const int ldr = x->ldr;
+    const int M = x->M, N = x->N, K = x->K;
+    const bool consumer = x->ln_stats != nullptr, producer = x->row_part != nullptr;
+    CVCL_CHECK_ARG(A8 && W8 && w_scale && M > 0 && N > 0 && K > 0 && (!a_scale != !a_block_scales) && (producer || (!C != !c8)) &&
                        (!c8 == !c_block_scales), "cvcl_gemm_fp8: null / inconsistent operands");
+    CVCL_CHECK_ARG(!consumer || (a_block_scales && x->ln_colsum && bias && !R && !producer && ((uintptr_t)x->ln_stats & 15) == 0 &&
+                                 ((uintptr_t)x->ln_colsum & 15) == 0 && cvcl_gemm_fp8_ln_supported(M, N, K)),
+                   "cvcl_gemm_fp8: ln_stats needs MX input, ln_colsum, the folded bias, no residual and a shape the 8-wave kernel takes");
+    CVCL_CHECK_ARG(!x->ln_colsum || consumer, "cvcl_gemm_fp8: ln_colsum without ln_stats");
+    CVCL_CHECK_ARG(!producer || (C && c8 && c_block_scales && R && a_block_scales && act == CVCL_ACT_NONE && N % 64 == 0 &&
+                                 ((uintptr_t)x->row_part & 7) == 0),
+                   "cvcl_gemm_fp8: row_part goes with MX input, bias + residual, and both outputs (C and c8 / c_block_scales)");
     CVCL_CHECK_ARG(K % 128 == 0 && N % 128 == 0 && lda % 16 == 0 && ldw % 16 == 0 && (!C || ldc % 8 == 0) && (!c8 || ldc8 % 8 == 0) &&
                        (!R || ldr % 8 == 0),
                    "cvcl_gemm_fp8: needs K %% 128 == 0, N %% 128 == 0 and 16-byte aligned rows (M %d N %d K %d)", M, N, K);
@@ -464,16 +532,18 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
     CVCL_CHECK_ARG(al16(A8) && al16(W8) && al16(C) && al16(R) && al16(bias) && al16(w_scale) && (((uintptr_t)c8 & 7) == 0) &&
                        (((uintptr_t)a_block_scales & 3) == 0), "cvcl_gemm_fp8: operands must be 16-byte aligned");
     CVCL_CHECK_ARG(act == CVCL_ACT_NONE || act == CVCL_ACT_RELU || act == CVCL_ACT_GELU, "cvcl_gemm_fp8: activation %d", act);
-    CVCL_CHECK_ARG(!c8 || !R, "cvcl_gemm_fp8: the MX output mode takes no residual");
+    CVCL_CHECK_ARG(!c8 || !R || producer, "cvcl_gemm_fp8: the MX output mode takes no residual");
     hipStream_t st = (hipStream_t)stream;
     // Large shapes: the 8-wave kernel (gemm8f_kernel.h)
-    const int kind = M >= 4 ? pick_8f(a_scale, a_block_scales, C, c8, act, R, M, N, K, lda, ldw) : -1;
+    int kind = (M >= 4 && !producer) ? pick_8f(a_scale, a_block_scales, C, c8, act, R, M, N, K, lda, ldw) : -1;
+    if (consumer) kind = c8 ? 4 : 3;                         // (shape vetted by cvcl_gemm_fp8_ln_supported above)
     if (kind >= 0) {
         bool use8f = true;
         g8f::Dev g;
         g.A = (const unsigned char*)A8; g.W = (const unsigned char*)W8; g.C = (bf16_t*)C; g.R = (const bf16_t*)R;
         g.sa = a_scale; g.sw = w_scale; g.bias = bias; g.a_bs = (const unsigned char*)a_block_scales;
         g.C8 = (unsigned char*)c8; g.c_bs = (unsigned char*)c_block_scales;
+        g.ln_stats = x->ln_stats; g.ln_colsum = x->ln_colsum;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.ldr = ldr; g.ldc8 = ldc8; g.act = act;
         g.ncol = N / 256;
         const int share = cvcl_gemm_cu_share();
@@ -494,11 +564,20 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
         const int grid8 = total < cus ? (int)((total + 7) & ~7L) : (cus & ~7);
         // the last round of 256-wide tiles must be reasonably full: at N = 768 (proj / fc2 of ViT-B, 2.3 rounds of 256-row tiles
         // = 77 % of the slots) the 128 x 128 kernel below (two workgroups per CU, 4.6 rounds = 92 %) is the faster one
-        use8f = (double)total / ((double)((total + grid8 - 1) / grid8) * grid8) >= 0.85;
+        use8f = consumer || (double)total / ((double)((total + grid8 - 1) / grid8) * grid8) >= 0.85;
       if (use8f) {
         CvclProfScope prof(stream, CVCL_K_GEMM);
         int rc;
-        if (bm == 256)
+        if (kind >= 3) {
+            const bool gelu = act == CVCL_ACT_GELU;
+            CVCL_CHECK_ARG(act == CVCL_ACT_NONE || gelu, "cvcl_gemm_fp8: the folded kinds take no ReLU");
+            if (bm == 256)
+                rc = kind == 3 ? (gelu ? launch_8f<4, 3, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<4, 3, CVCL_ACT_NONE>(g, grid8, st))
+                               : (gelu ? launch_8f<4, 4, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<4, 4, CVCL_ACT_NONE>(g, grid8, st));
+            else
+                rc = kind == 3 ? (gelu ? launch_8f<3, 3, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<3, 3, CVCL_ACT_NONE>(g, grid8, st))
+                               : (gelu ? launch_8f<3, 4, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<3, 4, CVCL_ACT_NONE>(g, grid8, st));
+        } else if (bm == 256)
             rc = kind == 1 ? launch_8f<4, 1, CVCL_ACT_NONE>(g, grid8, st)
                : kind == 2 ? (act == CVCL_ACT_GELU ? launch_8f<4, 2, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<4, 2, CVCL_ACT_NONE>(g, grid8, st))
                            : (act == CVCL_ACT_GELU ? launch_8f<4, 0, CVCL_ACT_GELU>(g, grid8, st) : launch_8f<4, 0, CVCL_ACT_NONE>(g, grid8, st));
@@ -515,6 +594,7 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
     d.A = (const unsigned char*)A8; d.W = (const unsigned char*)W8; d.C = (bf16_t*)C; d.R = (const bf16_t*)R;
     d.sa = a_scale; d.sw = w_scale; d.bias = bias;
     d.a_bs = (const unsigned char*)a_block_scales; d.C8 = (unsigned char*)c8; d.c_bs = (unsigned char*)c_block_scales;
+    d.row_part = x->row_part;
     d.M = M; d.N = N; d.K = K; d.lda = lda; d.ldw = ldw; d.ldc = ldc; d.ldr = ldr; d.act = act; d.ldc8 = ldc8;
     d.num_m_tiles = cvcl_div_up(M, F8_BM);
     const int ntn = N / F8_BN;
@@ -533,18 +613,42 @@ extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void
     CvclProfScope prof(stream, CVCL_K_GEMM);
     const bool mxa = a_block_scales != nullptr, mxo = c8 != nullptr;
     int rc;
-    if (mxo) {
+    if (producer) {
+        rc = launch_fp8<CVCL_ACT_NONE, true, 2>(d, grid, st);
+    } else if (mxo) {
         CVCL_CHECK_ARG(!mxa, "cvcl_gemm_fp8: MX input together with MX output is not instantiated");
-        rc = act == CVCL_ACT_GELU ? launch_fp8<CVCL_ACT_GELU, false, true>(d, grid, st)
-           : act == CVCL_ACT_RELU ? launch_fp8<CVCL_ACT_RELU, false, true>(d, grid, st) : launch_fp8<CVCL_ACT_NONE, false, true>(d, grid, st);
+        rc = act == CVCL_ACT_GELU ? launch_fp8<CVCL_ACT_GELU, false, 1>(d, grid, st)
+           : act == CVCL_ACT_RELU ? launch_fp8<CVCL_ACT_RELU, false, 1>(d, grid, st) : launch_fp8<CVCL_ACT_NONE, false, 1>(d, grid, st);
     } else if (mxa) {
         CVCL_CHECK_ARG(act == CVCL_ACT_NONE, "cvcl_gemm_fp8: MX input is instantiated without activation only");
-        rc = launch_fp8<CVCL_ACT_NONE, true, false>(d, grid, st);
+        rc = launch_fp8<CVCL_ACT_NONE, true, 0>(d, grid, st);
     } else {
-        rc = act == CVCL_ACT_GELU ? launch_fp8<CVCL_ACT_GELU, false, false>(d, grid, st)
-           : act == CVCL_ACT_RELU ? launch_fp8<CVCL_ACT_RELU, false, false>(d, grid, st) : launch_fp8<CVCL_ACT_NONE, false, false>(d, grid, st);
+        rc = act == CVCL_ACT_GELU ? launch_fp8<CVCL_ACT_GELU, false, 0>(d, grid, st)
+           : act == CVCL_ACT_RELU ? launch_fp8<CVCL_ACT_RELU, false, 0>(d, grid, st) : launch_fp8<CVCL_ACT_NONE, false, 0>(d, grid, st);
     }
     if (rc) return rc;
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_gemm_fp8_mx(const void* A8, const float* a_scale, const void* a_block_scales, int lda, const void* W8,
+                                const float* w_scale, int ldw, void* C, int ldc, void* c8, void* c_block_scales, int ldc8,
+                                const float* bias, int act, const void* R, int ldr, int M, int N, int K, void* stream) {
+    cvcl_gemm_fp8_args x = {};
+    x.A8 = A8; x.a_scale = a_scale; x.a_block_scales = a_block_scales; x.lda = lda; x.W8 = W8; x.w_scale = w_scale; x.ldw = ldw;
+    x.C = C; x.ldc = ldc; x.c8 = c8; x.c_block_scales = c_block_scales; x.ldc8 = ldc8; x.bias = bias; x.act = act; x.R = R; x.ldr = ldr;
+    x.M = M; x.N = N; x.K = K;
+    return cvcl_gemm_fp8_ex(&x, stream);
+}
+
+extern "C" int cvcl_quant_rows_mx(const void* x, long x_row_stride, void* q, void* block_scales, long rows, int K, void* stream) {
+    CVCL_CHECK_ARG(x && q && block_scales && rows > 0 && K > 0 && K % 128 == 0 && x_row_stride % 8 == 0 && ((uintptr_t)x & 15) == 0 &&
+                       ((uintptr_t)q & 7) == 0, "cvcl_quant_rows_mx: bad args (K %d)", K);
+    CvclProfScope prof(stream, CVCL_K_LAYERNORM);
+    const long total = rows * (K >> 3);
+    const int grid = (int)std::min<long>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(quant_rows_mx_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_row_stride, (unsigned char*)q,
+                       (unsigned char*)block_scales, rows, K);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

@@ -46,6 +46,17 @@ class GemmArgs(C.Structure):
     ]
 
 
+class GemmFp8Args(C.Structure):
+    _fields_ = [
+        ("A8", C.c_void_p), ("a_scale", C.c_void_p), ("a_block_scales", C.c_void_p), ("lda", C.c_int),
+        ("W8", C.c_void_p), ("w_scale", C.c_void_p), ("ldw", C.c_int),
+        ("C", C.c_void_p), ("ldc", C.c_int), ("c8", C.c_void_p), ("c_block_scales", C.c_void_p), ("ldc8", C.c_int),
+        ("bias", C.c_void_p), ("act", C.c_int), ("R", C.c_void_p), ("ldr", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("row_part", C.c_void_p),
+    ]
+
+
 class ConvBnParams(C.Structure):
     _fields_ = [("w", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
                 ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p)]
@@ -160,6 +171,9 @@ SIGNATURES = {
     "cvcl_gemm_tn_colsum": (_I, [_P, _I, _P, _I, C.c_long, _I, _I, _P, _I, _P, _P, C.c_size_t, _P]),
     "cvcl_attention_mx": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "cvcl_gemm_fp8_mx": (_I, [_P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
+    "cvcl_gemm_fp8_ex": (_I, [C.POINTER(GemmFp8Args), _P]),
+    "cvcl_gemm_fp8_ln_supported": (_I, [_I, _I, _I]),
+    "cvcl_quant_rows_mx": (_I, [_P, C.c_long, _P, _P, C.c_long, _I, _P]),
     "cvcl_gemm_fp8": (_I, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P]),
     "cvcl_resnext50_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "cvcl_resnext50_centres_floats": (_SZ, []),

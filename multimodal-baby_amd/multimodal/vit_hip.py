@@ -65,6 +65,22 @@ def _packed(model, dt, device):
                 H.check(lib.cvcl_quant_rows_fp8(H.F32, H.ptr(wf), K, None, None, 0.0, H.ptr(q), H.ptr(sc), N, K, H.stream_ptr()),
                         "cvcl_quant_rows_fp8")
                 bw[name + "_q"], bw[name + "_s"] = q, sc
+            # LayerNorm folded into qkv / fc1 (round 5; cvcl_gemm_fp8_ex): W' = e4m3(W diag(gamma)) with its own row scales, s = the row
+            # sums of the DEQUANTISED matrix (what the MFMA multiplies: rstd (x W'^T - mean s) stays exact algebra), b' = b + W beta
+            for name, lin, norm in (("qkv", blk.attn.qkv, blk.norm1), ("fc1", blk.mlp.fc1, blk.norm2)):
+                Wf = lin.weight.detach().double()
+                g, be = norm.weight.detach().double(), norm.bias.detach().double()
+                wl = (Wf * g[None, :]).float().contiguous()
+                N, K = wl.shape
+                q = torch.empty(N, K, dtype=torch.uint8, device=device)
+                sc = torch.empty(N, dtype=torch.float32, device=device)
+                H.check(lib.cvcl_quant_rows_fp8(H.F32, H.ptr(wl), K, None, None, 0.0, H.ptr(q), H.ptr(sc), N, K, H.stream_ptr()),
+                        "cvcl_quant_rows_fp8")
+                b0 = lin.bias.detach().double() if lin.bias is not None else torch.zeros(N, dtype=torch.float64, device=Wf.device)
+                deq = q.view(torch.float8_e4m3fn).double().sum(1) * sc.double()
+                bw[name + "_q_ln"], bw[name + "_sw_ln"] = q, sc
+                bw[name + "_cs_ln"] = deq.float().contiguous()
+                bw[name + "_b8_ln"] = (b0 + Wf @ be).float().contiguous()
     if torch.device(device).type == "cuda":
         torch.cuda.current_stream(device).synchronize()      # packed once, then read by every stream that runs the trunk
     model._cache["w"] = (key, w)
@@ -91,6 +107,23 @@ def _gemm8_mx(q, sc, bs, wq, ws, out, out8, out_bs, bias, act=H.ACT_NONE, residu
     N = wq.shape[0]
     H.check(H.lib().cvcl_gemm_fp8_mx(H.ptr(q), H.ptr(sc), H.ptr(bs), K, H.ptr(wq), H.ptr(ws), K, H.ptr(out), N, H.ptr(out8), H.ptr(out_bs), N,
                                      H.ptr(bias), act, H.ptr(residual), N, M, N, K, H.stream_ptr()), "cvcl_gemm_fp8_mx")
+
+
+def _gemm8_ex(q, bs, wq, ws, bias, *, out=None, out8=None, out_bs=None, act=H.ACT_NONE, residual=None, ln_stats=None, ln_colsum=None,
+              row_part=None):
+    """cvcl_gemm_fp8_ex with MX input: the LayerNorm-folded consumer (ln_stats, ln_colsum) / producer (row_part: bf16 ``out`` + residual
+    AND the MX copy ``out8`` / ``out_bs`` of the stored rows AND their strip sums)."""
+    import ctypes as C
+    M, K = q.shape
+    N = wq.shape[0]
+    a = H.GemmFp8Args()
+    a.A8, a.a_scale, a.a_block_scales, a.lda = H.ptr(q), None, H.ptr(bs), K
+    a.W8, a.w_scale, a.ldw = H.ptr(wq), H.ptr(ws), K
+    a.C, a.ldc, a.c8, a.c_block_scales, a.ldc8 = H.ptr(out), N, H.ptr(out8), H.ptr(out_bs), N
+    a.bias, a.act, a.R, a.ldr = H.ptr(bias), act, H.ptr(residual), N
+    a.M, a.N, a.K = M, N, K
+    a.ln_stats, a.ln_colsum, a.row_part = H.ptr(ln_stats), H.ptr(ln_colsum), H.ptr(row_part)
+    H.check(H.lib().cvcl_gemm_fp8_ex(C.byref(a), H.stream_ptr()), "cvcl_gemm_fp8_ex")
 
 
 def ln_fold_mode(model):
@@ -203,7 +236,34 @@ def _vit_forward_impl(model, x: torch.Tensor, slot) -> torch.Tensor:
             bs_m = torch.empty(Dm // 128 * B * T * 4 + 16, dtype=torch.uint8, device=dev)[:Dm // 128 * B * T * 4].view(Dm // 128, B * T, 4)
             bs_d = torch.empty(D // 128 * B * T * 4 + 16, dtype=torch.uint8, device=dev)[:D // 128 * B * T * 4].view(D // 128, B * T, 4)
             mx_att = D // bw0["heads"] == 64 and bw0["heads"] % 2 == 0 and T > 32
-            for bw in w["blocks"]:
+            # LayerNorm folded into the e4m3 qkv / fc1 (round 5): the proj / fc2 epilogues leave the MX-quantised raw residual rows
+            # and their strip sums; no LayerNorm + row-quantise pass between the linears (24 of them in a ViT-B)
+            lib8 = H.lib()
+            fold8 = (mx_att and ln_fold_mode(model) is not False and D % 128 == 0 and D <= 1024 and
+                     bool(lib8.cvcl_gemm_fp8_ln_supported(B * T, 3 * D, D)) and bool(lib8.cvcl_gemm_fp8_ln_supported(B * T, Dm, D)))
+            if fold8:
+                M8 = B * T
+                q_x = torch.empty(M8, D, dtype=torch.uint8, device=dev)          # the residual rows, MX e4m3
+                bs_x = torch.empty(D // 128 * M8 * 4 + 16, dtype=torch.uint8, device=dev)[:D // 128 * M8 * 4].view(D // 128, M8, 4)
+                st8 = torch.empty(M8 + 1, 2, dtype=torch.float32, device=dev)[:M8]
+                part8 = torch.empty(M8, D // 64, 2, dtype=torch.float32, device=dev)
+                blocks = w["blocks"]
+                H.check(lib.cvcl_quant_rows_mx(H.ptr(h), D, H.ptr(q_x), H.ptr(bs_x), M8, D, s), "cvcl_quant_rows_mx")
+                H.check(lib.cvcl_row_stats(cd, H.ptr(h), D, H.ptr(st8), M8, D, blocks[0]["eps"], s), "cvcl_row_stats")
+                for i, bw in enumerate(blocks):
+                    _gemm8_ex(q_x, bs_x, bw["qkv_q_ln"], bw["qkv_sw_ln"], bw["qkv_b8_ln"], out=qkv, ln_stats=st8, ln_colsum=bw["qkv_cs_ln"])
+                    H.check(lib.cvcl_attention_mx(H.ptr(qkv), H.ptr(q_d), H.ptr(bs_d), B, T, bw["heads"], 64, bw["scale"], s), "cvcl_attention_mx")
+                    _gemm8_ex(q_d, bs_d, bw["proj_q"], bw["proj_s"], bw["proj_b"], out=h, residual=h, out8=q_x, out_bs=bs_x, row_part=part8)
+                    H.check(lib.cvcl_row_stats_finalize(H.ptr(part8), D // 64, H.ptr(st8), M8, D, bw["eps"], s), "cvcl_row_stats_finalize")
+                    _gemm8_ex(q_x, bs_x, bw["fc1_q_ln"], bw["fc1_sw_ln"], bw["fc1_b8_ln"], out8=q_m, out_bs=bs_m, act=H.ACT_GELU,
+                              ln_stats=st8, ln_colsum=bw["fc1_cs_ln"])
+                    if i + 1 < len(blocks):
+                        _gemm8_ex(q_m, bs_m, bw["fc2_q"], bw["fc2_s"], bw["fc2_b"], out=h, residual=h, out8=q_x, out_bs=bs_x, row_part=part8)
+                        H.check(lib.cvcl_row_stats_finalize(H.ptr(part8), D // 64, H.ptr(st8), M8, D, blocks[i + 1]["eps"], s),
+                                "cvcl_row_stats_finalize")
+                    else:
+                        _gemm8_mx(q_m, None, bs_m, bw["fc2_q"], bw["fc2_s"], h, None, None, bw["fc2_b"], residual=h)
+            for bw in (w["blocks"] if not fold8 else ()):
                 _quant(h, B * T, D, q_d, sc, (bw["n1w"], bw["n1b"], bw["eps"]))
                 _gemm8(q_d, sc, bw["qkv_q"], bw["qkv_s"], qkv, bw["qkv_b"])
                 if mx_att:

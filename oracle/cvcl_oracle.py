@@ -548,14 +548,28 @@ def fp8_mx(y: Tensor) -> Tensor:
     return ((blk / scale).clamp(-448, 448).to(torch.float8_e4m3fn).to(y.dtype) * scale).reshape(shp)
 
 
+def fp8_folded_linear(h: Tensor, W: Tensor, b: Tensor, gamma: Tensor, beta: Tensor, eps: float) -> Tensor:
+    """LayerNorm(h) W^T + b with the e4m3 storage points of the product's FOLDED form (round 5; csrc/gemm8f_kernel.h KIND 3 / 4):
+    the RAW rows h (already at their bf16 storage point) MX-quantised per 32 elements, W diag(gamma) quantised per output channel,
+    and the normalisation applied to the product:  rstd (h8 . W8^T) - mean rstd s + (b + W beta),  s = the row sums of the
+    dequantised weight; mean / rstd are those of the stored rows."""
+    h8 = fp8_mx(h)
+    W8 = fp8_rows(W * gamma[None, :])
+    mean = h.mean(dim=-1, keepdim=True)
+    rstd = torch.rsqrt(h.var(dim=-1, unbiased=False, keepdim=True) + eps)
+    return rstd * (h8 @ W8.t()) - (rstd * mean) * W8.sum(dim=1) + (b + W @ beta)
+
+
 def vit_forward(p: Dict[str, Tensor], x: Tensor, patch: int, num_heads: int, quant: Quant = None,
-                prefix: str = "", eps: float = 1e-6, taps: Optional[Dict[str, Tensor]] = None, fp8: bool = False) -> Tensor:
+                prefix: str = "", eps: float = 1e-6, taps: Optional[Dict[str, Tensor]] = None, fp8: bool = False,
+                fp8_fold: bool = False) -> Tensor:
     """``VisionTransformer.forward`` (vit:245-250): prepare_tokens (:232-243; pos-embed
     interpolation :210-230, the identity at the native resolution) -> depth x pre-LN
     ``Block`` (:133-149; attention :106-130 scale head_dim**-0.5, MLP :87-103 GELU-erf)
     -> LayerNorm -> cls token.  Returns [B, D] (the ``head`` is applied by the caller,
     multimodal.py:91-92).  ``fp8``: the e4m3 storage points of the product's configs[4] path on top of ``quant`` -- the operands of
-    the four linears of every block: LayerNorm outputs per row, attention and GELU outputs per 32-element block, weights per row."""
+    the four linears of every block: LayerNorm outputs per row, attention and GELU outputs per 32-element block, weights per row;
+    ``fp8_fold``: LayerNorm folded into qkv / fc1 (fp8_folded_linear) as the product does at benchmark sizes."""
     pp = {k[len(prefix):]: v for k, v in p.items() if k.startswith(prefix)} if prefix else p
     B, C, H, W = x.shape
     D = pp["cls_token"].shape[-1]
@@ -574,16 +588,24 @@ def vit_forward(p: Dict[str, Tensor], x: Tensor, patch: int, num_heads: int, qua
         qa = (lambda t: fp8_rows(t)) if fp8 else (lambda t: _q(quant, t))           # per-row e4m3 | the bf16 storage point
         qm = (lambda t: fp8_mx(_q(quant, t))) if fp8 else (lambda t: _q(quant, t))  # MX e4m3 of the bf16-rounded tensor
         qw = (lambda t: fp8_rows(t)) if fp8 else (lambda t: _q(quant, t))
-        y = qa(layer_norm(h, pp[bp + "norm1.weight"], pp[bp + "norm1.bias"], eps))
-        qkv = _q(quant, y @ qw(pp[bp + "attn.qkv.weight"]).t() + pp[bp + "attn.qkv.bias"])
+        if fp8 and fp8_fold:                                                             # (the product's folded form, see above)
+            qkv = _q(quant, fp8_folded_linear(h, pp[bp + "attn.qkv.weight"], pp[bp + "attn.qkv.bias"], pp[bp + "norm1.weight"],
+                                              pp[bp + "norm1.bias"], eps))
+        else:
+            y = qa(layer_norm(h, pp[bp + "norm1.weight"], pp[bp + "norm1.bias"], eps))
+            qkv = _q(quant, y @ qw(pp[bp + "attn.qkv.weight"]).t() + pp[bp + "attn.qkv.bias"])
         qkv = qkv.reshape(B, T, 3, num_heads, hd).permute(2, 0, 3, 1, 4)                # :119
         q, k, v = qkv[0], qkv[1], qkv[2]
         a = torch.softmax((q @ k.transpose(-2, -1)) * (hd ** -0.5), dim=-1)             # :123-124
         o = qm((_q(quant, a) @ v).transpose(1, 2).reshape(B, T, D))                     # :127
         o = o @ qw(pp[bp + "attn.proj.weight"]).t() + pp[bp + "attn.proj.bias"]
         h = _q(quant, h + _q(quant, o))                                                  # :146
-        y = qa(layer_norm(h, pp[bp + "norm2.weight"], pp[bp + "norm2.bias"], eps))
-        f = qm(gelu_erf(y @ qw(pp[bp + "mlp.fc1.weight"]).t() + pp[bp + "mlp.fc1.bias"]))
+        if fp8 and fp8_fold:
+            f = qm(gelu_erf(fp8_folded_linear(h, pp[bp + "mlp.fc1.weight"], pp[bp + "mlp.fc1.bias"], pp[bp + "norm2.weight"],
+                                              pp[bp + "norm2.bias"], eps)))
+        else:
+            y = qa(layer_norm(h, pp[bp + "norm2.weight"], pp[bp + "norm2.bias"], eps))
+            f = qm(gelu_erf(y @ qw(pp[bp + "mlp.fc1.weight"]).t() + pp[bp + "mlp.fc1.bias"]))
         f = f @ qw(pp[bp + "mlp.fc2.weight"]).t() + pp[bp + "mlp.fc2.bias"]
         h = _q(quant, h + _q(quant, f))                                                  # :147
         if taps is not None:

@@ -392,3 +392,43 @@ def test_vit_finetune_gradients_vs_oracle_autograd(dev, D, heads, depth, B, patc
             worst = (cos, n, rel)
         assert cos > 0.99 and rel < 0.1, (n, cos, rel)
     print("worst parameter gradient:", worst)
+
+
+def test_vit_fp8_folded_layernorm_vs_emulation_and_unfolded(dev):
+    """Round 5: at benchmark-like sizes the e4m3 path folds nn.LayerNorm into qkv / fc1 (reference Block, vit:136-149): the proj /
+    fc2 epilogues leave the MX-quantised raw residual rows + their strip sums, qkv / fc1 multiply those and normalise the product
+    (cvcl_gemm_fp8_ex).  Against (a) the oracle's emulation of the same storage points (fp8_fold=True), (b) the unfolded e4m3 path
+    (LayerNorm + per-row quantisation passes) and (c) the fp32 mode: the folded form must cost no more accuracy than either."""
+    import torch.nn.functional as F
+    from multimodal import _hip as H
+    from multimodal import vision_transformer_dino_mugs as vits
+    torch.manual_seed(5)
+    model = vits.vit_base(patch_size=16, num_classes=0).to(dev).eval()
+    with torch.no_grad():                                   # LayerNorms away from the identity: gamma / beta take part in the fold
+        for n, prm in model.named_parameters():
+            if "norm" in n and n.endswith("weight"):
+                prm.uniform_(0.6, 1.4)
+            if "norm" in n and n.endswith("bias"):
+                prm.normal_(0, 0.2)
+    for prm in model.parameters():
+        prm.requires_grad_(False)
+    B = 16
+    assert H.lib().cvcl_gemm_fp8_ln_supported(B * 197, 2304, 768) and H.lib().cvcl_gemm_fp8_ln_supported(B * 197, 3072, 768)
+    x = torch.randn(B, 3, 224, 224, device=dev)
+    model.compute_dtype, model.fp8_linears = torch.float32, False
+    ref32 = model(x).float().cpu()
+    model.compute_dtype, model.fp8_linears = torch.bfloat16, True
+    model.ln_fold = False
+    unf = model(x).float().cpu()
+    model.ln_fold = None
+    fold = model(x).float().cpu()
+    assert torch.equal(fold, model(x).float().cpu()) and torch.isfinite(fold).all()
+    assert not torch.equal(fold, unf)                       # (the folded path really ran)
+    p = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.startswith("head.")}
+    xc = x.cpu()
+    emu = O.vit_forward(p, xc, 16, 12, quant=O.bf16_round, fp8=True, fp8_fold=True)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    r_fold, r_unf, r_emu = rel(fold, ref32), rel(unf, ref32), rel(emu, ref32)
+    print(f"rel-L2 vs fp32: folded {r_fold:.4f}, unfolded {r_unf:.4f}, emulation of the folded form {r_emu:.4f}; folded vs its emulation {rel(fold, emu):.4f}")
+    assert r_fold <= 1.15 * r_emu + 1e-3 and r_fold <= 1.25 * r_unf + 1e-3 and r_fold < 0.2
+    assert float(F.cosine_similarity(fold, emu, dim=1).min()) > 0.99
