@@ -180,6 +180,11 @@ typedef struct {
      *   weight-gradient GEMM's own operand loads (fixed summation order, deterministic).
      * No prologue / gather / statistics / BN-tail options with these. */
     int a_trans, w_trans; float* a_rowsum;
+    /* f32_split != 0 (fp32 only, round 5): fp32 operands, arithmetic on the bf16 MFMA with every element split into two bf16 parts
+     * (hi.hi + hi.lo + lo.hi, fp32 accumulation): products good to ~2^-16 relative, ~4x the exact-fp32 kernel's speed.  For the
+     * trainable tail of the bf16 configurations (the text transformer's linears and their gradients; the reference under bf16
+     * autocast runs them as plain bf16 GEMMs); the fp32 parity mode never sets it. */
+    int f32_split;
 } cvcl_gemm_args;
 int cvcl_gemm_grid_m(int dtype, int M, int N, int has_prologue);   /* needs a GPU (occupancy query) */
 int cvcl_gemm(int dtype, const cvcl_gemm_args* args, void* stream);

@@ -99,9 +99,16 @@ template <typename T> struct TileRegs {
 // W -- the gradient GEMMs of nn.Linear (dW = dY^T X, dX = dY W) and of the similarity logits read their operands as they lie,
 // no transposed copies.  A K-major tile is fetched as 32 k-rows x 128 contiguous elements (full 128-byte segments per k-row) and
 // scattered into the same [row][k] LDS image the fragment reads expect (ds_write_b32, 2-way banked = free).
+// TR bit 2 (round 5) = SPLIT arithmetic for fp32 operands: every element is split into two bf16 parts on its way into LDS
+// (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits between them) and the product is formed as hi.hi + hi.lo + lo.hi on
+// v_mfma_f32_32x32x16_bf16 -- three MFMAs at 16x the fp32 instruction's rate, fp32 accumulation, products good to ~2^-16 relative
+// (the dropped lo.lo term and the split's remainder).  The trainable tail's linears in the bf16 configurations (text transformer,
+// reference multimodal/multimodal.py:553-573: under Lightning's bf16 autocast these are plain bf16 GEMMs; here they keep fp32
+// operands and ~fp32 results at a quarter of the exact kernel's time).  The exact mode stays the parity mode.
 template <typename T, int PRO, bool LEAN, int MINW, int TR = 0>
 __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
-    static_assert(TR == 0 || (sizeof(T) == 4 && PRO == 0 && !LEAN), "K-major operands: fp32, no prologue");
+    static_assert(TR == 0 || (sizeof(T) == 4 && PRO == 0 && !LEAN), "K-major operands / split arithmetic: fp32, no prologue");
+    constexpr bool SPLIT = (TR & 4) != 0;
     constexpr int EPC = ElemTraits<T>::kPerChunk;   // elements per 16-B chunk
     constexpr int BK = 8 * EPC;
     constexpr int SROW = stage_rowb<T>();
@@ -239,6 +246,39 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
                     }
             }
             __syncthreads();                      // LDS free: previous tile consumed / epilogue staging drained
+            if constexpr (SPLIT) {
+                // LDS row image (128 of the 144 bytes): [hi of k 0..31 as bf16 | lo of k 0..31 as bf16]
+                auto split_store = [&](char* base, const Chunk<T>& c, bool kmajor, int j) __attribute__((always_inline)) {
+                    bf16_t hi[4], lo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = c.get(e);
+                        hi[e] = (bf16_t)x;
+                        lo[e] = (bf16_t)(x - (float)hi[e]);
+                    }
+                    if (!kmajor) {
+                        char* row = base + (r0 + 32 * j) * ROWB + kc * 8;
+                        *reinterpret_cast<bf16x4*>(row) = bf16x4{hi[0], hi[1], hi[2], hi[3]};
+                        *reinterpret_cast<bf16x4*>(row + 64) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            char* el = base + (r0 * 4 + e) * ROWB + (kc + 8 * j) * 2;
+                            *reinterpret_cast<bf16_t*>(el) = hi[e];
+                            *reinterpret_cast<bf16_t*>(el + 64) = lo[e];
+                        }
+                    }
+                };
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    split_store(sA, t.a[j], (TR & 1) != 0, j);
+                    split_store(sW, t.w[j], (TR & 2) != 0, j);
+                    if constexpr ((TR & 1) != 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rsum[e] += t.a[j].get(e);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if constexpr ((TR & 1) == 0) t.a[j].store((T*)(sA + (r0 + 32 * j) * ROWB + kc * 16));
@@ -255,6 +295,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
                     for (int e = 0; e < 4; ++e) *(float*)(sW + (r0 * 4 + e) * ROWB + (kc + 8 * j) * 4) = t.w[j].get(e);
                 }
             }
+            }
             __syncthreads();
             // advance the load position and put the next tile's loads in flight under the MFMAs (and the epilogue)
             if (++l_kt == ktiles) {
@@ -264,6 +305,27 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
                 if (l_live) set_rows(l_mt);
             }
             if (l_live) issue();
+            if constexpr (SPLIT) {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {                   // 16 k per step: chunk g2 * 2 + h of the hi / lo half-rows
+                    bf16x8 wh[2], wl[2], ah[2], al[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const char* wr = sW + (wn * 64 + q * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
+                        const char* ar = sA + (wm * 64 + q * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
+                        wh[q] = *reinterpret_cast<const bf16x8*>(wr); wl[q] = *reinterpret_cast<const bf16x8*>(wr + 64);
+                        ah[q] = *reinterpret_cast<const bf16x8*>(ar); al[q] = *reinterpret_cast<const bf16x8*>(ar + 64);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {           // small terms first
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[nt], ah[mt], acc[nt][mt], 0, 0, 0);
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], al[mt], acc[nt][mt], 0, 0, 0);
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[nt], ah[mt], acc[nt][mt], 0, 0, 0);
+                        }
+                }
+            } else {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 Frag fw[2], fa[2];
@@ -276,6 +338,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) FragOps<T>::mma(acc[nt][mt], fw[nt], fa[mt]);
+            }
             }
         }
 
@@ -1007,12 +1070,13 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.C2 = nullptr;
     d.a_rowsum = a->a_rowsum;
     const int tr = (a->a_trans ? 1 : 0) | (a->w_trans ? 2 : 0);
-    if (tr || a->a_rowsum) {
+    const bool split = a->f32_split != 0;
+    if (tr || a->a_rowsum || split) {
         // K-major operands / fused row sums: the fp32 gradient GEMMs of the trainable tail (no prologue, gather, statistics or BN tail)
-        CVCL_CHECK_ARG(sizeof(T) == 4, "cvcl_gemm: a_trans / w_trans / a_rowsum are fp32 options");
+        CVCL_CHECK_ARG(sizeof(T) == 4, "cvcl_gemm: a_trans / w_trans / a_rowsum / f32_split are fp32 options");
         CVCL_CHECK_ARG(!a->a_rowsum || a->a_trans, "cvcl_gemm: a_rowsum goes with a_trans (the bias gradient beside dW = dY^T X)");
         CVCL_CHECK_ARG(!a->a_scale && !(a->gather_stride > 1) && !a->stats && !a->centre && !a->c_scale && !a->C_pre && !a->G && a->C,
-                       "cvcl_gemm: K-major operands take no prologue / gather / statistics / BN-tail options");
+                       "cvcl_gemm: K-major operands / split arithmetic take no prologue / gather / statistics / BN-tail options");
     }
     const bool lean = is_lean(a, d);
     if constexpr (sizeof(T) == 2) {
@@ -1055,8 +1119,9 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
             a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) && !a->a_rowsum &&
             // measured cost models (us, MI355X): the split-K VALU kernel runs ~13.4 GMAC/s-per-us of work on any shape; the
             // 128-tile fp32 MFMA kernel needs ~4.6 us per 64-deep K step per round of <= 256 tiles, whatever M and N are
+            // (~1.2 us with split arithmetic: 24 bf16 MFMAs per 32-deep tile instead of 64 fp32 ones, the rest is staging)
             (double)a->M * a->N * a->K / 13.4e6 + 5.0 <
-                12.0 + (a->K / 64.0) * 4.6 * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256)) {
+                12.0 + (a->K / 64.0) * (split ? 1.2 : 4.6) * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256)) {
             CvclProfScope prof(stream, CVCL_K_GEMM_F32);
             const dim3 grid(cvcl_div_up(a->N, 16), cvcl_div_up(a->M, 16));
 #define CVCL_SMALL(TR_) hipLaunchKernelGGL(gemm_f32_small_kernel<TR_>, grid, dim3(256), 0, stream, (const float*)a->A, (const float*)a->W, \
@@ -1066,12 +1131,16 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
             CVCL_LAUNCH_CHECK();
             return CVCL_OK;
         }
-        if (tr) {
+        if (tr || split) {
             CVCL_CHECK_ARG(pro_kind(a) == 0, "cvcl_gemm: K-major operands take no prologue");
-            switch (tr) {
+            switch (tr | (split ? 4 : 0)) {
                 case 1: return launch_gemm_w<float, 0, false, 1, 1>(a, d, stream);
                 case 2: return launch_gemm_w<float, 0, false, 1, 2>(a, d, stream);
-                default: return launch_gemm_w<float, 0, false, 1, 3>(a, d, stream);
+                case 3: return launch_gemm_w<float, 0, false, 1, 3>(a, d, stream);
+                case 4: return launch_gemm_w<float, 0, false, 1, 4>(a, d, stream);
+                case 5: return launch_gemm_w<float, 0, false, 1, 5>(a, d, stream);
+                case 6: return launch_gemm_w<float, 0, false, 1, 6>(a, d, stream);
+                default: return launch_gemm_w<float, 0, false, 1, 7>(a, d, stream);
             }
         }
     }

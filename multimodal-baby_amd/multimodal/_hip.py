@@ -43,6 +43,7 @@ class GemmArgs(C.Structure):
         ("A2", C.c_void_p), ("W2", C.c_void_p), ("K2", C.c_int), ("lda2", C.c_int), ("ldw2", C.c_int), ("centre2", C.c_void_p),
         ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p), ("row_part", C.c_void_p),
         ("a_trans", C.c_int), ("w_trans", C.c_int), ("a_rowsum", C.c_void_p),
+        ("f32_split", C.c_int),
     ]
 
 
@@ -362,7 +363,8 @@ def cvcl_dtype(t: torch.dtype) -> int:
 
 def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None, a_shift=None, a_relu=False,
          exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None, centre=None,
-         ln_stats=None, ln_colsum=None, row_part=None, query_ln=False, a_trans=False, w_trans=False, a_rowsum=None):
+         ln_stats=None, ln_colsum=None, row_part=None, query_ln=False, a_trans=False, w_trans=False, a_rowsum=None,
+         split=False):
     """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype.
     ``centre`` [N] f32 (convolution epilogues): C = round(A' W^T - centre), statistics of that (cvcl_hip.h "Centred storage").
     fp32 only: ``a_trans`` -- A is given as [K, M]; ``w_trans`` -- W is given as [K, N] (the operands of a gradient GEMM as they
@@ -385,6 +387,7 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
     a.A, a.W, a.C = ptr(A), ptr(W), ptr(out)
     a.M, a.N, a.K, a.lda, a.ldw, a.ldc = M, N, K, lda, ldw, N
     a.a_trans, a.w_trans, a.a_rowsum = int(a_trans), int(w_trans), ptr(a_rowsum, torch.float32)
+    a.f32_split = int(bool(split) and dt == F32)           # (fp32 operands on the bf16 MFMA, hi / lo split: cvcl_hip.h)
     a.a_scale, a.a_shift, a.a_relu = ptr(a_scale, torch.float32), ptr(a_shift, torch.float32), int(a_relu)
     if gather is not None:
         a.gather_ho, a.gather_wo, a.gather_hi, a.gather_wi, a.gather_stride = gather

@@ -79,7 +79,8 @@ class VisionEncoder(nn.Module):
     def _eager_forward(self, x):
         if getattr(self, "vit_dino", False):
             cls = self.model(x)                               # pre-head cls token (reference :91)
-            return ops.linear_f32(cls, self.model.head.weight, self.model.head.bias), None   # reference :92
+            return ops.linear_f32(cls, self.model.head.weight, self.model.head.bias,
+                                  split=getattr(self.model, "compute_dtype", None) == torch.bfloat16), None   # reference :92
         layer = self.model[-2] if self.embedding_type == "spatial" else self.model.layer4     # reference :96-99
         with Hook(layer, requires_grad=False) as hook:                # reference :100-102
             features = self.model(x)
@@ -316,7 +317,8 @@ class TextEncoder(nn.Module):
             pos = self.pos_embed if self.pos_embed_type in ("sinusoidal", "learned") else None
             layer = self.transformer_encoder.layers[0]
             if self.training or torch.is_grad_enabled():
-                ret, raw_output = text_train.transformer_text_train(self.embedding.weight, layer, pos, x, x_len, self.training)
+                ret, raw_output = text_train.transformer_text_train(self.embedding.weight, layer, pos, x, x_len, self.training,
+                                                                    split=bool(self.__dict__.get("fp32_split", False)))
             else:
                 ret, raw_output = ops.transformer_text(self.embedding.weight, layer, pos, x, x_len)
         else:

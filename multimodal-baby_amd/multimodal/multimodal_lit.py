@@ -88,6 +88,8 @@ class MultiModalLitModel(LightningModule):
         p = str(precision)
         dt = torch.bfloat16 if p in ("bf16", "16", "bf16-mixed", "16-mixed", "fp8", "8") else torch.float32
         self.vision_encoder.set_compute_dtype(dt)
+        # the text transformer's fp32 linears: exact-fp32 MFMA in the parity mode, hi / lo split bf16 MFMA (~2^-16) otherwise
+        self.text_encoder.__dict__["fp32_split"] = dt == torch.bfloat16
         if getattr(self.vision_encoder, "vit_dino", False):
             self.vision_encoder.model.fp8_linears = p in ("fp8", "8")
 

@@ -227,27 +227,27 @@ class InfoNCE(torch.autograd.Function):
 
 
 class LinearF32(torch.autograd.Function):
-    """nn.Linear in fp32 on the exact-fp32 MFMA GEMM (fc 2048->E, multimodal/multimodal.py:192; ViT head :190)."""
+    """nn.Linear on fp32 operands (fc 2048->E, multimodal/multimodal.py:192; ViT head :190; the text transformer's linears
+    :553-573).  ``split`` False: the exact-fp32 MFMA GEMM (the parity mode); True (the bf16 configurations): the same operands on the
+    bf16 MFMA with every element split into two bf16 parts -- ~2^-16 relative, ~4x faster (cvcl_gemm_args.f32_split)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, split=False):
         x = x.contiguous()
-        y = H.gemm(x, weight.contiguous(), bias=bias)
+        y = H.gemm(x, weight.contiguous(), bias=bias, split=split)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.split = bool(split)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        M, K = x.shape
-        N = weight.shape[0]
-        need_x, need_w, need_b = ctx.needs_input_grad
-        return linear_backward(x, weight, dy, (need_x, need_w, need_b and ctx.has_bias))
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        return linear_backward(x, weight, dy.contiguous(), (need_x, need_w, need_b and ctx.has_bias), split=ctx.split) + (None,)
 
 
-def linear_backward(x, weight, dy, needs):
+def linear_backward(x, weight, dy, needs, split=False):
     """(dx, dw, db) of y = x W^T + b for dy [M, N]: dW[N,K] = dY^T X and dX[M,K] = dY W as GEMMs over operands read K-major in
     place; db = the column sums of dY comes out of the dW GEMM's own operand loads (a_rowsum).  needs = (dx, dw, db) wanted."""
     M, K = x.shape
@@ -257,11 +257,11 @@ def linear_backward(x, weight, dy, needs):
     if need_b:
         db = torch.empty(N, dtype=_F, device=x.device)
     if need_w:                                       # A' = dY^T: dY is [K' = M][N] in memory; W' = X^T: X is [K' = M][K]
-        dw = H.gemm(dy, x, a_trans=True, w_trans=True, a_rowsum=db)
+        dw = H.gemm(dy, x, a_trans=True, w_trans=True, a_rowsum=db, split=split)
     elif need_b:
         H.check(H.lib().cvcl_colsum_f32(H.ptr(dy), H.ptr(db), M, N, H.stream_ptr()), "cvcl_colsum_f32")
     if need_x:                                       # W' = W^T: W is [K' = N][K] in memory
-        dx = H.gemm(dy, weight.contiguous(), w_trans=True)
+        dx = H.gemm(dy, weight.contiguous(), w_trans=True, split=split)
     return dx, dw, db
 
 
@@ -294,8 +294,8 @@ def infonce(logits):
     return InfoNCE.apply(logits)
 
 
-def linear_f32(x, weight, bias=None):
-    return LinearF32.apply(x, weight, bias)
+def linear_f32(x, weight, bias=None, split=False):
+    return LinearF32.apply(x, weight, bias, split)
 
 
 def _embed_gather(table, tok, pos=None):

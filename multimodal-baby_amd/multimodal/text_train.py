@@ -78,10 +78,11 @@ class LinearReluF32(torch.autograd.Function):
     """relu(x W^T + b) with the ReLU fused into the GEMM epilogue; backward masks dy with the saved output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, split=False):
         x = x.contiguous()
-        y = H.gemm(x, weight.contiguous(), bias=bias, act=H.ACT_RELU)
+        y = H.gemm(x, weight.contiguous(), bias=bias, act=H.ACT_RELU, split=split)
         ctx.save_for_backward(x, weight, y)
+        ctx.split = bool(split)
         return y
 
     @staticmethod
@@ -89,11 +90,11 @@ class LinearReluF32(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         dz = torch.empty_like(y)
         H.check(H.lib().cvcl_relu_bwd(H.ptr(y), H.ptr(dy.contiguous()), H.ptr(dz), y.numel(), H.stream_ptr()), "cvcl_relu_bwd")
-        return _linear_bwd(x, weight, dz, ctx.needs_input_grad, True)
+        return _linear_bwd(x, weight, dz, ctx.needs_input_grad, True, ctx.split) + (None,)
 
 
-def _linear_bwd(x, weight, dy, needs, has_bias):
-    return linear_backward(x, weight, dy, (needs[0], needs[1], needs[2] and has_bias))
+def _linear_bwd(x, weight, dy, needs, has_bias, split=False):
+    return linear_backward(x, weight, dy, (needs[0], needs[1], needs[2] and has_bias), split=split)
 
 
 class LayerNormF32(torch.autograd.Function):
@@ -174,8 +175,9 @@ class SeqSumDiv(torch.autograd.Function):
         return dx, None, None, None
 
 
-def transformer_text_train(table, layer, pos_embed, tok, length, training: bool):
-    """Differentiable embedding(+pos) -> post-norm TransformerEncoderLayer -> sum/len (multimodal.py:553-573)."""
+def transformer_text_train(table, layer, pos_embed, tok, length, training: bool, split: bool = False):
+    """Differentiable embedding(+pos) -> post-norm TransformerEncoderLayer -> sum/len (multimodal.py:553-573).  ``split``: the four
+    linears (and their gradients) on the bf16 MFMA with hi / lo split fp32 operands (ops.LinearF32) -- the bf16 configurations."""
     B, L = tok.shape
     if L > 32:
         raise NotImplementedError("utterances are at most 25 tokens (MAX_LEN_UTTERANCE); got L > 32")
@@ -185,15 +187,15 @@ def transformer_text_train(table, layer, pos_embed, tok, length, training: bool)
     pf = float(layer.dropout.p) if training else 0.0
     p2 = float(layer.dropout2.p) if training else 0.0
     x = EmbedGatherPos.apply(table, pos_embed, tok)
-    qkv = LinearF32.apply(x, sa.in_proj_weight, sa.in_proj_bias)
+    qkv = LinearF32.apply(x, sa.in_proj_weight, sa.in_proj_bias, split)
     att = AttentionSmall.apply(qkv, tok, sa.num_heads, p_attn, _seed())
-    o = LinearF32.apply(att, sa.out_proj.weight, sa.out_proj.bias)
+    o = LinearF32.apply(att, sa.out_proj.weight, sa.out_proj.bias, split)
     y = DropoutAdd.apply(o, x, p1, _seed(), 0, 1)                          # x + dropout1(self_attn(x))
     h1 = LayerNormF32.apply(y, layer.norm1.weight, layer.norm1.bias, layer.norm1.eps)
-    f = LinearReluF32.apply(h1, layer.linear1.weight, layer.linear1.bias)
+    f = LinearReluF32.apply(h1, layer.linear1.weight, layer.linear1.bias, split)
     if pf > 0:
         f = DropoutAdd.apply(f, None, pf, _seed(), 0, 1)
-    g = LinearF32.apply(f, layer.linear2.weight, layer.linear2.bias)
+    g = LinearF32.apply(f, layer.linear2.weight, layer.linear2.bias, split)
     y2 = DropoutAdd.apply(g, h1, p2, _seed(), 0, 1)                        # h1 + dropout2(ffn(h1))
     h2 = LayerNormF32.apply(y2, layer.norm2.weight, layer.norm2.bias, layer.norm2.eps)
     ret = SeqSumDiv.apply(h2, length, B, L)

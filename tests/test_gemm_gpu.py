@@ -652,3 +652,27 @@ def test_linear_backward_reads_operands_in_place(dev):
         assert db2 is None and maxrel(dw2.cpu(), dw.cpu()) < 2e-5     # (without the row sums the small-product kernel may run: another summation order)
         _, _, db3 = ops.linear_backward(x.to(dev), w.to(dev), dy.to(dev), (False, False, True))
         assert maxrel(db3.cpu(), dy.double().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 1536, 512), (1280, 512, 2048), (512, 2048, 1280), (333, 130, 77)])
+@pytest.mark.parametrize("ta,tw", [(False, False), (True, True), (False, True)])
+def test_gemm_f32_split_arithmetic(H, dev, M, N, K, ta, tw):
+    """cvcl_gemm_args.f32_split: fp32 operands on the bf16 MFMA as hi + lo bf16 parts (hi.hi + hi.lo + lo.hi, fp32 accumulation) --
+    the text transformer's linears and their gradients in the bf16 configurations.  ~2^-16 per product: two orders of magnitude
+    closer to float64 than a bf16 GEMM of the same operands, and within 3e-5 of the result's scale."""
+    g = torch.Generator().manual_seed(M + 3 * N + 5 * K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    Ad = (A.t().contiguous() if ta else A).to(dev)
+    Wd = (W.t().contiguous() if tw else W).to(dev)
+    rs = torch.empty(M, device=dev) if ta else None
+    y = H.gemm(Ad, Wd, a_trans=ta, w_trans=tw, a_rowsum=rs, bias=bias.to(dev), split=True)
+    ref = A.double() @ W.double().t() + bias.double()
+    err = maxrel(y.cpu(), ref)
+    bf = maxrel((A.bfloat16().double() @ W.bfloat16().double().t() + bias.double()), ref)
+    exact = maxrel(H.gemm(Ad, Wd, a_trans=ta, w_trans=tw, bias=bias.to(dev)).cpu(), ref)
+    print(f"split {err:.2e}  exact fp32 {exact:.2e}  bf16 operands {bf:.2e}")
+    assert err < 3e-5 and err < bf / 50
+    if ta:
+        assert float((rs.double().cpu() - A.double().sum(1)).abs().max()) < 2e-5 * float(A.abs().sum(1).max())
