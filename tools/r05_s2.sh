@@ -16,4 +16,7 @@ python3 bench.py --config c5 --steps 20 --warmup 5 --no-cpu-baseline --no-roofli
 python3 bench.py --config c2 --steps 30 --warmup 8 --no-cpu-baseline --no-parity --no-roofline --no-extras > $O/bench_c2_quick.json 2>$O/bench_c2_quick.err
 python3 tools/tail_copies.py c2 > $O/tail_copies_c2.txt 2>&1
 python3 tools/tail_bench.py c2 20 > $O/tail_c2.json 2>$O/tail_c2.err
+python3 tools/tail_bench.py c4 20 > $O/tail_c4.json 2>$O/tail_c4.err
+python3 bench.py --config c4 --steps 30 --warmup 8 --no-cpu-baseline --no-roofline --no-extras > $O/bench_c4.json 2>$O/bench_c4.err
+python3 bench.py --config c4p14 --steps 30 --warmup 8 --no-cpu-baseline --no-parity --no-roofline --no-extras > $O/bench_c4p14.json 2>$O/bench_c4p14.err
 ls -la $O
