@@ -42,7 +42,7 @@ EMBEDDING_DIM = 512
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA)
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 WORKLOADS = {
     "c2": "C2 = BASELINE configs[1]: CVCL saycam_contrastive, frozen random-init ResNeXt-50 32x4d (BN train mode) + embedding "
@@ -477,7 +477,7 @@ def static_traffic(kernel_name):
     """PMC L2 <-> fabric bytes per launch of one kernel from the tracked summary of separate rocprofv3 --pmc passes of this
     command (tools/pmc_bench.sh + tools/pmc_summary.py; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  STATIC: collected on an
     earlier box of this round, not in the run that prints the line.  -> (bytes per launch | None, source)."""
-    for rnd in (PROFILE_ROUND, "r03", "r02"):
+    for rnd in (PROFILE_ROUND, "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.json")
         try:
             with open(path) as f:
@@ -493,20 +493,21 @@ def static_traffic_vit(cfg):
     """The same for the ViT configurations: HBM bytes per launch averaged over the trunk's GEMM launches (the bf16 8-wave kernel, or
     the two e4m3 kernels), from the tracked per-kernel summary of tools/pmc_cfg.sh <cfg> (FETCH_SIZE x 2 + WRITE_SIZE; STATIC).
     -> (bytes per launch | None, source)."""
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_{cfg}_summary.json")
-    try:
-        with open(path) as f:
-            pm = json.load(f)
-        n = tot = 0.0
-        for k, v in pm.items():
-            if k.startswith(("gemm8w_kernel", "gemm8f_kernel", "gemm_fp8_kernel")) and "hbm_read_MB_x2" in v:
-                n += v["dispatches_per_pass"]
-                tot += (v["hbm_read_MB_x2"] + v["hbm_write_MB"]) * 1e6 * v["dispatches_per_pass"]
-        if n:
-            return int(tot / n), (f"profiles/{PROFILE_ROUND}_pmc_{cfg}_summary.json (static: separate rocprofv3 --pmc passes on an earlier "
-                                  "box, tools/pmc_cfg.sh; mean over the trunk's GEMM launches)")
-    except Exception:
-        pass
+    for rnd in (PROFILE_ROUND, "r04"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{cfg}_summary.json")
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+            n = tot = 0.0
+            for k, v in pm.items():
+                if k.startswith(("gemm8w_kernel", "gemm8f_kernel", "gemm_fp8_kernel")) and "hbm_read_MB_x2" in v:
+                    n += v["dispatches_per_pass"]
+                    tot += (v["hbm_read_MB_x2"] + v["hbm_write_MB"]) * 1e6 * v["dispatches_per_pass"]
+            if n:
+                return int(tot / n), (f"profiles/{rnd}_pmc_{cfg}_summary.json (static: separate rocprofv3 --pmc passes on an earlier "
+                                      "box, tools/pmc_cfg.sh; mean over the trunk's GEMM launches)")
+        except Exception:
+            pass
     return None, None
 
 
@@ -647,14 +648,16 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
         if batch_size == PER_GPU_BATCH:
             # the bytes the step ACTUALLY moves (PMC, static summary of the same command at this batch) against the same clock:
             # what fraction of the HBM peak the whole step sustains on its real traffic
-            try:
-                with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_hbm_traffic.json")) as f:
-                    gb = json.load(f)["trunk_total"]["total_GB"]
-                res["whole_step"].update({"pmc_traffic_gb_per_step": round(gb, 2),
-                                          "pmc_traffic_frac_of_hbm_peak": round(gb / (elapsed / steps) / HBM_PEAK_GBS, 4),
-                                          "pmc_traffic_source": f"profiles/{PROFILE_ROUND}_pmc_hbm_traffic.json (static)"})
-            except Exception:
-                pass
+            for rnd in (PROFILE_ROUND, "r04"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.json")) as f:
+                        gb = json.load(f)["trunk_total"]["total_GB"]
+                    res["whole_step"].update({"pmc_traffic_gb_per_step": round(gb, 2),
+                                              "pmc_traffic_frac_of_hbm_peak": round(gb / (elapsed / steps) / HBM_PEAK_GBS, 4),
+                                              "pmc_traffic_source": f"profiles/{rnd}_pmc_hbm_traffic.json (static)"})
+                    break
+                except Exception:
+                    pass
 
     if roofline and precision != "32":
         # further passes of the same steps with HIP events around every launch (on the launch stream).  The roofline figures come
@@ -780,6 +783,43 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
     res["hbm_peak_gb"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
     set_trunk_streams(0)
     torch.cuda.synchronize()
+    if world == 1 and precision != "32" and batch_size <= 1024:
+        # the trainable TAIL on its own (round 5): the frozen trunk replaced by its cached output, nothing else on the GPU -- fc / head,
+        # text encoder forward + backward, L2 normalise, logits, InfoNCE forward + backward, AdamW.  Event-timed per step; launches =
+        # every device activity torch's profiler sees in a step (library kernels, torch's own kernels, device-to-device copies)
+        try:
+            with frozen_trunk_cached(ve, cfg, batch[0]):
+                for _ in range(3):
+                    step()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n_t = 10
+                e0.record()
+                for _ in range(n_t):
+                    step()
+                e1.record()
+                torch.cuda.synchronize()
+                res["tail_ms_per_step"] = round(e0.elapsed_time(e1) / n_t, 4)
+                H.prof_enable(True)
+                for _ in range(n_t):
+                    step()
+                torch.cuda.synchronize()
+                tp = H.prof_collect()
+                H.prof_enable(False)
+                res["tail_library_launches_per_step"] = int(sum(v[1] for v in tp.values()) // n_t)
+                try:
+                    from torch.profiler import ProfilerActivity, profile
+                    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof_:
+                        for _ in range(3):
+                            step()
+                        torch.cuda.synchronize()
+                    n_dev = sum(1 for ev in prof_.events() if str(ev.device_type).endswith("CUDA"))
+                    res["tail_launches_per_step"] = round(n_dev / 3, 1) if n_dev else None
+                except Exception:
+                    res["tail_launches_per_step"] = None
+        except Exception as e:                                  # the side measurement must never take the bench line down
+            res["tail_error"] = repr(e)[:200]
+        torch.cuda.synchronize()
     del lit, ve, opt, engine, batch, upd
     import gc
     gc.collect()
@@ -840,6 +880,9 @@ def sub_record(r):
     if r.get("roofline"):
         out["roofline"] = {k: v for k, v in r["roofline"].items() if k not in ("by_kernel", "timing", "concurrent")}
         out["kernel_ms_per_step"] = r["kernel_ms_per_step"]
+    for k in ("tail_ms_per_step", "tail_launches_per_step", "tail_library_launches_per_step", "tail_error"):
+        if k in r:
+            out[k] = r[k]
     return out
 
 
@@ -948,6 +991,12 @@ def main(argv=None):
             line["gap_ms_per_step"] = r["gap_ms_per_step"]
             line["launches_per_step"] = r["launches_per_step"]
             line["event_bracket_of_a_null_kernel_us"] = r["event_bracket_of_a_null_kernel_us"]
+        for k in ("tail_ms_per_step", "tail_launches_per_step", "tail_library_launches_per_step", "tail_error"):
+            if k in r:
+                line[k] = r[k]
+        if "tail_ms_per_step" in r:
+            line["tail_note"] = ("the step with the frozen trunk replaced by its cached output (fc / head, text encoder, loss, backward, "
+                                 "AdamW), nothing else on the GPU; tail_launches_per_step = device activities torch.profiler sees per step")
         line.update(extras)
         if world == 1 and not a.no_cpu_baseline and cfg == "c2":
             line["cpu_baseline"] = cpu_baseline()
