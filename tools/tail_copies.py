@@ -30,7 +30,7 @@ with bench.frozen_trunk_cached(ve, cfg, batch[0]):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -43,3 +43,26 @@ for ev in prof.events():
         groups[(ev.name, str(ev.input_shapes)[:60], " <- ".join(s.split("/")[-1][:70] for s in stack))] += 1
 for (name, shapes, stack), n in sorted(groups.items(), key=lambda kv: -kv[1]):
     print(f"{n / 3:5.1f}/step  {name:18s} {shapes:60s} {stack}")
+
+print("---- device activities per step (kernels / memcpy / memset), by name ----")
+dev_ev = collections.Counter()
+for ev in prof.events():
+    if str(ev.device_type).endswith("CUDA"):
+        dev_ev[ev.name[:100]] += 1
+for name, n in sorted(dev_ev.items(), key=lambda kv: -kv[1])[:60]:
+    print(f"{n / 3:5.1f}/step  {name}")
+print("---- CPU ops that launched a Memcpy ----")
+try:
+    ka = prof.profiler.kineto_results.events()
+    byid = {}
+    for e in ka:
+        if e.device_type().name == "CPU":
+            byid.setdefault(e.correlation_id(), []).append(e.name())
+    c = collections.Counter()
+    for e in ka:
+        if e.device_type().name != "CPU" and "emcpy" in e.name():
+            c[(e.name(), tuple(byid.get(e.correlation_id(), []))[:3])] += 1
+    for (n, ops), k in sorted(c.items(), key=lambda kv: -kv[1]):
+        print(f"{k / 3:5.1f}/step  {n}  <- {ops}")
+except Exception as e:
+    print("kineto correlation not available:", repr(e))
