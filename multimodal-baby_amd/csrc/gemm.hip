@@ -1119,9 +1119,11 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
             a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) && !a->a_rowsum &&
             // measured cost models (us, MI355X): the split-K VALU kernel runs ~13.4 GMAC/s-per-us of work on any shape; the
             // 128-tile fp32 MFMA kernel needs ~4.6 us per 64-deep K step per round of <= 256 tiles, whatever M and N are
-            // (~1.2 us with split arithmetic: 24 bf16 MFMAs per 32-deep tile instead of 64 fp32 ones, the rest is staging)
+            // (4.2 us with split arithmetic, measured -- profiles/r05_tail_c4_kernel_stats.csv: the 128-tile kernel's K step is bound
+            // by its serial load -> LDS -> multiply structure at one wave per SIMD, not by the matrix pipe; what the split buys is
+            // 768 instead of 4096 cycles of matrix pipe per tile and wave, i.e. less interference with the trunk GEMMs beside it)
             (double)a->M * a->N * a->K / 13.4e6 + 5.0 <
-                12.0 + (a->K / 64.0) * (split ? 1.2 : 4.6) * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256)) {
+                12.0 + (a->K / 64.0) * (split ? 4.2 : 4.6) * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256)) {
             CvclProfScope prof(stream, CVCL_K_GEMM_F32);
             const dim3 grid(cvcl_div_up(a->N, 16), cvcl_div_up(a->M, 16));
 #define CVCL_SMALL(TR_) hipLaunchKernelGGL(gemm_f32_small_kernel<TR_>, grid, dim3(256), 0, stream, (const float*)a->A, (const float*)a->W, \

@@ -108,7 +108,10 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
     const unsigned a_unit = (unsigned)BM * (unsigned)p.lda, w_unit = (unsigned)BN * (unsigned)p.ldw;
     const unsigned a_lim = (unsigned)(p.M - 1) * (unsigned)p.lda + 48;
     int l_t = 0, l_ks = 0, l_j = tj, l_i = ti;
-    int l_kt = 0, c_kt = 0;                                  // running 128-k tile counters (load side / multiply side): MX scale ring slot = counter & 3
+    // MX scale ring: the slot of a 128-k tile = its running number & 3, derived from (tile, k stage) on both sides (separate
+    // running counters ended up in scratch: the closures' by-reference captures + the epilogue's compiler barriers, and a scratch
+    // reload sits behind an s_waitcnt vmcnt(0) -- INSIDE the K loop it drained the stage ring every other stage)
+    const int KS2 = KS >> 1;
     auto issue = [&](int buf) __attribute__((always_inline)) {
         char* base = smem + buf * STAGE_BYTES + wave * 2048;
         const int k0 = l_ks * BKB;
@@ -135,20 +138,21 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
         // MX input: with the first stage of a 128-k tile, the 4 block-scale bytes of the tile's 256 rows (1 KiB; one wave per K tile)
         if constexpr (MXA) {
             if ((l_ks & 1) == 0) {
-                if (wave == (LNF ? 4 : 2) + (l_kt & 3))
+                const int l_slot = (l_t * KS2 + (l_ks >> 1)) & 3;
+                if (wave == (LNF ? 4 : 2) + l_slot)
                     glds16(p.a_bs + ((long)(l_ks >> 1) * p.M + min(l_i * BM + lane * 4, (p.M - 1) & ~3)) * 4,     // (as sa: granules of 4 rows)
-                           smem + MXS_OFF + (l_kt & 3) * 1024);
-                ++l_kt;
+                           smem + MXS_OFF + l_slot * 1024);
             }
         }
-        if (++l_ks == KS) {
+        l_ks = __builtin_amdgcn_readfirstlane(l_ks + 1);
+        if (l_ks == KS) {
             l_ks = 0;
             if (l_t + 1 < nt) {
-                ++l_t;
+                l_t = __builtin_amdgcn_readfirstlane(l_t + 1);
                 int di = step_i, dj = step_j;
                 if (l_j + dj >= p.ncol) { dj -= p.ncol; ++di; }
-                l_j += dj;
-                l_i += di;
+                l_j = __builtin_amdgcn_readfirstlane(l_j + dj);
+                l_i = __builtin_amdgcn_readfirstlane(l_i + di);
                 const unsigned da = (unsigned)di * a_unit, dw = (unsigned)dj * w_unit;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) { a_raw[j] += da; w_off[j] += dw; }
@@ -300,14 +304,14 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
     __builtin_amdgcn_s_barrier();
     read_frags(0, std::integral_constant<int, 0>{});
     const int mxs_row = (wm * (BM / 2) + l31) * 4;
-    auto read_scales = [&]() __attribute__((always_inline)) {            // the scales of K tile c_kt (running count) -> aw
+    auto read_scales = [&](int kt_running) __attribute__((always_inline)) {   // the scales of that 128-k tile (running number) -> aw
         if constexpr (MXA) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) aw[mt] = *reinterpret_cast<const unsigned*>(smem + MXS_OFF + (c_kt & 3) * 1024 + mxs_row + mt * 128);
-            ++c_kt;
+            for (int mt = 0; mt < MT; ++mt)
+                aw[mt] = *reinterpret_cast<const unsigned*>(smem + MXS_OFF + (kt_running & 3) * 1024 + mxs_row + mt * 128);
         }
     };
-    read_scales();
+    read_scales(0);
 
     int after_epi = 0, epi_ops = 0;
     int c_ks = 0, c_i = ti, c_j = tj, c_t = 0;
@@ -329,14 +333,16 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
             advance();
             c_ks = 0;
             epi_ops = epilogue(c_i * BM, c_j * BN, c_t & 1);
-            ++c_t;
+            c_t = __builtin_amdgcn_readfirstlane(c_t + 1);
             after_epi = 3;
             c_i += step_i;
             c_j += step_j;
             if (c_j >= p.ncol) { c_j -= p.ncol; ++c_i; }
+            c_i = __builtin_amdgcn_readfirstlane(c_i);
+            c_j = __builtin_amdgcn_readfirstlane(c_j);
             __builtin_amdgcn_sched_barrier(0);
             read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
-            if constexpr (MXA) read_scales();                    // (KS is even: the next stage opens a K tile)
+            if constexpr (MXA) read_scales(c_t * KS2);           // (KS is even: the next stage opens a K tile; c_t = the next tile already)
         } else {
             read_frags((g + 1) & 3, std::integral_constant<int, 1 - q>{});
             issue(g & 3);                                       // stage g+4 into the buffer stage g occupied
@@ -351,9 +357,9 @@ __global__ __launch_bounds__(512, 2) void gemm8f_kernel(Dev p) {
             advance();
             // the next stage's MX scales (its K tile's slot was filled >= 2 stages ago, behind a counted wait and this barrier)
             if constexpr (MXA) {
-                if (c_ks & 1) { __builtin_amdgcn_sched_barrier(0); read_scales(); }        // (the next stage opens a K tile)
+                if (c_ks & 1) { __builtin_amdgcn_sched_barrier(0); read_scales(c_t * KS2 + ((c_ks + 1) >> 1)); }   // (the next stage opens a K tile)
             }
-            ++c_ks;
+            c_ks = __builtin_amdgcn_readfirstlane(c_ks + 1);
         }
     };
     for (int g = 0; g < S; g += 2) {
