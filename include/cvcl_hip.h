@@ -285,6 +285,14 @@ int cvcl_pack_conv_weight(int dtype, int kind, const float* w_oihw, void* out, i
 int cvcl_stem_conv_stats_rows(int dtype, int B, int H, int W);
 int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void* y_nhwc, float* stats, int stats_rows,
                       const float* centre /* [64] or NULL */, int B, int H, int W, void* stream);
+/* (bf16: y_nhwc == NULL = statistics only -- the first pass of the fused stem below.)
+ * conv1 + bn1 + relu + maxpool in ONE pass (round 5; torchvision ResNet.forward conv1 -> bn1 -> relu -> maxpool, reached from
+ * multimodal/multimodal.py:101): the raw [B,H/2,W/2,64] tensor is never written -- in train mode its BatchNorm statistics come from
+ * a statistics-only cvcl_stem_conv7x7 pass, then this kernel recomputes the convolution and pools it out of LDS:
+ * y NHWC bf16 [B, ceil(H/4), ceil(W/4), 64], bit-identical to cvcl_stem_conv7x7 + cvcl_bn_relu_maxpool.  bf16, W <= 252. */
+int cvcl_stem_pool_supported(int dtype, int H, int W);
+int cvcl_stem_pool(int dtype, const float* x_nchw, const void* w_packed, const float* scale, const float* shift,
+                   const float* centre /* [64] or NULL */, void* y_nhwc, int B, int H, int W, void* stream);
 /* relu(bn(x)) then maxpool 3x3/2 pad 1: [B,H,W,C] -> [B,ceil(H/2),ceil(W/2),C] */
 int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int B, int H, int W,
                          int C, void* stream);

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("" ::: "memory");
-            if (oy < Ho) {
+            if (oy < Ho && y) {                                   // (y == NULL: statistics only -- the fused stem below recomputes the tile)
                 bf16_t* drow = y + (((long)b * Ho + oy) * Wo + ox0) * 64 + (lane & 7) * 8;
 #pragma unroll
                 for (int rd = 0; rd < 2; ++rd) {
@@ -370,6 +370,153 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
         const float v = (red[(0 * 2 + which) * 64 + c] + red[(1 * 2 + which) * 64 + c]) +
                         (red[(2 * 2 + which) * 64 + c] + red[(3 * 2 + which) * 64 + c]);
         stats[((long)blockIdx.x * 2 + which) * 64 + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem 7x7 stride 2 + BatchNorm + ReLU + maxpool 3x3 stride 2 pad 1 in ONE pass (round 5; torchvision ResNet.forward
+// conv1 -> bn1 -> relu -> maxpool, reached from multimodal/multimodal.py:101): NCHW fp32 image -> NHWC bf16 [B, H/4, W/4, 64].
+// The raw stem output [B, 112, 112, 64] (411 MB at B = 256) is never written: train mode runs stem_mfma_kernel with y = NULL first
+// (statistics only), bn_finalize, then this kernel RECOMPUTES the convolution (it is 30 GFLOP) and pools it out of LDS --
+// 0.57 + 0.72 GB of traffic become 0.15 + 0.26 GB.  Bit-identical to the two-pass form: the same MFMA sequence per output, the same
+// rounding of the raw value to bf16 before the affine, and round(max) == max(round) on the non-negative post-ReLU values.
+// One 512-thread workgroup per CU; an item = STEMP_TP pooled rows of one image = 2 TP + 1 convolution rows (the first one shared
+// with the previous item: 25 % recomputation at TP = 2) = 4 TP + 7 input rows per channel.  Convolution tiles (16 pixels x 64
+// channels, 24 MFMAs) are dealt to the 8 waves and land, normalised, in an LDS band [conv row][pixel + 1][64 channels]; after a
+// barrier every thread takes (pooled pixel, 8 channels) units: nine 16-byte LDS reads, packed integer maxima, one 16-byte store.
+constexpr int STEMP_TP = 2;
+constexpr int STEMP_CR = 2 * STEMP_TP + 1;             // convolution rows per item
+constexpr int STEMP_ROWS = 2 * STEMP_CR + 5;           // input rows per channel
+constexpr int STEMP_BW = 128;                          // band row width in pixels (column 0 = the left padding column)
+__global__ __launch_bounds__(512, 1) void stem_pool_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                                bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, const float* __restrict__ centre,
+                                                                int B, int Hin, int Win) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned int* patch = (unsigned int*)smem;                 // [3 * STEMP_ROWS][STEM_PITCH] dwords (2 bf16 each)
+    char* band = smem + 3 * STEMP_ROWS * STEM_PITCH * 4;       // [STEMP_CR][STEMP_BW][64] bf16
+    float* cen = reinterpret_cast<float*>(band + STEMP_CR * STEMP_BW * 128);      // [64] -centre | [64] scale | [64] shift
+    const int Ho = Hin / 2, Wo = Win / 2;
+    const int Hp = (Ho - 1) / 2 + 1, Wp = (Wo - 1) / 2 + 1;
+    const int bands = cvcl_div_up(Hp, STEMP_TP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pix = lane & 15, kb = lane >> 4;
+
+    bf16x8 wf[4][6];                                           // all 64 output channels' weights, register resident
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks)
+            wf[nt][ks] = *reinterpret_cast<const bf16x8*>(wp + ((nt * 6 + ks) * 16 + pix) * 32 + kb * 8);
+    const int mtiles_per_row = cvcl_div_up(Wo, 16);
+    int koff[6];
+#pragma unroll
+    for (int ks = 0; ks < 6; ++ks) {
+        const int r = min(4 * ks + kb, 20);
+        const int c = r / 7, ky = r - c * 7;
+        koff[ks] = (c * STEMP_ROWS + ky) * STEM_PITCH;
+    }
+    for (int i = tid; i < 3 * STEMP_ROWS * STEM_PITCH; i += 512) patch[i] = 0u;       // pad columns stay zero for good
+    for (int i = tid; i < STEMP_CR * STEMP_BW * 32; i += 512) reinterpret_cast<unsigned*>(band)[i] = 0u;   // (padding columns: never rewritten)
+    if (tid < 64) {
+        cen[tid] = centre ? -centre[tid] : 0.f;
+        cen[64 + tid] = scale[tid];
+        cen[128 + tid] = shift[tid];
+    }
+    const int bx = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    for (int item = bx; item < B * bands; item += gridDim.x) {
+        const int b = item / bands, bnd = item - b * bands;
+        const int p0 = bnd * STEMP_TP;
+        const int oy_first = 2 * p0 - 1;                      // convolution row of band row 0 (-1 for the first item: padding)
+        // ---- stage: rows (c, iy) <- x[b][c][2 oy_first - 3 + iy][*] as bf16 at columns x + 3 (see stem_mfma_kernel) ----
+        {
+            constexpr int NROW = 3 * STEMP_ROWS, NV = (NROW + 15) / 16;      // 8 waves x 2 batches x NV slots >= NROW
+            const int vec_per_row = Win / 4, jl = min(lane, vec_per_row - 1);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 v[NV];
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int r = min((half * NV + i) * 8 + wave_u, NROW - 1);
+                    const int c = r / STEMP_ROWS, iy = r - c * STEMP_ROWS;
+                    const int yin = min(max(2 * oy_first - 3 + iy, 0), Hin - 1);
+                    v[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + yin) * Win + 4 * jl);
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int r = (half * NV + i) * 8 + wave_u;
+                    const int iy = r % STEMP_ROWS, yin = 2 * oy_first - 3 + iy;
+                    if (r < NROW && lane < vec_per_row) {
+                        const bool ok = yin >= 0 && yin < Hin;
+                        const unsigned u01 = ok ? round2(f32x2{v[i][0], v[i][1]}) : 0u, u23 = ok ? round2(f32x2{v[i][2], v[i][3]}) : 0u;
+                        char* dst = reinterpret_cast<char*>(patch + r * STEM_PITCH) + 8 * lane + 6;
+                        *reinterpret_cast<unsigned short*>(dst) = (unsigned short)u01;
+                        *reinterpret_cast<unsigned*>(dst + 2) = (u01 >> 16) | (u23 << 16);
+                        *reinterpret_cast<unsigned short*>(dst + 6) = (unsigned short)(u23 >> 16);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- convolution tiles of the band's STEMP_CR rows: wave w takes tiles w, w + 8, ... (row-major) ----
+        for (int t = wave_u; t < STEMP_CR * mtiles_per_row; t += 8) {
+            const int ty = t / mtiles_per_row, tx = t - ty * mtiles_per_row;
+            const int ox0 = tx * 16, ox = ox0 + pix;
+            const int oy = oy_first + ty;
+            char* brow = band + (ty * STEMP_BW + ox + 1) * 128 + kb * 8;
+            if (oy < 0 || oy >= Ho) {                          // a padding row of the pooling window: zeros (post-ReLU domain)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<u32x2*>(brow + nt * 32) = u32x2{0u, 0u};
+                continue;
+            }
+            f32x4 acc[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(cen + nt * 16 + kb * 4);
+            const unsigned int* row0 = patch + 2 * ty * STEM_PITCH + (ox < Wo ? ox : 0);
+#pragma unroll
+            for (int ks = 0; ks < 6; ++ks) {
+                const unsigned int* src = row0 + koff[ks];
+                u32x4 raw = {src[0], src[1], src[2], src[3]};
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], bfrag, acc[nt], 0, 0, 0);
+            }
+            const bool inside = ox < Wo;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                // what the two-pass form stores, then what bn_relu_maxpool computes from it: relu(raw_bf16 * scale + shift)
+                const u32x2 o = {round2(f32x2{acc[nt][0], acc[nt][1]}), round2(f32x2{acc[nt][2], acc[nt][3]})};
+                const f32x4 sc4 = *reinterpret_cast<const f32x4*>(cen + 64 + nt * 16 + kb * 4);
+                const f32x4 sh4 = *reinterpret_cast<const f32x4*>(cen + 128 + nt * 16 + kb * 4);
+                const f32x2 r01 = widen2(o[0]), r23 = widen2(o[1]);
+                const f32x2 v01 = {fmaxf(fmaf(r01[0], sc4[0], sh4[0]), 0.f), fmaxf(fmaf(r01[1], sc4[1], sh4[1]), 0.f)};
+                const f32x2 v23 = {fmaxf(fmaf(r23[0], sc4[2], sh4[2]), 0.f), fmaxf(fmaf(r23[1], sc4[3], sh4[3]), 0.f)};
+                *reinterpret_cast<u32x2*>(brow + nt * 32) = inside ? u32x2{round2(v01), round2(v23)} : u32x2{0u, 0u};
+            }
+        }
+        __syncthreads();
+        // ---- pool: (pooled row pr, pooled pixel pc, 8-channel chunk c8) units; band row 2 pr + dy, band column 2 pc + dx ----
+        typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+        for (int u = tid; u < STEMP_TP * Wp * 8; u += 512) {
+            const int c8 = u & 7, q = u >> 3;
+            const int pr = q / Wp, pc = q - pr * Wp;
+            if (p0 + pr >= Hp) continue;
+            const char* src = band + ((2 * pr) * STEMP_BW + 2 * pc) * 128 + c8 * 16;
+            u16x8 m = *reinterpret_cast<const u16x8*>(src);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    // (2 pc + dx <= Wo + 1 < STEMP_BW; the band's right padding columns are zero)
+                    m = __builtin_elementwise_max(m, *reinterpret_cast<const u16x8*>(src + (dy * STEMP_BW + dx) * 128));
+                }
+            *reinterpret_cast<u16x8*>(y + (((long)b * Hp + p0 + pr) * Wp + pc) * 64 + c8 * 8) = m;
+        }
+        // (the next item's staging touches only the patch, which nobody reads after the barrier above; its convolution phase
+        // rewrites the band behind the staging barrier, which every thread reaches with its pooling done)
     }
 }
 
@@ -1063,7 +1210,8 @@ extern "C" int cvcl_stem_conv_stats_rows(int dtype, int B, int H, int W) {
 
 extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_packed, void* y_nhwc, float* stats,
                                  int stats_rows, const float* centre, int B, int H, int W, void* stream) {
-    CVCL_CHECK_ARG(x_nchw && w_packed && y_nhwc && B > 0 && H % 2 == 0 && W % 2 == 0, "cvcl_stem_conv7x7: bad args");
+    CVCL_CHECK_ARG(x_nchw && w_packed && (y_nhwc || (dtype == CVCL_BF16 && stats)) && B > 0 && H % 2 == 0 && W % 2 == 0,
+                   "cvcl_stem_conv7x7: bad args");                 // (bf16: y_nhwc NULL = statistics only)
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16) {
         CVCL_CHECK_ARG(W + 6 + 8 <= 2 * STEM_PITCH && W % 4 == 0 && W / 4 <= 64,
@@ -1108,6 +1256,37 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
     }
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y_nhwc, (long)B * (H / 2) * (W / 2), 64, stats, stats_rows, stream);
+    return CVCL_OK;
+}
+
+// conv1 7x7/2 + bn1 + relu + maxpool 3x3/2 in one pass (stem_pool_mfma_kernel; bf16): x NCHW fp32 -> y NHWC bf16 [B, H/4, W/4, 64]
+extern "C" int cvcl_stem_pool_supported(int dtype, int H, int W) {
+    return dtype == CVCL_BF16 && H % 2 == 0 && W % 4 == 0 && W / 4 <= 64 && W + 6 + 8 <= 2 * STEM_PITCH && W / 2 + 2 <= STEMP_BW;
+}
+
+extern "C" int cvcl_stem_pool(int dtype, const float* x_nchw, const void* w_packed, const float* scale, const float* shift,
+                              const float* centre, void* y_nhwc, int B, int H, int W, void* stream) {
+    CVCL_CHECK_ARG(x_nchw && w_packed && scale && shift && y_nhwc && B > 0, "cvcl_stem_pool: bad args");
+    CVCL_CHECK_ARG(cvcl_stem_pool_supported(dtype, H, W), "cvcl_stem_pool: bf16 and a width <= %d only (got dtype %d, %d x %d)",
+                   2 * (STEMP_BW - 2), dtype, H, W);
+    const size_t lds = (size_t)3 * STEMP_ROWS * STEM_PITCH * 4 + (size_t)STEMP_CR * STEMP_BW * 128 + 3 * 64 * 4;
+    static CvclLdsAttr attr;
+    if (!attr.ready()) {
+        if (hipFuncSetAttribute((const void*)stem_pool_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            cvcl_set_error("cvcl_stem_pool: cannot raise the dynamic LDS limit");
+            return CVCL_ELAUNCH;
+        }
+        attr.mark();
+    }
+    const int Hp = (H / 2 - 1) / 2 + 1;
+    const int items = B * cvcl_div_up(Hp, STEMP_TP);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const int grid = items < cus ? items : cus;
+    CvclProfScope prof(stream, CVCL_K_STEM);
+    hipLaunchKernelGGL(stem_pool_mfma_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, x_nchw, (const bf16_t*)w_packed,
+                       (bf16_t*)y_nhwc, scale, shift, centre, B, H, W);
+    CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
 
@@ -1592,11 +1771,20 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     int h = H / 2, wd = W / 2;
     char* RAW = buf[2];
     const int srows = cvcl_stem_conv_stats_rows(dtype, B, H, W);
-    if ((rc = cvcl_stem_conv7x7(dtype, x_nchw, layers[0].w, RAW, stats, kMaxStatsRows, centres, B, H, W, stream))) return rc;
-    if ((rc = finalize(0, srows, (long)B * h * wd, 64))) return rc;
     char* X = buf[0];
     char* OUT = buf[1];
-    if ((rc = cvcl_bn_relu_maxpool(dtype, RAW, scale_of(0), shift_of(0), X, B, h, wd, 64, stream))) return rc;
+    // bf16: the raw stem output is never stored -- statistics-only pass (train mode), then convolution + bn1 + relu + maxpool in
+    // one kernel (stem_pool_mfma_kernel: bit-identical, -1.0 GB of traffic per step at B = 256).  [lab: CVCL_STEM_POOL=0 two passes]
+    static const bool stem_pool_on = cvcl_lab_int("CVCL_STEM_POOL", 1) != 0;
+    if (stem_pool_on && cvcl_stem_pool_supported(dtype, H, W)) {
+        if (training && (rc = cvcl_stem_conv7x7(dtype, x_nchw, layers[0].w, nullptr, stats, kMaxStatsRows, centres, B, H, W, stream))) return rc;
+        if ((rc = finalize(0, srows, (long)B * h * wd, 64))) return rc;
+        if ((rc = cvcl_stem_pool(dtype, x_nchw, layers[0].w, scale_of(0), shift_of(0), centres, X, B, H, W, stream))) return rc;
+    } else {
+        if ((rc = cvcl_stem_conv7x7(dtype, x_nchw, layers[0].w, RAW, stats, kMaxStatsRows, centres, B, H, W, stream))) return rc;
+        if ((rc = finalize(0, srows, (long)B * h * wd, 64))) return rc;
+        if ((rc = cvcl_bn_relu_maxpool(dtype, RAW, scale_of(0), shift_of(0), X, B, h, wd, 64, stream))) return rc;
+    }
     h /= 2; wd /= 2;
     li = 1;
     BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, stream};

@@ -96,6 +96,8 @@ SIGNATURES = {
     "cvcl_pack_conv_weight": (_I, [_I, _I, _P, _P, _I, _I, _I, _P]),
     "cvcl_stem_conv_stats_rows": (_I, [_I, _I, _I, _I]),
     "cvcl_stem_conv7x7": (_I, [_I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "cvcl_stem_pool_supported": (_I, [_I, _I, _I]),
+    "cvcl_stem_pool": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "cvcl_bn_relu_maxpool": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_gconv3x3_stats_rows": (_I, [_I, _I, _I, _I, _I, _I]),
     "cvcl_gconv3x3": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),

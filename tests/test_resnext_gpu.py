@@ -80,6 +80,37 @@ def test_stem(H, dev, dt, B, S, centred):
     check_stats(st, rows, y)
 
 
+@pytest.mark.parametrize("centred", [False, True])
+@pytest.mark.parametrize("B,S", [(3, 64), (2, 224), (2, 72), (1, 96), (300, 32)])
+def test_fused_stem_pool_is_bit_identical_to_the_two_passes(H, dev, B, S, centred):
+    """Round 5: conv1 + bn1 + relu + maxpool in one kernel (cvcl_stem_pool), its BatchNorm statistics from a statistics-only stem pass
+    (cvcl_stem_conv7x7 with y = NULL) -- against the two-pass form it replaces (store the raw stem output, then cvcl_bn_relu_maxpool):
+    the same statistics rows and the same pooled tensor, bit for bit (incl. odd pooled sizes: S = 72 -> 36 -> 18, 96 -> 48 -> 24,
+    and more items than workgroups)."""
+    g = torch.Generator().manual_seed(S + B)
+    x = (torch.randn(B, 3, S, S, generator=g) + (1.5 if centred else 0.0)).to(dev)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    wp = pack(H, "bf16", H.PACK_STEM7, w, dev)
+    cen = (0.3 * torch.randn(64, generator=g)).to(dev) if centred else None
+    rows = H.lib().cvcl_stem_conv_stats_rows(H.BF16, B, S, S)
+    raw = torch.empty(B, S // 2, S // 2, 64, dtype=torch.bfloat16, device=dev)
+    st_a, st_b = stats_tensor(rows, 64, dev), stats_tensor(rows, 64, dev)
+    H.check(H.lib().cvcl_stem_conv7x7(H.BF16, H.ptr(x), H.ptr(wp), H.ptr(raw), H.ptr(st_a), rows, H.ptr(cen), B, S, S, H.stream_ptr()), "stem")
+    H.check(H.lib().cvcl_stem_conv7x7(H.BF16, H.ptr(x), H.ptr(wp), None, H.ptr(st_b), rows, H.ptr(cen), B, S, S, H.stream_ptr()), "stem stats only")
+    assert torch.equal(st_a, st_b)
+    scale = (0.5 + torch.rand(64, generator=g)).to(dev)
+    shift = (0.3 * torch.randn(64, generator=g)).to(dev)
+    Hp = (S // 2 - 1) // 2 + 1
+    two = torch.empty(B, Hp, Hp, 64, dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().cvcl_bn_relu_maxpool(H.BF16, H.ptr(raw), H.ptr(scale), H.ptr(shift), H.ptr(two), B, S // 2, S // 2, 64, H.stream_ptr()), "maxpool")
+    assert H.lib().cvcl_stem_pool_supported(H.BF16, S, S)
+    one = torch.full((B, Hp, Hp, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    H.check(H.lib().cvcl_stem_pool(H.BF16, H.ptr(x), H.ptr(wp), H.ptr(scale), H.ptr(shift), H.ptr(cen), H.ptr(one), B, S, S, H.stream_ptr()), "stem_pool")
+    torch.cuda.synchronize()
+    assert torch.equal(one.view(torch.int16), two.view(torch.int16))
+    assert float(two.float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_bn_finalize_and_maxpool(H, dev, dt):
     g = torch.Generator().manual_seed(2)
