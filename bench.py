@@ -388,7 +388,9 @@ def fp8_yardstick(ve, images, patch=16, fp8=True):
         from multimodal import _hip as H
         D = model.embed_dim
         rows = images.shape[0] * ((images.shape[2] // patch) * (images.shape[3] // patch) + 1)
-        fold8 = bool(fp8) and bool(H.lib().cvcl_gemm_fp8_ln_supported(rows, 3 * D, D)) and bool(H.lib().cvcl_gemm_fp8_ln_supported(rows, 4 * D, D))
+        from multimodal import vit_hip
+        fold8 = (bool(fp8) and vit_hip.ln_fold_mode(model) is True and bool(H.lib().cvcl_gemm_fp8_ln_supported(rows, 3 * D, D))
+                 and bool(H.lib().cvcl_gemm_fp8_ln_supported(rows, 4 * D, D)))
         emu = torch.cat([O.vit_forward(p, c, patch, heads, quant=O.bf16_round, fp8=fp8, fp8_fold=fold8) for c in chunks])
         out["emulation_vs_torch_fp32"] = dev(emu, ref)
         if fp8:

@@ -149,6 +149,18 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
         f32x4 sw_r[2][4], bias_r[2][4];
         float sa_r[2] = {1.f, 1.f};
         bf16x8 rpre[8];
+        // (the producer mode -- MXOUT == 2 -- sits at the 256-register cap: its residual rows are requested at the head of the
+        // epilogue instead of riding through the K loop, which kept a spilled value's reload inside the loop)
+        auto fetch_residual = [&]() {
+            if (p.R) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int m = m0 + wm * 64 + j * 8 + (lane >> 3);
+                    if (m >= p.M) m = p.M - 1;
+                    rpre[j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + (lane & 7) * 8);
+                }
+            }
+        };
         auto fetch_epilogue_operands = [&]() {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -166,14 +178,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
                     sa_r[mt] = p.sa[m];
                 }
             }
-            if (p.R) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int m = m0 + wm * 64 + j * 8 + (lane >> 3);
-                    if (m >= p.M) m = p.M - 1;
-                    rpre[j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + (lane & 7) * 8);
-                }
-            }
+            if constexpr (MXOUT != 2) fetch_residual();
         };
 
         for (int kt = 0; kt < ktiles; ++kt) {
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(F8Dev p) {
         // ---- epilogue: scales, bias, activation -> bf16 through the consumed buffer -> full 128-byte rows (+ residual)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if constexpr (MXOUT == 2) fetch_residual();
         char* stg = smem + (buf ^ 1) * F8_BUF + wave * 8192;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)

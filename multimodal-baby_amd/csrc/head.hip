@@ -38,6 +38,9 @@ __global__ __launch_bounds__(128) void embed_meanpool_fwd_kernel(const float* __
 constexpr int EMB_CHUNK = 4096;
 constexpr int EMB_GROUPS = 16;
 constexpr int EMB_PASS = 512;                      // floats of E per pass (the groups' partial sums: 16 x 512 floats of LDS)
+// MEANPOOL: the source row of position p is utterance p / L, scaled by 1 / len (embedding mean-pool, multimodal.py:496-503);
+// otherwise position p itself, unscaled (cvcl_embed_rows_bwd: the per-word embedding gather of the LSTM / transformer text encoders).
+template <bool MEANPOOL>
 __global__ __launch_bounds__(512) void embed_meanpool_bwd_kernel(const float* __restrict__ d_ret,
                                                                  const int64_t* __restrict__ tok,
                                                                  const int64_t* __restrict__ len,
@@ -81,11 +84,11 @@ __global__ __launch_bounds__(512) void embed_meanpool_bwd_kernel(const float* __
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int j = j0 + k * EMB_GROUPS;
-                        bb[k] = j < nm ? smatch[j] / L : -1;
+                        bb[k] = j < nm ? (MEANPOOL ? smatch[j] / L : smatch[j]) : -1;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        rden[k] = bb[k] >= 0 ? (float)len[bb[k]] : 1.f;
+                        rden[k] = (MEANPOOL && bb[k] >= 0) ? (float)len[bb[k]] : 1.f;
 #pragma unroll
                         for (int i = 0; i < EMB_PASS / 128; ++i) {
                             const int e = ebase + (t32 + 32 * i) * 4;
@@ -102,9 +105,14 @@ __global__ __launch_bounds__(512) void embed_meanpool_bwd_kernel(const float* __
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float r = 1.f / rden[k];
+                        if constexpr (MEANPOOL) {
+                            const float r = 1.f / rden[k];
 #pragma unroll
-                        for (int i = 0; i < EMB_PASS / 128; ++i) acc[i] += val[k][i] * r;       // (padding slots add 0 * 1)
+                            for (int i = 0; i < EMB_PASS / 128; ++i) acc[i] += val[k][i] * r;   // (padding slots add 0 * 1)
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < EMB_PASS / 128; ++i) acc[i] += val[k][i];
+                        }
                     }
                 }
             }
@@ -377,8 +385,18 @@ extern "C" int cvcl_embed_meanpool_bwd(const float* d_ret, const int64_t* tok, c
     CVCL_CHECK_ARG(d_ret && tok && len && d_table, "cvcl_embed_meanpool_bwd: null pointer");
     CvclProfScope prof(stream, CVCL_K_HEAD);
     CVCL_CHECK_ARG(B > 0 && L > 0 && E > 0 && V > 0, "cvcl_embed_meanpool_bwd: bad shape");
-    hipLaunchKernelGGL(embed_meanpool_bwd_kernel, dim3(V), dim3(512), 0, (hipStream_t)stream, d_ret, tok, len, d_table,
+    hipLaunchKernelGGL(embed_meanpool_bwd_kernel<true>, dim3(V), dim3(512), 0, (hipStream_t)stream, d_ret, tok, len, d_table,
                        B, L, E);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+// d_table[v] = sum over positions p with tok[p] == v of dx[p, :] (position order within fixed match groups); padding row 0 -> 0
+extern "C" int cvcl_embed_rows_bwd(const float* dx, const int64_t* tok, float* d_table, int n_pos, int E, int V, void* stream) {
+    CVCL_CHECK_ARG(dx && tok && d_table && n_pos > 0 && E > 0 && V > 0, "cvcl_embed_rows_bwd: bad args");
+    CvclProfScope prof(stream, CVCL_K_HEAD);
+    hipLaunchKernelGGL(embed_meanpool_bwd_kernel<false>, dim3(V), dim3(512), 0, (hipStream_t)stream, dx, tok, (const int64_t*)nullptr,
+                       d_table, n_pos, 1, E);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

@@ -634,15 +634,22 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
         // window, which leaves the maximum unchanged -- no branch around a load (branches made every tap wait for the previous one)
         constexpr int EPC = ElemTraits<T>::kPerChunk, NC = 8 / EPC;              // 8 channels = 1 (bf16) or 2 (fp32) chunks
         Chunk<T> tap[9][NC];
+        const T* src[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int yin = min(max(2 * oy - 1 + ky, 0), H - 1), xin = min(max(2 * ox - 1 + kx, 0), W - 1);
-                const T* src = x + (((long)b * H + yin) * W + xin) * C + cc * 8;
-#pragma unroll
-                for (int q = 0; q < NC; ++q) tap[ky * 3 + kx][q].load(src + q * EPC);
+                src[ky * 3 + kx] = x + (((long)b * H + yin) * W + xin) * C + cc * 8;
             }
+        // (round 5: the scheduler had sunk every tap's load next to its use -- nine s_waitcnt vmcnt(0), nine dependent round trips
+        // per output, in the ISA -- although the source issued them together; the barriers pin "all addresses, all loads, then math")
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) tap[t][q].load(src[t] + q * EPC);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -1773,9 +1780,11 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     const int srows = cvcl_stem_conv_stats_rows(dtype, B, H, W);
     char* X = buf[0];
     char* OUT = buf[1];
-    // bf16: the raw stem output is never stored -- statistics-only pass (train mode), then convolution + bn1 + relu + maxpool in
-    // one kernel (stem_pool_mfma_kernel: bit-identical, -1.0 GB of traffic per step at B = 256).  [lab: CVCL_STEM_POOL=0 two passes]
-    static const bool stem_pool_on = cvcl_lab_int("CVCL_STEM_POOL", 1) != 0;
+    // [lab: CVCL_STEM_POOL=1] the fused stem (cvcl_stem_pool: statistics-only pass, then convolution + bn1 + relu + maxpool in one
+    // kernel; bit-identical, -1.0 GB of traffic per step at B = 256) -- measured and NOT the default (profiles/r05_ab_stem.txt, same
+    // box: C2 5.13 -> 5.22 ms): the stem convolution itself runs at 116 us for 30 GFLOP (LDS-gather-bound), so recomputing it costs
+    // more than the 411 MB it stops writing; the API and its bit-identity test stay for when the convolution gets faster.
+    static const bool stem_pool_on = cvcl_lab_int("CVCL_STEM_POOL", 0) != 0;
     if (stem_pool_on && cvcl_stem_pool_supported(dtype, H, W)) {
         if (training && (rc = cvcl_stem_conv7x7(dtype, x_nchw, layers[0].w, nullptr, stats, kMaxStatsRows, centres, B, H, W, stream))) return rc;
         if ((rc = finalize(0, srows, (long)B * h * wd, 64))) return rc;

@@ -961,59 +961,6 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
         dx[i] = y[i] > 0.f ? dy[i] : 0.f;
 }
 
-// d_table[v] = sum over positions (b,l) with tok == v of dx[b,l,:], in (b,l) order; padding row 0 -> 0.
-// Same deterministic per-vocabulary-row scan as embed_meanpool_bwd_kernel (head.hip), without the /len.
-__global__ __launch_bounds__(128) void embed_rows_bwd_kernel(const float* __restrict__ dx, const int64_t* __restrict__ tok,
-                                                             float* __restrict__ d_table, int total, int E) {
-    __shared__ int stok[8192];
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    constexpr int MAXR = 8;
-    for (int ebase = 0; ebase < E; ebase += 128 * MAXR) {
-        float acc[MAXR];
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) acc[i] = 0.f;
-        if (v != 0) {
-            for (int c0 = 0; c0 < total; c0 += 8192) {
-                const int n = min(8192, total - c0);
-                __syncthreads();
-                for (int i = tid; i < n; i += 128) stok[i] = (int)tok[c0 + i];
-                __syncthreads();
-                for (int base = 0; base < n; base += 64) {
-                    const bool hit = (base + lane) < n && stok[base + lane] == v;
-                    unsigned long long mm = __ballot(hit);
-                    while (mm) {
-                        int pos[8];
-                        int nb = 0;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            pos[k] = 0;
-                            if (mm) { const int bit = __ffsll((long long)mm) - 1; mm &= mm - 1; pos[k] = c0 + base + bit; nb = k + 1; }
-                        }
-                        float val[8][MAXR];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-#pragma unroll
-                            for (int i = 0; i < MAXR; ++i) {
-                                const int e = ebase + tid + 128 * i;
-                                val[k][i] = (k < nb && e < E) ? dx[(long)pos[k] * E + e] : 0.f;
-                            }
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (k < nb) {
-#pragma unroll
-                                for (int i = 0; i < MAXR; ++i) acc[i] += val[k][i];
-                            }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MAXR; ++i) {
-            const int e = ebase + tid + 128 * i;
-            if (e < E) d_table[(long)v * E + e] = acc[i];
-        }
-    }
-}
 
 // dx[b,l,:] = d_ret[b,:] / len[b] for every l (backward of seq_sum_div: pads included, as in the forward)
 __global__ __launch_bounds__(256) void seq_sum_div_bwd_kernel(const float* __restrict__ d_ret, const int64_t* __restrict__ len,
@@ -1206,13 +1153,6 @@ extern "C" int cvcl_relu_bwd(const float* y, const float* dy, float* dx, long n,
     return CVCL_OK;
 }
 
-extern "C" int cvcl_embed_rows_bwd(const float* dx, const int64_t* tok, float* d_table, int n_pos, int E, int V, void* stream) {
-    CVCL_CHECK_ARG(dx && tok && d_table && n_pos > 0 && E > 0 && V > 0, "cvcl_embed_rows_bwd: bad args");
-    CvclProfScope prof(stream, CVCL_K_HEAD);
-    hipLaunchKernelGGL(embed_rows_bwd_kernel, dim3(V), dim3(128), 0, (hipStream_t)stream, dx, tok, d_table, n_pos, E);
-    CVCL_LAUNCH_CHECK();
-    return CVCL_OK;
-}
 
 extern "C" int cvcl_seq_sum_div_bwd(const float* d_ret, const int64_t* len, float* dx, int B, int L, int E, void* stream) {
     CVCL_CHECK_ARG(d_ret && len && dx && B > 0 && L > 0 && E > 0, "cvcl_seq_sum_div_bwd: bad args");

@@ -209,7 +209,11 @@ class MultiModalLitModel(LightningModule):
         # DDP).  The optimised loss carries the scale; the logged / returned values are the unscaled joint loss and the rank's
         # own ce means.
         lm_scale = parallel.local_term_scale(self.model.global_negatives) if (self.training and self.lambda_lm) else 1.0
-        loss = self.lambda_mm * infonce_loss + (self.lambda_lm * lm_scale) * lm_ce_loss
+        if isinstance(lm_ce_loss, float) and torch.is_tensor(infonce_loss):
+            # contrastive term only (lambda_lm = 0, the BASELINE configurations): no "+ 0." / "1.0 *" elementwise launches
+            loss = infonce_loss if self.lambda_mm == 1 else self.lambda_mm * infonce_loss
+        else:
+            loss = self.lambda_mm * infonce_loss + (self.lambda_lm * lm_scale) * lm_ce_loss
         logged = loss if lm_scale == 1.0 else (self.lambda_mm * infonce_loss + self.lambda_lm * lm_ce_loss).detach()
         log(f"{stage}_loss", logged)
         ret.update({"loss": loss})

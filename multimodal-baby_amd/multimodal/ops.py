@@ -31,11 +31,14 @@ class EmbedMeanPool(torch.autograd.Function):
         ctx.save_for_backward(tok, length)
         ctx.shape = (V, E)
         ctx.mark_non_differentiable(*([out] if out is not None else []))
+        ctx.set_materialize_grads(False)       # (no zero-filled [B, L, E] gradient for the non-differentiable per-word output)
         return ret, out
 
     @staticmethod
     def backward(ctx, d_ret, _d_out):
         tok, length = ctx.saved_tensors
+        if d_ret is None:
+            return None, None, None, None
         V, E = ctx.shape
         B, L = tok.shape
         d_table = torch.empty(V, E, dtype=_F, device=d_ret.device)
@@ -213,10 +216,13 @@ class InfoNCE(torch.autograd.Function):
         loss = scalars[0].clone()
         metrics = scalars[1:].clone()
         ctx.mark_non_differentiable(metrics)
+        ctx.set_materialize_grads(False)
         return loss, metrics
 
     @staticmethod
     def backward(ctx, d_loss, _d_metrics):
+        if d_loss is None:
+            return None
         logits, row_lse, col_lse = ctx.saved_tensors
         N = logits.shape[0]
         d_logits = torch.empty_like(logits)

@@ -239,7 +239,11 @@ def _vit_forward_impl(model, x: torch.Tensor, slot) -> torch.Tensor:
             # LayerNorm folded into the e4m3 qkv / fc1 (round 5): the proj / fc2 epilogues leave the MX-quantised raw residual rows
             # and their strip sums; no LayerNorm + row-quantise pass between the linears (24 of them in a ViT-B)
             lib8 = H.lib()
-            fold8 = (mx_att and ln_fold_mode(model) is not False and D % 128 == 0 and D <= 1024 and
+            # OPT-IN (model.ln_fold = True / $CVCL_LN_FOLD=1): measured on one box (profiles/r05_ab_c5_fold.txt) the folded step is
+            # 9.00 ms against 8.75 -- per block the two quantise passes it removes (2 x 28 us) are paid back by the MX-input kinds
+            # of qkv / fc1 (+12 / +13 us) and the producers' second store stream (+18 us each), and the passes were hidden behind
+            # the other trunk stream's GEMMs anyway.
+            fold8 = (mx_att and ln_fold_mode(model) is True and D % 128 == 0 and D <= 1024 and
                      bool(lib8.cvcl_gemm_fp8_ln_supported(B * T, 3 * D, D)) and bool(lib8.cvcl_gemm_fp8_ln_supported(B * T, Dm, D)))
             if fold8:
                 M8 = B * T

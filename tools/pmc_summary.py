@@ -12,6 +12,7 @@ def load(c):
 F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
 KERNELS = (("gemm_glds_kernel", "gemm_glds"), ("gemm8w_kernel", "gemm8w"), ("gemm_pro_kernel", "gemm_pro"), ("gconv_mfma_kernel", "gconv_mfma"),
            ("bn_add_relu_kernel", "bn_add_relu"), ("bn_relu_apply_kernel", "bn_relu_apply"), ("stem_mfma_kernel", "stem_mfma"),
+           ("stem_pool_mfma_kernel", "stem_pool_mfma"),
            ("bn_relu_maxpool_kernel", "bn_relu_maxpool"), ("bn_finalize_kernel", "bn_finalize"), ("avgpool_kernel", "avgpool"),
            ("gram_pro_kernel", "gram_pro"), ("gram_reduce_kernel", "gram_reduce"), ("bn_from_gram_kernel", "bn_from_gram"))
 out, tot_r, tot_w = collections.OrderedDict(), 0.0, 0.0
