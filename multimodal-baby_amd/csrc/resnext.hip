@@ -249,64 +249,54 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
         const int c = r / 7, ky = r - c * 7;
         koff[ks] = (c * STEM_ROWS + ky) * STEM_PITCH;
     }
-    for (int i = tid; i < 2 * 3 * STEM_ROWS * STEM_PITCH; i += 256) patch[i] = 0u;   // (both patch buffers) pad columns stay zero for good
-    char* wst = smem + 2 * 3 * STEM_ROWS * STEM_PITCH * 4 + wave * (16 * STEM_OPITCH);  // this wave's output slot: 16 pixels
+    for (int i = tid; i < 3 * STEM_ROWS * STEM_PITCH; i += 256) patch[i] = 0u;       // pad columns stay zero for good
+    char* wst = smem + 3 * STEM_ROWS * STEM_PITCH * 4 + wave * (16 * STEM_OPITCH);  // this wave's output slot: 16 pixels
     // centred storage: the accumulators start at -centre[channel] (64 floats in LDS behind the output slots, re-read per tile:
     // the weights already hold 96 registers)
-    float* cen = reinterpret_cast<float*>(smem + 2 * 3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH);
+    float* cen = reinterpret_cast<float*>(smem + 3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH);
     if (tid < 64) cen[tid] = centre ? -centre[tid] : 0.f;                           // (visible after the first item's barrier)
-    __syncthreads();                                                                // (the zeroed pad columns, before the first deposit)
     // (XCD-major item order, as in gconv_mfma_kernel: adjacent bands of an image share 5 of their 13 input rows -- 0.247 GB read for
     // a 0.154 GB input in the plain order; time-neutral for this kernel, the traffic is what it saves)
     const int bx = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
-    // Round 5: the patch is double-buffered and the NEXT item's input rows are requested before this item's tiles are multiplied
-    // (they land in registers behind the MFMAs and are written to the other patch buffer when the loop comes round): the staging
-    // round trip (~2 x 2 us per item: half of an item's time at two workgroups per CU) leaves the critical path.  One barrier per item.
-    constexpr int NROW = 3 * STEM_ROWS, NV = 5;              // two batches of 5 slots: 10 x 4 rows >= 39
-    const int vec_per_row = Win / 4, jl = min(lane, vec_per_row - 1);
-    f32x4 pre[2 * NV];
-    auto request = [&](int item) __attribute__((always_inline)) {
+    for (int item = bx; item < B * bands; item += gridDim.x) {
         const int b = item / bands, band = item - b * bands;
         const int oy0 = band * STEM_TH;
+        __syncthreads();
+        // stage: rows (c, iy) <- x[b][c][2*oy0 - 3 + iy][*] as bf16 at columns x + 3 (the 3 + slack pad columns on either side were
+        // zeroed once and are never written).  Slot s of a wave is patch row 4 s + wave, a lane is one 16-byte vector of that row
+        // (Win / 4 <= 64 of them): the row, its channel, input row and validity are wave-uniform scalars -- no per-thread index
+        // arithmetic (the flat index form spent two runtime divisions per slot and phase).  All of a batch's loads are issued
+        // before the first LDS write; rows outside the image are staged as zeros.
+        {
+            constexpr int NROW = 3 * STEM_ROWS, NV = 5;          // two batches of 5 slots: 10 x 4 rows >= 39
+            const int vec_per_row = Win / 4, jl = min(lane, vec_per_row - 1);
 #pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) {
-            const int r = min(i * 4 + wave_u, NROW - 1);
-            const int c = r / STEM_ROWS, iy = r - c * STEM_ROWS;
-            const int yin = min(max(2 * oy0 - 3 + iy, 0), Hin - 1);
-            pre[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + yin) * Win + 4 * jl);
-        }
-    };
-    // stage: rows (c, iy) <- x[b][c][2*oy0 - 3 + iy][*] as bf16 at columns x + 3 (the 3 + slack pad columns on either side were
-    // zeroed once and are never written).  Slot s of a wave is patch row 4 s + wave, a lane is one 16-byte vector of that row
-    // (Win / 4 <= 64 of them): the row, its channel, input row and validity are wave-uniform scalars.  Rows outside the image are
-    // staged as zeros.
-    auto deposit = [&](int item, unsigned int* pb) __attribute__((always_inline)) {
-        const int band = item % bands;
-        const int oy0 = band * STEM_TH;
+            for (int half = 0; half < 2; ++half) {
+                f32x4 v[NV];
 #pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) {
-            const int r = i * 4 + wave_u;
-            const int iy = r % STEM_ROWS, yin = 2 * oy0 - 3 + iy;
-            if (r < NROW && lane < vec_per_row) {
-                const bool ok = yin >= 0 && yin < Hin;
-                const unsigned u01 = ok ? round2(f32x2{pre[i][0], pre[i][1]}) : 0u, u23 = ok ? round2(f32x2{pre[i][2], pre[i][3]}) : 0u;
-                // four pixels from padded column 4 lane + 3 (odd): 2 + 4 + 2 bytes
-                char* dst = reinterpret_cast<char*>(pb + r * STEM_PITCH) + 8 * lane + 6;
-                *reinterpret_cast<unsigned short*>(dst) = (unsigned short)u01;
-                *reinterpret_cast<unsigned*>(dst + 2) = (u01 >> 16) | (u23 << 16);
-                *reinterpret_cast<unsigned short*>(dst + 6) = (unsigned short)(u23 >> 16);
+                for (int i = 0; i < NV; ++i) {
+                    const int r = min((half * NV + i) * 4 + wave_u, NROW - 1);
+                    const int c = r / STEM_ROWS, iy = r - c * STEM_ROWS;
+                    const int yin = min(max(2 * oy0 - 3 + iy, 0), Hin - 1);
+                    v[i] = *reinterpret_cast<const f32x4*>(x + (((long)b * 3 + c) * Hin + yin) * Win + 4 * jl);
+                }
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int r = (half * NV + i) * 4 + wave_u;
+                    const int iy = r % STEM_ROWS, yin = 2 * oy0 - 3 + iy;
+                    if (r < NROW && lane < vec_per_row) {
+                        const bool ok = yin >= 0 && yin < Hin;
+                        const unsigned u01 = ok ? round2(f32x2{v[i][0], v[i][1]}) : 0u, u23 = ok ? round2(f32x2{v[i][2], v[i][3]}) : 0u;
+                        // four pixels from padded column 4 lane + 3 (odd): 2 + 4 + 2 bytes
+                        char* dst = reinterpret_cast<char*>(patch + r * STEM_PITCH) + 8 * lane + 6;
+                        *reinterpret_cast<unsigned short*>(dst) = (unsigned short)u01;
+                        *reinterpret_cast<unsigned*>(dst + 2) = (u01 >> 16) | (u23 << 16);
+                        *reinterpret_cast<unsigned short*>(dst + 6) = (unsigned short)(u23 >> 16);
+                    }
+                }
             }
         }
-    };
-    if (bx < B * bands) request(bx);
-    int cur = 0;
-    for (int item = bx; item < B * bands; item += gridDim.x, cur ^= 1) {
-        const int b = item / bands, band = item - b * bands;
-        const int oy0 = band * STEM_TH;
-        unsigned int* patch_c = patch + cur * (3 * STEM_ROWS * STEM_PITCH);
-        deposit(item, patch_c);
         __syncthreads();
-        if (item + (int)gridDim.x < B * bands) request(item + gridDim.x);
         // m-tiles of the band in row-major order, wave w takes w, w + 4, ...: (row, tile in row) advance as scalars
         int ty = 0, tx = wave_u;
         while (tx >= mtiles_per_row) { tx -= mtiles_per_row; ++ty; }
@@ -316,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void stem_mfma_kernel(const float* __restri
             f32x4 acc[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt] = *reinterpret_cast<const f32x4*>(cen + nt * 16 + kb * 4);
-            const unsigned int* row0 = patch_c + 2 * ty * STEM_PITCH + (ox < Wo ? ox : 0);
+            const unsigned int* row0 = patch + 2 * ty * STEM_PITCH + (ox < Wo ? ox : 0);
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 const unsigned int* src = row0 + koff[ks];
@@ -1235,7 +1225,7 @@ extern "C" int cvcl_stem_conv7x7(int dtype, const float* x_nchw, const void* w_p
                        "cvcl_stem_conv7x7: width %d not supported by the staged patch", W);
         const int g = stem_grid(B, H);
         CVCL_CHECK_ARG(!stats || stats_rows >= g, "cvcl_stem_conv7x7: stats_rows %d < %d", stats_rows, g);
-        const size_t lds = (size_t)2 * 3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH + 64 * 4;
+        const size_t lds = (size_t)3 * STEM_ROWS * STEM_PITCH * 4 + 4 * 16 * STEM_OPITCH + 64 * 4;
         float* st = stats;
         CVCL_CHECK_ARG(st, "cvcl_stem_conv7x7: the bf16 kernel always emits statistics; pass a buffer");
         CvclProfScope prof(stream, CVCL_K_STEM);
