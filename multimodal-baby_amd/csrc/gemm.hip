@@ -974,6 +974,149 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const float* __rest
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// The trainable tail's fp32 GEMMs with split arithmetic (round 5): 64 x 64 output tile per 256-thread workgroup, one tile per
+// workgroup (no persistence), K step 32.  The products of the text transformer (reference multimodal/multimodal.py:553-573) are
+// 1280 x {512..2048} x {512..2048}: 128 x 128 tiles gave 40-160 workgroups, each walking its K tiles alone on a CU at ~2 us per
+// tile (load -> LDS -> multiply, one wave per SIMD: profiles/r05_tail_c4_kernel_stats.csv, 47-98 us per launch whatever the
+// arithmetic).  Here a launch is 256-640 small workgroups, 18 KiB of LDS and < 128 registers each, so several share a CU and hide each
+// other's load -> LDS -> multiply round trips; operands row-major or K-major (TR bits as gemm_kernel), fp32 in, hi / lo bf16 parts
+// in LDS, hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16, fp32 out (+ bias, ReLU), row sums of a K-major A for the bias gradient.
+constexpr int TS = 64;                                   // tile side
+template <int TR>
+__global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ C,
+                                                                int M, int N, int K, int lda, int ldw, int ldc, const float* __restrict__ bias,
+                                                                int act, float* __restrict__ a_rowsum, int vec) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TS * ROWB];
+    char* sA = smem;
+    char* sW = smem + TS * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1, l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS;
+    // staging roles.  row-major operand: chunk kc (4 k) of rows r0, r0 + 32; K-major operand: 4 rows 4 mc .. of k-rows kr, kr + 16
+    const int kc = tid & 7, r0 = tid >> 3, mc = tid & 15, kr = tid >> 4;
+    f32x4 ra[2], rw[2];
+    auto load_tile = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            auto fetch = [&](const float* base, int ld, bool kmajor, int row_base, int rows) -> f32x4 {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (!kmajor) {
+                    const int r = row_base + r0 + 32 * j, k = k0 + kc * 4;
+                    if (r < rows) {
+                        const float* p = base + (long)r * ld + k;
+                        if (vec && k + 3 < K) v = *reinterpret_cast<const f32x4*>(p);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = k + e < K ? p[e] : 0.f;
+                        }
+                    }
+                } else {
+                    const int kk = k0 + kr + 16 * j, r = row_base + mc * 4;
+                    if (kk < K) {
+                        const float* p = base + (long)kk * ld + r;
+                        if (vec && r + 3 < rows) v = *reinterpret_cast<const f32x4*>(p);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = r + e < rows ? p[e] : 0.f;
+                        }
+                    }
+                }
+                return v;
+            };
+            ra[j] = fetch(A, lda, (TR & 1) != 0, m0, M);
+            rw[j] = fetch(W, ldw, (TR & 2) != 0, n0, N);
+        }
+    };
+    float rsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            auto put = [&](char* base, const f32x4& v, bool kmajor) {
+                bf16_t hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)v[e]; lo[e] = (bf16_t)(v[e] - (float)hi[e]); }
+                if (!kmajor) {
+                    char* row = base + (r0 + 32 * j) * ROWB + kc * 8;
+                    *reinterpret_cast<bf16x4*>(row) = bf16x4{hi[0], hi[1], hi[2], hi[3]};
+                    *reinterpret_cast<bf16x4*>(row + 64) = bf16x4{lo[0], lo[1], lo[2], lo[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        char* el = base + (mc * 4 + e) * ROWB + (kr + 16 * j) * 2;
+                        *reinterpret_cast<bf16_t*>(el) = hi[e];
+                        *reinterpret_cast<bf16_t*>(el + 64) = lo[e];
+                    }
+                }
+            };
+            put(sA, ra[j], (TR & 1) != 0);
+            put(sW, rw[j], (TR & 2) != 0);
+            if constexpr ((TR & 1) != 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rsum[e] += ra[j][e];
+            }
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int ktiles = (K + 31) / 32;
+    load_tile(0);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        __syncthreads();                                   // the previous tile's fragment reads are done
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < ktiles) load_tile((kt + 1) * 32);     // in flight under the MFMAs
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const char* wr = sW + (wn * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
+            const char* ar = sA + (wm * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wr), wl = *reinterpret_cast<const bf16x8*>(wr + 64);
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ar), al = *reinterpret_cast<const bf16x8*>(ar + 64);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);      // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+        }
+    }
+    // this lane: output row m = m0 + wm * 32 + l31, columns n0 + wn * 32 + 8 g + 4 h + e
+    const int m = m0 + wm * 32 + l31;
+    if (m < M) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * 32 + 8 * g + 4 * h;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = acc[4 * g + e] + ((bias && n + e < N) ? bias[n + e] : 0.f);
+                if (act == CVCL_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            }
+            float* dst = C + (long)m * ldc + n;
+            if (n + 3 < N && (ldc & 3) == 0 && vec) *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < N) dst[e] = v[e];
+            }
+        }
+    }
+    if constexpr ((TR & 1) != 0) {
+        // row sums of the K-major A (the bias gradient beside dW = dY^T X): the 16 k-row slices of a row group through LDS, fixed order
+        if (a_rowsum && blockIdx.y == 0) {
+            __syncthreads();
+            float* part = reinterpret_cast<float*>(smem);          // [16][64]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[kr * 64 + mc * 4 + e] = rsum[e];
+            __syncthreads();
+            if (tid < 64 && m0 + tid < M) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += part[i * 64 + tid];
+                a_rowsum[m0 + tid] = t;
+            }
+        }
+    }
+}
+
 }  // namespace
 extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream);
 extern "C" int cvcl_gemm_pro_supported(const cvcl_gemm_args* a);
@@ -1115,21 +1258,37 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     CVCL_CHECK_ARG(a->C && !a->c_scale, "cvcl_gemm: statistics-only / BN-tail epilogues need the direct-to-LDS bf16 path");
     if constexpr (sizeof(T) == 4) {
         auto al16p = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+        // measured cost models (us, MI355X): the split-K VALU kernel runs ~13.4 GMAC/s-per-us of work on any shape; the 128-tile
+        // fp32 MFMA kernel needs ~4.6 us per 64-deep K step per round of <= 256 tiles, whatever M and N are (4.2 with split
+        // arithmetic: its K step is bound by the serial load -> LDS -> multiply structure at one wave per SIMD, not by the matrix
+        // pipe); the 64 x 64 split kernel ~1 us per (tile, 32-deep K step) with ~4 workgroups per CU overlapping
+        static const bool split64_on = cvcl_lab_int("CVCL_SPLIT64", 1) != 0;
+        const bool split64_ok = split64_on && split && pro_kind(a) == 0 && !(a->gather_stride > 1) && !a->stats && !a->R && !a->centre && !a->exp_scale &&
+                                (a->act == CVCL_ACT_NONE || a->act == CVCL_ACT_RELU);
+        const double t_small = (double)a->M * a->N * a->K / 13.4e6 + 5.0;
+        const double t_mfma128 = 12.0 + (a->K / 64.0) * (split ? 4.2 : 4.6) * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256);
+        const double t_split64 = split64_ok ? 6.0 + (double)cvcl_div_up(a->M, TS) * cvcl_div_up(a->N, TS) * cvcl_div_up(a->K, 32) / 1024.0 +
+                                              0.25 * cvcl_div_up(a->K, 32) : 1e30;
         if (pro_kind(a) == 0 && !(a->gather_stride > 1) && !a->stats && !a->R && !a->centre && a->act == CVCL_ACT_NONE && a->K % 4 == 0 &&
-            a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) && !a->a_rowsum &&
-            // measured cost models (us, MI355X): the split-K VALU kernel runs ~13.4 GMAC/s-per-us of work on any shape; the
-            // 128-tile fp32 MFMA kernel needs ~4.6 us per 64-deep K step per round of <= 256 tiles, whatever M and N are
-            // (4.2 us with split arithmetic, measured -- profiles/r05_tail_c4_kernel_stats.csv: the 128-tile kernel's K step is bound
-            // by its serial load -> LDS -> multiply structure at one wave per SIMD, not by the matrix pipe; what the split buys is
-            // 768 instead of 4096 cycles of matrix pipe per tile and wave, i.e. less interference with the trunk GEMMs beside it)
-            (double)a->M * a->N * a->K / 13.4e6 + 5.0 <
-                12.0 + (a->K / 64.0) * (split ? 4.2 : 4.6) * cvcl_div_up((long)cvcl_div_up(a->M, BM) * cvcl_div_up(a->N, BN), 256)) {
+            a->lda % 4 == 0 && a->ldw % 4 == 0 && al16p(a->A) && al16p(a->W) && !a->a_rowsum && t_small < t_mfma128 && t_small < t_split64) {
             CvclProfScope prof(stream, CVCL_K_GEMM_F32);
             const dim3 grid(cvcl_div_up(a->N, 16), cvcl_div_up(a->M, 16));
 #define CVCL_SMALL(TR_) hipLaunchKernelGGL(gemm_f32_small_kernel<TR_>, grid, dim3(256), 0, stream, (const float*)a->A, (const float*)a->W, \
                                            (float*)a->C, a->M, a->N, a->K, a->lda, a->ldw, a->ldc, a->exp_scale, a->bias)
             switch (tr) { case 0: CVCL_SMALL(0); break; case 1: CVCL_SMALL(1); break; case 2: CVCL_SMALL(2); break; default: CVCL_SMALL(3); }
 #undef CVCL_SMALL
+            CVCL_LAUNCH_CHECK();
+            return CVCL_OK;
+        }
+        if (split64_ok && t_split64 < t_mfma128) {
+            // the tail's products: many 64 x 64 workgroups (gemm_f32_split_kernel)
+            const int vec = (a->lda % 4 == 0) && (a->ldw % 4 == 0) && al16p(a->A) && al16p(a->W) && al16p(a->C);
+            CvclProfScope prof(stream, CVCL_K_GEMM_F32);
+            const dim3 grid(cvcl_div_up(a->M, TS), cvcl_div_up(a->N, TS));
+#define CVCL_SPLIT(TR_) hipLaunchKernelGGL(gemm_f32_split_kernel<TR_>, grid, dim3(256), 0, stream, (const float*)a->A, (const float*)a->W, \
+                                           (float*)a->C, a->M, a->N, a->K, a->lda, a->ldw, a->ldc, a->bias, a->act, a->a_rowsum, vec)
+            switch (tr) { case 0: CVCL_SPLIT(0); break; case 1: CVCL_SPLIT(1); break; case 2: CVCL_SPLIT(2); break; default: CVCL_SPLIT(3); }
+#undef CVCL_SPLIT
             CVCL_LAUNCH_CHECK();
             return CVCL_OK;
         }
