@@ -26,6 +26,7 @@
 //  * the BatchNorm(+ReLU) of the *producer* layer is applied to A while it is staged (per-K scale /
 //    shift), so a normalised activation tensor is never written to HBM.
 #include <cstdlib>
+#include <type_traits>
 
 #include "cvcl_common.h"
 
@@ -995,11 +996,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const float* __r
     const int m0 = blockIdx.x * TS, n0 = blockIdx.y * TS;
     // staging roles.  row-major operand: chunk kc (4 k) of rows r0, r0 + 32; K-major operand: 4 rows 4 mc .. of k-rows kr, kr + 16
     const int kc = tid & 7, r0 = tid >> 3, mc = tid & 15, kr = tid >> 4;
-    f32x4 ra[2], rw[2];
-    auto load_tile = [&](int k0) __attribute__((always_inline)) {
+    // K tiles are requested PF tiles ahead into a ring of register sets: with one workgroup per CU (dW of a 2048 x 512 weight is
+    // exactly 256 tiles) nothing else hides the ~1 us load round trip of a tile whose multiply takes 0.1 us -- the first version,
+    // one tile ahead, ran 50 us per launch at 1.3 us per K step
+    constexpr int PF = 4;
+    f32x4 ra[PF][2], rw[PF][2];
+    // FAST (a workgroup-uniform property: 16-byte aligned operands, the tile inside M x N, K a multiple of 128): unconditional
+    // 16-byte loads -- a branch between a load and its use makes the compiler wait for ALL outstanding loads (vmcnt(0)) and the ring
+    // of requests collapses to one tile in flight
+    auto load_tile = [&](f32x4 (&qa)[2], f32x4 (&qw)[2], int k0, auto FAST) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             auto fetch = [&](const float* base, int ld, bool kmajor, int row_base, int rows) -> f32x4 {
+                if constexpr (decltype(FAST)::value) {
+                    if (!kmajor) return *reinterpret_cast<const f32x4*>(base + (long)(row_base + r0 + 32 * j) * ld + k0 + kc * 4);
+                    return *reinterpret_cast<const f32x4*>(base + (long)(k0 + kr + 16 * j) * ld + row_base + mc * 4);
+                }
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (!kmajor) {
                     const int r = row_base + r0 + 32 * j, k = k0 + kc * 4;
@@ -1024,12 +1036,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const float* __r
                 }
                 return v;
             };
-            ra[j] = fetch(A, lda, (TR & 1) != 0, m0, M);
-            rw[j] = fetch(W, ldw, (TR & 2) != 0, n0, N);
+            qa[j] = fetch(A, lda, (TR & 1) != 0, m0, M);
+            qw[j] = fetch(W, ldw, (TR & 2) != 0, n0, N);
         }
     };
     float rsum[4] = {0.f, 0.f, 0.f, 0.f};
-    auto store_tile = [&]() __attribute__((always_inline)) {
+    auto store_tile = [&](const f32x4 (&qa)[2], const f32x4 (&qw)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             auto put = [&](char* base, const f32x4& v, bool kmajor) {
@@ -1049,11 +1061,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const float* __r
                     }
                 }
             };
-            put(sA, ra[j], (TR & 1) != 0);
-            put(sW, rw[j], (TR & 2) != 0);
+            put(sA, qa[j], (TR & 1) != 0);
+            put(sW, qw[j], (TR & 2) != 0);
             if constexpr ((TR & 1) != 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) rsum[e] += ra[j][e];
+                for (int e = 0; e < 4; ++e) rsum[e] += qa[j][e];
             }
         }
     };
@@ -1061,23 +1073,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const float* __r
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int ktiles = (K + 31) / 32;
-    load_tile(0);
-    for (int kt = 0; kt < ktiles; ++kt) {
-        __syncthreads();                                   // the previous tile's fragment reads are done
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < ktiles) load_tile((kt + 1) * 32);     // in flight under the MFMAs
+    auto k_loop = [&](auto FAST) __attribute__((always_inline)) {
+        // (the ring's tail: requests past the last tile re-read the last one -- harmless, never stored -- so that no branch sits
+        // between a request and its use on the fast path)
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-            const char* wr = sW + (wn * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
-            const char* ar = sA + (wm * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
-            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wr), wl = *reinterpret_cast<const bf16x8*>(wr + 64);
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ar), al = *reinterpret_cast<const bf16x8*>(ar + 64);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);      // small terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+        for (int u = 0; u < PF; ++u) load_tile(ra[u], rw[u], min(u, ktiles - 1) * 32, FAST);
+        for (int kt0 = 0; kt0 < ktiles; kt0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int kt = kt0 + u;
+                // (fast path: K is a multiple of 32 PF, the body is ONE basic block -- with a branch per step the compiler's wait
+                // insertion lost count across the back edge and drained the ring, vmcnt(0), at every fourth step)
+                if (decltype(FAST)::value || kt < ktiles) {     // (uniform)
+                    __syncthreads();                           // the previous tile's fragment reads are done
+                    store_tile(ra[u], rw[u]);
+                    __syncthreads();
+                    load_tile(ra[u], rw[u], min(kt + PF, ktiles - 1) * 32, FAST);     // PF tiles ahead, in flight under the next multiplies
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const char* wr = sW + (wn * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
+                        const char* ar = sA + (wm * 32 + l31) * ROWB + (g2 * 2 + h) * 16;
+                        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wr), wl = *reinterpret_cast<const bf16x8*>(wr + 64);
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ar), al = *reinterpret_cast<const bf16x8*>(ar + 64);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, ah, acc, 0, 0, 0);      // small terms first
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, al, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, ah, acc, 0, 0, 0);
+                    }
+                }
+            }
         }
-    }
+    };
+    if (vec && m0 + TS <= M && n0 + TS <= N && (K & (32 * PF - 1)) == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     // this lane: output row m = m0 + wm * 32 + l31, columns n0 + wn * 32 + 8 g + 4 h + e
     const int m = m0 + wm * 32 + l31;
     if (m < M) {
