@@ -392,13 +392,8 @@ __device__ inline bf16x4 att_tr_read(const char* p) {
 template <bool MX, int NTC>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                 unsigned char* __restrict__ out8, unsigned char* __restrict__ out_bs,
-                                                                float* __restrict__ lse, int B, int Tn, int heads, float scale, int NT,
-                                                                int skew_bit, int skew_sleeps) {
+                                                                float* __restrict__ lse, int B, int Tn, int heads, float scale, int NT) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // (lab, round 5) phase skew between the two workgroups of a CU: the workgroups of the first dispatch round whose index has
-    // `skew_bit` set start `skew_sleeps` x ~4 us late, so that one stages K / V (HBM-bound) while its neighbour multiplies (VALU-bound)
-    if (skew_sleeps > 0 && blockIdx.x < 512u && ((blockIdx.x >> skew_bit) & 1u))
-        for (int i = 0; i < skew_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
     const int Tpad = 32 * NT;
     char* sK = smem;                                                // [Tpad][ATT_KP]
     char* sV = sK + Tpad * ATT_KP;                                  // [Tpad][ATT_VP]
@@ -802,9 +797,8 @@ int launch_attention_mfma_n(const void* qkv, void* out, void* out8, void* out_bs
         }
         attr_set.mark();
     }
-    static const int skew_bit = cvcl_lab_int("CVCL_ATT_SKEW_BIT", 8), skew_sleeps = cvcl_lab_int("CVCL_ATT_SKEW_SLEEPS", 0);
     hipLaunchKernelGGL((attention_mfma_kernel<MX, NTC>), dim3(B * heads), dim3(ATT_THREADS), lds, s, (const bf16_t*)qkv, (bf16_t*)out,
-                       (unsigned char*)out8, (unsigned char*)out_bs, lse, B, T, heads, scale, nt, skew_bit, skew_sleeps);
+                       (unsigned char*)out8, (unsigned char*)out_bs, lse, B, T, heads, scale, nt);
     return CVCL_OK;
 }
 template <bool MX>
