@@ -113,7 +113,13 @@ class VisionEncoder(nn.Module):
     def _graph_forward(self, x):
         graphs = self.__dict__.setdefault("_graphs", {})
         key = (tuple(x.shape), str(x.device), getattr(self.model, "compute_dtype", None))
-        fp = tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        # (the parameter LIST is cached: the module-tree walk of ~160 parameters cost more host time per call than reading their
+        # pointers and versions; re-registering a parameter changes the list's identity check below)
+        plist = self.__dict__.get("_graph_params")
+        if plist is None or len(plist[1]) != plist[0]:
+            ps = list(self.model.parameters())
+            plist = self.__dict__["_graph_params"] = (len(ps), ps)
+        fp = tuple((p.data_ptr(), p._version) for p in plist[1])
         entry = graphs.get(key)
         if entry is not None and entry[5] != fp:              # weights changed since the capture: the packed copies are stale
             entry = None
@@ -142,10 +148,12 @@ class VisionEncoder(nn.Module):
     def train(self, mode: bool = True):
         if mode and self.__dict__.get("_graphs"):
             self.__dict__["_graphs"] = {}
+        self.__dict__["_graph_params"] = None
         return super().train(mode)
 
     def load_state_dict(self, *a, **k):
         self.__dict__["_graphs"] = {}
+        self.__dict__["_graph_params"] = None
         return super().load_state_dict(*a, **k)
 
     def _load_from_state_dict(self, *a, **k):                 # a parent's load_state_dict reaches this module here, not above

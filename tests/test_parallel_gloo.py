@@ -53,8 +53,9 @@ def _worker(rank, world, port, global_negatives, out, deferred=False):
     fi = O.l2_normalize(x_all[sl] @ proj_used.t())
     ft = O.l2_normalize(O.embedding_meanpool(table, tok_all[sl], len_all[sl])[0])
     if global_negatives:
+        n0 = parallel.COLLECTIVES["all_gather"]
         fi, ft = parallel.gather_features(fi, ft)
-        assert fi.shape == (world * B, E)
+        assert fi.shape == (world * B, E) and parallel.COLLECTIVES["all_gather"] == n0 + 1       # both feature matrices in ONE collective
     lpi, lpt = O.similarity_logits(fi, ft, nlt)
     loss = O.contrastive_loss(lpi, lpt)[0]
     loss.backward()
