@@ -488,6 +488,9 @@ int cvcl_stem_im2col(const float* x_nchw, void* col_bf16, int B, int H, int W, v
  * d_mm (zero except at the winners), from which d image rows = d_mm . text rows and d text rows = d_mm^T . image rows.
  * sim == "mean" needs no kernel of its own: mean over locations / words (cvcl_seq_sum_div) then cvcl_sim_logits.     */
 int cvcl_bf16_to_f32(const void* x, float* y, long n, void* stream);      /* n % 8 == 0, 16-byte aligned */
+/* its backward under --finetune_cnn (the gradient of the layer-4 map returns to the bf16 trunk, round to nearest even):
+ * reference multimodal/multimodal.py:175-185 lets autograd run through nn.Sequential(trunk, Conv2d(2048, E, 1))          */
+int cvcl_f32_to_bf16(const float* x, void* y, long n, void* stream);      /* n % 8 == 0, 16-byte aligned */
 int cvcl_spatial_max_fwd(const float* mm, const int64_t* len, const float* neg_log_temp, float* logits, uint8_t* arg,
                          int Bi, int HW, int Bt, int L, void* stream);
 int cvcl_spatial_max_bwd(const float* d_logits, const uint8_t* arg, const int64_t* len, const float* neg_log_temp,

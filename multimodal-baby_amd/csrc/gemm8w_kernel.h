@@ -60,6 +60,7 @@ struct Dev {
     // row gather of a strided 1x1 convolution: output row m = (b, oy, ox) reads A row (b, oy * gs, ox * gs); gs <= 1 = off
     int gs, g_hw, g_wo, g_hi, g_wi;
     int a_rows;                     // rows of A (= M without the gather)
+    int skew;                       // start skew span in 10 ns ticks (0 = off): see "start skew" in the kernel
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
@@ -78,6 +79,19 @@ __device__ __forceinline__ int swz(int g) { return (0x78 >> (2 * g)) & 3; }
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a count that is a constant only after unrolling (the switch folds), tied to the value it makes valid
+__device__ __forceinline__ void wait_vm_value(int n, u32x4& v) {
+#define CVCL_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(v) : : "memory"); break;
+    switch (n) {
+        CVCL_W(0) CVCL_W(1) CVCL_W(2) CVCL_W(3) CVCL_W(4) CVCL_W(5) CVCL_W(6) CVCL_W(7) CVCL_W(8) CVCL_W(9) CVCL_W(10) CVCL_W(11)
+        CVCL_W(12) CVCL_W(13) CVCL_W(14) CVCL_W(15) CVCL_W(16) CVCL_W(17) CVCL_W(18) CVCL_W(19) CVCL_W(20) CVCL_W(21) CVCL_W(22)
+        CVCL_W(23) CVCL_W(24) CVCL_W(25) CVCL_W(26) CVCL_W(27) CVCL_W(28) CVCL_W(29) CVCL_W(30) CVCL_W(31) CVCL_W(32) CVCL_W(33)
+        CVCL_W(34) CVCL_W(35) CVCL_W(36) CVCL_W(37) CVCL_W(38) CVCL_W(39) CVCL_W(40)
+        default: asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) : : "memory"); break;
+    }
+#undef CVCL_W
 }
 
 // What bounds it, what was tried (pipeline ablations, 4-wave / 8-phase / staggered variants, store flavours): DESIGN.md section 5;
@@ -133,6 +147,15 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         ti = (s / p.ncol) * 8 + xcd;
         nt = ti < p.tiles_m ? (p.tiles_m - ti + p.grid_m - 1) / p.grid_m : 0;
     }
+    // ---- start skew (round 5) ----
+    // Every tile of a launch costs the same, so workgroups that start together reach their epilogues together: all CUs write (and, with a
+    // residual, read) their 112 KiB of output in the same few microseconds -- a 29 MB burst the memory system takes 5-7 us to absorb
+    // while no MFMA runs -- and then multiply together while the memory system idles.  A workgroup therefore starts k / (G / 8) of
+    // p.skew late (k = its index inside the XCD = how many tiles it owns, descending): the epilogues of the chip are spread over a
+    // tile period and overlap the other CUs' K loops.  The workgroups with one tile fewer are the late ones.
+    int skew_k = 0, skew_n = 1;
+    if constexpr (FLAT) { skew_k = b >> 3; skew_n = cpx; }
+    else { skew_k = (b >> 3) / p.ncol; skew_n = max(p.grid_m >> 3, 1); }
     const int KS = p.K / BK;
     const int S = nt * KS;
     if (S == 0) {                                            // more workgroup rows than m-tiles: an all-zero statistics row
@@ -289,22 +312,44 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         float st_sum[8], st_sq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
-        // EPI 2: the residual rows of block mi are in flight from block mi - 2 on (an exposed load per block cost ~0.7 us x MI per
-        // tile: the proj linear of ViT-B ran 104 us against 72 us of K loop)
-        bf16x8 rr[MI][2];
+        // EPI 2: the residual rows of block mi are in flight from block mi - RAHEAD on (an exposed load per block cost ~0.7 us x MI
+        // per tile: the proj linear of ViT-B ran 104 us against 72 us of K loop).
+        // Round 5 -- the loads are inline asm with HAND-COUNTED waits.  As plain C++ loads they were waited for by the compiler,
+        // and hipcc answers "loads and stores both outstanding" with s_waitcnt vmcnt(0) (it models their completion as unordered):
+        // every use of a residual row -- 2 MI per tile, each behind the previous row group's stores -- DRAINED the queue: the
+        // acknowledgement of the stores just issued plus the three K stages of prefetch in flight, ~0.7 us x 2 MI per tile (proj
+        // 102 us in the network against 64 us with the plain epilogue).  Loads and stores do retire in issue order (the K loop's
+        // counted waits rest on the same fact), so the wait for rows (mi, j) allows exactly the operations issued after their
+        // load: the later residual loads and the stores of the row groups before (res_younger below).  RAHEAD 2 -> as many
+        // blocks as the registers the finished accumulators leave hold.
+        constexpr int RAHEAD = MI <= 7 ? (LNF ? 5 : MI) : (LNF ? 4 : 2);      // (MI = 8: what compiles without scratch)
+        constexpr int RSTORES = LNF ? 2 : 1;                     // stores per row group: C (+ row_part)
+        u32x4 rr[MI][2];
         auto load_res = [&](int mi) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 int m = m0 + wm * (BM / 2) + mi * 16 + j * 8 + r_row0;
                 if (m >= p.M) m = p.M - 1;
-                rr[mi][j] = *reinterpret_cast<const bf16x8*>(p.R + (long)m * p.ldr + n0 + wn * 64 + r_chunk * 8);
+                const bf16_t* src = p.R + (long)m * p.ldr + n0 + wn * 64 + r_chunk * 8;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rr[mi][j]) : "v"(src) : "memory");
             }
         };
-        if constexpr (RES) { load_res(0); if (MI > 1) load_res(1); }
+        // operations issued between the load of rows (mi, j) and their use, in a FULL tile (every store is issued): the loads of
+        // later row groups that are already out + the stores of the row groups before
+        auto res_younger = [](int mi, int j) {
+            const int i = 2 * mi + j;                                              // row group: loads are issued in this order
+            const int loaded = 2 * (mi + RAHEAD < MI ? mi + RAHEAD + 1 : MI);      // row-group loads issued before this use
+            const int older_blocks = mi > RAHEAD ? mi - RAHEAD : 0;                // blocks whose stores precede the load of (mi, j)
+            return (loaded - 1 - i) + RSTORES * (i - 2 * older_blocks);
+        };
+        if constexpr (RES) {
+#pragma unroll
+            for (int mi = 0; mi < RAHEAD; ++mi) load_res(mi);
+        }
         const float* lnf = lds_acc + (LNF && EPI == 1 ? parity * 1024 : 0);     // LNF consumer: [256 b'][256 s][256 rows x (rstd, -mean rstd)]
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            if constexpr (RES) { if (mi + 2 < MI) load_res(mi + 2); }
+            if constexpr (RES) { if (mi + RAHEAD < MI) load_res(mi + RAHEAD); }
             f32x2 rs = {1.f, 0.f};
             if constexpr (LNF && EPI == 1) rs = *reinterpret_cast<const f32x2*>(lnf + 512 + (wm * (BM / 2) + mi * 16 + e_row) * 2);
 #pragma unroll
@@ -341,10 +386,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                 const int row = j * 8 + r_row0;
                 bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + row * 128 + ((r_chunk ^ ((row >> 1) & 7)) << 4));
                 const int m = m0 + wm * (BM / 2) + mi * 16 + row, n = n0 + wn * 64 + r_chunk * 8;
+                if constexpr (RES) {
+                    if (!full) wait_vm<0>();                         // ragged last tile: lanes skip stores -- drain instead of counting
+                    wait_vm_value(res_younger(mi, j), rr[mi][j]);
+                }
                 if (full || m < p.M) {
                     if constexpr (LIN) {
                         if constexpr (RES) {
-                            const bf16x8 r = rr[mi][j];
+                            const bf16x8 r = __builtin_bit_cast(bf16x8, rr[mi][j]);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)r[e]);
                         }
@@ -405,6 +454,11 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         return (full && p.C != nullptr) ? ESTORES : 0;
     };
 
+    if (p.skew > 0) {
+        const long wait = (long)p.skew * skew_k / skew_n;
+        const long t0 = wall_clock64();
+        while ((long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
     // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----
     issue(0); advance(); issue(1); advance(); issue(2); advance(); issue(3); advance();
     if constexpr (EPI == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this thread's LDS writes above (-centre)

@@ -413,6 +413,14 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 8; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(x + i * 8), b = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+        *reinterpret_cast<bf16x8*>(y + i * 8) = bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3],
+                                                       (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+    }
+}
+
 // ---- avg pool backward: dx[b,p,c] = d_pooled[b,c] / HW -------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dp, T* __restrict__ dx, int B, int HW, int C) {
@@ -720,6 +728,14 @@ extern "C" int cvcl_bf16_to_f32(const void* x, float* y, long n, void* stream) {
     CVCL_CHECK_ARG(x && y && n > 0 && n % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cvcl_bf16_to_f32: bad args");
     CvclProfScope prof(stream, CVCL_K_OTHER);
     hipLaunchKernelGGL(bf16_to_f32_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+    CVCL_LAUNCH_CHECK();
+    return CVCL_OK;
+}
+
+extern "C" int cvcl_f32_to_bf16(const float* x, void* y, long n, void* stream) {
+    CVCL_CHECK_ARG(x && y && n > 0 && n % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "cvcl_f32_to_bf16: bad args");
+    CvclProfScope prof(stream, CVCL_K_OTHER);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

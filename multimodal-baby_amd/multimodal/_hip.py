@@ -153,6 +153,7 @@ SIGNATURES = {
     "cvcl_gemm8w_tile_rows": (_I, [_I, _I]),
     "cvcl_gemm8w_stats_rows": (_I, [_I, _I]),
     "cvcl_bf16_to_f32": (_I, [_P, _P, C.c_long, _P]),
+    "cvcl_f32_to_bf16": (_I, [_P, _P, C.c_long, _P]),
     "cvcl_spatial_max_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_spatial_max_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "cvcl_lstm_add_dout": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

@@ -436,12 +436,17 @@ class MultiModalModel(nn.Module):
         image_features, image_feature_map = self.encode_image(image)
         text_features, text_outputs = self.encode_text(text, text_length)
         if self.embedding_type == "spatial":                                 # reference :757-780
-            if self.training and self.global_negatives and parallel.is_distributed():
-                raise NotImplementedError("spatial embeddings under data parallelism need --local_negatives")
             Bi, E, Hh, Ww = image_features.shape
             Bt, L, _ = text_features.shape
             rows_i = image_features.permute(0, 2, 3, 1).reshape(Bi * Hh * Ww, E)
             rows_t = text_features.reshape(Bt * L, E)
+            if self.training and self.global_negatives and parallel.is_distributed():
+                # global negatives: the per-location / per-word rows and the lengths of every rank, rank-major; every rank
+                # evaluates the replicated N_g x N_g spatial logits and back-propagates into its own rows (SUM over ranks)
+                rows_i = parallel.gather_rows(rows_i.view(Bi, Hh * Ww * E)).view(-1, E)
+                rows_t = parallel.gather_rows(rows_t.view(Bt, L * E)).view(-1, E)
+                text_length = parallel.gather_rows(text_length)
+                Bi, Bt = Bi * parallel.world_size(), Bt * parallel.world_size()
             nlt = self._temperature_on(rows_i.device)
             if self.sim == "max":        # best location per word, summed over all L positions, / len
                 logits_per_image = ops.spatial_max_logits(rows_i, rows_t, text_length, nlt, Bi, Hh * Ww, Bt, L)

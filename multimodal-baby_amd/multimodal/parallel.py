@@ -144,6 +144,37 @@ def local_term_scale(global_negatives: bool) -> float:
     return 1.0 / world_size() if (global_negatives and is_distributed()) else 1.0
 
 
+class _AllGatherRows(torch.autograd.Function):
+    """cat_r(x_r) along dim 0 (rank-major); backward hands each rank the gradient rows of its own shard (every rank evaluates the same
+    replicated loss: no reduction).  The spatial head's exchange -- per-location image rows, per-word text rows and the utterance
+    lengths differ in shape, so they travel one tensor per collective."""
+
+    @staticmethod
+    def forward(ctx, x):
+        world = dist.get_world_size()
+        x = x.contiguous()
+        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        COLLECTIVES["all_gather"] += 1
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(out, x)
+        else:
+            dist.all_gather(list(out.unbind(0)), x)
+        ctx.rows = x.shape[0]
+        return out.reshape((world * x.shape[0],) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, g):
+        r = dist.get_rank()
+        return g[r * ctx.rows:(r + 1) * ctx.rows].contiguous()
+
+
+def gather_rows(x: torch.Tensor) -> torch.Tensor:
+    """[B, ...] per rank -> [world*B, ...] on every rank (rank-major), differentiable for floating-point x."""
+    if not is_distributed():
+        return x
+    return _AllGatherRows.apply(x)
+
+
 def gather_features(image_features: torch.Tensor, text_features: torch.Tensor):
     """[B,E] per rank -> [world*B, E] on every rank (rank-major row order)."""
     if not is_distributed():

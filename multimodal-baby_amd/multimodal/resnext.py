@@ -341,6 +341,25 @@ class ResNet(nn.Module):
         return self.fc(pooled)                           # e.g. nn.Identity (utils.build_dino_mugs)
 
 
+class _RowsToF32(torch.autograd.Function):
+    """bf16 rows of the layer-4 map -> fp32 operand of the 1x1 projection; backward rounds the gradient to the trunk's bf16."""
+
+    @staticmethod
+    def forward(ctx, rows):
+        rows = rows.contiguous()
+        out = torch.empty(rows.shape, dtype=torch.float32, device=rows.device)
+        H.check(H.lib().cvcl_bf16_to_f32(H.ptr(rows), H.ptr(out), rows.numel(), H.stream_ptr()), "cvcl_bf16_to_f32")
+        ctx.dtype = rows.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        d_out = d_out.contiguous()
+        dx = torch.empty(d_out.shape, dtype=ctx.dtype, device=d_out.device)
+        H.check(H.lib().cvcl_f32_to_bf16(H.ptr(d_out, torch.float32), H.ptr(dx), d_out.numel(), H.stream_ptr()), "cvcl_f32_to_bf16")
+        return dx
+
+
 class SpatialResNet(nn.Sequential):
     """embedding_type='spatial' vision model of the reference (multimodal.py:181-185):
     ``nn.Sequential(*list(resnet.children())[:-2], nn.Conv2d(2048, E, 1))`` -- same child indices, hence the same
@@ -368,17 +387,15 @@ class SpatialResNet(nn.Sequential):
 
     def forward(self, x):
         r = self._resnet
-        if torch.is_grad_enabled() and any(p.requires_grad for c, b, _ in r.conv_bn_pairs() for p in (c.weight, b.weight, b.bias)):
-            raise NotImplementedError("fine-tuning the trunk together with spatial embeddings is not implemented")
+        # --finetune_cnn (reference multimodal.py:175-185: autograd through the whole nn.Sequential): r.trunk then returns
+        # trunk_train's differentiable layer-4 map, and the gradient of the 1x1 projection flows back into it below
         _pooled, fmap = r.trunk(x)                           # fmap: NCHW view of the NHWC layer-4 map
         for hook in list(self[7]._forward_hooks.values()):   # the reference hooks model[-2] = layer4
             hook(self[7], (fmap,), fmap)
         B, Cc, Hh, Ww = fmap.shape
         rows = fmap.permute(0, 2, 3, 1).reshape(B * Hh * Ww, Cc)
         if rows.dtype != torch.float32:
-            r32 = torch.empty(rows.shape, dtype=torch.float32, device=rows.device)
-            H.check(H.lib().cvcl_bf16_to_f32(H.ptr(rows), H.ptr(r32), rows.numel(), H.stream_ptr()), "cvcl_bf16_to_f32")
-            rows = r32
+            rows = _RowsToF32.apply(rows)
         proj = self[8]
         feat = ops.linear_f32(rows, proj.weight.view(proj.out_channels, Cc), proj.bias)       # [B*H*W, E]
         return feat.view(B, Hh, Ww, proj.out_channels).permute(0, 3, 1, 2)

@@ -2,6 +2,7 @@
 share the box's one GPU over the gloo backend (CVCL_DIST_BACKEND=gloo; RCCL refuses two ranks on one device).
 
     dist_worker.py bench_step OUT            one C2 step at 256 pairs per rank through DataParallelEngine + OverlappedUpdate
+    dist_worker.py spatial_step OUT          --embedding_type spatial under global negatives (sim max and mean), fp32 parity mode
     dist_worker.py train OUT -- <train.py args>   Trainer.fit through train.py; dumps the trainable parameters
     dist_worker.py rccl_w1 OUT               ONE rank, backend nccl (= RCCL), $CVCL_FORCE_DIST=1: the whole multi-GPU path on one GPU
 
@@ -53,6 +54,53 @@ def bench_step(out_dir):
                 "centres": None if centres is None else centres["frozen"],
                 "collectives_per_step": {k: (parallel.COLLECTIVES[k] - coll0[k]) / 2 for k in coll0}},
                os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def spatial_step(out_dir):
+    """--embedding_type spatial under data-parallel GLOBAL negatives: every rank runs the product model on its own shard (fp32 parity
+    mode, frozen trunk, trainable 1x1 projection + word embeddings) through DataParallelEngine, and dumps what the oracle needs to
+    rebuild the global step: its layer-4 maps, tokens, lengths, the loss and the reduced gradients."""
+    import argparse
+    import train as train_entry
+    from multimodal import parallel
+    from multimodal.multimodal_data_module import SyntheticDataModule
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    dist.init_process_group(backend=os.environ.get("CVCL_DIST_BACKEND", "gloo"))
+    res = {}
+    for sim in ("max", "mean"):
+        argv = (f"--dataset synthetic --batch_size 4 --gpus 1 --text_encoder embedding --embedding_dim 32 --embedding_type spatial "
+                f"--sim {sim} --normalize_features --lambda_lm 0 --optimize_unused --checkpoint_callback False --logger False "
+                f"--precision 32 --seed 7").split()
+        args = train_entry._setup_parser().parse_args(argv)
+        torch.manual_seed(7)                                                   # replicas start identical
+        dm = SyntheticDataModule(args)
+        ve = train_entry.VisionEncoder(args=args)
+        te = train_entry.TextEncoder(dm.read_vocab(), image_feature_map_dim=ve.last_cnn_out_dim, args=args)
+        lit = train_entry.MultiModalLitModel(ve, te, args).to(device)
+        lit.set_precision(32)
+        lit.train()
+        engine = parallel.DataParallelEngine(device, global_negatives=True).attach(lit)
+        dm.setup()
+        it = iter(dm.train_dataloader())
+        for _ in range(rank + 1):                                              # a different shard per rank
+            x, y, y_len, _ = next(it)
+        fmaps = []
+        hook = lit.vision_encoder.model[7].register_forward_hook(lambda m, i, o: fmaps.append(o.detach().float().cpu().clone()))
+        coll0 = dict(parallel.COLLECTIVES)
+        out = lit.training_step((x.to(device), y.to(device), y_len.to(device), None), 0)
+        out["loss"].backward()
+        engine.reduce_gradients()
+        torch.cuda.synchronize()
+        hook.remove()
+        res[sim] = {"fmap": fmaps[0], "tok": y, "len": y_len, "loss": float(out["loss"].detach()),
+                    "grads": {k: v.grad.detach().cpu().clone() for k, v in lit.named_parameters() if v.grad is not None},
+                    "params": {k: v.detach().cpu().clone() for k, v in lit.named_parameters() if v.requires_grad},
+                    "all_gathers": parallel.COLLECTIVES["all_gather"] - coll0["all_gather"]}
+    torch.save(res, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -144,6 +192,8 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if mode == "bench_step":
         bench_step(out)
+    elif mode == "spatial_step":
+        spatial_step(out)
     elif mode == "train":
         train(out, sys.argv[sys.argv.index("--") + 1:])
     else:

@@ -91,6 +91,43 @@ def test_eight_ranks_global_negatives_n2048_vs_oracle(tmp_path):
     _global_negatives_vs_oracle(tmp_path, 8)
 
 
+def test_two_ranks_spatial_embeddings_under_global_negatives_vs_oracle(tmp_path):
+    """--embedding_type spatial with data-parallel GLOBAL negatives (reference multimodal.py:757-787 applied to the concatenated
+    per-location / per-word rows; round 4 raised NotImplementedError here): two ranks x 4 pairs -> the 8 x 8 spatial logits on every
+    rank.  Oracle: the reference's spatial similarity + symmetric InfoNCE on the ranks' layer-4 maps and tokens, concatenated in rank
+    order; loss identical on both ranks, gradients of the 1x1 projection and the word embeddings = the oracle's (SUM over ranks)."""
+    import torch.nn.functional as F
+    _run_ranks(["spatial_step", str(tmp_path)], world=2, timeout=900)
+    r = [torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in range(2)]
+    for sim in ("max", "mean"):
+        a, b = r[0][sim], r[1][sim]
+        assert not torch.equal(a["tok"], b["tok"])                                                # different shards
+        for k, v in a["params"].items():
+            assert torch.equal(v, b["params"][k]), k                                               # identical replicas
+        fmap = torch.cat([a["fmap"], b["fmap"]])
+        tok, ln = torch.cat([a["tok"], b["tok"]]), torch.cat([a["len"], b["len"]])
+        w8 = a["params"]["vision_encoder.model.8.weight"].clone().requires_grad_()
+        b8 = a["params"]["vision_encoder.model.8.bias"].clone().requires_grad_()
+        emb = a["params"]["text_encoder.embedding.weight"].clone().requires_grad_()
+        nlt = a["params"]["model.logit_neg_log_temperature"].clone().requires_grad_()
+        feat = F.normalize(F.conv2d(fmap, w8, b8), p=2, dim=1)
+        txt = F.normalize(F.embedding(tok, emb, padding_idx=0), p=2, dim=-1)
+        lpi, lpt = O.spatial_similarity_logits(feat, txt, ln, nlt, sim)
+        assert lpi.shape == (8, 8)
+        loss = O.contrastive_loss(lpi, lpt)[0]
+        loss.backward()
+        for x in (a, b):
+            assert abs(x["loss"] - float(loss)) < 2e-4 * max(1.0, abs(float(loss))), (sim, x["loss"], float(loss))
+            g = x["grads"]
+            assert maxrel(g["vision_encoder.model.8.weight"], w8.grad) < 5e-4, sim
+            assert maxrel(g["vision_encoder.model.8.bias"], b8.grad) < 5e-4, sim
+            assert maxrel(g["text_encoder.embedding.weight"], emb.grad) < 5e-4, sim
+            assert abs(float(g["model.logit_neg_log_temperature"]) - float(nlt.grad)) < 5e-4 * max(1.0, abs(float(nlt.grad))), sim
+            assert x["all_gathers"] == 3                                                           # image rows, text rows, lengths
+        for k in a["grads"]:
+            assert torch.equal(a["grads"][k], b["grads"][k]), (sim, k)
+
+
 def test_rccl_world1_drives_the_whole_multi_gpu_path_bit_identically(tmp_path):
     """The RCCL branch on the one GPU there is: a world-size-1 ``nccl`` process group with $CVCL_FORCE_DIST=1 runs the feature
     all-gather (all_gather_into_tensor), the bucketed all-reduce launched from the gradient hooks / from trunk_train's side

@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
     std::function<void()> run;
     void* lib = nullptr;
     if (var == "old") {
-        lib = dlopen("multimodal-baby_amd/lib/libcvcl_hip.so", RTLD_NOW | RTLD_GLOBAL);
+        lib = dlopen(getenv("CVCL_HIP_LIB") ? getenv("CVCL_HIP_LIB") : "multimodal-baby_amd/lib/libcvcl_hip.so", RTLD_NOW | RTLD_GLOBAL);
         if (!lib) { printf("dlopen: %s\n", dlerror()); return 2; }
         gemm_fn g = (gemm_fn)dlsym(lib, "cvcl_gemm");
         rows_fn rf = (rows_fn)dlsym(lib, "cvcl_gemm_stats_rows");
