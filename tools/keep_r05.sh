@@ -6,7 +6,7 @@ cp $O/gemm_per_layer.csv $P/r05_gemm_per_layer.csv 2>/dev/null
 cp $O/gemm_per_layer_vit.csv $P/r05_gemm_per_layer_vit.csv 2>/dev/null
 cp $O/gemm_per_layer_vit_fp8.csv $P/r05_gemm_per_layer_vit_fp8.csv 2>/dev/null
 for c in c4 c5; do cp $O/pmc_${c}_summary.txt $P/r05_pmc_${c}_summary.txt 2>/dev/null; cp $O/pmc_${c}_summary.json $P/r05_pmc_${c}_summary.json 2>/dev/null; done
-cp $O/r05_pmc_hbm_traffic.json $P/r05_pmc_hbm_traffic.json 2>/dev/null
+python3 tools/pmc_summary.py r05 > /dev/null 2>&1   # from gpurun_out/pmc (passes counted from the stem launches)
 cp $O/blaslt_compare.txt $P/r05_blaslt_compare.txt 2>/dev/null
-for c in c2 c4 c4p14 c5; do tail -1 $O/$c.log | cut -c1-4000 > $P/r05_bench_line_$c.json 2>/dev/null; done
+for c in c2 c4 c4p14 c5; do grep -h '^{"metric"' $O/$c.log | tail -1 > $P/r05_bench_line_$c.json 2>/dev/null; done   # (the line bench.py printed under rocprofv3: step times there include the profiler)
 ls -la $P | grep r05

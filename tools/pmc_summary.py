@@ -10,6 +10,11 @@ def load(c):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     return rows
 F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
+# trunk passes in the profiled command = launches of the stem kernel (one per pass): bench steps + warm-up + the calibration pass of the
+# storage centres + (round 5) the pass that fills the cache of the tail-only measurement -- counted, not assumed
+n_stem = sum(1 for r in F if "stem_mfma" in r["Kernel_Name"] or "stem_pool_mfma" in r["Kernel_Name"])
+if n_stem:
+    steps = n_stem
 KERNELS = (("gemm_glds_kernel", "gemm_glds"), ("gemm8w_kernel", "gemm8w"), ("gemm_pro_kernel", "gemm_pro"), ("gconv_mfma_kernel", "gconv_mfma"),
            ("bn_add_relu_kernel", "bn_add_relu"), ("bn_relu_apply_kernel", "bn_relu_apply"), ("stem_mfma_kernel", "stem_mfma"),
            ("stem_pool_mfma_kernel", "stem_pool_mfma"),
