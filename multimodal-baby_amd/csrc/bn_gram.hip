@@ -64,6 +64,15 @@ template <int NT> constexpr int gp_lds_bytes() { return 2 * GP_PM * gp_pitch<NT>
 // producer waves per SIMD interleave.  K = 256 keeps one (its nine accumulator tiles leave no registers for twelve waves)
 template <int NT> constexpr int gp_producer_threads() { return NT == 8 ? 256 : 512; }
 
+// The workgroup-wide barrier protocol of gram_pro_kernel.  The producer and the consumer waves run different code and must meet at
+// exactly the same barriers, in this order: rounds * NPF step barriers (one per staged tile), gp_exchange_barriers<NT>() for the
+// consumers' row-step exchange (two per accumulator tile when a tile's four row steps are shared by several waves), then two for the
+// producers' column sums.  Both roles take the middle count from here; the consumer's exchange loop is checked against it at compile time.
+template <int NT> __host__ __device__ constexpr int gp_exchange_barriers() {
+    constexpr int NPAIR = NT / 2, KG = 4 / NPAIR;
+    return KG > 1 ? 2 * (NT + 1) : 0;
+}
+
 // ---- producer waves (waves 4 ..): chunk s_c of rows s_r + RPP * i of every tile; a thread's 8 columns never change
 template <int NT>
 __device__ __forceinline__ void gram_producer(const GramDev& p, char* smem, const int tid, const int rounds) {
@@ -140,12 +149,10 @@ __device__ __forceinline__ void gram_producer(const GramDev& p, char* smem, cons
             tile += G;
         }
     }
-    // ---- epilogue: the consumers' exchange barriers, then the column sums: the RPP staging rows of a column in a fixed order
-    constexpr int NPAIR = NT / 2, KG = 4 / NPAIR;
-    if constexpr (KG > 1) {
+    // ---- epilogue: the consumers' exchange barriers (gp_exchange_barriers: the one definition both roles count from), then the
+    // column sums: the RPP staging rows of a column in a fixed order
 #pragma unroll
-        for (int t = 0; t < NT + 1; ++t) { __syncthreads(); __syncthreads(); }
-    }
+    for (int t = 0; t < gp_exchange_barriers<NT>(); ++t) __syncthreads();
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);        // [RPP][K] floats (<= 16 KiB)
 #pragma unroll
@@ -169,6 +176,7 @@ __device__ __forceinline__ void gram_consumer(const GramDev& p, char* smem, cons
     constexpr int I0 = C % NPAIR, I1 = NT - 1 - I0, kg = C / NPAIR;
     constexpr int NACC = NT + 1;
     constexpr int NPF = 16 / NT;
+    static_assert(NACC * (KG > 1 ? 2 : 0) == gp_exchange_barriers<NT>(), "the exchange loop below and the producers' barrier count");
     // fragment addressing (wgrad.hip): 16-lane group g4 reads a [4 m][16 col] block; lane q supplies row q / 4, cols 4 (q % 4) .. + 3
     const int g4 = lane >> 4, q = lane & 15;
     const int frag_off = ((g4 >> 1) * 8 + (q >> 2)) * PITCH + ((g4 & 1) * 16 + (q & 3) * 4) * 2;

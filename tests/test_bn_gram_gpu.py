@@ -32,7 +32,10 @@ def _gram(H, dev, a, K, a_scale=None, a_shift=None, relu=False):
     return G, s, ws, out
 
 
-@pytest.mark.parametrize("M,K", [(64, 64), (1000, 128), (4099, 256), (50000, 128), (70001, 256), (33000, 64)])
+# (M = 64 / 130: most workgroups own no tile; 33000 / 50000 / 70001: whole rounds with a ragged last one -- workgroups with fewer tiles
+# than rounds * NPF steps still meet every barrier of the producer / consumer protocol, for each K)
+@pytest.mark.parametrize("M,K", [(64, 64), (64, 128), (130, 256), (1000, 128), (4099, 256), (50000, 128), (70001, 256), (33000, 64),
+                                 (33000, 256), (70001, 64)])
 @pytest.mark.parametrize("prologue", [False, True])
 def test_gram_exact_on_small_integers(H, dev, M, K, prologue):
     g = torch.Generator().manual_seed(M + K)
