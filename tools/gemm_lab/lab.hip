@@ -121,6 +121,13 @@ int main(int argc, char** argv) {
         memset(&a, 0, sizeof(a));
         a.A = dA; a.W = dW; a.C = dC; a.M = M; a.N = N; a.K = K; a.lda = Kp; a.ldw = Kp; a.ldc = N;
         if (want_stats) { a.stats = dStats; a.stats_rows = 2048; stats_rows = rf(CVCL_BF16, &a); }
+        // $LAB_RES=1: bias + residual epilogue (R = a bf16 [M, N] tensor of its own); $LAB_ROWPART=1: + the LayerNorm-fold producer's row sums
+        if (getenv("LAB_RES")) {
+            bf16_t* dR; CK(hipMalloc(&dR, (size_t)M * N * 2)); CK(hipMemset(dR, 0, (size_t)M * N * 2));
+            float* dB; CK(hipMalloc(&dB, (size_t)N * 4)); CK(hipMemset(dB, 0, (size_t)N * 4));
+            a.R = dR; a.ldr = N; a.bias = dB;
+            if (getenv("LAB_ROWPART")) { float* dP; CK(hipMalloc(&dP, (size_t)M * (N / 64) * 8)); a.row_part = dP; }
+        }
         if (getenv("LAB_GELU")) { CK(hipMemset(dStats, 0, (size_t)N * 4)); a.bias = dStats; a.act = CVCL_ACT_GELU; skip_check = true; }
         run = [=]() { int rc = g(CVCL_BF16, &a, st); if (rc) { printf("cvcl_gemm rc %d\n", rc); exit(3); } };
     } else if (var[0] == 'd') {
