@@ -615,48 +615,76 @@ __global__ __launch_bounds__(256) void stem_tiled_f32_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // BN + ReLU + maxpool 3x3 stride 2 pad 1 (NHWC), 8 channels per thread
 // ------------------------------------------------------------------------------------------------
+// output rows per thread (round 5): R vertically adjacent outputs share input rows -- 3 (2 R + 1) taps for R outputs instead of 9 R, and
+// (2 R + 1) / R instead of 3 input rows fetched per output row across the L2s (the counters had FETCH_SIZE at 1.5 x the input:
+// consecutive output rows belong to workgroups on different XCDs)
+#ifndef CVCL_POOL_ROWS
+#define CVCL_POOL_ROWS 2
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, T* __restrict__ y,
                                                               int B, int H, int W, int C) {
+    constexpr int R = CVCL_POOL_ROWS, NR = 2 * R + 1, NTAP = 3 * NR;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, CC = C / 8;
-    const long total = (long)B * Ho * Wo * CC;
+    const int Hq = (Ho + R - 1) / R;
+    const long total = (long)B * Hq * Wo * CC;
     // (measured in round 3: an XCD-major block order -- consecutive 32-pixel blocks on one XCD so that the input row two output
     // rows share is fetched by one L2 instead of two -- made this kernel 7 % SLOWER (0.132 -> 0.142 ms); plain order kept)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cc = (int)(i % CC);
         const long p = i / CC;
-        const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((long)Wo * Ho));
-        float sc[8], sh[8], m[8];
+        const int ox = (int)(p % Wo), oq = (int)((p / Wo) % Hq), b = (int)(p / ((long)Wo * Hq));
+        const int oy = R * oq;
+        float sc[8], sh[8], m[R][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e]; m[e] = 0.f; }  // relu output >= 0
-        // all nine taps are loaded from clamped (always valid) addresses before any is used; a clamped tap repeats a pixel of the
-        // window, which leaves the maximum unchanged -- no branch around a load (branches made every tap wait for the previous one)
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = scale[cc * 8 + e]; sh[e] = shift[cc * 8 + e];
+#pragma unroll
+            for (int r = 0; r < R; ++r) m[r][e] = 0.f;                           // relu output >= 0
+        }
+        // all taps (input rows 2 oy - 1 .. 2 oy + 2 R - 1) are loaded from clamped (always valid) addresses before any is used; a
+        // clamped tap repeats a pixel of the window it belongs to, which leaves the maximum unchanged -- no branch around a load
+        // (branches made every tap wait for the previous one).  Output r's window is rows 2 r .. 2 r + 2 of the NR; where an output
+        // does not exist (Ho not a multiple of R) its rows clamp into the image and its result is not stored
         constexpr int EPC = ElemTraits<T>::kPerChunk, NC = 8 / EPC;              // 8 channels = 1 (bf16) or 2 (fp32) chunks
-        Chunk<T> tap[9][NC];
-        const T* src[9];
+        Chunk<T> tap[NTAP][NC];
+        const T* src[NTAP];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < NR; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int yin = min(max(2 * oy - 1 + ky, 0), H - 1), xin = min(max(2 * ox - 1 + kx, 0), W - 1);
+                // only row 0 can fall above the image (-> row 0, inside output 0's window); rows below it clamp to H - 1, which lies
+                // inside the window of the last existing output
+                const int yin = min(max(2 * oy - 1 + ky, 0), H - 1);
+                const int xin = min(max(2 * ox - 1 + kx, 0), W - 1);
                 src[ky * 3 + kx] = x + (((long)b * H + yin) * W + xin) * C + cc * 8;
             }
-        // (round 5: the scheduler had sunk every tap's load next to its use -- nine s_waitcnt vmcnt(0), nine dependent round trips
-        // per output, in the ISA -- although the source issued them together; the barriers pin "all addresses, all loads, then math")
+        // (the scheduler had sunk every tap's load next to its use -- nine s_waitcnt vmcnt(0), nine dependent round trips per
+        // output, in the ISA -- although the source issued them together; the barriers pin "all addresses, all loads, then math")
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NTAP; ++t)
 #pragma unroll
             for (int q = 0; q < NC; ++q) tap[t][q].load(src[t] + q * EPC);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], fmaf(tap[t][e / EPC].get(e % EPC), sc[e], sh[e]));
-        T* dst = y + (((long)b * Ho + oy) * Wo + ox) * C + cc * 8;
+            for (int e = 0; e < 8; ++e) {
+                const float v = fmaf(tap[t][e / EPC].get(e % EPC), sc[e], sh[e]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[e] = ElemTraits<T>::from_f(m[e]);
+                for (int r = 0; r < R; ++r)
+                    if (t >= 6 * r && t < 6 * r + 9) m[r][e] = fmaxf(m[r][e], v);
+            }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if (oy + r < Ho) {
+                T* dst = y + (((long)b * Ho + oy + r) * Wo + ox) * C + cc * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e] = ElemTraits<T>::from_f(m[r][e]);
+            }
+        }
     }
 }
 
@@ -1302,7 +1330,7 @@ extern "C" int cvcl_bn_relu_maxpool(int dtype, const void* x, const float* scale
     CVCL_CHECK_ARG(x && scale && shift && y && C % 8 == 0, "cvcl_bn_relu_maxpool: bad args");
     CvclProfScope prof(stream, CVCL_K_MAXPOOL);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long total = (long)B * Ho * Wo * (C / 8);
+    const long total = (long)B * ((Ho + CVCL_POOL_ROWS - 1) / CVCL_POOL_ROWS) * Wo * (C / 8);          // a thread owns CVCL_POOL_ROWS output rows
     const int grid = grid_for(total, 256, 8192);
     if (dtype == CVCL_F32)
         hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream,

@@ -112,6 +112,27 @@ def test_fused_stem_pool_is_bit_identical_to_the_two_passes(H, dev, B, S, centre
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Hh,Ww", [(2, 16, 16), (1, 15, 17), (3, 14, 9), (1, 7, 7), (2, 113, 112), (2, 112, 112), (1, 1, 5), (1, 2, 2)])
+def test_bn_relu_maxpool_shapes(H, dev, dt, B, Hh, Ww):
+    """relu(bn(x)) -> max_pool2d(3, stride 2, pad 1) (torchvision ResNet stem, reference multimodal.py:155-158) on even and odd
+    extents: a thread owns two output rows (round 5), the last one of an odd output height on its own; borders clamp into the
+    window they belong to."""
+    g = torch.Generator().manual_seed(Hh * 31 + Ww)
+    Cn = 64
+    x = _q(dt)(torch.randn(B, Cn, Hh, Ww, generator=g) * 2)
+    scale, shift = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g)
+    ref = F.max_pool2d(torch.relu(x.double() * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]), 3, 2, 1)
+    cd = H.BF16 if dt == "bf16" else H.F32
+    xd = nhwc(x).to(_t(dt)).to(dev)
+    Ho, Wo = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+    y = torch.full((B, Ho, Wo, Cn), float("nan"), dtype=_t(dt), device=dev)
+    sc_d, sh_d = scale.to(dev), shift.to(dev)
+    H.check(H.lib().cvcl_bn_relu_maxpool(cd, H.ptr(xd), H.ptr(sc_d), H.ptr(sh_d), H.ptr(y), B, Hh, Ww, Cn, H.stream_ptr()), "maxpool")
+    assert ref.shape == (B, Cn, Ho, Wo) and torch.isfinite(y.float()).all()
+    assert maxrel(y.float(), nhwc(ref.float())) < (5e-3 if dt == "bf16" else 1e-6)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_bn_finalize_and_maxpool(H, dev, dt):
     g = torch.Generator().manual_seed(2)
     B, S, Cn = 2, 16, 64
