@@ -38,15 +38,6 @@ int g8_grid_m(int tiles_m, int ncol) {
     return lean_on && lean < gm ? lean : gm;
 }
 
-// start skew span (gemm8w_kernel.h "start skew") in 10 ns ticks: a share of the estimated tile period -- K / 32 stages of ~0.75 us and
-// an epilogue -- when the launch has at least two rounds to spread
-int g8_skew(long tiles, int grid, int K) {
-    static const int pct = cvcl_lab_int("CVCL_G8_SKEW", 0);
-    if (pct <= 0 || tiles < 2L * grid) return 0;
-    const long tile_ns = (long)(K / 32) * 750 + 3000;
-    return (int)(tile_ns * pct / 10000);                // per mille of the period, 10 ns ticks
-}
-
 template <int MI, int EPI, bool LNF = false>
 int g8_launch(const g8w::Dev& d, int grid, hipStream_t stream) {
     static CvclLdsAttr attr;
@@ -109,7 +100,6 @@ int g8_linear(g8w::Dev d, const cvcl_gemm_args* a, hipStream_t st) {
     CvclProfScope prof(st, CVCL_K_GEMM8W);
     d.tiles_m = cvcl_div_up(d.M, pl.bm);
     d.grid_m = g8_superrow(pl.grid, d.ncol);
-    d.skew = g8_skew((long)d.tiles_m * d.ncol, pl.grid, d.K);
     const bool tall = pl.bm == 256;
     if (a->ln_stats) return tall ? g8_launch<8, 1, true>(d, pl.grid, st) : g8_launch<7, 1, true>(d, pl.grid, st);
     if (a->row_part) return tall ? g8_launch<8, 2, true>(d, pl.grid, st) : g8_launch<7, 2, true>(d, pl.grid, st);
@@ -179,7 +169,6 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     d.ncol = a->N / 256;
     d.gs = gather ? a->gather_stride : 1; d.g_hw = gather ? a->gather_ho * a->gather_wo : 1; d.g_wo = gather ? a->gather_wo : 1;
     d.g_hi = a->gather_hi; d.g_wi = a->gather_wi; d.a_rows = (int)a_rows;
-    d.skew = 0;
     int bm, grid;
     // a plain product without BN statistics has no reason to keep a column tile per workgroup: it takes the linear epilogue's
     // supertile walk (bias NULL = 0) -- the large square products of tools/blaslt_compare.py; every convolution of the trunk asks
@@ -191,7 +180,6 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
         d.grid_m = g8_grid_m(d.tiles_m, d.ncol);
         if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= d.grid_m, "cvcl_gemm8w: stats_rows %d < %d", a->stats_rows, d.grid_m);
         grid = d.grid_m * d.ncol;
-        d.skew = g8_skew((long)d.tiles_m * d.ncol, grid, d.K);
     } else {
         return g8_linear(d, a, (hipStream_t)stream);
     }

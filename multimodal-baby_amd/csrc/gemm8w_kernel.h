@@ -60,7 +60,6 @@ struct Dev {
     // row gather of a strided 1x1 convolution: output row m = (b, oy, ox) reads A row (b, oy * gs, ox * gs); gs <= 1 = off
     int gs, g_hw, g_wo, g_hi, g_wi;
     int a_rows;                     // rows of A (= M without the gather)
-    int skew;                       // start skew span in 10 ns ticks (0 = off): see "start skew" in the kernel
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
@@ -147,15 +146,6 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         ti = (s / p.ncol) * 8 + xcd;
         nt = ti < p.tiles_m ? (p.tiles_m - ti + p.grid_m - 1) / p.grid_m : 0;
     }
-    // ---- start skew (round 5) ----
-    // Every tile of a launch costs the same, so workgroups that start together reach their epilogues together: all CUs write (and, with a
-    // residual, read) their 112 KiB of output in the same few microseconds -- a 29 MB burst the memory system takes 5-7 us to absorb
-    // while no MFMA runs -- and then multiply together while the memory system idles.  A workgroup therefore starts k / (G / 8) of
-    // p.skew late (k = its index inside the XCD = how many tiles it owns, descending): the epilogues of the chip are spread over a
-    // tile period and overlap the other CUs' K loops.  The workgroups with one tile fewer are the late ones.
-    int skew_k = 0, skew_n = 1;
-    if constexpr (FLAT) { skew_k = b >> 3; skew_n = cpx; }
-    else { skew_k = (b >> 3) / p.ncol; skew_n = max(p.grid_m >> 3, 1); }
     const int KS = p.K / BK;
     const int S = nt * KS;
     if (S == 0) {                                            // more workgroup rows than m-tiles: an all-zero statistics row
@@ -454,11 +444,6 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
         return (full && p.C != nullptr) ? ESTORES : 0;
     };
 
-    if (p.skew > 0) {
-        const long wait = (long)p.skew * skew_k / skew_n;
-        const long t0 = wall_clock64();
-        while ((long)wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-    }
     // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----
     issue(0); advance(); issue(1); advance(); issue(2); advance(); issue(3); advance();
     if constexpr (EPI == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this thread's LDS writes above (-centre)

@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 5: start skew of the 8-wave kernel (CVCL_G8_SKEW = per mille of the estimated tile period), product kernel through cvcl_gemm
+# round 5: start skew of the 8-wave kernel (CVCL_G8_SKEW = per mille of the estimated tile period), product kernel through cvcl_gemm.
+# Result: profiles/r05_gemm_lab.txt (no setting gains).  The switch lived in gemm8w_kernel.h / gemm8w.hip of commit c475ccc and was removed
+# afterwards: check that commit out to re-run this script.
 L=tools/gemm_lab/lab
 export CVCL_HIP_LIB=$PWD/multimodal-baby_amd/lib/libcvcl_hip_lab.so
 for shape in "50432 2304 768" "50432 768 768" "50432 3072 768" "50432 768 3072" "50176 1024 512" "50176 512 1024" "200704 512 512" "12544 2048 1024" "8192 8192 8192"; do
