@@ -740,6 +740,9 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
                              else "gemm8w_kernel<linear epilogue> (bf16 ViT linears: bias / GELU / residual; 8-wave 256|224 x 256 tiles)"),
                   "dominant_class_by_time": dom, "bound": "mfma", "achieved": family["tflops"], "peak": peak_tf, "unit": "TFLOP/s",
                   "frac": family["mfma_frac"], "traffic": static_traffic_vit(cfg)[0], "traffic_source": static_traffic_vit(cfg)[1],
+                  "traffic_note": ("L2 <-> fabric bytes (FETCH_SIZE x 2 + WRITE_SIZE), Infinity-Cache hits included: a 4 MB L2 holds the 8 m-tiles of a "
+                                   "supertile's A block OR the W matrix (3.5-4.7 MB), not both, so W is re-read once per super-row (e.g. fc1: "
+                                   "28 x 4.7 MB on top of 77 MB of A) -- served by the 256 MB Infinity Cache, not by HBM"),
                   "other_bound_frac": family["hbm_frac"],
                   "avg_launch_us": family["avg_launch_us"], "launches_per_step": family["launches_per_step"],
                   "algorithmic_bytes_per_launch": int(nbytes / launches), "algorithmic_flops_per_launch": int(flops / launches)}
