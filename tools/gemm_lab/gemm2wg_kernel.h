@@ -33,6 +33,7 @@ struct Dev {
     const float* bias;
     int M, N, K, lda, ldw, ldc, act;
     int tiles_m, ncol, sr;          // m-tiles, column tiles (N / 128), super-row height of the tile walk
+    int skew;                       // VAR bit 1: start delay of the second dispatch wave, 10 ns ticks
 };
 
 __device__ __forceinline__ void glds16(const bf16_t* src, char* lds_wave_base) {
@@ -199,6 +200,14 @@ __global__ __launch_bounds__(256, 2) void gemm2wg_kernel(Dev p) {
         return full ? ESTORES : 0;
     };
 
+    // VAR bit 1: the workgroups of the SECOND dispatch wave (blockIdx >= G / 2: the second slot of every CU) start half a tile period
+    // late (p.skew, 10 ns ticks) -- equal tiles keep two co-resident workgroups in phase as surely as a barrier would
+    if constexpr (VAR & 2) {
+        if (b >= (G >> 1)) {
+            const long t0 = wall_clock64();
+            while ((long)wall_clock64() - t0 < (long)p.skew) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     // ---- prologue: stages 0..2 in flight, stage 0 landed and in registers ----
     issue(0); advance(); issue(1); advance(); issue(2); advance();
     wait_vm<12>();

@@ -154,6 +154,10 @@ int main(int argc, char** argv) {
         if (mi == 8 && prio) run = [=]() { launch_d<8, 0, 1>(d, grid, st); };
         if (mi == 7 && !prio && !gelu) run = [=]() { launch_d<7, 0, 0>(d, grid, st); };
         if (mi == 7 && prio && !gelu) run = [=]() { launch_d<7, 0, 1>(d, grid, st); };
+        d.skew = getenv("LAB_SKEW_US") ? (int)(atof(getenv("LAB_SKEW_US")) * 100) : 0;
+        if (mi == 7 && !prio && gelu && d.skew > 0) run = [=]() { launch_d<7, 1, 2>(d, grid, st); };
+        else if (mi == 7 && !prio && !gelu && d.skew > 0) run = [=]() { launch_d<7, 0, 2>(d, grid, st); };
+        else
         if (mi == 7 && !prio && gelu) run = [=]() { launch_d<7, 1, 0>(d, grid, st); };
         if (mi == 7 && prio && gelu) run = [=]() { launch_d<7, 1, 1>(d, grid, st); };
     } else if (var[0] == 'q') {
