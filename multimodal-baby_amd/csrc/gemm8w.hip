@@ -38,17 +38,17 @@ int g8_grid_m(int tiles_m, int ncol) {
     return lean_on && lean < gm ? lean : gm;
 }
 
-template <int MI, int EPI, bool LNF = false>
+template <int MI, int EPI, bool LNF = false, int ACT = CVCL_ACT_NONE>
 int g8_launch(const g8w::Dev& d, int grid, hipStream_t stream) {
     static CvclLdsAttr attr;
     if (!attr.ready()) {
-        if (hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, LNF>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)g8w::gemm8w_kernel<MI, EPI, LNF, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, g8w::LDS_BYTES) != hipSuccess) {
             cvcl_set_error("cvcl_gemm8w: cannot raise the dynamic LDS limit to %d", g8w::LDS_BYTES);
             return CVCL_ELAUNCH;
         }
         attr.mark();
     }
-    hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, LNF>), dim3(grid), dim3(512), g8w::LDS_BYTES, stream, d);
+    hipLaunchKernelGGL((g8w::gemm8w_kernel<MI, EPI, LNF, ACT>), dim3(grid), dim3(512), g8w::LDS_BYTES, stream, d);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }
@@ -101,10 +101,18 @@ int g8_linear(g8w::Dev d, const cvcl_gemm_args* a, hipStream_t st) {
     d.tiles_m = cvcl_div_up(d.M, pl.bm);
     d.grid_m = g8_superrow(pl.grid, d.ncol);
     const bool tall = pl.bm == 256;
-    if (a->ln_stats) return tall ? g8_launch<8, 1, true>(d, pl.grid, st) : g8_launch<7, 1, true>(d, pl.grid, st);
     if (a->row_part) return tall ? g8_launch<8, 2, true>(d, pl.grid, st) : g8_launch<7, 2, true>(d, pl.grid, st);
     if (a->R) return tall ? g8_launch<8, 2>(d, pl.grid, st) : g8_launch<7, 2>(d, pl.grid, st);
-    return tall ? g8_launch<8, 1>(d, pl.grid, st) : g8_launch<7, 1>(d, pl.grid, st);
+    // the bias / activation epilogue: one instantiation per activation (gemm8w_kernel.h "ACT")
+#define G8_ACT(LNF_)                                                                                                                       \
+    switch (a->act) {                                                                                                                      \
+    case CVCL_ACT_GELU: return tall ? g8_launch<8, 1, LNF_, CVCL_ACT_GELU>(d, pl.grid, st) : g8_launch<7, 1, LNF_, CVCL_ACT_GELU>(d, pl.grid, st); \
+    case CVCL_ACT_RELU: return tall ? g8_launch<8, 1, LNF_, CVCL_ACT_RELU>(d, pl.grid, st) : g8_launch<7, 1, LNF_, CVCL_ACT_RELU>(d, pl.grid, st); \
+    default: return tall ? g8_launch<8, 1, LNF_>(d, pl.grid, st) : g8_launch<7, 1, LNF_>(d, pl.grid, st);                                 \
+    }
+    if (a->ln_stats) { G8_ACT(true) }
+    G8_ACT(false)
+#undef G8_ACT
 }
 
 }  // namespace

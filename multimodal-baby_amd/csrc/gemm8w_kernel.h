@@ -95,10 +95,14 @@ __device__ __forceinline__ void wait_vm_value(int n, u32x4& v) {
 
 // What bounds it, what was tried (pipeline ablations, 4-wave / 8-phase / staggered variants, store flavours): DESIGN.md section 5;
 // the experiment switches live in tools/gemm_lab/gemm8w_lab_kernel.h, not here.
-template <int MI, int EPI, bool LNF>
+// ACT (round 5: a template parameter, EPI 1 only): the activation used to be tested per PAIR of outputs on the run-time p.act -- two
+// scalar compares and branches around every pair, which cut the epilogue into basic blocks of one pair each: the GELU of a pair ran
+// as one dependent chain (s_nop between its packed operations in the ISA) with no other pair to interleave.
+template <int MI, int EPI, bool LNF, int ACT = CVCL_ACT_NONE>
 __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     constexpr int BM = MI * 32;
     static_assert(!LNF || EPI >= 1, "LNF goes with the linear epilogues");
+    static_assert(ACT == CVCL_ACT_NONE || EPI == 1, "activations go with the bias epilogue");
     constexpr int ESTORES = MI * 2 + (LNF && EPI == 2 ? MI * 2 : 0);     // global stores per lane per full tile epilogue
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -357,10 +361,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                         if constexpr (LNF && EPI == 1)
                             v = __builtin_elementwise_fma(v, f32x2{rs[0], rs[0]}, __builtin_elementwise_fma(f32x2{rs[1], rs[1]}, f32x2{cs_r[e], cs_r[e + 1]}, b2));
                         else v = v + b2;
-                        if constexpr (!RES) {
-                            if (p.act == CVCL_ACT_RELU) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
-                            else if (p.act == CVCL_ACT_GELU) v = gelu_bf16out2(v);
-                        }
+                        if constexpr (ACT == CVCL_ACT_RELU) v = f32x2{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f)};
+                        else if constexpr (ACT == CVCL_ACT_GELU) v = gelu_bf16out2(v);
                         q[e] = (bf16_t)v[0];
                         q[e + 1] = (bf16_t)v[1];
                     }
