@@ -301,8 +301,12 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     const int r_chunk = lane & 7, r_row0 = lane >> 3;        // read-back: row 8j + (lane >> 3), 16-byte chunk lane & 7
 
     // -> a lower bound on the VMEM instructions this call issued (exact for a full tile with stores and no residual)
-    auto epilogue = [&](int m0, int n0, int parity) __attribute__((always_inline)) -> int {
-        const bool full = m0 + BM <= p.M;
+    // FULL (round 5): a tile with all BM rows inside M and an output to store runs a copy of the epilogue WITHOUT the per-row-group
+    // tests (m < M, C != NULL): every such test is a scalar branch that ends a basic block, and the blocks -- one row group each --
+    // were scheduled one by one (the staging read-back of a group could not move above the stores of the previous one)
+    auto epilogue_body = [&](int m0, int n0, int parity, auto FULL, const bool full_rt) __attribute__((always_inline)) -> int {
+        constexpr int fmode = decltype(FULL)::value;           // 1 / 0: known at compile time; -1: the run-time value (RES)
+        const bool full = fmode < 0 ? full_rt : fmode == 1;
         float st_sum[8], st_sq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { st_sum[e] = 0.f; st_sq[e] = 0.f; }
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                             st_sum[e] += f;
                             st_sq[e] = fmaf(f, f, st_sq[e]);
                         }
-                        if (p.C) stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
+                        if (full || p.C) stream_store(v, reinterpret_cast<bf16x8*>(p.C + (long)m * p.ldc + n));
                     }
                 }
             }
@@ -443,7 +447,16 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
                 for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = c4;
             }
         }
-        return (full && p.C != nullptr) ? ESTORES : 0;
+        return full ? ESTORES : 0;
+    };
+    auto epilogue = [&](int m0, int n0, int parity) __attribute__((always_inline)) -> int {
+        // (the residual epilogue keeps ONE copy with the run-time test: without the branches the compiler holds more of the tile's
+        // residual rows and spills -- and a scratch reload waits vmcnt(0) in the middle of the counted waits; C is never NULL there)
+        if constexpr (RES) return epilogue_body(m0, n0, parity, std::integral_constant<int, -1>{}, m0 + BM <= p.M);
+        else {
+            if (m0 + BM <= p.M && p.C != nullptr) return epilogue_body(m0, n0, parity, std::integral_constant<int, 1>{}, true);
+            return epilogue_body(m0, n0, parity, std::integral_constant<int, 0>{}, false);
+        }
     };
 
     // ---- prologue: stages 0..3 in flight, stage 0 landed and in registers ----

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float y = fmaf((float)v[e], cs[e], cb[e]);
-                            const float idv = p.r_scale ? fmaf((float)r[e], rs[e], rb[e]) : (float)r[e];
+                            const float idv = fmaf((float)r[e], rs[e], rb[e]);      // (r_scale == NULL: rs = 1, rb = 0 in the table -- the same bits as r)
                             v[e] = (bf16_t)fmaxf(y + idv, 0.f);
                         }
                     } else {
