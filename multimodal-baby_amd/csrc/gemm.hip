@@ -106,6 +106,13 @@ template <typename T> struct TileRegs {
 // (the dropped lo.lo term and the split's remainder).  The trainable tail's linears in the bf16 configurations (text transformer,
 // reference multimodal/multimodal.py:553-573: under Lightning's bf16 autocast these are plain bf16 GEMMs; here they keep fp32
 // operands and ~fp32 results at a quarter of the exact kernel's time).  The exact mode stays the parity mode.
+// lo part of the split: bf16(x - hi) -- 0 when hi is not finite (|x| beyond the bf16 range rounds hi to inf; x - inf would make
+// lo = -inf and the lo.hi product NaN where the exact fp32 GEMM gives inf; an inf / NaN operand stays inf / NaN through hi alone)
+__device__ __forceinline__ bf16_t split_lo(float x, bf16_t hi) {
+    const float h = (float)hi;
+    return (bf16_t)(__builtin_isfinite(h) ? x - h : 0.f);
+}
+
 template <typename T, int PRO, bool LEAN, int MINW, int TR = 0>
 __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
     static_assert(TR == 0 || (sizeof(T) == 4 && PRO == 0 && !LEAN), "K-major operands / split arithmetic: fp32, no prologue");
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
                     for (int e = 0; e < 4; ++e) {
                         const float x = c.get(e);
                         hi[e] = (bf16_t)x;
-                        lo[e] = (bf16_t)(x - (float)hi[e]);
+                        lo[e] = split_lo(x, hi[e]);
                     }
                     if (!kmajor) {
                         char* row = base + (r0 + 32 * j) * ROWB + kc * 8;
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const float* __r
             auto put = [&](char* base, const f32x4& v, bool kmajor) {
                 bf16_t hi[4], lo[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)v[e]; lo[e] = (bf16_t)(v[e] - (float)hi[e]); }
+                for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)v[e]; lo[e] = split_lo(v[e], hi[e]); }
                 if (!kmajor) {
                     char* row = base + (r0 + 32 * j) * ROWB + kc * 8;
                     *reinterpret_cast<bf16x4*>(row) = bf16x4{hi[0], hi[1], hi[2], hi[3]};

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(128) void embed_meanpool_fwd_kernel(const float* __
 // order.  Deterministic, no atomics; writes every row (zeros where the word does not occur; row 0 = padding_idx gets no gradient).
 // d_ret[b] / len[b] is accumulated as d_ret[b] * (1 / len[b]) (one division per match instead of one per element: <= 1 ulp).
 constexpr int EMB_CHUNK = 4096;
+static_assert(EMB_CHUNK <= 65536, "smatch holds chunk-relative positions as 16-bit values");
 constexpr int EMB_GROUPS = 16;
 constexpr int EMB_PASS = 512;                      // floats of E per pass (the groups' partial sums: 16 x 512 floats of LDS)
 // MEANPOOL: the source row of position p is utterance p / L, scaled by 1 / len (embedding mean-pool, multimodal.py:496-503);
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(512) void embed_meanpool_bwd_kernel(const float* __
                                                                  const int64_t* __restrict__ len,
                                                                  float* __restrict__ d_table, int B, int L, int E) {
     __shared__ int stok[EMB_CHUNK];
-    __shared__ int smatch[EMB_CHUNK];
+    __shared__ unsigned short smatch[EMB_CHUNK];            // chunk-relative positions (0..4095): 16 + 8 + 32 KiB of LDS in all
     __shared__ int wcount[8];
     __shared__ __attribute__((aligned(16))) float part[EMB_GROUPS][EMB_PASS];
     const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(512) void embed_meanpool_bwd_kernel(const float* __
                     int before = nm, all = nm;
 #pragma unroll
                     for (int w = 0; w < 8; ++w) { const int c = wcount[w]; if (w < wave) before += c; all += c; }
-                    if (hit) smatch[before + __popcll(mm & ((1ull << lane) - 1ull))] = c0 + base + tid;
+                    if (hit) smatch[before + __popcll(mm & ((1ull << lane) - 1ull))] = (unsigned short)(base + tid);
                     nm = all;
                     __syncthreads();
                 }
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(512) void embed_meanpool_bwd_kernel(const float* __
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int j = j0 + k * EMB_GROUPS;
-                        bb[k] = j < nm ? (MEANPOOL ? smatch[j] / L : smatch[j]) : -1;
+                        bb[k] = j < nm ? (MEANPOOL ? (c0 + smatch[j]) / L : c0 + smatch[j]) : -1;
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -341,26 +342,31 @@ extern "C" int cvcl_embed_meanpool_fwd(const float* table, const int64_t* tok, c
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void spatial_max_fwd_kernel(const float* __restrict__ mm, const int64_t* __restrict__ len,
                                                               const float* __restrict__ neg_log_temp, float* __restrict__ logits,
-                                                              uint8_t* __restrict__ arg, int HW, int Bt, int L) {
-    extern __shared__ float colmax[];                           // [Bt * L]
+                                                              uint8_t* __restrict__ arg, int HW, int Bt, int L, int chunk_t) {
+    extern __shared__ float colmax[];                           // [chunk_t * L]: the utterances are walked chunk_t at a time
     const int i = blockIdx.x, ncol = Bt * L;
     const float* base = mm + (long)i * HW * ncol;
-    for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
-        float best = base[c];
-        int bp = 0;
-        for (int p = 1; p < HW; ++p) {
-            const float v = base[(long)p * ncol + c];
-            if (v > best) { best = v; bp = p; }
-        }
-        colmax[c] = best;
-        arg[(long)i * ncol + c] = (uint8_t)bp;
-    }
-    __syncthreads();
     const float scale = expf(*neg_log_temp);
-    for (int t = threadIdx.x; t < Bt; t += blockDim.x) {
-        float s = 0.f;
-        for (int l = 0; l < L; ++l) s += colmax[t * L + l];
-        logits[(long)i * Bt + t] = s / (float)len[t] * scale;
+    for (int t0 = 0; t0 < Bt; t0 += chunk_t) {
+        const int nt = min(chunk_t, Bt - t0), c0 = t0 * L;
+        for (int cc = threadIdx.x; cc < nt * L; cc += blockDim.x) {
+            const int c = c0 + cc;
+            float best = base[c];
+            int bp = 0;
+            for (int p = 1; p < HW; ++p) {
+                const float v = base[(long)p * ncol + c];
+                if (v > best) { best = v; bp = p; }
+            }
+            colmax[cc] = best;
+            arg[(long)i * ncol + c] = (uint8_t)bp;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+            float s = 0.f;
+            for (int l = 0; l < L; ++l) s += colmax[t * L + l];
+            logits[(long)i * Bt + t0 + t] = s / (float)len[t0 + t] * scale;
+        }
+        __syncthreads();
     }
 }
 
@@ -525,10 +531,14 @@ extern "C" int cvcl_spatial_max_fwd(const float* mm, const int64_t* len, const f
                                     int Bi, int HW, int Bt, int L, void* stream) {
     CVCL_CHECK_ARG(mm && len && neg_log_temp && logits && arg && Bi > 0 && HW > 0 && HW <= 256 && Bt > 0 && L > 0,
                    "cvcl_spatial_max_fwd: bad args");
-    const size_t lds = (size_t)Bt * L * sizeof(float);
-    CVCL_CHECK_ARG(lds <= 64 * 1024, "cvcl_spatial_max_fwd: %d text positions exceed the LDS row buffer", Bt * L);
+    CVCL_CHECK_ARG(L <= 8192, "cvcl_spatial_max_fwd: L = %d exceeds the LDS row buffer", L);
+    // the per-utterance maxima live in LDS, at most 8192 (utterance, word) columns (32 KiB) at a time: the global batch of a
+    // data-parallel run (2048 utterances padded to 25 words) is walked in chunks, same values as one pass
+    const int chunk_t = Bt < 8192 / L ? Bt : 8192 / L;
+    const size_t lds = (size_t)chunk_t * L * sizeof(float);
     CvclProfScope prof(stream, CVCL_K_HEAD);
-    hipLaunchKernelGGL(spatial_max_fwd_kernel, dim3(Bi), dim3(256), lds, (hipStream_t)stream, mm, len, neg_log_temp, logits, arg, HW, Bt, L);
+    hipLaunchKernelGGL(spatial_max_fwd_kernel, dim3(Bi), dim3(256), lds, (hipStream_t)stream, mm, len, neg_log_temp, logits, arg, HW, Bt, L,
+                       chunk_t);
     CVCL_LAUNCH_CHECK();
     return CVCL_OK;
 }

@@ -41,6 +41,19 @@ POS_EMBED_TYPE = "no_pos_embed"
 
 _TORCHVISION_MODELS = {"resnext50_32x4d": resnext.resnext50_32x4d}
 
+# Registration epoch: advanced whenever ANY nn.Module registers a parameter or a sub-module (torch's global registration hooks:
+# ``m.x = Parameter / Module``, ``register_parameter``, ``add_module``, ``load_state_dict(assign=True)``).  VisionEncoder's eval
+# graph cache keeps its parameter list only while the epoch stands still (see ``_graph_forward``).
+_REGISTRATIONS = [0]
+
+
+def _note_registration(*_a):
+    _REGISTRATIONS[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_note_registration)
+torch.nn.modules.module.register_module_module_registration_hook(_note_registration)
+
 
 def set_parameter_requires_grad(model, feature_extracting=True):
     if feature_extracting:
@@ -79,13 +92,18 @@ class VisionEncoder(nn.Module):
     def _eager_forward(self, x):
         if getattr(self, "vit_dino", False):
             cls = self.model(x)                               # pre-head cls token (reference :91)
-            return ops.linear_f32(cls, self.model.head.weight, self.model.head.bias,
-                                  split=getattr(self.model, "compute_dtype", None) == torch.bfloat16), None   # reference :92
+            return ops.linear_f32(cls, self.model.head.weight, self.model.head.bias, split=self._head_split()), None   # reference :92
         layer = self.model[-2] if self.embedding_type == "spatial" else self.model.layer4     # reference :96-99
         with Hook(layer, requires_grad=False) as hook:                # reference :100-102
             features = self.model(x)
             feature_map = hook.activation
         return features, feature_map
+
+    def _head_split(self) -> bool:
+        """Arithmetic of the ViT head's fp32 GEMM, decided once per module so that EVERY call site of the layer (batched forward,
+        one-image-at-a-time forward, graph replay) runs the same kernel and tests/test_batching-style comparisons stay bit-level:
+        split-bf16 products in the bf16 compute mode, the exact fp32 MFMA otherwise (the parity mode)."""
+        return getattr(self.model, "compute_dtype", None) == torch.bfloat16
 
     # ---- evaluation callers (eval.py:196-232, analysis loops calling encode_image one frame at a time): HIP-graph replay ----
     # An eval-mode, no-grad pass is ~66 (ResNeXt) / ~110 (ViT) small dependent launches; the host's launch lead is 0.15-0.2 ms of a
@@ -114,11 +132,12 @@ class VisionEncoder(nn.Module):
         graphs = self.__dict__.setdefault("_graphs", {})
         key = (tuple(x.shape), str(x.device), getattr(self.model, "compute_dtype", None))
         # (the parameter LIST is cached: the module-tree walk of ~160 parameters cost more host time per call than reading their
-        # pointers and versions; re-registering a parameter changes the list's identity check below)
+        # pointers and versions.  It is valid while no nn.Module anywhere registered a parameter or a sub-module since it was
+        # taken -- ``model.fc = nn.Linear(...)``, ``load_state_dict(assign=True)``, ``register_parameter`` all pass torch's
+        # global registration hooks, which advance _REGISTRATIONS; in-place edits and ``.data`` swaps show in the fingerprint)
         plist = self.__dict__.get("_graph_params")
-        if plist is None or len(plist[1]) != plist[0]:
-            ps = list(self.model.parameters())
-            plist = self.__dict__["_graph_params"] = (len(ps), ps)
+        if plist is None or plist[0] != _REGISTRATIONS[0]:
+            plist = self.__dict__["_graph_params"] = (_REGISTRATIONS[0], list(self.model.parameters()))
         fp = tuple((p.data_ptr(), p._version) for p in plist[1])
         entry = graphs.get(key)
         if entry is not None and entry[5] != fp:              # weights changed since the capture: the packed copies are stale
@@ -158,11 +177,18 @@ class VisionEncoder(nn.Module):
 
     def _load_from_state_dict(self, *a, **k):                 # a parent's load_state_dict reaches this module here, not above
         self.__dict__["_graphs"] = {}
+        self.__dict__["_graph_params"] = None
         return super()._load_from_state_dict(*a, **k)
+
+    def _apply(self, fn, *a, **k):                            # .to() / .cuda() / .float(): new storage, maybe new Parameter objects
+        self.__dict__["_graphs"] = {}
+        self.__dict__["_graph_params"] = None
+        return super()._apply(fn, *a, **k)
 
     def __getstate__(self):                                   # (checkpoints pickle whole encoders: graphs are never part of them)
         d = dict(self.__dict__)
         d.pop("_graphs", None)
+        d.pop("_graph_params", None)
         return d
 
     def _forward_unbatched(self, x):
@@ -171,7 +197,7 @@ class VisionEncoder(nn.Module):
         for i in x:
             out = self.model(i.unsqueeze(0))
             if getattr(self, "vit_dino", False):
-                out = ops.linear_f32(out, self.model.head.weight, self.model.head.bias)
+                out = ops.linear_f32(out, self.model.head.weight, self.model.head.bias, split=self._head_split())
             outs.append(out.squeeze(0))
         return torch.stack(outs)
 
@@ -442,11 +468,21 @@ class MultiModalModel(nn.Module):
             rows_t = text_features.reshape(Bt * L, E)
             if self.training and self.global_negatives and parallel.is_distributed():
                 # global negatives: the per-location / per-word rows and the lengths of every rank, rank-major; every rank
-                # evaluates the replicated N_g x N_g spatial logits and back-propagates into its own rows (SUM over ranks)
+                # evaluates the replicated N_g x N_g spatial logits and back-propagates into its own rows (SUM over ranks).
+                # L is the pad length of THIS rank's batch (the collate pads to the batch's longest utterance), so the word rows
+                # are first padded with zero rows to the rank-invariant length every rank knows without a collective
+                # (parallel.common_text_length): a zero row adds 0 to both similarities, which sum over all L positions
+                # (reference :763-777) -- the value is the reference's on the concatenated batch padded to any common L.
+                Lg = parallel.common_text_length(L)
+                if Lg != L:
+                    rows_t = torch.nn.functional.pad(rows_t.view(Bt, L, E), (0, 0, 0, Lg - L)).reshape(Bt * Lg, E)
+                    L = Lg
+                world = parallel.world_size()
+                parallel.check_spatial_global_bytes(Bi * world * Hh * Ww, Bt * world * L, self.sim, rows_i.device)
                 rows_i = parallel.gather_rows(rows_i.view(Bi, Hh * Ww * E)).view(-1, E)
                 rows_t = parallel.gather_rows(rows_t.view(Bt, L * E)).view(-1, E)
                 text_length = parallel.gather_rows(text_length)
-                Bi, Bt = Bi * parallel.world_size(), Bt * parallel.world_size()
+                Bi, Bt = Bi * world, Bt * world
             nlt = self._temperature_on(rows_i.device)
             if self.sim == "max":        # best location per word, summed over all L positions, / len
                 logits_per_image = ops.spatial_max_logits(rows_i, rows_t, text_length, nlt, Bi, Hh * Ww, Bt, L)

@@ -38,7 +38,14 @@ import torch.distributed as dist
 
 # collectives issued by this module since import: {"all_gather": n, "all_reduce": n, "broadcast": n} -- read by bench.py's multi-rank
 # line (collectives per step) and by the tests (one feature all-gather per step)
-COLLECTIVES = {"all_gather": 0, "all_reduce": 0}
+COLLECTIVES = {"all_gather": 0, "all_reduce": 0, "broadcast": 0}
+
+# Common per-word length of the spatial head's text rows under global negatives.  The collate pads every batch to ITS OWN longest
+# utterance (multimodal_data_module.multiModalDataset_collate_fn; reference multimodal_data_module.py:92-110), so two ranks'
+# [B, L, E] word rows generally differ in L while RCCL's all-gather wants one size on every rank.  A rank-local decision about a
+# collective's size is a hang, so the size is a constant every rank knows without talking: the data module's bound on an
+# utterance (MAX_LEN_UTTERANCE = 25 tokens).  A data module with longer utterances sets this before training, on every rank.
+SPATIAL_TEXT_LEN = None
 
 
 def is_distributed() -> bool:
@@ -175,6 +182,40 @@ def gather_rows(x: torch.Tensor) -> torch.Tensor:
     return _AllGatherRows.apply(x)
 
 
+def common_text_length(L: int) -> int:
+    """The rank-invariant L the spatial head pads its per-word rows to before they are all-gathered (``SPATIAL_TEXT_LEN``, default
+    MAX_LEN_UTTERANCE).  Raises on a batch longer than that -- loudly on this rank, instead of a mis-sized collective on all."""
+    limit = SPATIAL_TEXT_LEN
+    if limit is None:
+        from .multimodal_data_module import MAX_LEN_UTTERANCE
+        limit = MAX_LEN_UTTERANCE
+    if L > limit:
+        raise ValueError(f"spatial embeddings under data-parallel global negatives gather per-word rows padded to {limit} tokens, "
+                         f"this rank's batch has L = {L}; set multimodal.parallel.SPATIAL_TEXT_LEN on every rank (or use --local_negatives)")
+    return int(limit)
+
+
+def check_spatial_global_bytes(n_loc_rows: int, n_word_rows: int, sim: str, device) -> None:
+    """The replicated spatial match map of the GLOBAL batch is [N_g*HW, N_g*L] fp32, twice for sim='max' (the map and its
+    gradient): 2 x 20 GB at 8 ranks x 256 pairs x 7x7 x 25.  Refuse with a message what would otherwise be an out-of-memory
+    kill somewhere inside the step."""
+    if sim != "max" or device.type != "cuda":
+        return
+    need = 2 * 4 * n_loc_rows * n_word_rows                                        # the map and its gradient
+    total = torch.cuda.get_device_properties(device).total_memory
+    if need > 0.6 * total:
+        raise RuntimeError(f"the global-negatives spatial match map needs {need / 2**30:.1f} GiB of the device's {total / 2**30:.0f} GiB "
+                           f"({n_loc_rows} location rows x {n_word_rows} word rows, fp32, forward + gradient): use --local_negatives, "
+                           f"--sim mean or a smaller per-rank batch")
+
+
+def broadcast_from_rank0(t: torch.Tensor) -> torch.Tensor:
+    """In-place broadcast of rank 0's ``t`` (every rank must call it: see ResNet.request_centre_sync for the one caller)."""
+    COLLECTIVES["broadcast"] += 1
+    dist.broadcast(t, src=0)
+    return t
+
+
 def gather_features(image_features: torch.Tensor, text_features: torch.Tensor):
     """[B,E] per rank -> [world*B, E] on every rank (rank-major row order)."""
     if not is_distributed():
@@ -210,6 +251,12 @@ class DataParallelEngine:
         self._listen(False)
         if not is_distributed():
             return self
+        # attach() is called by every rank (it builds the rank's buckets): the one rank-synchronous point before the first step.
+        # Trunks that keep rank-local calibration state adopt rank 0's at their next train-mode pass (ResNet.request_centre_sync).
+        for m in module.modules():
+            req = getattr(m, "request_centre_sync", None)
+            if callable(req):
+                req()
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()                                   # roughly the order gradients become ready
         cur, cur_bytes = [], 0

@@ -137,11 +137,24 @@ class ResNet(nn.Module):
     # (trunk_train) tracks instead: its weights move every step, so each layer's c follows the previous step's batch mean.
     # $CVCL_CENTRED_STORAGE=0 switches the whole mechanism off (plain storage, the round-2 numerics).
     def recalibrate_centres(self):
-        """Forget the calibrated (frozen path) and the tracked (fine-tuning path) centres: the next train-mode pass starts over."""
+        """Forget the calibrated (frozen path) and the tracked (fine-tuning path) centres: the next train-mode pass starts over.
+        Data parallel: a COLLECTIVE call, like every other state change of a replicated model -- all ranks call it, and all ranks'
+        next train-mode pass adopts rank 0's new calibration (``request_centre_sync``)."""
         self.__dict__["_centres"] = None
         self.__dict__["_track_centres"] = None
         self.__dict__["_centres_restored"] = None
         self.__dict__["_track_restored"] = None
+        from . import parallel
+        if parallel.is_distributed():
+            self.request_centre_sync()
+
+    def request_centre_sync(self):
+        """Data parallel: ask this replica's NEXT train-mode pass to take part in one broadcast of rank 0's storage centres, whatever
+        its own cache says (hit, restored from a checkpoint, freshly calibrated).  Raised only at rank-synchronous points --
+        ``DataParallelEngine.attach`` and ``recalibrate_centres`` -- so either every rank enters the broadcast or none does: the
+        decision never depends on a rank's local cache state (a checkpoint resumed on some ranks only, a weight re-allocated on one
+        rank, a rank-local extra forward).  A cache miss WITHOUT a pending request recalibrates locally and talks to nobody."""
+        self.__dict__["_centre_sync_pending"] = True
 
     def export_centres(self):
         """Checkpoint form of the calibrated / tracked centres (CPU tensors), or None when there are none yet."""
@@ -162,8 +175,9 @@ class ResNet(nn.Module):
     def import_centres(self, state):
         """Adopt centres saved by ``export_centres``: the next train-mode pass uses them instead of calibrating (whatever the
         weights' new storage addresses are), so a resumed bf16 run evaluates the same forward function as the run that saved it.
-        Each rank of a multi-GPU run calibrates on its own first shard; a checkpoint carries the saving rank's (rank 0's) centres
-        and every rank adopts those on resume -- a centre only has to be within ~sigma of the batch mean."""
+        A checkpoint carries rank 0's centres (the ones every replica of a data-parallel run holds after the broadcast at its first
+        step); on resume ``DataParallelEngine.attach`` requests the same broadcast again, so the replicas agree even when only some
+        ranks restored a checkpoint."""
         self.__dict__["_centres"] = None
         self.__dict__["_centres_restored"] = state["frozen"].clone() if state.get("frozen") is not None else None
         self.__dict__["_track_centres"] = None
@@ -187,33 +201,43 @@ class ResNet(nn.Module):
         """-> [53, 2048] f32 centres for a train-mode pass over ``x``'s distribution (calibrating first if need be), or None."""
         if not self.centred_storage():
             return None
+        from . import parallel
+        sync = bool(self.__dict__.get("_centre_sync_pending")) and parallel.is_distributed()
         hit = self.__dict__.get("_centres")
         if hit is not None and hit[0] == key:
             if hit[2] is not None:
                 torch.cuda.current_stream(x.device).wait_event(hit[2])     # (calibrated on another trunk stream)
-            return hit[1]
-        pend = self.__dict__.pop("_centres_restored", None)
-        if pend is not None:                                  # restored from a checkpoint: no calibration pass
-            centres = pend.to(device=x.device, dtype=torch.float32).contiguous()
-            self.__dict__["_centres"] = (key, centres, None)
-            return centres
-        lib = H.lib()
-        B, _, Hh, Ww = x.shape
-        moments = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=x.device)
-        fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
-        pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
-        # a plain-storage train-mode pass that leaves every layer's batch mean behind and touches no BatchNorm buffer
-        H.check(lib.cvcl_resnext50_fwd_deferred_stats(dt, B, Hh, Ww, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap), H.ptr(pooled),
-                                                      BN_EPS, H.ptr(moments), None, H.stream_ptr()), "cvcl_resnext50_fwd_deferred_stats")
-        centres = moments.view(53, 2, 2048)[:, 0, :].contiguous()
-        from . import parallel
-        if parallel.is_distributed():
-            # data parallel: every replica must evaluate the SAME bf16 forward function, so rank 0's calibration is adopted by all
-            # (a centre only has to be within ~sigma of a rank's batch mean; the ranks see shards of one distribution).  All ranks
-            # reach this point together: on their first train-mode pass, or after recalibrate_centres() / a change of weights
-            parallel.dist.broadcast(centres, src=0)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(x.device))
+            if not sync:
+                return hit[1]
+            centres = hit[1]
+        else:
+            pend = self.__dict__.pop("_centres_restored", None)
+            if pend is not None:                                  # restored from a checkpoint: no calibration pass
+                centres = pend.to(device=x.device, dtype=torch.float32).contiguous()
+                if not sync:
+                    self.__dict__["_centres"] = (key, centres, None)
+                    return centres
+            else:
+                lib = H.lib()
+                B, _, Hh, Ww = x.shape
+                moments = torch.empty(lib.cvcl_resnext50_moments_floats(), dtype=torch.float32, device=x.device)
+                fmap = torch.empty(B, Hh // 32, Ww // 32, 2048, dtype=self.compute_dtype, device=x.device)
+                pooled = torch.empty(B, 2048, dtype=torch.float32, device=x.device)
+                # a plain-storage train-mode pass that leaves every layer's batch mean behind and touches no BatchNorm buffer
+                H.check(lib.cvcl_resnext50_fwd_deferred_stats(dt, B, Hh, Ww, H.ptr(x), arr, len(arr), H.ptr(ws), nb, H.ptr(fmap),
+                                                              H.ptr(pooled), BN_EPS, H.ptr(moments), None, H.stream_ptr()),
+                        "cvcl_resnext50_fwd_deferred_stats")
+                centres = moments.view(53, 2, 2048)[:, 0, :].contiguous()
+        if sync:
+            # data parallel: every replica must evaluate the SAME bf16 forward function, so rank 0's centres are adopted by all (a
+            # centre only has to be within ~sigma of a rank's batch mean; the ranks see shards of one distribution).  Every rank is
+            # here: the request was raised at a rank-synchronous point (request_centre_sync), not by this rank's cache state
+            self.__dict__["_centre_sync_pending"] = False
+            centres = parallel.broadcast_from_rank0(centres.clone() if hit is not None and centres is hit[1] else centres)
+        ready = None
+        if x.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(x.device))
         self.__dict__["_centres"] = (key, centres, ready)
         return centres
 
@@ -312,6 +336,7 @@ class ResNet(nn.Module):
         d["_track_centres"] = None
         d["_centres_restored"] = None
         d["_track_restored"] = None
+        d["_centre_sync_pending"] = False
         return d
 
     def __setstate__(self, d):

@@ -52,7 +52,8 @@ def bench_step(out_dir):
     torch.save({"pooled": pooled.cpu(), "tok": batch[1].cpu(), "len": batch[2].cpu(), "losses": losses, "grads": grads,
                 "before": {k: v.cpu() for k, v in before.items()}, "after1": after1,
                 "centres": None if centres is None else centres["frozen"],
-                "collectives_per_step": {k: (parallel.COLLECTIVES[k] - coll0[k]) / 2 for k in coll0}},
+                "collectives_per_step": {k: (parallel.COLLECTIVES[k] - coll0[k]) / 2 for k in coll0},
+                "broadcasts_total": parallel.COLLECTIVES["broadcast"]},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -88,6 +89,9 @@ def spatial_step(out_dir):
         it = iter(dm.train_dataloader())
         for _ in range(rank + 1):                                              # a different shard per rank
             x, y, y_len, _ = next(it)
+        # the collate pads a batch to ITS longest utterance, so two ranks' token matrices differ in width on real data (the synthetic
+        # set's utterances all have one length): rank r's batch carries 2 r + 1 more PAD columns
+        y = torch.nn.functional.pad(y, (0, 2 * rank + 1), value=0)
         fmaps = []
         hook = lit.vision_encoder.model[7].register_forward_hook(lambda m, i, o: fmaps.append(o.detach().float().cpu().clone()))
         coll0 = dict(parallel.COLLECTIVES)

@@ -121,3 +121,70 @@ def test_world2_gradients_equal_single_process(global_negatives, deferred):
         assert torch.allclose(gt, g_table, atol=1e-5), rank
         assert torch.allclose(gn, g_nlt, atol=1e-5), rank
     assert torch.equal(res[0][2], res[1][2])             # replicas stay bit-identical
+
+
+def _centre_worker(rank, world, port, out):
+    """Rank-divergent cache states of the frozen ResNeXt's storage centres: rank 0 holds a cache HIT, rank 1 a pending
+    checkpoint restore.  The round-5 code broadcast from inside the cache-miss branch only -- here neither rank would have
+    entered it (silently different centres), and a hit / miss split would have left one rank alone in the collective."""
+    sys.path.insert(0, os.path.join(ROOT, "multimodal-baby_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from multimodal import parallel, resnext
+    dist.init_process_group(backend="gloo")
+    net = resnext.ResNet.__new__(resnext.ResNet)                 # the protocol only: no parameters, no device
+    torch.nn.Module.__init__(net)
+    net.__dict__.update(compute_dtype=torch.bfloat16, _centres=None, _centres_restored=None)
+    x = torch.zeros(1)
+    key = ("weights", 1)
+    mine = torch.full((53, 2048), float(rank + 1))
+    if rank == 0:
+        net.__dict__["_centres"] = (key, mine.clone(), None)                     # calibrated earlier on this rank
+    else:
+        net.import_centres({"frozen": mine.clone()})                             # this rank resumed a checkpoint
+    n0 = parallel.COLLECTIVES["broadcast"]
+    first = net._calibrated_centres(x, None, None, None, 0, key).clone()         # no request pending: nobody talks
+    assert parallel.COLLECTIVES["broadcast"] == n0 and torch.equal(first, mine)
+    holder = torch.nn.Module()
+    holder.trunk = net
+    holder.w = torch.nn.Parameter(torch.zeros(3))
+    parallel.DataParallelEngine(torch.device("cpu")).attach(holder)             # the rank-synchronous point
+    assert net.__dict__["_centre_sync_pending"] is True
+    second = net._calibrated_centres(x, None, None, None, 0, key).clone()        # every rank enters ONE broadcast
+    assert parallel.COLLECTIVES["broadcast"] == n0 + 1 and net.__dict__["_centre_sync_pending"] is False
+    third = net._calibrated_centres(x, None, None, None, 0, key).clone()         # cached again: no further collective
+    assert parallel.COLLECTIVES["broadcast"] == n0 + 1
+    out.put((rank, first, second, third))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_storage_centres_sync_is_rank_synchronous():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_centre_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, first, second, third in res:
+        assert float(first[0, 0]) == rank + 1                    # rank-local state before the engine is attached
+        assert torch.equal(second, res[0][1]) and torch.equal(third, res[0][1])      # rank 0's centres on every rank afterwards
+
+
+def test_common_text_length_is_a_constant_every_rank_knows():
+    sys.path.insert(0, os.path.join(ROOT, "multimodal-baby_amd"))
+    from multimodal import parallel
+    from multimodal.multimodal_data_module import MAX_LEN_UTTERANCE
+    assert parallel.common_text_length(3) == parallel.common_text_length(MAX_LEN_UTTERANCE) == MAX_LEN_UTTERANCE == 25
+    with pytest.raises(ValueError, match="SPATIAL_TEXT_LEN"):
+        parallel.common_text_length(MAX_LEN_UTTERANCE + 1)
+    parallel.SPATIAL_TEXT_LEN = 40
+    try:
+        assert parallel.common_text_length(26) == 40
+    finally:
+        parallel.SPATIAL_TEXT_LEN = None
+    parallel.check_spatial_global_bytes(10 ** 9, 10 ** 9, "max", torch.device("cpu"))       # host tensors: nothing to guard

@@ -61,9 +61,11 @@ def test_spatial_head_golden(dev, sim):
 
 
 @pytest.mark.parametrize("sim", ["max", "mean"])
-@pytest.mark.parametrize("Bi,HW,Bt,L,E", [(256, 49, 256, 5, 512), (9, 4, 7, 25, 40)])
+@pytest.mark.parametrize("Bi,HW,Bt,L,E", [(256, 49, 256, 5, 512), (9, 4, 7, 25, 40), (12, 4, 700, 13, 24)])
 def test_spatial_logits_oracle_sizes(dev, sim, Bi, HW, Bt, L, E):
-    """C2-sized batch (256 images x 49 locations x 256 utterances) and a ragged small case vs the oracle, incl. gradients."""
+    """C2-sized batch (256 images x 49 locations x 256 utterances), a ragged small case and one with more (utterance, word)
+    columns than the max kernel keeps in LDS at a time (700 x 13 > 8192: the chunk walk a data-parallel global batch padded to
+    25 words takes) vs the oracle, incl. gradients."""
     from multimodal.multimodal import MultiModalModel
     g = torch.Generator().manual_seed(Bi + L)
     side = int(HW ** 0.5)

@@ -458,6 +458,30 @@ def test_eval_hip_graph_replay_is_bit_identical_to_eager_launches(dev, config):
         first.mul_(-1.0)
         f3_eager, _ = ve(xs[1][0])
     assert torch.equal(f3, f3_eager) and torch.equal(f4, f4_eager) and not torch.equal(f3, f4) and not torch.equal(f3, f2)
+    # a Parameter OBJECT replaced between eval calls -- the head swapped for a new nn.Linear, a weight re-registered through
+    # load_state_dict(assign=True) on a parent: the cached parameter list would still hold the old objects; the
+    # registration epoch drops it, the fingerprint of the NEW objects differs, the graph is re-captured
+    import torch.nn as nn
+    ve.enable_hip_graphs(True)
+    with torch.no_grad():
+        f5, _ = ve(xs[1][0])
+        name = "head" if config == "c4" else "fc"
+        old_head = getattr(ve.model, name)
+        new_head = nn.Linear(old_head.in_features, old_head.out_features).to(dev)
+        new_head.weight.copy_(old_head.weight * 3.0)
+        new_head.bias.copy_(old_head.bias)
+        for q in new_head.parameters():
+            q.requires_grad_(False)
+        setattr(ve.model, name, new_head)
+        f6, _ = ve(xs[1][0])
+        # (every 4-d weight: the encoder is registered twice in the lit module -- vision_encoder and model.image_embed -- and an
+        # assigning load applies both aliases' entries in turn)
+        sd = {k: (v * 0.25 if v.is_floating_point() and v.dim() == 4 else v.clone()) for k, v in lit.state_dict().items()}
+        lit.load_state_dict(sd, assign=True)
+        f7, _ = ve(xs[1][0])
+        ve.enable_hip_graphs(False)
+        f7_eager, _ = ve(xs[1][0])
+    assert not torch.equal(f5, f6) and not torch.equal(f6, f7) and torch.equal(f7, f7_eager)
     # gradients enabled or train mode: never a graph
     ve.enable_hip_graphs(True)
     ve._graphs.clear()
