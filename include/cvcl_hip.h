@@ -26,6 +26,9 @@
  *    CVCL_GEMM8W            on       cvcl_gemm never selects the 8-wave 256 x 256 kernel (everything on the 128 x 128 kernels)
  *    CVCL_GEMM_PRO          on       cvcl_gemm refuses the BN-prologue kernel (callers normalise the operand themselves)
  *    CVCL_F32_TILED         on       fp32 parity mode: the direct (one thread per output) stem / grouped-conv kernels
+ *    CVCL_FINALIZE_ON_LOAD  on       bf16 train-mode trunk: partial rows + a cvcl_bn_finalize launch behind EVERY convolution (the launch
+ *                                    sequence of rounds 1-5) instead of accumulated statistics that the consumer of the raw tensor turns
+ *                                    into its channels' affine itself ("BatchNorm accumulators" below; tests/test_finalize_on_load_gpu.py)
  *  Experiment switches of earlier rounds (CVCL_FUSED_TAIL_STAGES, CVCL_CONV3_PRO_STAGES, CVCL_DS_RECOMPUTE,
  *  CVCL_PRO_DEPTH, CVCL_GCONV_LDS_KB, CVCL_GEMM_MINW, CVCL_GEMM_GLDS, CVCL_GCONV_WGRAD_BAND) exist only in a library built with
  *  -DCVCL_LAB (tools/README.md); the kernel-variant switches of the 8-wave GEMM live in tools/gemm_lab/.
@@ -40,11 +43,18 @@
 extern "C" {
 #endif
 
-#define CVCL_ABI_VERSION 4
+#define CVCL_ABI_VERSION 5
 
 enum { CVCL_OK = 0, CVCL_EINVAL = -1, CVCL_ELAUNCH = -2, CVCL_EWORKSPACE = -3, CVCL_EUNSUPPORTED = -4 };
 enum { CVCL_F32 = 0, CVCL_BF16 = 1 };
 enum { CVCL_ACT_NONE = 0, CVCL_ACT_RELU = 1, CVCL_ACT_GELU = 2 };
+/* BatchNorm accumulators (round 6).  A convolution hands its per-channel batch statistics on either as partial ROWS (one per
+ * workgroup, reduced by cvcl_bn_finalize) or, with stats_rows == CVCL_STATS_ACCUMULATE, by atomically ADDING them to a caller-zeroed
+ * accumulator: int64 [8][2][N] (8 rows = one per XCD; [0] sums, [1] sums of squares), fixed point with 24 fractional bits -- integer
+ * addition commutes, so the totals are bit-deterministic.  sum = (acc[0][0][n] + ... + acc[7][0][n]) / 2^24.  The bf16 train-mode
+ * trunk (cvcl_resnext50_fwd*) uses them so that the consumer of a raw tensor forms its BatchNorm affine itself instead of waiting
+ * for a cvcl_bn_finalize launch ($CVCL_FINALIZE_ON_LOAD). */
+#define CVCL_STATS_ACCUMULATE (-1)
 
 int cvcl_abi_version(void);
 const char* cvcl_last_error(void);
@@ -142,7 +152,9 @@ typedef struct {
     /* optional epilogue */
     const float* exp_scale; const float* bias; int act;
     const void* R; int ldr;
-    float* stats; int stats_rows;    /* stats_rows = capacity (>= cvcl_gemm_stats_rows(dtype, args)); rows written = that value */
+    float* stats; int stats_rows;    /* stats_rows = capacity (>= cvcl_gemm_stats_rows(dtype, args)); rows written = that value.
+                                      * stats_rows == CVCL_STATS_ACCUMULATE (bf16): stats points to int64 accumulators [8][2][N] that the
+                                      * launch ADDS its per-channel (sum, sum of squares) to -- see "BatchNorm accumulators" below */
     /* Bottleneck tail (bf16): C = relu(round(A'W^T) * c_scale[N] + c_shift[N] + (R | R * r_scale[N] + r_shift[N])).
      * With C == NULL and stats != NULL the product is not stored, only its column statistics (same rounding). */
     const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;

@@ -173,6 +173,90 @@ __device__ inline float block_max(float v, float* scratch) {
     return r;
 }
 
+// ---- BatchNorm statistics ACCUMULATORS (round 6; cvcl_hip.h "CVCL_STATS_ACCUMULATE") ---------------------------------------------
+// The convolution kernels hand their per-channel (sum, sum of squares) to BatchNorm either as one partial ROW per workgroup
+// (stats[rows][2][N] floats, reduced by cvcl_bn_finalize) or, in accumulate mode, by ADDING them to an int64 accumulator
+// acc[8][2][N]: fixed point with 24 fractional bits, one row per XCD (the adds of an XCD's workgroups meet in that XCD's L2; measured
+// free next to the row stores, and exact: tools/probes/atomic_probe.hip).  Integer addition commutes, so the totals are bit-
+// deterministic whatever the arrival order; the rounding of a partial sum to 2^-24 moves a mean by < 1e-8 / a variance by < 1e-8
+// absolute at the trunk's row counts (eps is 1e-5).  A consumer sums the 8 rows of its channels and forms (scale, shift) itself.
+constexpr int kBnAccRows = 8;
+constexpr double kBnAccScale = 16777216.0;                  // 2^24
+__device__ __forceinline__ int cvcl_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; }     // HW_REG_XCC_ID[3:0]
+__device__ __forceinline__ void cvcl_bn_acc_add(float* stats_as_acc, int N, int n, float s, float q) {
+    long long* row = reinterpret_cast<long long*>(stats_as_acc) + (long)cvcl_xcc_id() * 2 * N;
+    __hip_atomic_fetch_add(row + n, __double2ll_rn((double)s * kBnAccScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(row + N + n, __double2ll_rn((double)q * kBnAccScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one partial (s, q) of channel n from workgroup row `row`: a row store or an accumulator add
+__device__ __forceinline__ void cvcl_bn_stats_out(float* stats, int acc_mode, long row, int N, int n, float s, float q) {
+    if (acc_mode) cvcl_bn_acc_add(stats, N, n, s, q);
+    else {
+        stats[(row * 2 + 0) * N + n] = s;
+        stats[(row * 2 + 1) * N + n] = q;
+    }
+}
+
+// the running-statistics update r <- (1 - m) r + m x: one spelling, shared by the in-place, the deferred and the on-load forms
+__device__ inline float bn_ema(float r, float x, float m) { return fmaf(m, x, (1.f - m) * r); }
+
+// finalize-on-load source: the accumulators of the layer whose output a kernel is about to normalise (csrc/resnext.hip)
+struct BnSrc {
+    const long long* acc;           // [8][2][C] accumulators of the STORED tensor (NULL: no finalize-on-load, read scale / shift)
+    int C;
+    double count;
+    const float* gamma; const float* beta; const float* centre;
+    float* running_mean; float* running_var; int64_t* nbt;
+    float momentum, eps;
+    float* moments; int moments_ld;
+    float* scale_out; float* shift_out;
+};
+
+// channels [c0, c0 + NCH) by the first NCH threads of the workgroup; on return (behind a barrier) sc_out / sh_out [NCH] in LDS hold
+// the slice's affine.  The expressions after the sums are bn_finalize_kernel's.
+template <int NCH>
+__device__ __forceinline__ void bn_slice_affine(const BnSrc& b, int c0, bool publish, float* sc_out, float* sh_out) {
+    const int c = threadIdx.x;
+    if (c < NCH) {
+        const int ch = c0 + c;
+        long long v[2 * kBnAccRows];
+#pragma unroll
+        for (int r = 0; r < kBnAccRows; ++r) {
+            v[2 * r] = b.acc[((long)r * 2 + 0) * b.C + ch];
+            v[2 * r + 1] = b.acc[((long)r * 2 + 1) * b.C + ch];
+        }
+        long long S = 0, Q = 0;
+#pragma unroll
+        for (int r = 0; r < kBnAccRows; ++r) { S += v[2 * r]; Q += v[2 * r + 1]; }
+        const double s = (double)S * (1.0 / kBnAccScale), q = (double)Q * (1.0 / kBnAccScale);
+        const double mean = s / b.count;
+        double var = q / b.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float sc = b.gamma[ch] / sqrtf((float)var + b.eps);
+        const float sh = b.beta[ch] - (float)mean * sc;
+        sc_out[c] = sc;
+        sh_out[c] = sh;
+        if (publish) {
+            if (b.scale_out) { b.scale_out[ch] = sc; b.shift_out[ch] = sh; }
+            const double unbiased = b.count > 1.0 ? var * b.count / (b.count - 1.0) : var;
+            const float true_mean = b.centre ? (float)(mean + (double)b.centre[ch]) : (float)mean;
+            if (b.moments) {
+                b.moments[ch] = true_mean;
+                b.moments[b.moments_ld + ch] = (float)unbiased;
+            } else if (b.running_mean) {
+                b.running_mean[ch] = bn_ema(b.running_mean[ch], true_mean, b.momentum);
+                b.running_var[ch] = bn_ema(b.running_var[ch], (float)unbiased, b.momentum);
+            }
+        }
+    }
+    if (publish && !b.moments && b.nbt && c0 == 0 && threadIdx.x == 0) *b.nbt += 1;
+    __syncthreads();
+}
+
+// cvcl_conv1x1_gram with the operand's BatchNorm affine formed inside the kernel from `src` (internal, C++ linkage: bn_gram.hip)
+int cvcl_conv1x1_gram_src(const void* A, int lda, long M, int K, const float* a_scale, const float* a_shift, const BnSrc* src, int a_relu,
+                          void* workspace, size_t workspace_bytes, const double** gram_out, void* stream);
+
 // sum_{i < n} load(i), UN loads in flight per wait, additions in index order (same result as the plain loop, deterministic).
 // A `for (...) acc += p[i]` loop waits for every load before issuing the next (one L2 / HBM round trip per element): these
 // reductions are pure latency, so batching the loads is the whole optimisation.  load(i) must be valid for every i < n.

@@ -41,6 +41,7 @@ struct GemmDev {
     const void* R; int ldr;
     const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;   // BN-apply epilogue
     float* stats;
+    int stats_acc;         // stats is an int64 accumulator [8][2][N] (CVCL_STATS_ACCUMULATE), not partial rows
     const float* centre;   // storage centre of a raw convolution output (NULL = 0): accumulators start at -centre[n]
     int vec_in;    // A/W rows are 16-byte aligned and K is a whole number of chunks
     int vec_out;   // C/R rows are 16-byte aligned
@@ -495,8 +496,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
             if (n < p.N) {
                 const float s = red[((0 + 2 * wn_) * 2 + 0) * 64 + c] + red[((1 + 2 * wn_) * 2 + 0) * 64 + c];
                 const float q = red[((0 + 2 * wn_) * 2 + 1) * 64 + c] + red[((1 + 2 * wn_) * 2 + 1) * 64 + c];
-                p.stats[((long)blockIdx.x * 2 + 0) * p.N + n] = s;
-                p.stats[((long)blockIdx.x * 2 + 1) * p.N + n] = q;
+                cvcl_bn_stats_out(p.stats, p.stats_acc, blockIdx.x, p.N, n, s, q);
             }
         }
     }
@@ -789,8 +789,7 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(GemmDev p) {
             const int wn_ = tid >> 6, c = tid & 63, n = n0 + tid;
             const float sv = red[((0 + 2 * wn_) * 2 + 0) * 64 + c] + red[((1 + 2 * wn_) * 2 + 0) * 64 + c];
             const float qv = red[((0 + 2 * wn_) * 2 + 1) * 64 + c] + red[((1 + 2 * wn_) * 2 + 1) * 64 + c];
-            p.stats[((long)blockIdx.x * 2 + 0) * p.N + n] = sv;
-            p.stats[((long)blockIdx.x * 2 + 1) * p.N + n] = qv;
+            cvcl_bn_stats_out(p.stats, p.stats_acc, blockIdx.x, p.N, n, sv, qv);
         }
     }
 }
@@ -887,7 +886,7 @@ template <typename T> int grid_m_query(int M, int N);
 template <typename T, int PRO, bool LEAN, int MINW, int TR = 0>
 int launch_gemm_w(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     const int gm = grid_m_query<T>(a->M, a->N);      // same capacity for every variant (see grid_m_query)
-    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
+    if (a->stats) CVCL_CHECK_ARG(a->stats_rows == CVCL_STATS_ACCUMULATE || a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
     static CvclLdsAttr attr_set;
     constexpr int lds = gemm_lds_bytes<T>();
     if (!attr_set.ready()) {
@@ -1188,7 +1187,7 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
     if ((long)a->N * a->K < min_intensity * (a->N + a->K)) return -1;
     const bool plain = !a->bias && !a->R && a->act == CVCL_ACT_NONE;
     if (a->stats) {
-        if (!plain || a->stats_rows < cvcl_gemm8w_stats_rows(a->M, a->N)) return -1;
+        if (!plain || (a->stats_rows != CVCL_STATS_ACCUMULATE && a->stats_rows < cvcl_gemm8w_stats_rows(a->M, a->N))) return -1;
         return 0;
     }
     if (plain) return 0;
@@ -1201,7 +1200,7 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
 inline bool pick_gemm_pro(int dtype, const cvcl_gemm_args* a) {
     static const bool on = cvcl_env_on("CVCL_GEMM_PRO");
     if (!on || dtype != CVCL_BF16 || !cvcl_gemm_pro_supported(a)) return false;
-    return !a->stats || a->stats_rows >= cvcl_gemm_pro_stats_rows(a->M, a->N);
+    return !a->stats || a->stats_rows == CVCL_STATS_ACCUMULATE || a->stats_rows >= cvcl_gemm_pro_stats_rows(a->M, a->N);
 }
 
 inline bool is_lean(const cvcl_gemm_args* a, const GemmDev& d) {
@@ -1212,7 +1211,7 @@ inline int pro_kind(const cvcl_gemm_args* a) { return !a->a_scale ? 0 : (a->a_re
 template <int EPI>
 int launch_gemm_glds(const cvcl_gemm_args* a, GemmDev& d, hipStream_t stream) {
     const int gm = grid_m_query<bf16_t>(a->M, a->N);
-    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
+    if (a->stats) CVCL_CHECK_ARG(a->stats_rows == CVCL_STATS_ACCUMULATE || a->stats_rows >= gm, "cvcl_gemm: stats_rows %d < grid_m %d", a->stats_rows, gm);
     static CvclLdsAttr attr_set;
     if (!attr_set.ready()) {
         if (hipFuncSetAttribute((const void*)gemm_glds_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GL_LDS) != hipSuccess) {
@@ -1239,6 +1238,7 @@ int launch_gemm(const cvcl_gemm_args* a, hipStream_t stream) {
     d.g_s = a->gather_stride;
     d.exp_scale = a->exp_scale; d.bias = a->bias; d.act = a->act;
     d.R = a->R; d.ldr = a->ldr; d.stats = a->stats; d.centre = a->centre;
+    d.stats_acc = a->stats && a->stats_rows == CVCL_STATS_ACCUMULATE;
     d.c_scale = a->c_scale; d.c_shift = a->c_shift; d.r_scale = a->r_scale; d.r_shift = a->r_shift;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
     d.vec_in = (a->K % EPC == 0) && (a->lda % EPC == 0) && (a->ldw % EPC == 0) && al16(a->A) && al16(a->W);

@@ -172,6 +172,7 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
     g8w::Dev d;
     d.A = (const bf16_t*)a->A; d.W = (const bf16_t*)a->W; d.C = (bf16_t*)a->C; d.R = (const bf16_t*)a->R;
     d.bias = a->bias; d.stats = a->stats; d.centre = a->centre;
+    d.stats_acc = a->stats && a->stats_rows == CVCL_STATS_ACCUMULATE;
     d.ln_stats = a->ln_stats; d.ln_colsum = a->ln_colsum; d.row_part = a->row_part;
     d.M = a->M; d.N = a->N; d.K = a->K; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr; d.act = a->act;
     d.ncol = a->N / 256;
@@ -186,7 +187,7 @@ extern "C" int cvcl_gemm8w(int epi, const cvcl_gemm_args* a, void* stream) {
         bm = cvcl_gemm8w_tile_rows(a->M, a->N);
         d.tiles_m = cvcl_div_up(a->M, bm);
         d.grid_m = g8_grid_m(d.tiles_m, d.ncol);
-        if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= d.grid_m, "cvcl_gemm8w: stats_rows %d < %d", a->stats_rows, d.grid_m);
+        if (a->stats) CVCL_CHECK_ARG(d.stats_acc || a->stats_rows >= d.grid_m, "cvcl_gemm8w: stats_rows %d < %d", a->stats_rows, d.grid_m);
         grid = d.grid_m * d.ncol;
     } else {
         return g8_linear(d, a, (hipStream_t)stream);

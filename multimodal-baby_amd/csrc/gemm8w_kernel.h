@@ -53,6 +53,7 @@ constexpr int MAX_BIAS_N = (LDS_BYTES - ACC_OFF) / 4;               // 4096
 struct Dev {
     const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
     const float* bias; float* stats;
+    int stats_acc;                  // stats is an int64 accumulator [8][2][N] (CVCL_STATS_ACCUMULATE), not partial rows
     const float* ln_stats; const float* ln_colsum; float* row_part;     // LNF (see above)
     const float* centre;            // EPI 0: storage centre of the output (NULL = 0): accumulators start at -centre[n]
     int M, N, K, lda, ldw, ldc, ldr, act;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
     const int KS = p.K / BK;
     const int S = nt * KS;
     if (S == 0) {                                            // more workgroup rows than m-tiles: an all-zero statistics row
-        if (EPI == 0 && p.stats && ti < p.grid_m && tid < BN) {
+        if (EPI == 0 && p.stats && !p.stats_acc && ti < p.grid_m && tid < BN) {
             p.stats[((long)ti * 2 + 0) * p.N + tj * BN + tid] = 0.f;
             p.stats[((long)ti * 2 + 1) * p.N + tj * BN + tid] = 0.f;
         }
@@ -529,8 +530,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(Dev p) {
             const int wn_ = tid >> 6, c = tid & 63, n = tj * BN + tid;   // column strip wn_: waves wn_ (upper rows) and wn_ + 4
             const float sv = lds_acc[((wn_) * 2 + 0) * 64 + c] + lds_acc[((wn_ + 4) * 2 + 0) * 64 + c];
             const float qv = lds_acc[((wn_) * 2 + 1) * 64 + c] + lds_acc[((wn_ + 4) * 2 + 1) * 64 + c];
-            p.stats[((long)ti * 2 + 0) * p.N + n] = sv;
-            p.stats[((long)ti * 2 + 1) * p.N + n] = qv;
+            cvcl_bn_stats_out(p.stats, p.stats_acc, ti, p.N, n, sv, qv);
         }
     }
 }

@@ -35,6 +35,7 @@ struct ProDev {
     const bf16_t* A; const bf16_t* W; bf16_t* C; const bf16_t* R;
     const float* a_scale; const float* a_shift; const float* c_scale; const float* c_shift; const float* r_scale; const float* r_shift;
     float* stats;
+    int stats_acc;                  // stats is an int64 accumulator [8][2][N] (CVCL_STATS_ACCUMULATE), not partial rows
     const float* centre;            // storage centre of the output (NULL = 0): accumulators start at -centre[n]
     int M, N, lda, ldw, ldc, ldr;
     int tiles;
@@ -403,8 +404,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
         __syncthreads();
         if (tid < PN) {
             const int wn_ = tid >> 6, c = tid & 63, n = n0 + tid;
-            p.stats[((long)blockIdx.x * 2 + 0) * p.N + n] = red[(wn_ * 2 + 0) * 64 + c] + red[((wn_ + 4) * 2 + 0) * 64 + c];
-            p.stats[((long)blockIdx.x * 2 + 1) * p.N + n] = red[(wn_ * 2 + 1) * 64 + c] + red[((wn_ + 4) * 2 + 1) * 64 + c];
+            cvcl_bn_stats_out(p.stats, p.stats_acc, blockIdx.x, p.N, n, red[(wn_ * 2 + 0) * 64 + c] + red[((wn_ + 4) * 2 + 0) * 64 + c],
+                              red[(wn_ * 2 + 1) * 64 + c] + red[((wn_ + 4) * 2 + 1) * 64 + c]);
         }
     }
 }
@@ -468,11 +469,12 @@ extern "C" int cvcl_gemm_pro(const cvcl_gemm_args* a, void* stream) {
     d.A = (const bf16_t*)a->A; d.W = (const bf16_t*)a->W; d.C = (bf16_t*)a->C; d.R = (const bf16_t*)a->R;
     d.a_scale = a->a_scale; d.a_shift = a->a_shift; d.c_scale = a->c_scale; d.c_shift = a->c_shift;
     d.r_scale = a->r_scale; d.r_shift = a->r_shift; d.stats = a->stats; d.centre = a->centre;
+    d.stats_acc = a->stats && a->stats_rows == CVCL_STATS_ACCUMULATE;
     d.M = a->M; d.N = a->N; d.lda = a->lda; d.ldw = a->ldw; d.ldc = a->ldc; d.ldr = a->ldr;
     d.A2 = (const bf16_t*)a->A2; d.W2 = (const bf16_t*)a->W2; d.centre2 = a->centre2; d.lda2 = a->lda2; d.ldw2 = a->ldw2;
     d.tiles = cvcl_div_up(a->M, PM);
     const int gx = cvcl_gemm_pro_stats_rows(a->M, a->N);
-    if (a->stats) CVCL_CHECK_ARG(a->stats_rows >= gx, "cvcl_gemm_pro: stats_rows %d < %d", a->stats_rows, gx);
+    if (a->stats) CVCL_CHECK_ARG(d.stats_acc || a->stats_rows >= gx, "cvcl_gemm_pro: stats_rows %d < %d", a->stats_rows, gx);
     dim3 grid(gx, a->N / PN);
     const int mode = a->c_scale ? (a->A2 ? PRO_TAIL_DS : PRO_TAIL) : (a->C ? PRO_STORE : PRO_STATS);
     CvclProfScope prof(stream, CVCL_K_GEMM_PRO);

@@ -13,6 +13,7 @@
 //                          channels per group, one tap x 32 channels per step for 32 per group),
 //                          input band staged in LDS with BN+ReLU applied on the way in
 //   fp32 (parity mode)   : direct VALU kernels with identical semantics + a column-statistics pass
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -21,6 +22,7 @@
 namespace {
 
 constexpr int kMaxStatsRows = 1024;
+constexpr size_t kTrunkAccLayer = (size_t)kBnAccRows * 2 * 2048;     // int64 slots of one layer's BatchNorm accumulators [8][2][2048]
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping
@@ -28,7 +30,7 @@ constexpr int kMaxStatsRows = 1024;
 // stats [rows][2][C] partial sums -> scale = gamma / sqrt(var + eps), shift = beta - mean * scale;
 // running_mean/var EMA with the unbiased variance (nn.BatchNorm2d train mode), num_batches_tracked += 1.
 // the running-statistics update r <- (1 - m) r + m x: one spelling, shared by the in-place and the deferred form (identical bits)
-__device__ inline float bn_ema(float r, float x, float m) { return fmaf(m, x, (1.f - m) * r); }
+// (bn_ema lives in cvcl_common.h: shared with the finalize-on-load consumers)
 
 // moments != NULL: the batch mean / unbiased variance are written there ([2][C]) and the running statistics are left alone --
 // `bn_apply_moments_kernel` applies them later (cvcl_resnext50_fwd_deferred_stats: passes pipelined on two streams).
@@ -88,6 +90,19 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     }
     if (!moments && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
 }
+
+// ---- finalize-on-load (round 6; BnSrc / bn_slice_affine in cvcl_common.h) ---------------------------------------------------------------
+// bn_finalize is a 5 us kernel of dependent L2 round trips between a convolution and the consumer of its output: 45 launches per
+// pass, each with two kernel boundaries on the trunk's dependent chain.  Where the consumer's workgroups normalise a FIXED set of
+// channels -- the grouped 3x3's 64-channel slabs (BN1 of all 16 Bottlenecks), the Gram launch's K <= 256 operand columns (BN2 of
+// layers 1-2) -- the producing convolution ACCUMULATES its partial sums instead of writing partial rows (int64 fixed point, one row
+// per XCD: order-independent = deterministic) and the consumer forms its channels' (scale, shift) in its prologue: one round trip of
+// 16 independent loads per channel, no launch; the workgroup with ``publish`` set also leaves the batch moments / running statistics
+// (and the affine, for later readers) behind.  61 -> 38 launches of the bn_finalize class per pass; one pass in flight 5.66 -> 5.46 ms
+// per C2 step, two passes in flight unchanged (the other pass already ran in those gaps) -- profiles/r06_fol_ab.txt, which also holds
+// what was measured and dropped: partial ROWS reduced redundantly in every consumer workgroup (bit-identical to bn_finalize, but 3-8 us
+// of dependent loads and an ordered fp64 chain inside every consumer: no gain), and channel-sliced 1024-thread forms of the
+// elementwise passes of layers 3-4 finalizing BN2 / BN3 on load (18 launches left, but 2-3 us more per pass than the launch saved).
 
 // deferred running-statistics update of the whole trunk: all 53 layers in one launch, from the moments a pass left behind
 struct ApplyMomentsAll {
@@ -702,6 +717,8 @@ struct GconvDev {
     const float* centre;            // storage centre of the output (NULL = 0): the accumulators start at -centre[channel]
     int B, H, W, C, cg, stride, Ho, Wo, TH, bands, rows_in;
     float act_floor; // 0 = ReLU after the affine; -inf = none (a_scale == NULL: plain convolution of x, used by the data gradient)
+    BnSrc src;       // src.acc != NULL: the input's BatchNorm affine is formed here from its producer's accumulators (finalize-on-load)
+    int stats_acc;   // stats is an int64 accumulator [8][2][C] (cvcl_common.h), not partial rows
 };
 // Phase ablation for timing studies is a BUILD option (no run-time flag in the loop: the per-slot tests it needed cost branches in
 // every work item): -DCVCL_GCONV_ABLATE=<bits>, 1 skip the BN math, 2 skip the MFMA loop (and the stores), 4 skip the stores,
@@ -734,11 +751,25 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
     // staging role: 8 chunks (of 8 channels) per pixel, 32 pixels per pass
     const int s_chunk = tid & 7, s_pix0 = tid >> 3;
     f32x2 sc[4], sh[4];                                           // (channel pairs: the staging math runs on packed fp32)
+    if (p.src.acc) {
+        // finalize-on-load: this slab's 64 input channels from the producing convolution's accumulators (the band buffers are not
+        // in use yet); the workgroups of grid column 0 publish the moments
+        float* aff = reinterpret_cast<float*>(smem);
+        bn_slice_affine<GC_CS>(p.src, c0, blockIdx.x == 0, aff, aff + 64);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int ch = c0 + s_chunk * 8 + 2 * e;
-        sc[e] = p.a_scale ? f32x2{p.a_scale[ch], p.a_scale[ch + 1]} : f32x2{1.f, 1.f};
-        sh[e] = p.a_scale ? f32x2{p.a_shift[ch], p.a_shift[ch + 1]} : f32x2{0.f, 0.f};
+        for (int e = 0; e < 4; ++e) {
+            const int cl = s_chunk * 8 + 2 * e;
+            sc[e] = f32x2{aff[cl], aff[cl + 1]};
+            sh[e] = f32x2{aff[64 + cl], aff[64 + cl + 1]};
+        }
+        __syncthreads();                                          // (the band staging below overwrites the scratch)
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = c0 + s_chunk * 8 + 2 * e;
+            sc[e] = p.a_scale ? f32x2{p.a_scale[ch], p.a_scale[ch + 1]} : f32x2{1.f, 1.f};
+            sh[e] = p.a_scale ? f32x2{p.a_shift[ch], p.a_shift[ch + 1]} : f32x2{0.f, 0.f};
+        }
     }
     const bool relu_in = p.act_floor == 0.f;                      // (-inf: no activation -- the data-gradient use)
     f32x2 ssum[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}}, ssq[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};     // (channel pairs: packed fp32)
@@ -904,8 +935,7 @@ __global__ __launch_bounds__(256, WIDE ? 2 : 3) void gconv_mfma_kernel(GconvDev 
         for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
         if (pix == 0 && p.stats) {
             const int ch = c0 + wave * 16 + kb * 4 + e;
-            p.stats[((long)blockIdx.x * 2 + 0) * p.C + ch] = s;
-            p.stats[((long)blockIdx.x * 2 + 1) * p.C + ch] = q;
+            cvcl_bn_stats_out(p.stats, p.stats_acc, blockIdx.x, p.C, ch, s, q);
         }
     }
 }
@@ -1380,11 +1410,17 @@ extern "C" int cvcl_gconv3x3_stats_rows(int dtype, int B, int H, int W, int C, i
     return cvcl_col_stats_rows((long)B * Ho * Wo);
 }
 
-extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed,
-                             void* y, float* stats, int stats_rows, const float* centre, int B, int H, int W, int C, int groups,
-                             int stride, void* stream) {
+// src != NULL (bf16 only, internal: the trunk's launch sequence): the input's BatchNorm affine comes from its producer's partial
+// rows inside the kernel (finalize-on-load) instead of from a_scale / a_shift
+static int gconv3x3_impl(int dtype, const void* x, const float* a_scale, const float* a_shift, const BnSrc* src, const void* w_packed,
+                         void* y, float* stats, int stats_rows, const float* centre, int B, int H, int W, int C, int groups,
+                         int stride, void* stream) {
     CVCL_CHECK_ARG(x && w_packed && y && (!a_scale == !a_shift), "cvcl_gconv3x3: null pointer");
-    const float act_floor = a_scale ? 0.f : -INFINITY;
+    CVCL_CHECK_ARG(!src || (dtype == CVCL_BF16 && src->acc && src->gamma && src->beta && src->C == C && src->count > 0 &&
+                            (const void*)src->acc != (const void*)stats),
+                   "cvcl_gconv3x3: finalize-on-load source");
+    CVCL_CHECK_ARG(stats_rows != CVCL_STATS_ACCUMULATE || dtype == CVCL_BF16, "cvcl_gconv3x3: accumulators exist for bf16 only");
+    const float act_floor = (a_scale || src) ? 0.f : -INFINITY;
     CVCL_CHECK_ARG(B > 0 && (stride == 1 || stride == 2) && groups > 0 && C % groups == 0, "cvcl_gconv3x3: bad shape");
     const int cg = C / groups;
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -1395,12 +1431,18 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
         const GconvPlan g = gconv_plan(B, H, W, C, stride);
         CVCL_CHECK_ARG(g.lds <= 160 * 1024 && g.rows_in * (W + 2) <= 10 * 32 && g.TH * ((W - 1) / stride + 1) <= 128,
                        "cvcl_gconv3x3: feature map too wide for one staged band (%zu B, %d pixels)", g.lds, g.rows_in * (W + 2));
-        CVCL_CHECK_ARG(!stats || stats_rows >= g.grid_x, "cvcl_gconv3x3: stats_rows %d < %d", stats_rows, g.grid_x);
+        CVCL_CHECK_ARG(!stats || stats_rows == CVCL_STATS_ACCUMULATE || stats_rows >= g.grid_x, "cvcl_gconv3x3: stats_rows %d < %d", stats_rows, g.grid_x);
         GconvDev d;
         d.x = x; d.a_scale = a_scale; d.a_shift = a_shift; d.w = w_packed; d.y = y; d.stats = stats; d.centre = centre;
         d.B = B; d.H = H; d.W = W; d.C = C; d.cg = cg; d.stride = stride; d.Ho = Ho; d.Wo = Wo;
         d.TH = g.TH; d.bands = g.bands; d.rows_in = g.rows_in;
         d.act_floor = act_floor;
+        d.src = BnSrc{};
+        d.stats_acc = stats && stats_rows == CVCL_STATS_ACCUMULATE;
+        if (src) {
+            CVCL_CHECK_ARG(g.lds >= 2048, "cvcl_gconv3x3: band buffers smaller than the finalize-on-load scratch");
+            d.src = *src;
+        }
         CvclProfScope prof(stream, CVCL_K_GCONV);
         int rc;
         const int slots = cvcl_div_up(g.rows_in * (W + 2), 32);
@@ -1471,6 +1513,12 @@ extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, con
     CVCL_LAUNCH_CHECK();
     if (stats) return cvcl_col_stats(CVCL_F32, y, (long)B * Ho * Wo, C, stats, stats_rows, stream);
     return CVCL_OK;
+}
+
+extern "C" int cvcl_gconv3x3(int dtype, const void* x, const float* a_scale, const float* a_shift, const void* w_packed,
+                             void* y, float* stats, int stats_rows, const float* centre, int B, int H, int W, int C, int groups,
+                             int stride, void* stream) {
+    return gconv3x3_impl(dtype, x, a_scale, a_shift, nullptr, w_packed, y, stats, stats_rows, centre, B, H, W, C, groups, stride, stream);
 }
 
 extern "C" int cvcl_bn_add_relu(int dtype, const void* raw, const float* scale, const float* shift, const void* idn,
@@ -1547,7 +1595,7 @@ inline size_t act_elems(int B, int H, int W) {
 extern "C" size_t cvcl_resnext50_workspace_bytes(int dtype, int B, int H, int W) {
     const size_t es = dtype == CVCL_BF16 ? 2 : 4;
     return 5 * al256(act_elems(B, H, W) * es) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)53 * 2 * 2048 * 4) +
-           al256((size_t)53 * 2048 * 4) + al256(cvcl_conv1x1_gram_workspace_bytes(256));
+           al256((size_t)53 * 2048 * 4) + al256(cvcl_conv1x1_gram_workspace_bytes(256)) + al256(53 * kTrunkAccLayer * 8);
 }
 
 extern "C" size_t cvcl_resnext50_centres_floats(void) { return (size_t)53 * 2048; }
@@ -1565,7 +1613,9 @@ struct BlockCtx {
     float* stats;
     void* gram_ws;                   // cvcl_conv1x1_gram workspace (K = 256)
     void* stream;
+    long long* acc;                  // BatchNorm accumulators of the block's layers [n_layers][8][2][2048], zeroed for this pass; or NULL
 };
+constexpr size_t kAccLayer = kTrunkAccLayer;
 
 // cen = the block's storage centres ([n_layers][2048] floats, "Centred storage" in cvcl_hip.h) or NULL
 int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, const char* X, char* R1, char* R2, char* R3, char* RD,
@@ -1587,6 +1637,7 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     //  launches are skipped and the consumers read the (scale, shift) of an earlier pass; only meaningful on a repeated batch]
     static const int skip_after = cvcl_lab_int("CVCL_SKIP_FINALIZE_AFTER", 0);
     static long finalize_calls = 0;
+    const int stats_cap = kMaxStatsRows;
     auto finalize = [&](int l, int rows, long count, int C) -> int {
         if (skip_after > 0 && ++finalize_calls > skip_after) return CVCL_OK;
         if (training)
@@ -1595,6 +1646,21 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
                                       mom ? mom + (size_t)l * 4096 : nullptr, 2048, centre_of(l), stream);
         return CVCL_OK;                                   // eval mode: every layer's affine was produced up front
     };
+    // finalize-on-load (csrc/resnext.hip "finalize-on-load"): layer l's convolution ACCUMULATES its statistics into acc_of(l) and the
+    // consumer of its raw output forms the affine itself -- no cvcl_bn_finalize launch for that layer
+    auto acc_of = [&](int l) { return c.acc + (size_t)l * kAccLayer; };
+    auto bn_src = [&](int l, long count, int C) {
+        BnSrc b;
+        b.acc = acc_of(l); b.C = C; b.count = (double)count;
+        b.gamma = L[l].gamma; b.beta = L[l].beta; b.centre = centre_of(l);
+        b.running_mean = L[l].running_mean; b.running_var = L[l].running_var; b.nbt = L[l].num_batches_tracked;
+        b.momentum = c.momentum; b.eps = c.eps;
+        b.moments = mom ? mom + (size_t)l * 4096 : nullptr; b.moments_ld = 2048;
+        b.scale_out = scale_of(l); b.shift_out = shift_of(l);
+        return b;
+    };
+    static const bool fol_on = cvcl_env_on("CVCL_FINALIZE_ON_LOAD");               // (0: partial rows + a bn_finalize launch per layer)
+    const bool use_acc = fol_on && c.acc && training && dtype == CVCL_BF16 && skip_after == 0;
     // (which forms this block takes -- the explanations sit at the launches below)
     static const int pro_stages = cvcl_lab_int("CVCL_CONV3_PRO_STAGES", 2);
     const bool pro = dtype == CVCL_BF16 && stage < pro_stages && (width == 128 || width == 256);
@@ -1603,10 +1669,11 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     static const bool ds_recompute_on = cvcl_lab_int("CVCL_DS_RECOMPUTE", 1) != 0 && cvcl_env_on("CVCL_GEMM_PRO");
     const bool ds_recompute = ds_recompute_on && first && stride == 1 && inplanes == 64 && fused_tail && pro && width == 128;
     static const bool gram_on = cvcl_lab_int("CVCL_BN_GRAM", 1) != 0;
-    auto gram_stats = [&](int l, const void* A, int K, const float* a_scale, const float* a_shift, int a_relu) -> int {
+    auto gram_stats = [&](int l, const void* A, int K, const float* a_scale, const float* a_shift, int a_relu, const BnSrc* src = nullptr) -> int {
         if (skip_after > 0 && ++finalize_calls > skip_after) return CVCL_OK;          // [lab: the Gram launches go as well]
         const double* g = nullptr;
-        int r = cvcl_conv1x1_gram(A, K, m_out, K, a_scale, a_shift, a_relu, c.gram_ws, cvcl_conv1x1_gram_workspace_bytes(256), &g, stream);
+        int r = cvcl_conv1x1_gram_src(A, K, m_out, K, src ? nullptr : a_scale, src ? nullptr : a_shift, src, a_relu, c.gram_ws,
+                                      cvcl_conv1x1_gram_workspace_bytes(256), &g, stream);
         if (r) return r;
         return cvcl_bn_from_gram(g, K, m_out, L[l].w, K, outc, L[l].gamma, L[l].beta, L[l].running_mean, L[l].running_var,
                                  L[l].num_batches_tracked, c.momentum, c.eps, scale_of(l), shift_of(l), mom ? mom + (size_t)l * 4096 : nullptr,
@@ -1618,6 +1685,12 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // pass (gemm_pro.hip PRO_TAIL_DS) instead of being written to HBM (411 MB at B = 256) and read back; its own launch shrinks to a
     // Gram launch for its BN statistics (train mode) or disappears (eval mode).  $CVCL_DS_RECOMPUTE=0: the stored form.
     const bool ds_gram = ds_recompute && training && gram_on;
+    // BN2 of layers 1-2: formed by the Gram launch (the first reader of relu(bn2(.)); it publishes the affine for the tail pass behind
+    // it).  (Layers 3-4 keep partial rows + cvcl_bn_finalize for BN2 / BN3 / the downsample BatchNorm: their consumers are elementwise
+    // passes whose workgroups touch every channel.  Re-blocked into channel-sliced 1024-thread workgroups that finalize on load they
+    // cost 2-3 us more per launch than the launch they save once two passes overlap: profiles/r06_fol_ab.txt.)
+    static const int fol_gram_lab = cvcl_lab_int("CVCL_FOL_GRAM", 1);                // [lab: 0 = BN2 of layers 1-2 keeps its finalize launch]
+    const bool fol2 = use_acc && fused_tail && pro && gram_on && fol_gram_lab != 0;
     if (first) {
         if (ds_gram) {
             if ((rc = gram_stats(ld, X, inplanes, nullptr, nullptr, 0))) return rc;
@@ -1627,26 +1700,37 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
             a.A = X; a.W = L[ld].w; a.C = ds_recompute ? nullptr : RD;
             a.M = (int)m_out; a.N = outc; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = outc;
             if (stride > 1) { a.gather_ho = ho; a.gather_wo = wo; a.gather_hi = h; a.gather_wi = wd; a.gather_stride = stride; }
-            a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+            a.stats = training ? stats : nullptr; a.stats_rows = stats_cap;
             a.centre = centre_of(ld);
             if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
             if ((rc = finalize(ld, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
         }
     }
     // conv1 1x1: X [m_in, inplanes] -> R1 [m_in, width]
+    int rows1 = 0;
+    static const int fol1_lab = cvcl_lab_int("CVCL_FOL_CONV1", 1);                   // [lab: 0 = BN1 keeps its finalize launch]
+    const bool fol1 = use_acc && fol1_lab != 0;
     {
         cvcl_gemm_args a = {};
         a.A = X; a.W = L[l1].w; a.C = R1;
         a.M = (int)m_in; a.N = width; a.K = inplanes; a.lda = inplanes; a.ldw = inplanes; a.ldc = width;
-        a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+        a.stats = training ? (fol1 ? (float*)acc_of(l1) : stats) : nullptr;
+        a.stats_rows = fol1 ? CVCL_STATS_ACCUMULATE : stats_cap;
         a.centre = centre_of(l1);
         if ((rc = cvcl_gemm(dtype, &a, stream))) return rc;
-        if ((rc = finalize(l1, cvcl_gemm_stats_rows(dtype, &a), m_in, width))) return rc;
+        rows1 = training ? cvcl_gemm_stats_rows(dtype, &a) : 0;
     }
+    // BN1's statistics -> affine: inside conv2's prologue (every workgroup of the grouped convolution normalises one fixed slab of
+    // 64 channels: 16 accumulator loads per channel)
+    if (!fol1 && (rc = finalize(l1, rows1, m_in, width))) return rc;
     // conv2 grouped 3x3 (stride here): R1 -> R2 [m_out, width], BN1+ReLU fused into the load
-    if ((rc = cvcl_gconv3x3(dtype, R1, scale_of(l1), shift_of(l1), L[l2].w, R2, training ? stats : nullptr,
-                            kMaxStatsRows, centre_of(l2), B, h, wd, width, 32, stride, stream))) return rc;
-    if ((rc = finalize(l2, cvcl_gconv3x3_stats_rows(dtype, B, h, wd, width, stride), m_out, width))) return rc;
+    {
+        const BnSrc src1 = fol1 ? bn_src(l1, m_in, width) : BnSrc{};
+        if ((rc = gconv3x3_impl(dtype, R1, fol1 ? nullptr : scale_of(l1), fol1 ? nullptr : shift_of(l1), fol1 ? &src1 : nullptr, L[l2].w, R2,
+                                training ? (fol2 ? (float*)acc_of(l2) : stats) : nullptr, fol2 ? CVCL_STATS_ACCUMULATE : stats_cap,
+                                centre_of(l2), B, h, wd, width, 32, stride, stream))) return rc;
+    }
+    if (!fol2 && (rc = finalize(l2, training ? cvcl_gconv3x3_stats_rows(dtype, B, h, wd, width, stride) : 0, m_out, width))) return rc;
     // conv3 1x1: relu(bn2(R2)) -> R3 [m_out, outc].  Layers 1-2 (K = width <= 256, bandwidth-bound): BN2 + ReLU rides conv3's
     // operand load (gemm_pro.hip: applied once per element, W resident in registers) -- no pass of its own over the tensor.
     // Layers 3-4 (MFMA-bound, 4-8 column-tile workgroups per A tile): BN2 + ReLU is applied in place first (one pass over the
@@ -1673,11 +1757,12 @@ int bottleneck_fwd(const BlockCtx& c, int stage, bool first, int h, int wd, cons
     // of the operand (bn_gram.hip: sum y = w.s, sum y^2 = w^T G w -- one read of the narrow tensor, K <= 256 <= N / 2) instead of
     // a statistics-only run of the whole GEMM.  [lab: CVCL_BN_GRAM=0 the statistics-only pass]
     if (fused_tail && training && pro && gram_on) {
-        if ((rc = gram_stats(l3, R2, width, scale_of(l2), shift_of(l2), 1))) return rc;
+        const BnSrc s2 = fol2 ? bn_src(l2, m_out, width) : BnSrc{};
+        if ((rc = gram_stats(l3, R2, width, scale_of(l2), shift_of(l2), 1, fol2 ? &s2 : nullptr))) return rc;
     } else if (!fused_tail || training) {
         cvcl_gemm_args a = conv3_args();
         a.C = fused_tail ? nullptr : R3;
-        a.stats = training ? stats : nullptr; a.stats_rows = kMaxStatsRows;
+        a.stats = training ? stats : nullptr; a.stats_rows = stats_cap;
         if (a.C || a.stats) { if ((rc = cvcl_gemm(dtype, &a, stream))) return rc; }
         if ((rc = finalize(l3, a.stats ? cvcl_gemm_stats_rows(dtype, &a) : 0, m_out, outc))) return rc;
     } else {
@@ -1714,7 +1799,7 @@ inline size_t block_act_bytes(int dtype, int B, int h, int w, int stage) {
 
 extern "C" size_t cvcl_resnext50_block_workspace_bytes(int dtype, int B, int h, int w, int stage) {
     return 3 * block_act_bytes(dtype, B, h, w, stage) + al256((size_t)kMaxStatsRows * 2 * 2048 * 4) + al256((size_t)4 * 4096 * 4) +
-           al256(cvcl_conv1x1_gram_workspace_bytes(256));
+           al256(cvcl_conv1x1_gram_workspace_bytes(256)) + al256(4 * kAccLayer * 8);
 }
 
 extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stage, int first, int training, const void* x_nhwc,
@@ -1733,7 +1818,13 @@ extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stag
     char* R1 = p; char* R2 = p + ab; char* RD = p + 2 * ab; p += 3 * ab;
     float* stats = (float*)p; p += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
     float* aff = (float*)p; p += al256((size_t)4 * 4096 * 4);
-    void* gram_ws = p;
+    void* gram_ws = p; p += al256(cvcl_conv1x1_gram_workspace_bytes(256));
+    long long* acc = (long long*)p;
+    if (training && dtype == CVCL_BF16 &&
+        hipMemsetAsync(acc, 0, (size_t)n_layers * kAccLayer * 8, (hipStream_t)stream) != hipSuccess) {
+        cvcl_set_error("cvcl_resnext50_block_fwd: cannot clear the BatchNorm accumulators");
+        return CVCL_ELAUNCH;
+    }
     if (!training) {                                      // eval mode: affines from the running statistics
         const int planes = 64 << stage;
         const int Cs[4] = {planes * 2, planes * 2, planes * 4, planes * 4};
@@ -1744,7 +1835,7 @@ extern "C" int cvcl_resnext50_block_fwd(int dtype, int B, int h, int w, int stag
             if (rc) return rc;
         }
     }
-    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, stream};
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, stream, (training && dtype == CVCL_BF16) ? acc : nullptr};
     return bottleneck_fwd(ctx, stage, first != 0, h, w, (const char*)x_nhwc, R1, R2, R1, RD, (char*)out_nhwc, layers, aff, nullptr,
                           centres);
 }
@@ -1768,7 +1859,13 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     float* stats = (float*)w; w += al256((size_t)kMaxStatsRows * 2 * 2048 * 4);
     float* affine = (float*)w; w += al256((size_t)53 * 2 * 2048 * 4);
     float* eval_centres = (float*)w; w += al256((size_t)53 * 2048 * 4);   // eval mode without caller centres: the running means (see below)
-    void* gram_ws = w;
+    void* gram_ws = w; w += al256(cvcl_conv1x1_gram_workspace_bytes(256));
+    // BatchNorm accumulators of the 53 layers (bf16 train mode: finalize-on-load), cleared once per pass ahead of the stem
+    long long* acc = (training && dtype == CVCL_BF16) ? (long long*)w : nullptr;
+    if (acc && hipMemsetAsync(acc, 0, 53 * kTrunkAccLayer * 8, (hipStream_t)stream) != hipSuccess) {
+        cvcl_set_error("cvcl_resnext50_fwd: cannot clear the BatchNorm accumulators");
+        return CVCL_ELAUNCH;
+    }
     int rc, li = 0;
 
     // (scale, shift) of layer l live at affine + l * 4096
@@ -1830,12 +1927,13 @@ static int resnext50_fwd_impl(int dtype, int B, int H, int W, int training, cons
     }
     h /= 2; wd /= 2;
     li = 1;
-    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, stream};
+    BlockCtx ctx = {dtype, B, training, momentum, eps, stats, gram_ws, stream, nullptr};
     for (int stage = 0; stage < 4; ++stage) {
         for (int bi = 0; bi < kLayers[stage]; ++bi) {
             const int stride = (stage > 0 && bi == 0) ? 2 : 1;
             const bool last = (stage == 3 && bi == kLayers[3] - 1);
             char* dst = last ? (char*)layer4_out_nhwc : OUT;
+            ctx.acc = acc ? acc + (size_t)li * kTrunkAccLayer : nullptr;
             if ((rc = bottleneck_fwd(ctx, stage, bi == 0, h, wd, X, buf[2], buf[3], buf[2], buf[4], dst, layers + li,
                                      affine + (size_t)li * 4096, moments ? moments + (size_t)li * 4096 : nullptr,
                                      centres ? centres + (size_t)li * 2048 : nullptr))) return rc;

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcvcl_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 PACK_DENSE, PACK_STEM7, PACK_GCONV3 = 0, 1, 2
 KERNEL_CLASSES = ("gemm", "gconv3x3", "stem7x7", "bn_finalize", "bn_add_relu", "bn_relu_maxpool", "avgpool", "head",
                   "other", "attention", "layernorm", "lstm", "gemm_f32", "bn_relu_apply", "bn_bwd", "wgrad", "gemm8w", "gemm_pro")
@@ -367,7 +367,7 @@ def cvcl_dtype(t: torch.dtype) -> int:
 def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None, a_shift=None, a_relu=False,
          exp_scale=None, gather=None, stats=None, M=None, lda=None, pre_out=None, gelu_grad_of=None, centre=None,
          ln_stats=None, ln_colsum=None, row_part=None, query_ln=False, a_trans=False, w_trans=False, a_rowsum=None,
-         split=False):
+         split=False, stats_acc=None):
     """C = act(A' W^T * exp(*exp_scale) + bias) (+ residual).  A [M,K], W [N,K] row-major, same dtype.
     ``centre`` [N] f32 (convolution epilogues): C = round(A' W^T - centre), statistics of that (cvcl_hip.h "Centred storage").
     fp32 only: ``a_trans`` -- A is given as [K, M]; ``w_trans`` -- W is given as [K, N] (the operands of a gradient GEMM as they
@@ -401,6 +401,10 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
         a.R, a.ldr = ptr(residual), N
     if stats is not None:
         a.stats, a.stats_rows = ptr(stats, torch.float32), stats.shape[0]
+    if stats_acc is not None:                             # int64 [8, 2, N], zeroed by the caller: statistics ACCUMULATED (cvcl_hip.h)
+        if stats is not None or stats_acc.dtype != torch.int64 or tuple(stats_acc.shape) != (8, 2, N) or not stats_acc.is_contiguous():
+            raise CvclError("stats_acc: a contiguous int64 [8, 2, N] accumulator (and no stats rows)")
+        a.stats, a.stats_rows = stats_acc.data_ptr(), STATS_ACCUMULATE
     if pre_out is not None:                               # act = GELU: also keep the pre-activation
         a.C_pre = ptr(pre_out, A.dtype)
     if gelu_grad_of is not None:                          # C = (A W^T) * gelu'(gelu_grad_of)
@@ -412,6 +416,9 @@ def gemm(A, W, out=None, *, bias=None, act=ACT_NONE, residual=None, a_scale=None
         return bool(lib().cvcl_gemm_ln_supported(C.byref(a)))
     check(lib().cvcl_gemm(dt, C.byref(a), stream_ptr()), "cvcl_gemm")
     return out
+
+
+STATS_ACCUMULATE = -1          # cvcl_hip.h CVCL_STATS_ACCUMULATE
 
 
 def gemm_grid_m(dtype: int, M: int, N: int, has_prologue: bool = False) -> int:
