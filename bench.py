@@ -42,7 +42,7 @@ EMBEDDING_DIM = 512
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled MFMA)
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 WORKLOADS = {
     "c2": "C2 = BASELINE configs[1]: CVCL saycam_contrastive, frozen random-init ResNeXt-50 32x4d (BN train mode) + embedding "
@@ -479,7 +479,7 @@ def static_traffic(kernel_name):
     """PMC L2 <-> fabric bytes per launch of one kernel from the tracked summary of separate rocprofv3 --pmc passes of this
     command (tools/pmc_bench.sh + tools/pmc_summary.py; FETCH_SIZE x2 gfx950 correction + WRITE_SIZE).  STATIC: collected on an
     earlier box of this round, not in the run that prints the line.  -> (bytes per launch | None, source)."""
-    for rnd in (PROFILE_ROUND, "r04", "r03", "r02"):
+    for rnd in (PROFILE_ROUND, "r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.json")
         try:
             with open(path) as f:
@@ -495,7 +495,7 @@ def static_traffic_vit(cfg):
     """The same for the ViT configurations: HBM bytes per launch averaged over the trunk's GEMM launches (the bf16 8-wave kernel, or
     the two e4m3 kernels), from the tracked per-kernel summary of tools/pmc_cfg.sh <cfg> (FETCH_SIZE x 2 + WRITE_SIZE; STATIC).
     -> (bytes per launch | None, source)."""
-    for rnd in (PROFILE_ROUND, "r04"):
+    for rnd in (PROFILE_ROUND, "r05", "r04"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_{cfg}_summary.json")
         try:
             with open(path) as f:
@@ -650,7 +650,7 @@ def measure(cfg, precision, batch_size, steps, warmup, device, world, rank, *, r
         if batch_size == PER_GPU_BATCH:
             # the bytes the step ACTUALLY moves (PMC, static summary of the same command at this batch) against the same clock:
             # what fraction of the HBM peak the whole step sustains on its real traffic
-            for rnd in (PROFILE_ROUND, "r04"):
+            for rnd in (PROFILE_ROUND, "r05", "r04"):
                 try:
                     with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_traffic.json")) as f:
                         gb = json.load(f)["trunk_total"]["total_GB"]

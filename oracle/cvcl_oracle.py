@@ -23,7 +23,11 @@ Pinning status
   ``ResNet(Bottleneck, [3,4,6,3], groups=32, width_per_group=4)`` definition (v1.5:
   stride on the 3x3) and is anchored on the reference's call sites
   (``multimodal/multimodal.py:96-102,155-158,192``; ``multimodal/utils.py:207-209``),
-  the 25 028 904-parameter / 4.23 GMAC counts and self-consistency tests.
+  the 25 028 904-parameter / 4.23 GMAC counts and self-consistency tests.  Second anchor
+  (round 6): with groups = 1 these functions are ResNet-50 v1.5 and agree with the
+  independent ``transformers.ResNetModel`` on the same weights to 1e-9 in float64
+  (``tests/test_oracle_resnet_anchor.py``: wiring, strides, BatchNorm train / eval
+  semantics) -- the ``groups = 32`` keyword and the widths are what stays unpinned.
 
 ``quant`` argument: ``None`` keeps everything fp32 (the reference numerics).  Passing
 ``bf16_round`` emulates the storage points of the HIP bf16 path (operands and stored
