@@ -183,10 +183,20 @@ __device__ inline float block_max(float v, float* scratch) {
 constexpr int kBnAccRows = 8;
 constexpr double kBnAccScale = 16777216.0;                  // 2^24
 __device__ __forceinline__ int cvcl_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; }     // HW_REG_XCC_ID[3:0]
+// A partial that is not finite, or beyond 2^28 in magnitude (a workgroup's sum over ~3000 stored bf16 values: activations of ~300 rms),
+// cannot be represented: it POISONS the channel instead -- the sum-of-squares accumulator is raised to 2^62 (atomic max; the legitimate
+// adds of <= 1024 workgroups stay below that), which the consumer turns into a NaN affine, exactly what cvcl_bn_finalize produces from
+// a non-finite partial row: a diverged run fails as loudly in either form.
+constexpr long long kBnAccPoison = 1LL << 62;
+constexpr float kBnAccMaxPartial = 268435456.f;             // 2^28
 __device__ __forceinline__ void cvcl_bn_acc_add(float* stats_as_acc, int N, int n, float s, float q) {
     long long* row = reinterpret_cast<long long*>(stats_as_acc) + (long)cvcl_xcc_id() * 2 * N;
-    __hip_atomic_fetch_add(row + n, __double2ll_rn((double)s * kBnAccScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(row + N + n, __double2ll_rn((double)q * kBnAccScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fabsf(s) < kBnAccMaxPartial && fabsf(q) < kBnAccMaxPartial) {          // (false for NaN / inf)
+        __hip_atomic_fetch_add(row + n, __double2ll_rn((double)s * kBnAccScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(row + N + n, __double2ll_rn((double)q * kBnAccScale), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        __hip_atomic_fetch_max(row + N + n, kBnAccPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // one partial (s, q) of channel n from workgroup row `row`: a row store or an accumulator add
 __device__ __forceinline__ void cvcl_bn_stats_out(float* stats, int acc_mode, long row, int N, int n, float s, float q) {
@@ -226,12 +236,14 @@ __device__ __forceinline__ void bn_slice_affine(const BnSrc& b, int c0, bool pub
             v[2 * r + 1] = b.acc[((long)r * 2 + 1) * b.C + ch];
         }
         long long S = 0, Q = 0;
+        bool poisoned = false;
 #pragma unroll
-        for (int r = 0; r < kBnAccRows; ++r) { S += v[2 * r]; Q += v[2 * r + 1]; }
+        for (int r = 0; r < kBnAccRows; ++r) { S += v[2 * r]; Q += v[2 * r + 1]; poisoned |= v[2 * r + 1] >= kBnAccPoison || v[2 * r + 1] < 0; }
         const double s = (double)S * (1.0 / kBnAccScale), q = (double)Q * (1.0 / kBnAccScale);
         const double mean = s / b.count;
         double var = q / b.count - mean * mean;
         if (var < 0.0) var = 0.0;
+        if (poisoned) var = __builtin_nan("");                    // a non-finite / unrepresentable partial sum: NaN affine (cvcl_bn_acc_add)
         const float sc = b.gamma[ch] / sqrtf((float)var + b.eps);
         const float sh = b.beta[ch] - (float)mean * sc;
         sc_out[c] = sc;

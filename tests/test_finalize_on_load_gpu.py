@@ -86,3 +86,20 @@ def test_trunk_pass_with_accumulated_statistics_vs_the_finalize_launches(tmp_pat
     # the two forms round sums of ~1e5 terms differently (2^-24 fixed point vs float64 of fp32 partials): 1e-9 on an affine, a flipped
     # bf16 rounding now and then downstream
     assert worst["stats"] < 2e-3 and worst["features"] < 5e-2, worst
+
+
+def test_non_finite_statistics_stay_loud(H, dev):
+    """A partial sum that is not finite (or beyond what the fixed point holds) must not turn into plausible statistics: the channel's
+    accumulator is poisoned (>= 2^62), which ``bn_slice_affine`` turns into a NaN affine -- what cvcl_bn_finalize makes of a
+    non-finite row."""
+    M, N, K = 12544, 256, 512
+    g = torch.Generator().manual_seed(2)
+    A = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16)
+    W = torch.randint(-1, 2, (N, K), generator=g).to(torch.bfloat16)
+    A[100, 0] = float("inf")                                      # output row 100 is inf / NaN (inf x 0) in every column
+    acc = torch.zeros(8, 2, N, dtype=torch.int64, device=dev)
+    H.gemm(A.to(dev), W.to(dev), stats_acc=acc)
+    torch.cuda.synchronize()
+    poisoned = acc[:, 1, :] >= 2 ** 62
+    assert bool((poisoned.sum(dim=0) == 1).all())                 # every channel, in the row of the XCD whose workgroup met the inf, only there
+    assert int((acc[:, 1, :][~poisoned] < 0).sum()) == 0
