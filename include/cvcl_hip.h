@@ -213,7 +213,9 @@ int cvcl_gemm_stats_rows(int dtype, const cvcl_gemm_args* args);
 int cvcl_gemm8w(int epi, const cvcl_gemm_args* args, void* stream);
 /* The bandwidth-bound form cvcl_gemm selects when the operand carries the producer's BatchNorm + ReLU (a_scale / a_shift /
  * a_relu) and K = 128 | 256, N % 256 == 0 (conv3 of ResNeXt layers 1-2 on the raw grouped-convolution output: torchvision
- * Bottleneck.forward conv3(relu(bn2(.)))): statistics only (C NULL), C + statistics, or the Bottleneck tail (c_scale ...).    */
+ * Bottleneck.forward conv3(relu(bn2(.)))): statistics only (C NULL), C + statistics, or the Bottleneck tail (c_scale ...).
+ * Round 6: the first two epilogues also take the operand as stored (a_scale == a_shift == NULL); cvcl_gemm routes such a product
+ * here from 2^17 rows up (conv1 of ResNeXt layer2.0: K = 256, N = 256, M = 802 816 at B = 256).                            */
 int cvcl_gemm_pro(const cvcl_gemm_args* args, void* stream);
 int cvcl_gemm_pro_supported(const cvcl_gemm_args* args);
 int cvcl_gemm_pro_stats_rows(int M, int N);

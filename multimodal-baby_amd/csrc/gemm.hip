@@ -1200,6 +1200,9 @@ inline int pick_gemm8w(int dtype, const cvcl_gemm_args* a) {
 inline bool pick_gemm_pro(int dtype, const cvcl_gemm_args* a) {
     static const bool on = cvcl_env_on("CVCL_GEMM_PRO");
     if (!on || dtype != CVCL_BF16 || !cvcl_gemm_pro_supported(a)) return false;
+    // a plain operand takes this kernel only where it is a byte stream: M >= 2^17 rows of K <= 256 (conv1 of layer2.0 at B >= 64);
+    // smaller products stay on the tiled kernels
+    if (!a->a_scale && a->M < (1 << 17)) return false;
     return !a->stats || a->stats_rows == CVCL_STATS_ACCUMULATE || a->stats_rows >= cvcl_gemm_pro_stats_rows(a->M, a->N);
 }
 

@@ -82,11 +82,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
     constexpr bool AFF_LDS = KT == 8;
     float* in_aff = reinterpret_cast<float*>(smem + 2 * ABUF + 8 * 4096 + 6 * PN * 4);      // [2][K]
     char* x2buf = smem + 2 * ABUF + 8 * 4096 + 6 * PN * 4 + 2 * 256 * 4;                     // DS: [2][64 rows][128 B] staged X tiles
+    // plain operand (a_scale == NULL, round 6): A is multiplied as stored -- conv1 of layer2.0 (M = 802 816, K = 256, N = 256: 822 MB
+    // of traffic for 105 GFLOP) streams through this kernel 15 % faster than through the 128 x 128 direct-to-LDS kernel
+    // It runs the SAME instruction stream with scale 1, shift 0 and the ReLU floor at -32768 (x * 1 + 0 rounds back to x for every
+    // bf16 x): a branch around the staging math sits between the tile loads and their use, and the compiler then waits for ALL loads
+    // in flight before it (measured: this launch 215 us with the branch, 150 without; the tails slowed down with it).
+    const bool plain = p.a_scale == nullptr;
+    const short fl = plain ? (short)-32768 : (short)0;            // ReLU on rounded bf16 pairs = packed int16 max
+    const s16x2 floor2 = s16x2{fl, fl};
     f32x2 sc[4], sh[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { sc[e] = f32x2{1.f, 1.f}; sh[e] = f32x2{0.f, 0.f}; }
     if constexpr (AFF_LDS) {
-        if (tid < K) { in_aff[tid] = p.a_scale[tid]; in_aff[K + tid] = p.a_shift[tid]; }
+        if (tid < K) { in_aff[tid] = plain ? 1.f : p.a_scale[tid]; in_aff[K + tid] = plain ? 0.f : p.a_shift[tid]; }
         __syncthreads();
-    } else {
+    } else if (!plain) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             sc[e] = f32x2{p.a_scale[s_c * 8 + 2 * e], p.a_scale[s_c * 8 + 2 * e + 1]};
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pro_kernel(ProDev p) {
             for (int e = 0; e < 4; ++e) {
                 // round(relu(y)) = relu(round(y)): the ReLU is one packed integer max on the rounded pair (relu2)
                 const unsigned y = round2(__builtin_elementwise_fma(widen2(araw[slot][i][e]), sc[e], sh[e]));
-                v[e] = relu2(y);
+                v[e] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, y), floor2));
             }
             *reinterpret_cast<u32x4*>(dst + r * PITCH + ((s_c ^ (r & 15)) << 4)) = v;
         }
@@ -438,10 +448,13 @@ int pro_launch(const ProDev& d, dim3 grid, hipStream_t stream) {
 
 }  // namespace
 
-// the cvcl_gemm argument blocks this kernel takes: bf16, BN + ReLU operand prologue, K = 128 | 256, N % 256 == 0, and one of
-// {statistics only, C + statistics, Bottleneck tail (c_scale / c_shift + residual)}
+// the cvcl_gemm argument blocks this kernel takes: bf16, BN + ReLU operand prologue (or, for the first two epilogues, the operand
+// as stored), K = 128 | 256, N % 256 == 0, and one of {statistics only, C + statistics, Bottleneck tail (c_scale / c_shift + residual)}
 extern "C" int cvcl_gemm_pro_supported(const cvcl_gemm_args* a) {
-    if (!a || !a->a_scale || !a->a_shift || !a->a_relu) return 0;
+    if (!a) return 0;
+    const bool plain = !a->a_scale && !a->a_shift;        // round 6: A as stored (no tail epilogue, no recomputed downsample)
+    if (!plain && (!a->a_scale || !a->a_shift || !a->a_relu)) return 0;
+    if (plain && (a->c_scale || a->A2 || a->W2)) return 0;
     if ((a->K != 128 && a->K != 256) || a->N % PN != 0 || a->M < 1) return 0;
     if (a->lda % 8 || a->ldw % 8 || (a->C && a->ldc % 8) || a->gather_stride > 1 || a->exp_scale || a->bias || a->C_pre || a->G) return 0;
     auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };

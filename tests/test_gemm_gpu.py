@@ -414,6 +414,36 @@ def _gemm_args(H, A, W, C=None, stats=None, a_scale=None, a_shift=None, c_scale=
     return a
 
 
+@pytest.mark.parametrize("M,N,K", [(200704, 256, 256), (131073, 512, 128), (802816, 256, 256)])
+def test_gemm_pro_plain_operand_streams_conv1_of_layer2(dev, M, N, K):
+    """Round 6: a plain bf16 product with K = 128 | 256, N % 256 == 0 and M >= 2^17 rows (conv1 of ResNeXt layer2.0 at B = 256 is the
+    last shape: reference torchvision Bottleneck.conv1 reached from multimodal/multimodal.py:101) is routed to the W-in-registers
+    streaming kernel of gemm_pro.hip with the operand multiplied as stored.  Integer operands: output and column statistics exact,
+    partial rows and accumulators alike (below 2^17 rows the dispatcher keeps the tiled kernels)."""
+    import ctypes as Cc
+    from multimodal import _hip as H
+    g = torch.Generator().manual_seed(M % 977 + N + K)
+    A = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16).to(dev)
+    W = torch.randint(-1, 2, (N, K), generator=g).to(torch.bfloat16).to(dev)
+    probe = _gemm_args(H, A, W, torch.empty(1, device=dev), torch.empty(1, 2, N, device=dev))
+    assert H.lib().cvcl_gemm_pro_supported(Cc.byref(probe)) == 1
+    rows = H.gemm_stats_rows(H.BF16, M, N, K)
+    assert rows == H.lib().cvcl_gemm_pro_stats_rows(M, N), "shape not routed to the streaming kernel"
+    st = torch.full((rows, 2, N), float("nan"), device=dev)
+    C = H.gemm(A, W, stats=st)
+    acc = torch.zeros(8, 2, N, dtype=torch.int64, device=dev)
+    C2 = H.gemm(A, W, stats_acc=acc)
+    torch.cuda.synchronize()
+    step = 65536
+    for i0 in range(0, M, step):                              # (float64 reference in slices: 800 k x 256 doubles at a time)
+        ref = (A[i0:i0 + step].double() @ W.double().t()).float().to(torch.bfloat16)
+        assert torch.equal(C[i0:i0 + step], ref) and torch.equal(C2[i0:i0 + step], ref)
+    cd = C.double()
+    want = torch.stack((cd.sum(0), (cd * cd).sum(0)))
+    assert torch.equal(st.double().sum(0), want)
+    assert torch.equal(acc.sum(0).double() / 2.0 ** 24, want)
+
+
 @pytest.mark.parametrize("M,N,K", [(12544, 256, 128), (5000, 512, 256), (63, 256, 128), (100352, 256, 128), (7777, 768, 256)])
 def test_gemm_pro_bn_relu_operand_three_epilogues(dev, M, N, K):
     """cvcl_gemm with the producer's BatchNorm + ReLU on the operand and K = 128 | 256 (conv3 of ResNeXt layers 1-2 on the raw
