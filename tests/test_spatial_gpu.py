@@ -213,3 +213,14 @@ def test_finetune_cnn_with_spatial_embeddings_vs_oracle(dev, precision):
             assert float(g.abs().sum()) > 0, k
         checked += 1
     assert checked == 159
+
+
+def test_global_spatial_match_map_guard(dev):
+    """Data-parallel global negatives with sim='max' replicate a [N_g HW, N_g L] fp32 match map and its gradient on every rank
+    (2 x 20 GB at 8 ranks x 256 pairs x 7x7 x 25 words): a size beyond the device is refused with a message naming the ways out,
+    instead of an out-of-memory kill inside the step; the sizes the configurations use pass."""
+    from multimodal import parallel
+    parallel.check_spatial_global_bytes(2048 * 49, 2048 * 25, "max", dev)                      # 8 ranks x 256 pairs: 41 GB, fits
+    parallel.check_spatial_global_bytes(10 ** 7, 10 ** 7, "mean", dev)                         # sim='mean' forms no match map
+    with pytest.raises(RuntimeError, match="local_negatives"):
+        parallel.check_spatial_global_bytes(16384 * 49, 16384 * 25, "max", dev)                # 64 ranks x 256: 2.6 TB
