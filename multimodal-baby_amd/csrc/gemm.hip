@@ -107,11 +107,19 @@ template <typename T> struct TileRegs {
 // (the dropped lo.lo term and the split's remainder).  The trainable tail's linears in the bf16 configurations (text transformer,
 // reference multimodal/multimodal.py:553-573: under Lightning's bf16 autocast these are plain bf16 GEMMs; here they keep fp32
 // operands and ~fp32 results at a quarter of the exact kernel's time).  The exact mode stays the parity mode.
-// lo part of the split: bf16(x - hi) -- 0 when hi is not finite (|x| beyond the bf16 range rounds hi to inf; x - inf would make
-// lo = -inf and the lo.hi product NaN where the exact fp32 GEMM gives inf; an inf / NaN operand stays inf / NaN through hi alone)
-__device__ __forceinline__ bf16_t split_lo(float x, bf16_t hi) {
-    const float h = (float)hi;
-    return (bf16_t)(__builtin_isfinite(h) ? x - h : 0.f);
+// hi / lo parts of the split: hi = bf16(x), lo = bf16(x - hi).  A FINITE x beyond the bf16 range (3.39e38 < |x| <= fp32 max) would
+// round hi to infinity -- x - inf makes lo = -inf, and inf times the OTHER operand's lo part (a small number of either sign) gives
+// -inf or NaN next to the hi.hi product's +inf: NaN where the exact fp32 GEMM gives a finite number or inf.  hi is clamped to the
+// largest finite bf16 there (lo = x - hi is then ~1e36, representable), so the product stays what the operands make it; an inf / NaN
+// operand keeps hi = inf / NaN with lo = 0 (its products are non-finite in either arithmetic).
+// (selects only: a branch in the staging code of a kernel with loads in flight makes the compiler drain them)
+__device__ __forceinline__ void split_hi_lo(float x, bf16_t& hi, bf16_t& lo) {
+    const bf16_t h0 = (bf16_t)x;
+    const bool hfin = __builtin_isfinite((float)h0), xfin = __builtin_isfinite(x);
+    const bf16_t hmax = __builtin_bit_cast(bf16_t, (unsigned short)(x < 0.f ? 0xFF7F : 0x7F7F));              // +-3.3895e38
+    const bf16_t h = (!hfin && xfin) ? hmax : h0;
+    hi = h;
+    lo = (bf16_t)(xfin ? x - (float)h : 0.f);
 }
 
 template <typename T, int PRO, bool LEAN, int MINW, int TR = 0>
@@ -262,8 +270,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_kernel(GemmDev p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float x = c.get(e);
-                        hi[e] = (bf16_t)x;
-                        lo[e] = split_lo(x, hi[e]);
+                        split_hi_lo(x, hi[e], lo[e]);
                     }
                     if (!kmajor) {
                         char* row = base + (r0 + 32 * j) * ROWB + kc * 8;
@@ -1053,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split_kernel(const float* __r
             auto put = [&](char* base, const f32x4& v, bool kmajor) {
                 bf16_t hi[4], lo[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { hi[e] = (bf16_t)v[e]; lo[e] = split_lo(v[e], hi[e]); }
+                for (int e = 0; e < 4; ++e) split_hi_lo(v[e], hi[e], lo[e]);
                 if (!kmajor) {
                     char* row = base + (r0 + 32 * j) * ROWB + kc * 8;
                     *reinterpret_cast<bf16x4*>(row) = bf16x4{hi[0], hi[1], hi[2], hi[3]};

@@ -706,3 +706,27 @@ def test_gemm_f32_split_arithmetic(H, dev, M, N, K, ta, tw):
     assert err < 3e-5 and err < bf / 50
     if ta:
         assert float((rs.double().cpu() - A.double().sum(1)).abs().max()) < 2e-5 * float(A.abs().sum(1).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(1280, 512, 512), (64, 64, 256)])
+def test_gemm_f32_split_operands_beyond_the_bf16_range(H, dev, M, N, K):
+    """A finite value that rounds to bf16 infinity (3.39e38 < |x| <= fp32 max: a sliver of the fp32 range) gets the largest finite
+    bf16 as its hi part (hi = inf made lo = x - inf = -inf, and inf times the other operand's lo part NaN): the row comes
+    out as the exact fp32 GEMM gives it -- finite where 3.4e38 w fits, +inf where it overflows -- never NaN; an inf / NaN operand
+    stays non-finite; finite rows are untouched."""
+    g = torch.Generator().manual_seed(K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.rand(N, K, generator=g) + 0.5                          # positive weights: row 3 of the product is +inf, not inf - inf
+    A[3].abs_()
+    A[3, 5] = 3.4e38
+    A[7, 1] = float("inf")
+    A[9, 2] = float("nan")
+    y = H.gemm(A.to(dev), W.to(dev), split=True).cpu()
+    exact = H.gemm(A.to(dev), W.to(dev)).cpu()
+    assert not bool(torch.isnan(y[3]).any()) and bool((y[3] > 1e38).all()) and not bool(torch.isnan(exact[3]).any())
+    fin = torch.isfinite(exact[3]) & (exact[3] < 3.2e38)             # (away from the overflow edge the two arithmetics agree)
+    assert int(fin.sum()) > 0 and maxrel(y[3][fin], exact[3][fin]) < 1e-4
+    assert not bool(torch.isfinite(y[7]).any()) and not bool(torch.isfinite(y[9]).any())
+    keep = torch.ones(M, dtype=torch.bool)
+    keep[[3, 7, 9]] = False
+    assert bool(torch.isfinite(y[keep]).all()) and maxrel(y[keep], exact[keep]) < 3e-5
