@@ -845,6 +845,11 @@ extern "C" int cvcl_attention_train(const void* qkv, void* out, float* lse, int 
 extern "C" int cvcl_attention(int dtype, const void* qkv, const int64_t* key_tok, void* out, int B, int T, int heads,
                               int head_dim, float scale, void* stream) {
     CVCL_CHECK_ARG(qkv && out && B > 0 && T > 0 && heads > 0 && head_dim > 0 && head_dim <= 128, "cvcl_attention: bad args");
+    // [lab: CVCL_SKIP_ATTENTION_AFTER=n -- what the image encoder's attention launches cost the STEP: after n calls they are skipped
+    //  (timing only: the blocks then multiply whatever the output buffer holds)]
+    static const int skip_after = cvcl_lab_int("CVCL_SKIP_ATTENTION_AFTER", 0);
+    static long calls = 0;
+    if (skip_after > 0 && T > 32 && ++calls > skip_after) return CVCL_OK;
     CvclProfScope prof(stream, CVCL_K_ATTENTION);
     hipStream_t s = (hipStream_t)stream;
     if (dtype == CVCL_BF16 && head_dim == 64 && !key_tok && T > 32 && T <= ATT_TPAD_MAX) {   // T <= 32: generic kernel below
